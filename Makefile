@@ -1,0 +1,32 @@
+# Builds librepsurf_hip.so (gfx950 only) and the CPU oracle.  No cmake, no torch dependency.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := repsurf_amd/csrc
+LIBDIR := repsurf_amd/lib
+# -ffp-contract=off: the index-producing kernels restate the reference CPU arithmetic
+# operation by operation; fused multiply-adds appear only where written (rs_fma).
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
+            -fhip-fp32-correctly-rounded-divide-sqrt -munsafe-fp-atomics -Wall -Wno-unused-function
+SRCS := $(CSRC)/rs_lib.cpp $(CSRC)/fps.hip $(CSRC)/ballquery.hip $(CSRC)/knn_umbrella.hip \
+        $(CSRC)/group.hip $(CSRC)/interp.hip
+OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
+
+all: $(LIBDIR)/librepsurf_hip.so oracle
+
+build/%.o: $(CSRC)/% $(CSRC)/rs_common.h include/repsurf_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIBDIR)/librepsurf_hip.so: $(OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle: oracle/_build/libgeom_oracle.so
+oracle/_build/libgeom_oracle.so: oracle/geom_oracle.c
+	@mkdir -p oracle/_build
+	gcc -O2 -std=c11 -fPIC -shared -ffp-contract=off -fno-fast-math -o $@ $< -lm
+
+clean:
+	rm -rf build $(LIBDIR)/librepsurf_hip.so oracle/_build
+
+.PHONY: all oracle clean

@@ -1,0 +1,199 @@
+/*
+ * repsurf_hip.h — C ABI of librepsurf_hip.so, the MI355X (gfx950) hot path of RepSurf-U.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes and a
+ * `void* stream` (a hipStream_t; NULL = the legacy default stream), allocates
+ * nothing, retains nothing across calls and never synchronises the host.
+ * Return value: 0 on success, RS_ERR_ARG for an invalid argument, or
+ * (RS_ERR_HIP_BASE + hipError_t) when the launch failed; rs_last_error() gives
+ * the text.  The reference exits the process on a failed launch
+ * (classification/modules/pointops/src/ballquery/ballquery_cuda_kernel.cu:95-100);
+ * we return the code and the Python host raises RuntimeError.
+ *
+ * Layouts: all point data is fp32, row-major, channels-last: xyz (b, n, 3),
+ * per-point features (b, n, c).  Indices are int32 like the reference CUDA
+ * path (classification/modules/pointops/functions/pointops.py:44,220,313).
+ * Grouped shared-MLP tiles are (rows, channels) with
+ * rows = ((b * npoint) + s) * nsample + k.
+ *
+ * Arithmetic contract: the index-producing kernels restate, operation by
+ * operation, the reference's CPU/PyTorch path (`cuda=False` branches of
+ * classification/modules/pointnet2_utils.py) so that FPS / ball-query / kNN
+ * indices are bit-exact against it; see DESIGN.md §3 and oracle/geom_oracle.c.
+ *
+ * Each declaration cites the reference interface it replaces.
+ */
+#ifndef REPSURF_HIP_H
+#define REPSURF_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_OK 0
+#define RS_ERR_ARG (-1)
+#define RS_ERR_HIP_BASE 1000
+
+/* ---- library ---------------------------------------------------------- */
+const char *rs_last_error(void);          /* thread-local text of the last failure */
+int rs_abi_version(void);                 /* bumped on any signature change */
+int rs_device_info(int *cu_count, int *wave_size, int *lds_bytes, char *arch, int arch_len);
+
+/* ---- sampling ---------------------------------------------------------
+ * Farthest point sampling.  Replaces furthestsampling_cuda_launcher(b,n,m,dataset,temp,idxs)
+ * (classification/modules/pointops/src/sampling/sampling_cuda_kernel.h:17, kernel .cu:58-168)
+ * with the CPU-path semantics of farthest_point_sample
+ * (classification/modules/pointnet2_utils.py:47-75): start[b] is the first pick
+ * (the CPU path draws it with torch.randint; NULL = index 0 like the CUDA kernel),
+ * d = ((dx*dx + dy*dy) + dz*dz) with separately rounded products, running min,
+ * arg-max = lowest index among maxima.  `temp` (b*n floats) is accepted for
+ * signature parity and only used when n is too large for the register-resident
+ * kernel (n > 16384); it may be NULL otherwise.  idx: (b, m) int32. */
+int rs_furthestsampling(int b, int n, int m, const float *xyz, const int *start,
+                        float *temp, int *idx, void *stream);
+
+/* Packed-batch FPS of the segmentation path: replaces
+ * furthestsampling_cuda_launcher(b, n_max, xyz, offset, new_offset, tmp, idx)
+ * (segmentation/modules/pointops/src/sampling/sampling_cuda_kernel.cu:14-171):
+ * cloud i owns rows [offset[i-1], offset[i]); picks new_offset[i]-new_offset[i-1]
+ * samples starting from its first row; idx holds global row numbers. */
+int rs_furthestsampling_offset(int b, int n_max, const float *xyz, const int *offset,
+                               const int *new_offset, float *temp, int *idx, void *stream);
+
+/* Row gather out[b, j, :] = points[b, idx[b, j], :] on channels-last data.
+ * Replaces gathering_forward/backward_cuda_launcher
+ * (classification/modules/pointops/src/sampling/sampling_cuda_kernel.h:15-16),
+ * which work on (b, c, n); the transposes around them
+ * (classification/modules/pointnet2_utils.py:31-35) disappear. */
+int rs_gather_rows(int b, int n, int m, int c, const float *points, const int *idx,
+                   float *out, void *stream);
+/* grad_points[b, idx[b,j], :] += grad_out[b, j, :]  (grad_points pre-zeroed by caller) */
+int rs_gather_rows_backward(int b, int n, int m, int c, const float *grad_out, const int *idx,
+                            float *grad_points, void *stream);
+
+/* ---- ball query --------------------------------------------------------
+ * Replaces ballquery_cuda_launcher_fast(b,n,m,radius,nsample,new_xyz,xyz,idx,stream)
+ * (classification/modules/pointops/src/ballquery/ballquery_cuda_kernel.h:17, .cu:47-101)
+ * with the semantics of query_ball_point(cuda=False)
+ * (classification/modules/pointnet2_utils.py:78-99): squared distance by the
+ * expanded formula of square_distance (:15-25), a point is inside when
+ * NOT (d > radius2) where radius2 = float32(radius**2 computed in double); the
+ * first nsample inside points in ascending index order, padded with the first.
+ * A centre with an empty ball gets zeros (the CUDA kernel's pre-zeroed rows;
+ * the CPU path would index out of range).  idx: (b, m, nsample) int32. */
+int rs_ballquery(int b, int n, int m, float radius2, int nsample, const float *new_xyz,
+                 const float *xyz, int *idx, void *stream);
+
+/* ---- kNN ----------------------------------------------------------------
+ * Replaces knnquery_cuda_launcher(b,n,m,nsample,xyz,new_xyz,idx,dist2,stream)
+ * (classification/modules/pointops/src/knnquery/knnquery_cuda_kernel.h:14) with the
+ * semantics of query_knn_point(cuda=False) (classification/modules/pointnet2_utils.py:102-111):
+ * expanded-formula distances, ascending by (distance, index).  dist2 may be NULL.
+ * nsample <= 64. */
+int rs_knnquery(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz,
+                int *idx, float *dist2, void *stream);
+
+/* Packed-batch kNN of the segmentation path: replaces knnquery_cuda_launcher
+ * (segmentation/modules/pointops/src/knnquery/knnquery_cuda_kernel.cu:65-108):
+ * direct-difference distances, strict '<' replacement, ascending output,
+ * dist2 (m, nsample) holds squared distances (Python takes the sqrt). */
+int rs_knnquery_offset(int m, int nsample, const float *xyz, const float *new_xyz,
+                       const int *offset, const int *new_offset, int b,
+                       int *idx, float *dist2, void *stream);
+
+/* ---- umbrella surface constructor ---------------------------------------
+ * Fuses group_by_umbrella + cal_normal + cal_center + xyz2sphere + cal_const +
+ * check_nan_umb (classification/modules/repsurface_utils.py:112-132,276-293;
+ * classification/modules/recons_utils.py:27-57,82-90,108-124,152-176;
+ * classification/modules/polar_utils.py:10-31) for the self-query case
+ * (new_xyz == xyz): kNN-k, drop the nearest, sort the k-1 offsets by azimuth,
+ * build the triangle fan, emit per triangle [centre(3), polar(3), normal(3), pos(1)].
+ * inv_sign: (b) floats of +-1 (the per-cloud random inversion drawn by the host
+ * from the CPU generator, recons_utils.py:50) or NULL.  knn_idx (b, n, k) int32 is
+ * optional (NULL to skip).  feat: (b, n, k-1, 10).  3 <= k <= 16. */
+int rs_umbrella_features(int b, int n, int k, const float *xyz, const float *inv_sign,
+                         int *knn_idx, float *feat, void *stream);
+
+/* ---- grouping ------------------------------------------------------------
+ * Builds the grouped shared-MLP input of sample_and_group
+ * (classification/modules/repsurface_utils.py:15-59) in one pass, replacing
+ * 3x grouping_forward_cuda_launcher_fast
+ * (classification/modules/pointops/src/grouping/grouping_cuda_kernel.h:19) + subtract +
+ * xyz2sphere + cat: row r = (b, s, j) of `out` (rows, 3 + 3*polar + cn + cf) is
+ * [center[idx]-new_center (3), polar of that offset (3, if polar), normal[idx] (cn), feature[idx] (cf)].
+ * feature may be NULL (cf = 0).  idx: (b, m, nsample). */
+int rs_group_features(int b, int n, int m, int nsample, int cn, int cf, int polar,
+                      const float *center, const float *new_center, const float *normal,
+                      const float *feature, const int *idx, float *out, void *stream);
+/* Backward of the gathered (normal, feature) channels: scatter-adds
+ * grad_out[:, cpos:cpos+cn] into grad_normal (b,n,cn) and grad_out[:, cpos+cn:] into
+ * grad_feature (b,n,cf) (either may be NULL; both pre-zeroed by the caller).
+ * Replaces grouping_backward_cuda_launcher (grouping_cuda_kernel.h:17). */
+int rs_group_features_backward(int b, int n, int m, int nsample, int cn, int cf, int polar,
+                               const float *grad_out, const int *idx, float *grad_normal,
+                               float *grad_feature, void *stream);
+/* group_all variant (sample_and_group_all, repsurface_utils.py:62-88):
+ * row (b, j) = [center (3), polar of center (3, if polar), normal (cn), feature (cf)]. */
+int rs_group_all_features(int b, int n, int cn, int cf, int polar, const float *center,
+                          const float *normal, const float *feature, float *out, void *stream);
+
+/* Plain grouping out[b, s, j, :] = points[b, idx[b,s,j], :] and its backward
+ * (index_points(is_group=True), classification/modules/pointnet2_utils.py:28-35). */
+int rs_group_rows(int b, int n, int m, int nsample, int c, const float *points,
+                  const int *idx, float *out, void *stream);
+int rs_group_rows_backward(int b, int n, int m, int nsample, int c, const float *grad_out,
+                           const int *idx, float *grad_points, void *stream);
+
+/* ---- three-NN interpolation (segmentation decoder; BASELINE config 4) ----
+ * Replaces nearestneighbor_cuda_launcher_fast / interpolation_forward_cuda_launcher_fast /
+ * interpolation_backward_cuda_launcher
+ * (classification/modules/pointops/src/interpolation/interpolation_cuda_kernel.h:18-23;
+ * kernels .cu:134-195,90-114), channels-last.  dist2 (b,n,3) squared distances
+ * (direct differences, like the kernel), idx (b,n,3). */
+int rs_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                int *idx, void *stream);
+int rs_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                         const float *weight, float *out, void *stream);
+int rs_three_interpolate_backward(int b, int c, int n, int m, const float *grad_out,
+                                  const int *idx, const float *weight, float *grad_points,
+                                  void *stream);
+
+/* ---- shared MLP (1x1 conv + BatchNorm(train) + ReLU [+ max over nsample]) ----
+ * The reference runs nn.Conv2d(1x1) -> nn.BatchNorm2d -> F.relu as three framework
+ * calls per layer (classification/modules/repsurface_utils.py:236-244).  Here one
+ * fp32-MFMA GEMM kernel per layer does
+ *     y[rows, cout] = act(x)[rows, cin] . w[cout, cin]^T + bias
+ * where act() optionally applies the previous layer's BatchNorm affine + ReLU
+ * while loading (x_scale/x_shift per input channel; NULL = identity), and the
+ * epilogue accumulates the per-channel sum / sum of squares that the next call
+ * of rs_bn_finalize turns into batch statistics.
+ * stats: (2, cout) floats, zeroed by the caller, accumulated with atomics. */
+int rs_mlp_gemm_fwd(int rows, int cin, int cout, const float *x, int ldx,
+                    const float *x_scale, const float *x_shift, int x_relu,
+                    const float *w, const float *bias, float *y, int ldy,
+                    float *stats, void *stream);
+
+/* BatchNorm statistics -> affine.  From stats (sum, sumsq over `rows` rows) computes
+ * mean/var (biased), scale = gamma / sqrt(var + eps), shift = beta - scale * mean,
+ * writes save_mean / save_invstd (for backward) and, when running_mean != NULL,
+ * updates the running statistics with `momentum` and the unbiased variance like
+ * nn.BatchNorm2d in training mode. */
+int rs_bn_finalize(int c, int rows, const float *stats, const float *gamma, const float *beta,
+                   float eps, float momentum, float *scale, float *shift, float *save_mean,
+                   float *save_invstd, float *running_mean, float *running_var, void *stream);
+
+/* out[g, c] = max_j relu(scale[c] * y[g*nsample + j, c] + shift[c]); arg[g, c] = winning j
+ * (torch.max(new_feature, 2)[0], repsurface_utils.py:244, fused with the last BN+ReLU).
+ * With scale2/shift2/y2 non-NULL the pre-activation is the sum of two BN outputs
+ * (bn_l0(mlp_l0) + bn_f0(mlp_f0), repsurface_utils.py:236-239). */
+int rs_bn_relu_maxpool(int groups, int nsample, int c, const float *y, const float *scale,
+                       const float *shift, float *out, int *arg, void *stream);
+
+/* z = relu(scale*y + shift [+ scale2*y2 + shift2]) elementwise, rows x c. */
+int rs_bn_relu(int rows, int c, const float *y, const float *scale, const float *shift,
+               const float *y2, const float *scale2, const float *shift2, float *z, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REPSURF_HIP_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of librepsurf_hip.so (the C ABI declared in include/repsurf_hip.h).
+
+There is NO fallback: if the shared library is missing or does not export a symbol this module
+raises, and every operator in repsurf_amd.ops raises with it.  Build with `make` at the repo
+root or `python -c "import __graft_entry__ as g; g.build()"`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librepsurf_hip.so")
+ABI_VERSION = 1
+
+c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+P = c_void_p  # device pointers and the stream travel as void*
+
+# name -> argtypes (restype is always int unless listed in _SPECIAL)
+SIGNATURES = {
+    "rs_furthestsampling": [c_int, c_int, c_int, P, P, P, P, P],
+    "rs_furthestsampling_offset": [c_int, c_int, P, P, P, P, P, P],
+    "rs_gather_rows": [c_int, c_int, c_int, c_int, P, P, P, P],
+    "rs_gather_rows_backward": [c_int, c_int, c_int, c_int, P, P, P, P],
+    "rs_ballquery": [c_int, c_int, c_int, c_float, c_int, P, P, P, P],
+    "rs_knnquery": [c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "rs_knnquery_offset": [c_int, c_int, P, P, P, P, c_int, P, P, P],
+    "rs_umbrella_features": [c_int, c_int, c_int, P, P, P, P, P],
+    "rs_group_features": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
+    "rs_group_features_backward": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "rs_group_all_features": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "rs_group_rows": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
+    "rs_group_rows_backward": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
+    "rs_three_nn": [c_int, c_int, c_int, P, P, P, P, P],
+    "rs_three_interpolate": [c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "rs_three_interpolate_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P],
+}
+_SPECIAL = {
+    "rs_last_error": ([], ctypes.c_char_p),
+    "rs_abi_version": ([], c_int),
+    "rs_device_info": ([ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.c_char_p, c_int], c_int),
+}
+
+_lib = None
+
+
+class RepSurfHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once, bind every declared symbol, check the ABI version."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RepSurfHipError(
+            f"{LIB_PATH} not found: the HIP library is not built (run `make` in the repo root). "
+            "repsurf_amd has no CPU or PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError -> missing export, propagate loudly
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    for name, (argtypes, restype) in _SPECIAL.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    got = lib.rs_abi_version()
+    if got != ABI_VERSION:
+        raise RepSurfHipError(f"librepsurf_hip ABI {got} != binding ABI {ABI_VERSION}: rebuild with `make`")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an ABI function; non-zero return -> RepSurfHipError with the library's message."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.rs_last_error()
+        raise RepSurfHipError(f"{name} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def device_info():
+    lib = load()
+    cu, wave, lds = c_int(), c_int(), c_int()
+    arch = ctypes.create_string_buffer(64)
+    rc = lib.rs_device_info(ctypes.byref(cu), ctypes.byref(wave), ctypes.byref(lds), arch, 64)
+    if rc != 0:
+        raise RepSurfHipError(f"rs_device_info failed: {lib.rs_last_error().decode()}")
+    return {"cu_count": cu.value, "wave_size": wave.value, "lds_bytes": lds.value, "arch": arch.value.decode()}

@@ -1,0 +1,52 @@
+"""Shared constructor for the RepSurf-U ScanObjectNN classifiers.
+
+Both shipped variants are: UmbrellaSurfaceConstructor -> a ladder of SurfaceAbstractionCD stages
+(the last one `group_all`) -> a 3-layer MLP head with log-softmax.  The attribute names
+(`surface_constructor`, `sa1..saN`, `classfier` [sic]) and the Sequential indices of the head
+are the reference's, so its checkpoints load
+(classification/models/repsurf/repsurf_ssg_umb.py:11-57, repsurf_ssg_umb_2x.py:11-61).
+"""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from modules.repsurface_utils import SurfaceAbstractionCD, UmbrellaSurfaceConstructor
+
+REPSURF_CHANNEL = 10
+
+
+class UmbrellaClassifier(nn.Module):
+    def __init__(self, args, stages, head_in):
+        """stages: list of dicts(npoint, radius, nsample, mlp); feature widths chain automatically."""
+        super().__init__()
+        pos_channel = (6 if args.return_polar else 3) if args.return_center else 0
+        self.init_nsample = args.num_point
+        self.return_dist = args.return_dist
+        self.surface_constructor = UmbrellaSurfaceConstructor(
+            args.group_size + 1, REPSURF_CHANNEL, return_dist=args.return_dist, aggr_type=args.umb_pool,
+            cuda=args.cuda_ops)
+        width = 0
+        self._stage_names = []
+        for i, st in enumerate(stages, 1):
+            last = i == len(stages)
+            sa = SurfaceAbstractionCD(
+                npoint=None if last else st["npoint"], radius=None if last else st["radius"],
+                nsample=None if last else st["nsample"], feat_channel=width + REPSURF_CHANNEL,
+                pos_channel=pos_channel, mlp=st["mlp"], group_all=last,
+                return_polar=args.return_polar, cuda=args.cuda_ops)
+            setattr(self, f"sa{i}", sa)
+            self._stage_names.append(f"sa{i}")
+            width = st["mlp"][-1]
+        self.head_in = head_in
+        self.classfier = nn.Sequential(
+            nn.Linear(head_in, 512), nn.BatchNorm1d(512), nn.ReLU(True), nn.Dropout(0.4),
+            nn.Linear(512, 256), nn.BatchNorm1d(256), nn.ReLU(True), nn.Dropout(0.4),
+            nn.Linear(256, args.num_class))
+
+    def forward(self, points):
+        center = points[:, :3, :]
+        normal = self.surface_constructor(center)
+        feature = None
+        for name in self._stage_names:
+            center, normal, feature = getattr(self, name)(center, normal, feature)
+        logits = self.classfier(feature.reshape(-1, self.head_in))
+        return F.log_softmax(logits, -1)

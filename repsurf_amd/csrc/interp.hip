@@ -1,0 +1,194 @@
+// interp.hip — three nearest neighbours + inverse-distance interpolation, and the packed-batch
+// kNN of the segmentation path (gfx950).
+//
+// rs_three_nn / rs_three_interpolate(+backward) replace the `nearestneighbor` / `interpolation`
+// operators of the reference (classification/modules/pointops/src/interpolation/
+// interpolation_cuda_kernel.cu:134-195, 90-114; Python side pointops.py:86-147) on channels-last
+// data.  Distances use direct differences ((dx*dx + dy*dy) + dz*dz, products rounded
+// separately); a candidate replaces a kept neighbour only when strictly closer, so equal
+// distances keep the lower index -- the order the reference's sequential scan produces.
+//
+// rs_knnquery_offset replaces the packed-batch knnquery of the segmentation path
+// (segmentation/modules/pointops/src/knnquery/knnquery_cuda_kernel.cu:65-108): each query scans
+// the rows [offset[i-1], offset[i]) of its own cloud; output ascending by (distance, index).
+#include "rs_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int IT_THREADS = 256;
+constexpr int IT_TILE = 2048;
+
+__global__ void __launch_bounds__(IT_THREADS)
+three_nn_kernel(int b, int n, int m, int blocks_per_cloud, const float *__restrict__ unknown,
+                const float *__restrict__ known, float *__restrict__ dist2, int *__restrict__ idx) {
+  __shared__ float4 tile[IT_TILE];
+  int cloud, chunk;
+  rs_xcd_remap(blockIdx.x, b, blocks_per_cloud, cloud, chunk);
+  const int q = chunk * IT_THREADS + threadIdx.x;
+  const int qc = min(q, n - 1);
+  const float *u = unknown + ((size_t)cloud * n + qc) * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
+  const float *kp = known + (size_t)cloud * m * 3;
+  float d1 = INFINITY, d2 = INFINITY, d3 = INFINITY;
+  int i1 = 0, i2 = 0, i3 = 0;
+  for (int t0 = 0; t0 < m; t0 += IT_TILE) {
+    const int tn = min(IT_TILE, m - t0);
+    __syncthreads();
+    for (int p = threadIdx.x; p < tn; p += IT_THREADS)
+      tile[p] = make_float4(kp[(t0 + p) * 3 + 0], kp[(t0 + p) * 3 + 1], kp[(t0 + p) * 3 + 2], 0.f);
+    __syncthreads();
+    for (int p = 0; p < tn; ++p) {
+      const float4 c = tile[p];
+      const float dx = ux - c.x, dy = uy - c.y, dz = uz - c.z;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      const int k = t0 + p;
+      if (d < d1) { d3 = d2; i3 = i2; d2 = d1; i2 = i1; d1 = d; i1 = k; }
+      else if (d < d2) { d3 = d2; i3 = i2; d2 = d; i2 = k; }
+      else if (d < d3) { d3 = d; i3 = k; }
+    }
+  }
+  if (q < n) {
+    const size_t o = ((size_t)cloud * n + q) * 3;
+    dist2[o + 0] = d1; dist2[o + 1] = d2; dist2[o + 2] = d3;
+    idx[o + 0] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+  }
+}
+
+// out[b, j, :] = sum_t w[b,j,t] * points[b, idx[b,j,t], :]
+__global__ void __launch_bounds__(IT_THREADS)
+interp_fwd_kernel(long long rows, int n, int m, int c, const float *__restrict__ points,
+                  const int *__restrict__ idx, const float *__restrict__ weight, float *__restrict__ out) {
+  const long long total = rows * c;
+  for (long long e = (long long)blockIdx.x * IT_THREADS + threadIdx.x; e < total;
+       e += (long long)gridDim.x * IT_THREADS) {
+    const long long r = e / c;
+    const int ch = (int)(e - r * c);
+    const long long cloud = r / n;
+    const float *base = points + cloud * m * c + ch;
+    const float v0 = weight[r * 3 + 0] * base[(long long)idx[r * 3 + 0] * c];
+    const float v1 = weight[r * 3 + 1] * base[(long long)idx[r * 3 + 1] * c];
+    const float v2 = weight[r * 3 + 2] * base[(long long)idx[r * 3 + 2] * c];
+    out[e] = (v0 + v1) + v2;
+  }
+}
+
+__global__ void __launch_bounds__(IT_THREADS)
+interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__ grad_out,
+                  const int *__restrict__ idx, const float *__restrict__ weight,
+                  float *__restrict__ grad_points) {
+  const long long total = rows * c;
+  for (long long e = (long long)blockIdx.x * IT_THREADS + threadIdx.x; e < total;
+       e += (long long)gridDim.x * IT_THREADS) {
+    const long long r = e / c;
+    const int ch = (int)(e - r * c);
+    const long long cloud = r / n;
+    float *base = grad_points + cloud * m * c + ch;
+    const float g = grad_out[e];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) atomicAdd(base + (long long)idx[r * 3 + t] * c, g * weight[r * 3 + t]);
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(IT_THREADS)
+knn_offset_kernel(int m, int nsample, int b, const float *__restrict__ xyz,
+                  const float *__restrict__ new_xyz, const int *__restrict__ offset,
+                  const int *__restrict__ new_offset, int *__restrict__ idx, float *__restrict__ dist2) {
+  const int q = blockIdx.x * IT_THREADS + threadIdx.x;
+  if (q >= m) return;
+  // cloud of this query: first i with q < new_offset[i]   (binary search; the reference walks linearly)
+  int lo = 0, hi = b - 1;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (q < new_offset[mid]) hi = mid; else lo = mid + 1; }
+  const int start = lo ? offset[lo - 1] : 0, end = offset[lo];
+  const float qx = new_xyz[q * 3 + 0], qy = new_xyz[q * 3 + 1], qz = new_xyz[q * 3 + 2];
+  float bd[K]; int bi[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { bd[j] = 1e10f; bi[j] = start; }   // knnquery_cuda_kernel.cu:86-87
+  for (int p = start; p < end; ++p) {
+    const float dx = qx - xyz[p * 3 + 0], dy = qy - xyz[p * 3 + 1], dz = qz - xyz[p * 3 + 2];
+    const float d = (dx * dx + dy * dy) + dz * dz;
+    if (d < bd[K - 1]) {
+      bd[K - 1] = d; bi[K - 1] = p;
+#pragma unroll
+      for (int j = K - 1; j > 0; --j) {
+        const bool sw = bd[j] < bd[j - 1];
+        const float td = bd[j]; const int ti = bi[j];
+        bd[j] = sw ? bd[j - 1] : td; bi[j] = sw ? bi[j - 1] : ti;
+        bd[j - 1] = sw ? td : bd[j - 1]; bi[j - 1] = sw ? ti : bi[j - 1];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) if (j < nsample) {
+    idx[(size_t)q * nsample + j] = bi[j];
+    if (dist2) dist2[(size_t)q * nsample + j] = bd[j];
+  }
+}
+
+inline int grid_for(long long work_items) {
+  long long blocks = (work_items + IT_THREADS - 1) / IT_THREADS;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" int rs_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                           int *idx, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0 && m >= 0, "rs_three_nn: negative size");
+  if (b == 0 || n == 0) return RS_OK;
+  RS_REQUIRE(m >= 3, "rs_three_nn: needs at least 3 known points (m=%d)", m);
+  RS_REQUIRE(unknown && known && dist2 && idx, "rs_three_nn: null pointer");
+  const int bpc = rs_cdiv(n, IT_THREADS);
+  hipLaunchKernelGGL(three_nn_kernel, dim3(b * bpc), dim3(IT_THREADS), 0, (hipStream_t)stream, b, n, m, bpc,
+                     unknown, known, dist2, idx);
+  RS_CHECK_LAUNCH("rs_three_nn");
+  return RS_OK;
+}
+
+extern "C" int rs_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                                    const float *weight, float *out, void *stream) {
+  RS_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "rs_three_interpolate: negative size");
+  const long long rows = (long long)b * n;
+  if (rows == 0 || c == 0) return RS_OK;
+  RS_REQUIRE(points && idx && weight && out, "rs_three_interpolate: null pointer");
+  hipLaunchKernelGGL(interp_fwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
+                     rows, n, m, c, points, idx, weight, out);
+  RS_CHECK_LAUNCH("rs_three_interpolate");
+  return RS_OK;
+}
+
+extern "C" int rs_three_interpolate_backward(int b, int c, int n, int m, const float *grad_out,
+                                             const int *idx, const float *weight, float *grad_points,
+                                             void *stream) {
+  RS_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "rs_three_interpolate_backward: negative size");
+  const long long rows = (long long)b * n;
+  if (rows == 0 || c == 0) return RS_OK;
+  RS_REQUIRE(grad_out && idx && weight && grad_points, "rs_three_interpolate_backward: null pointer");
+  hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
+                     rows, n, m, c, grad_out, idx, weight, grad_points);
+  RS_CHECK_LAUNCH("rs_three_interpolate_backward");
+  return RS_OK;
+}
+
+extern "C" int rs_knnquery_offset(int m, int nsample, const float *xyz, const float *new_xyz,
+                                  const int *offset, const int *new_offset, int b, int *idx,
+                                  float *dist2, void *stream) {
+  RS_REQUIRE(m >= 0 && nsample >= 0 && b >= 0, "rs_knnquery_offset: negative size");
+  if (m == 0 || nsample == 0 || b == 0) return RS_OK;
+  RS_REQUIRE(nsample <= 64, "rs_knnquery_offset: nsample=%d exceeds the supported maximum of 64", nsample);
+  RS_REQUIRE(xyz && new_xyz && offset && new_offset && idx, "rs_knnquery_offset: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(rs_cdiv(m, IT_THREADS)), block(IT_THREADS);
+#define RS_LAUNCH_KO(K) hipLaunchKernelGGL(knn_offset_kernel<K>, grid, block, 0, st, m, nsample, b, xyz, new_xyz, offset, new_offset, idx, dist2)
+  if (nsample <= 3) RS_LAUNCH_KO(3);
+  else if (nsample <= 9) RS_LAUNCH_KO(9);
+  else if (nsample <= 16) RS_LAUNCH_KO(16);
+  else if (nsample <= 32) RS_LAUNCH_KO(32);
+  else RS_LAUNCH_KO(64);
+#undef RS_LAUNCH_KO
+  RS_CHECK_LAUNCH("rs_knnquery_offset");
+  return RS_OK;
+}

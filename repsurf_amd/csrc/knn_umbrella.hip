@@ -1,0 +1,260 @@
+// knn_umbrella.hip — k nearest neighbours and the fused umbrella-surface constructor (gfx950).
+//
+// rs_knnquery computes query_knn_point(cuda=False)
+// (classification/modules/pointnet2_utils.py:102-111): expanded-formula squared distances,
+// the k smallest in ascending (distance, index) order.
+//
+// rs_umbrella_features fuses, for the self-query case, everything between the raw cloud and the
+// input of UmbrellaSurfaceConstructor.mlps (classification/modules/repsurface_utils.py:276-293):
+//   group_by_umbrella (:112-132)   kNN-k, drop the nearest, offsets, azimuth sort, fan pairing
+//   cal_normal  (classification/modules/recons_utils.py:27-57)   unit cross product, sign rule
+//   cal_center  (:82-90)           triangle centroid
+//   xyz2sphere  (classification/modules/polar_utils.py:10-31)    polar form of the centroid
+//   cal_const   (recons_utils.py:108-124)   <n, c> / sqrt(3)
+//   check_nan_umb (:152-176)       degenerate triangles take the first valid triangle's values
+// The reference materialises (B,N,N) distances, sorts every row, and runs ~25 framework ops
+// over (B,N,8,3,3) tensors.  Here one thread owns one point: the cloud sits in LDS as
+// (x,y,z,|p|^2) float4 (broadcast reads), the running top-k lives in registers as a sorted
+// list, and the 8 neighbours never leave the register file until the 8x10 feature tile is
+// written.  Arithmetic order follows the PyTorch CPU kernels operation by operation (probed in
+// tests/golden/make_golden.py): cross = fma(a1,b2,-(a2*b1)), norm = sqrt(fma(z,z,fma(y,y,x*x))),
+// mean = ((0+a)+b)/3, theta/float(pi), phi/float(2pi)+0.5.
+//
+// Azimuth order: torch sorts the 8 normalised azimuths with a stable sort.  atan2f of this
+// platform (ocml) and of the CPU (SLEEF) may differ in the last ulp, so keys closer than
+// RS_PHI_TIE are ordered by the exact sign of the 2-D cross product (in fp64, products of
+// floats are exact) -- the true angular order, identical in the oracle -- and exact ties keep
+// their kNN order.  oracle/geom_oracle.c uses the same rule and reports how many points had a
+// near-tie so the parity tests can account for them.
+#include "rs_common.h"
+#include <math.h>
+
+#define RS_PHI_TIE 4.8e-7f          // 8 ulp at 1.0 in normalised-azimuth units
+#define RS_PI_F 3.14159274101257324f      // float(np.pi)
+#define RS_TWO_PI_F 6.28318548202514648f  // float(2*np.pi)
+#define RS_SQRT3_F 1.73205077648162842f   // torch.sqrt(torch.Tensor([3]))
+
+namespace {
+
+constexpr int KNN_THREADS = 256;
+constexpr int KNN_TILE = 2048;   // points per LDS tile (32 KB as float4)
+
+// Sorted insertion of (d, p) into an ascending list of K; ties keep the earlier (lower) index.
+template <int K>
+__device__ __forceinline__ void knn_insert(float (&bd)[K], int (&bi)[K], float d, int p) {
+  if (d < bd[K - 1]) {
+    bd[K - 1] = d; bi[K - 1] = p;
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+      const bool sw = bd[j] < bd[j - 1];
+      const float td = bd[j]; const int ti = bi[j];
+      bd[j] = sw ? bd[j - 1] : td; bi[j] = sw ? bi[j - 1] : ti;
+      bd[j - 1] = sw ? td : bd[j - 1]; bi[j - 1] = sw ? ti : bi[j - 1];
+    }
+  }
+}
+
+// Scan the whole cloud for the K nearest of query (qx,qy,qz).  All threads of the workgroup
+// iterate in lockstep; `active` threads keep a list.
+template <int K>
+__device__ __forceinline__ void knn_scan(const float *__restrict__ pts, int n, float4 *tile,
+                                         float qx, float qy, float qz, float (&bd)[K], int (&bi)[K]) {
+  const float qq = rs_sqnorm(qx, qy, qz);
+#pragma unroll
+  for (int j = 0; j < K; ++j) { bd[j] = INFINITY; bi[j] = 0; }
+  for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
+    const int tn = min(KNN_TILE, n - t0);
+    __syncthreads();
+    for (int p = threadIdx.x; p < tn; p += KNN_THREADS) {
+      const float x = pts[(t0 + p) * 3 + 0], y = pts[(t0 + p) * 3 + 1], z = pts[(t0 + p) * 3 + 2];
+      tile[p] = make_float4(x, y, z, rs_sqnorm(x, y, z));
+    }
+    __syncthreads();
+    for (int p = 0; p < tn; ++p) {
+      const float4 c = tile[p];   // same address for every lane: LDS broadcast
+      const float d = rs_sqdist_expanded(qx, qy, qz, qq, c.x, c.y, c.z, c.w);
+      knn_insert<K>(bd, bi, d, t0 + p);
+    }
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(KNN_THREADS)
+knn_kernel(int b, int n, int m, int nsample, int blocks_per_cloud, const float *__restrict__ xyz,
+           const float *__restrict__ new_xyz, int *__restrict__ idx, float *__restrict__ dist2) {
+  __shared__ float4 tile[KNN_TILE];
+  int cloud, chunk;
+  rs_xcd_remap(blockIdx.x, b, blocks_per_cloud, cloud, chunk);
+  const int q = chunk * KNN_THREADS + threadIdx.x;
+  const int qc = min(q, m - 1);
+  const float *c = new_xyz + ((size_t)cloud * m + qc) * 3;
+  float bd[K]; int bi[K];
+  knn_scan<K>(xyz + (size_t)cloud * n * 3, n, tile, c[0], c[1], c[2], bd, bi);
+  if (q < m) {
+    int *orow = idx + ((size_t)cloud * m + q) * nsample;
+#pragma unroll
+    for (int j = 0; j < K; ++j) if (j < nsample) orow[j] = bi[j];
+    if (dist2) {
+      float *drow = dist2 + ((size_t)cloud * m + q) * nsample;
+#pragma unroll
+      for (int j = 0; j < K; ++j) if (j < nsample) drow[j] = bd[j];
+    }
+  }
+}
+
+// "b goes before a" for two fan neighbours a (earlier position) and b (later position).
+__device__ __forceinline__ bool phi_before(float ka, float xa, float ya, float kb, float xb, float yb) {
+  const float diff = kb - ka;
+  if (__builtin_expect(fabsf(diff) <= RS_PHI_TIE, 0)) {
+    const double cr = (double)xa * (double)yb - (double)xb * (double)ya;   // > 0: b is counter-clockwise of a
+    return cr < 0.0;
+  }
+  return diff < 0.f;
+}
+
+template <int K>
+__global__ void __launch_bounds__(KNN_THREADS)
+umbrella_kernel(int b, int n, int blocks_per_cloud, const float *__restrict__ xyz,
+                const float *__restrict__ inv_sign, int *__restrict__ knn_idx,
+                float *__restrict__ feat) {
+  constexpr int G = K - 1;
+  __shared__ float4 tile[KNN_TILE];
+  int cloud, chunk;
+  rs_xcd_remap(blockIdx.x, b, blocks_per_cloud, cloud, chunk);
+  const float *pts = xyz + (size_t)cloud * n * 3;
+  const int q = chunk * KNN_THREADS + threadIdx.x;
+  const int qc = min(q, n - 1);
+  const float qx = pts[qc * 3 + 0], qy = pts[qc * 3 + 1], qz = pts[qc * 3 + 2];
+
+  float bd[K]; int bi[K];
+  knn_scan<K>(pts, n, tile, qx, qy, qz, bd, bi);
+  if (q >= n) return;
+
+  if (knn_idx) {
+    int *orow = knn_idx + ((size_t)cloud * n + q) * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) orow[j] = bi[j];
+  }
+
+  // offsets of the k-1 neighbours that follow the nearest (repsurface_utils.py:119-121)
+  float ox[G], oy[G], oz[G], key[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const int p = bi[j + 1];
+    ox[j] = pts[p * 3 + 0] - qx; oy[j] = pts[p * 3 + 1] - qy; oz[j] = pts[p * 3 + 2] - qz;
+    key[j] = atan2f(oy[j], ox[j]) / RS_TWO_PI_F + 0.5f;    // xyz2sphere(...)[..., 2]
+  }
+  // stable odd-even transposition sort by azimuth (argsort, repsurface_utils.py:124)
+#pragma unroll
+  for (int round = 0; round < G; ++round) {
+#pragma unroll
+    for (int j = (round & 1); j + 1 < G; j += 2) {
+      const bool sw = phi_before(key[j], ox[j], oy[j], key[j + 1], ox[j + 1], oy[j + 1]);
+      const float tk = key[j], tx = ox[j], ty = oy[j], tz = oz[j];
+      key[j] = sw ? key[j + 1] : tk; ox[j] = sw ? ox[j + 1] : tx; oy[j] = sw ? oy[j + 1] : ty; oz[j] = sw ? oz[j + 1] : tz;
+      key[j + 1] = sw ? tk : key[j + 1]; ox[j + 1] = sw ? tx : ox[j + 1]; oy[j + 1] = sw ? ty : oy[j + 1]; oz[j + 1] = sw ? tz : oz[j + 1];
+    }
+  }
+
+  // triangle fan (origin, s_j, s_{j+1}): normal / centroid / polar / constant
+  float ux[G], uy[G], uz[G], cx[G], cy[G], cz[G], rho[G], th[G], ph[G], pos[G];
+  bool bad[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const int j2 = (j + 1 == G) ? 0 : j + 1;
+    const float ax = ox[j], ay = oy[j], az = oz[j], bx = ox[j2], by = oy[j2], bz = oz[j2];
+    const float nx = rs_fma(ay, bz, -(az * by));     // torch.cross (contracted on the CPU build)
+    const float ny = rs_fma(az, bx, -(ax * bz));
+    const float nz = rs_fma(ax, by, -(ay * bx));
+    const float len = sqrtf(rs_fma(nz, nz, rs_fma(ny, ny, nx * nx)));   // torch.norm
+    ux[j] = nx / len; uy[j] = ny / len; uz[j] = nz / len;
+    cx[j] = ((0.f + ax) + bx) / 3.f; cy[j] = ((0.f + ay) + by) / 3.f; cz[j] = ((0.f + az) + bz) / 3.f;
+  }
+  // keep x_n of the FIRST triangle positive, then the per-cloud random flip (recons_utils.py:45-55)
+  const float pm = (ux[0] > 0.f) ? 1.f : -1.f;
+  const float rs = inv_sign ? inv_sign[cloud] : 1.f;
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    ux[j] = (ux[j] * pm) * rs; uy[j] = (uy[j] * pm) * rs; uz[j] = (uz[j] * pm) * rs;
+    const float r = sqrtf(rs_sqnorm(cx[j], cy[j], cz[j]));
+    rho[j] = r;
+    th[j] = (r == 0.f) ? 0.f : acosf(cz[j] / r) / RS_PI_F;
+    ph[j] = atan2f(cy[j], cx[j]) / RS_TWO_PI_F + 0.5f;
+    pos[j] = ((ux[j] * cx[j] + uy[j] * cy[j]) + uz[j] * cz[j]) / RS_SQRT3_F;
+    bad[j] = (ux[j] != ux[j]) || (uy[j] != uy[j]) || (uz[j] != uz[j]);
+  }
+  // check_nan_umb: first valid triangle (0 when none) donates normal / centroid / constant
+  float fux = ux[0], fuy = uy[0], fuz = uz[0], fcx = cx[0], fcy = cy[0], fcz = cz[0], fpos = pos[0];
+  bool found = !bad[0];
+#pragma unroll
+  for (int j = 1; j < G; ++j) {
+    const bool take = !found && !bad[j];
+    fux = take ? ux[j] : fux; fuy = take ? uy[j] : fuy; fuz = take ? uz[j] : fuz;
+    fcx = take ? cx[j] : fcx; fcy = take ? cy[j] : fcy; fcz = take ? cz[j] : fcz;
+    fpos = take ? pos[j] : fpos;
+    found = found || !bad[j];
+  }
+  float *orow = feat + ((size_t)cloud * n + q) * (G * 10);
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const bool r = bad[j];
+    float *o = orow + j * 10;
+    o[0] = r ? fcx : cx[j]; o[1] = r ? fcy : cy[j]; o[2] = r ? fcz : cz[j];
+    o[3] = rho[j]; o[4] = th[j]; o[5] = ph[j];
+    o[6] = r ? fux : ux[j]; o[7] = r ? fuy : uy[j]; o[8] = r ? fuz : uz[j];
+    o[9] = r ? fpos : pos[j];
+  }
+}
+
+template <int K>
+void launch_knn(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx,
+                float *dist2, hipStream_t st) {
+  const int bpc = rs_cdiv(m, KNN_THREADS);
+  hipLaunchKernelGGL(knn_kernel<K>, dim3(b * bpc), dim3(KNN_THREADS), 0, st, b, n, m, nsample, bpc, xyz,
+                     new_xyz, idx, dist2);
+}
+template <int K>
+void launch_umb(int b, int n, const float *xyz, const float *inv_sign, int *knn_idx, float *feat,
+                hipStream_t st) {
+  const int bpc = rs_cdiv(n, KNN_THREADS);
+  hipLaunchKernelGGL(umbrella_kernel<K>, dim3(b * bpc), dim3(KNN_THREADS), 0, st, b, n, bpc, xyz, inv_sign,
+                     knn_idx, feat);
+}
+
+}  // namespace
+
+extern "C" int rs_knnquery(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz,
+                           int *idx, float *dist2, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "rs_knnquery: negative size");
+  if (b == 0 || m == 0 || nsample == 0) return RS_OK;
+  RS_REQUIRE(nsample <= 64, "rs_knnquery: nsample=%d exceeds the supported maximum of 64", nsample);
+  RS_REQUIRE(n >= nsample, "rs_knnquery: cloud of %d points cannot supply %d neighbours", n, nsample);
+  RS_REQUIRE(xyz && new_xyz && idx, "rs_knnquery: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (nsample <= 4) launch_knn<4>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
+  else if (nsample <= 9) launch_knn<9>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
+  else if (nsample <= 16) launch_knn<16>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
+  else if (nsample <= 32) launch_knn<32>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
+  else launch_knn<64>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
+  RS_CHECK_LAUNCH("rs_knnquery");
+  return RS_OK;
+}
+
+extern "C" int rs_umbrella_features(int b, int n, int k, const float *xyz, const float *inv_sign,
+                                    int *knn_idx, float *feat, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0, "rs_umbrella_features: negative size");
+  if (b == 0 || n == 0) return RS_OK;
+  RS_REQUIRE(k == 5 || k == 9 || k == 13 || k == 17,
+             "rs_umbrella_features: k=%d not built (group_size+1 must be 5, 9, 13 or 17)", k);
+  RS_REQUIRE(n >= k, "rs_umbrella_features: cloud of %d points cannot supply %d neighbours", n, k);
+  RS_REQUIRE(xyz && feat, "rs_umbrella_features: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  switch (k) {
+    case 5: launch_umb<5>(b, n, xyz, inv_sign, knn_idx, feat, st); break;
+    case 9: launch_umb<9>(b, n, xyz, inv_sign, knn_idx, feat, st); break;
+    case 13: launch_umb<13>(b, n, xyz, inv_sign, knn_idx, feat, st); break;
+    default: launch_umb<17>(b, n, xyz, inv_sign, knn_idx, feat, st); break;
+  }
+  RS_CHECK_LAUNCH("rs_umbrella_features");
+  return RS_OK;
+}

@@ -1,0 +1,99 @@
+"""Grouped shared-MLP stacks (1x1 conv -> BatchNorm -> ReLU ... -> pool over the group).
+
+Two interchangeable executors over the same nn.Conv2d / nn.BatchNorm2d parameter modules
+(state-dict compatible with the reference):
+
+  "hip"    hand-written fp32-MFMA kernels (repsurf_amd/csrc/mlp.hip) with fused BN-statistics
+           epilogues, BN+ReLU prologues and the group pool folded into the last layer; the
+           product path.
+  "torch"  plain PyTorch fp32 ops (F.linear / F.batch_norm / relu / max): the floating-point
+           REFERENCE the MFMA kernels are tested against (tests/test_mlp_gpu.py) and a debugging
+           aid (`REPSURF_MLP=torch`).  Never selected implicitly.
+
+Rows are (group, sample) pairs, channels last: x is (groups*nsample, C).
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+
+BACKEND = os.environ.get("REPSURF_MLP", "hip")
+
+
+def set_backend(name):
+    global BACKEND
+    if name not in ("hip", "torch"):
+        raise ValueError(name)
+    BACKEND = name
+
+
+def _w2d(conv):
+    w = conv.weight
+    return w.view(w.shape[0], w.shape[1])
+
+
+def _bn(y, bn):
+    """BatchNorm over rows (training: batch statistics + running-stat update, like nn.BatchNorm2d
+    over (B,C,nsample,npoint))."""
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    return F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                        bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
+
+
+# ------------------------------------------------------------------ torch executor (reference)
+def _torch_sa_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample):
+    loc = _bn(F.linear(x[:, :pos_channel], _w2d(mlp_l0), mlp_l0.bias), bn_l0)
+    feat = _bn(F.linear(x[:, pos_channel:], _w2d(mlp_f0), mlp_f0.bias), bn_f0)
+    h = F.relu(loc + feat)
+    for conv, bn in zip(convs, bns):
+        h = F.relu(_bn(F.linear(h, _w2d(conv), conv.bias), bn))
+    return h.view(-1, nsample, h.shape[1]).max(dim=1)[0]
+
+
+def _torch_sa_plain(x, convs, bns, nsample):
+    h = x
+    for conv, bn in zip(convs, bns):
+        h = F.relu(_bn(F.linear(h, _w2d(conv), conv.bias), bn))
+    return h.view(-1, nsample, h.shape[1]).max(dim=1)[0]
+
+
+def _torch_umbrella(x, mlps, group, aggr):
+    conv0, bn0, _, conv1, bn1, _, conv2 = mlps
+    h = F.relu(_bn(F.linear(x, _w2d(conv0), conv0.bias), bn0))
+    h = F.relu(_bn(F.linear(h, _w2d(conv1), conv1.bias), bn1))
+    h = F.linear(h, _w2d(conv2), conv2.bias).view(-1, group, conv2.weight.shape[0])
+    if aggr == "max":
+        return h.max(dim=1)[0]
+    if aggr == "avg":
+        return h.mean(dim=1)
+    return h.sum(dim=1)
+
+
+# ------------------------------------------------------------------ dispatch
+def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample):
+    """SurfaceAbstractionCD body (classification/modules/repsurface_utils.py:236-244):
+    relu(bn_l0(mlp_l0(x[:, :pos])) + bn_f0(mlp_f0(x[:, pos:]))) -> [conv, bn, relu]* -> max over nsample.
+    x (G*nsample, pos+feat) -> (G, mlp[-1])."""
+    if BACKEND == "torch":
+        return _torch_sa_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample)
+    from . import mlp_hip
+    return mlp_hip.sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample)
+
+
+def sa_mlp_plain(x, convs, bns, nsample):
+    """SurfaceAbstraction body (repsurface_utils.py:178-181)."""
+    if BACKEND == "torch":
+        return _torch_sa_plain(x, convs, bns, nsample)
+    from . import mlp_hip
+    return mlp_hip.sa_mlp_plain(x, convs, bns, nsample)
+
+
+def umbrella_mlp(x, mlps, group, aggr):
+    """UmbrellaSurfaceConstructor.mlps + aggregation (repsurface_utils.py:296-305):
+    conv-bn-relu-conv-bn-relu-conv then sum/max/avg over the `group` fan triangles.
+    x (P*group, C) -> (P, C)."""
+    if BACKEND == "torch":
+        return _torch_umbrella(x, mlps, group, aggr)
+    from . import mlp_hip
+    return mlp_hip.umbrella_mlp(x, mlps, group, aggr)

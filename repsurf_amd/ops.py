@@ -1,0 +1,250 @@
+"""Torch-facing operators over the C ABI of librepsurf_hip.so.
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and autograd graph
+bookkeeping; every computation below is a hand-written HIP kernel reached through
+repsurf_amd._lib.call().  All tensors must live on a HIP device — there is no CPU path.
+
+Layouts are channels-last (see include/repsurf_hip.h): xyz (B,N,3), features (B,N,C),
+indices int32.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.RepSurfHipError(
+                "repsurf_amd operators run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _i32c(t):
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# ----------------------------------------------------------------------------- sampling
+def furthestsampling(xyz, m, start=None):
+    """xyz (B,N,3) -> idx (B,m) int32.  start: (B,) first picks (None = index 0).
+    Semantics: farthest_point_sample(cuda=False), classification/modules/pointnet2_utils.py:47-75."""
+    _need_gpu(xyz, start)
+    xyz = _f32c(xyz)
+    b, n, _ = xyz.shape
+    idx = torch.empty((b, m), dtype=torch.int32, device=xyz.device)
+    st = None if start is None else _i32c(start)
+    temp = None
+    if n > 16384:
+        temp = torch.empty((b, n), dtype=torch.float32, device=xyz.device)
+    _lib.call("rs_furthestsampling", b, n, m, _p(xyz), _p(st), _p(temp), _p(idx), _stream())
+    return idx
+
+
+def furthestsampling_offset(xyz, offset, new_offset):
+    """Packed batches (segmentation): xyz (Ntot,3), offset/new_offset (B,) int32 prefix sums -> idx (Mtot,)."""
+    _need_gpu(xyz, offset, new_offset)
+    xyz, offset, new_offset = _f32c(xyz), _i32c(offset), _i32c(new_offset)
+    b = offset.numel()
+    sizes = torch.diff(offset.cpu(), prepend=torch.zeros(1, dtype=torch.int32))
+    n_max = int(sizes.max()) if b else 0
+    m_tot = int(new_offset[-1]) if b else 0
+    idx = torch.empty((m_tot,), dtype=torch.int32, device=xyz.device)
+    temp = torch.empty((xyz.shape[0],), dtype=torch.float32, device=xyz.device) if n_max > 16384 else None
+    _lib.call("rs_furthestsampling_offset", b, n_max, _p(xyz), _p(offset), _p(new_offset), _p(temp), _p(idx), _stream())
+    return idx
+
+
+class _GatherRows(Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        _need_gpu(points, idx)
+        points, idx = _f32c(points), _i32c(idx)
+        b, n, c = points.shape
+        per = idx.numel() // b
+        out = torch.empty(tuple(idx.shape) + (c,), dtype=torch.float32, device=points.device)
+        _lib.call("rs_gather_rows", b, n, per, c, _p(points), _p(idx), _p(out), _stream())
+        ctx.save_for_backward(idx)
+        ctx.dims = (b, n, per, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        b, n, per, c = ctx.dims
+        grad_out = _f32c(grad_out)
+        grad = torch.zeros((b, n, c), dtype=torch.float32, device=grad_out.device)
+        _lib.call("rs_gather_rows_backward", b, n, per, c, _p(grad_out), _p(idx), _p(grad), _stream())
+        return grad, None
+
+
+def gather_rows(points, idx):
+    """points (B,N,C), idx (B,S) or (B,S,K) -> (B,S,C) / (B,S,K,C); differentiable w.r.t. points.
+    index_points of classification/modules/pointnet2_utils.py:28-44 without the transposes."""
+    return _GatherRows.apply(points, idx)
+
+
+# ----------------------------------------------------------------------------- neighbour search
+def ballquery(radius, nsample, xyz, new_xyz):
+    """-> (B,S,nsample) int32; query_ball_point(cuda=False) semantics (pointnet2_utils.py:78-99).
+    The threshold is float32(radius**2) with the square taken in double, as torch's
+    tensor-vs-Python-scalar comparison does."""
+    _need_gpu(xyz, new_xyz)
+    xyz, new_xyz = _f32c(xyz), _f32c(new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz.device)
+    r2 = torch.tensor(float(radius) ** 2, dtype=torch.float32).item()
+    _lib.call("rs_ballquery", b, n, m, r2, nsample, _p(new_xyz), _p(xyz), _p(idx), _stream())
+    return idx
+
+
+def knnquery(nsample, xyz, new_xyz=None, return_dist=False):
+    """-> (B,S,nsample) int32 [, squared distances]; query_knn_point(cuda=False) semantics (:102-111)."""
+    if new_xyz is None:
+        new_xyz = xyz
+    _need_gpu(xyz, new_xyz)
+    xyz, new_xyz = _f32c(xyz), _f32c(new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz.device)
+    d2 = torch.empty((b, m, nsample), dtype=torch.float32, device=xyz.device) if return_dist else None
+    _lib.call("rs_knnquery", b, n, m, nsample, _p(xyz), _p(new_xyz), _p(idx), _p(d2), _stream())
+    return (idx, d2) if return_dist else idx
+
+
+def knnquery_offset(nsample, xyz, new_xyz, offset, new_offset):
+    """Packed batches: xyz (N,3), new_xyz (M,3) -> idx (M,nsample) int32, dist2 (M,nsample)."""
+    _need_gpu(xyz, new_xyz, offset, new_offset)
+    xyz, new_xyz, offset, new_offset = _f32c(xyz), _f32c(new_xyz), _i32c(offset), _i32c(new_offset)
+    m = new_xyz.shape[0]
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
+    d2 = torch.empty((m, nsample), dtype=torch.float32, device=xyz.device)
+    _lib.call("rs_knnquery_offset", m, nsample, _p(xyz), _p(new_xyz), _p(offset), _p(new_offset),
+              offset.numel(), _p(idx), _p(d2), _stream())
+    return idx, d2
+
+
+def umbrella_features(xyz, k=9, inv_sign=None, return_knn=False):
+    """xyz (B,N,3) -> (B,N,k-1,10) = [centroid, polar, normal, const] per fan triangle
+    (everything UmbrellaSurfaceConstructor does before self.mlps, repsurface_utils.py:276-293)."""
+    _need_gpu(xyz, inv_sign)
+    xyz = _f32c(xyz)
+    b, n, _ = xyz.shape
+    feat = torch.empty((b, n, k - 1, 10), dtype=torch.float32, device=xyz.device)
+    kidx = torch.empty((b, n, k), dtype=torch.int32, device=xyz.device) if return_knn else None
+    sg = None if inv_sign is None else _f32c(inv_sign.reshape(-1))
+    _lib.call("rs_umbrella_features", b, n, k, _p(xyz), _p(sg), _p(kidx), _p(feat), _stream())
+    return (feat, kidx) if return_knn else feat
+
+
+# ----------------------------------------------------------------------------- grouping
+class _GroupFeatures(Function):
+    @staticmethod
+    def forward(ctx, center, new_center, normal, feature, idx, polar):
+        _need_gpu(center, new_center, normal, feature, idx)
+        center, new_center, normal, idx = _f32c(center), _f32c(new_center), _f32c(normal), _i32c(idx)
+        feature = None if feature is None else _f32c(feature)
+        b, n, _ = center.shape
+        _, m, ns = idx.shape
+        cn = normal.shape[2]
+        cf = 0 if feature is None else feature.shape[2]
+        ctot = (6 if polar else 3) + cn + cf
+        out = torch.empty((b * m * ns, ctot), dtype=torch.float32, device=center.device)
+        _lib.call("rs_group_features", b, n, m, ns, cn, cf, int(polar), _p(center), _p(new_center),
+                  _p(normal), _p(feature), _p(idx), _p(out), _stream())
+        ctx.save_for_backward(idx)
+        ctx.dims = (b, n, m, ns, cn, cf, int(polar))
+        ctx.need = (ctx.needs_input_grad[2], feature is not None and ctx.needs_input_grad[3])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        b, n, m, ns, cn, cf, polar = ctx.dims
+        grad_out = _f32c(grad_out)
+        dev = grad_out.device
+        gn = torch.zeros((b, n, cn), dtype=torch.float32, device=dev) if ctx.need[0] else None
+        gf = torch.zeros((b, n, cf), dtype=torch.float32, device=dev) if ctx.need[1] else None
+        if gn is not None or gf is not None:
+            _lib.call("rs_group_features_backward", b, n, m, ns, cn, cf, polar, _p(grad_out), _p(idx),
+                      _p(gn), _p(gf), _stream())
+        return None, None, gn, gf, None, None
+
+
+def group_features(center, new_center, normal, feature, idx, polar=True):
+    """Grouped shared-MLP input of sample_and_group (repsurface_utils.py:36-57):
+    -> (B*S*ns, 3+3*polar+Cn+Cf) rows [offset, polar(offset), normal[idx], feature[idx]];
+    differentiable w.r.t. normal and feature."""
+    return _GroupFeatures.apply(center, new_center, normal, feature, idx, polar)
+
+
+def group_all_features(center, normal, feature, polar=True):
+    """sample_and_group_all (repsurface_utils.py:62-88) -> (B*N, 3+3*polar+Cn+Cf).
+    A pure per-row concat: differentiable pieces (normal, feature) are concatenated with torch.cat
+    so autograd needs no custom backward; the coordinate block comes from the HIP kernel."""
+    _need_gpu(center, normal, feature)
+    center = _f32c(center)
+    b, n, _ = center.shape
+    pos = torch.empty((b * n, 6 if polar else 3), dtype=torch.float32, device=center.device)
+    _lib.call("rs_group_all_features", b, n, 0, 0, int(polar), _p(center), None, None, _p(pos), _stream())
+    parts = [pos, normal.reshape(b * n, -1)]
+    if feature is not None:
+        parts.append(feature.reshape(b * n, -1))
+    return torch.cat(parts, dim=1)
+
+
+# ----------------------------------------------------------------------------- three-NN interpolation
+def three_nn(unknown, known):
+    """-> (sqrt-free) squared distances (B,n,3), idx (B,n,3) int32 (pointops.nearestneighbor)."""
+    _need_gpu(unknown, known)
+    unknown, known = _f32c(unknown), _f32c(known)
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknown.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknown.device)
+    _lib.call("rs_three_nn", b, n, m, _p(unknown), _p(known), _p(d2), _p(idx), _stream())
+    return d2, idx
+
+
+class _ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, points, idx, weight):
+        _need_gpu(points, idx, weight)
+        points, idx, weight = _f32c(points), _i32c(idx), _f32c(weight)
+        b, m, c = points.shape
+        n = idx.shape[1]
+        out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
+        _lib.call("rs_three_interpolate", b, c, m, n, _p(points), _p(idx), _p(weight), _p(out), _stream())
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (b, c, n, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        b, c, n, m = ctx.dims
+        grad_out = _f32c(grad_out)
+        grad = torch.zeros((b, m, c), dtype=torch.float32, device=grad_out.device)
+        _lib.call("rs_three_interpolate_backward", b, c, n, m, _p(grad_out), _p(idx), _p(weight), _p(grad), _stream())
+        return grad, None, None
+
+
+def three_interpolate(points, idx, weight):
+    """points (B,m,C), idx/weight (B,n,3) -> (B,n,C); differentiable w.r.t. points."""
+    return _ThreeInterpolate.apply(points, idx, weight)

@@ -1,0 +1,67 @@
+"""Shared test helpers."""
+import argparse
+import os
+import zlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def ref_args(**over):
+    """The canonical flag set of classification/scripts/scanobjectnn/repsurf_ssg_umb.sh."""
+    ns = argparse.Namespace(num_point=1024, return_dist=True, return_center=True, return_polar=True,
+                            group_size=8, umb_pool="sum", cuda_ops=True, num_class=15)
+    for k, v in over.items():
+        setattr(ns, k, v)
+    return ns
+
+
+def name_seeded_init(model):
+    """Weights that depend only on parameter names/shapes (same rule as tests/golden/make_golden.py)."""
+    with torch.no_grad():
+        for name, p in sorted(model.named_parameters()):
+            g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                v = (torch.rand(p.shape, generator=g) * 2 - 1) / fan_in ** 0.5
+            elif name.endswith("weight"):
+                v = 0.75 + 0.5 * torch.rand(p.shape, generator=g)
+            else:
+                v = (torch.rand(p.shape, generator=g) * 2 - 1) * 0.1
+            p.copy_(v.to(p.device))
+
+
+def disable_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+
+
+def cloud(seed, b, n, kind="uniform"):
+    r = np.random.RandomState(seed)
+    if kind == "uniform":
+        return (r.rand(b, n, 3) * 2 - 1).astype(np.float32)
+    if kind == "clustered":   # dense blobs: balls overflow nsample
+        c = r.rand(b, 8, 3) * 2 - 1
+        pick = r.randint(0, 8, (b, n))
+        return (np.take_along_axis(c, pick[..., None].repeat(3, -1), 1) + 0.05 * r.randn(b, n, 3)).astype(np.float32)
+    if kind == "grid":        # lattice: many exactly equal distances (tie rules)
+        side = int(round(n ** (1 / 3))) + 1
+        g = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+        out = np.stack([g[r.permutation(n)] for _ in range(b)]).astype(np.float32) / side
+        return out
+    if kind == "dup":         # duplicated points: zero distances, degenerate fan triangles
+        base = (r.rand(b, n // 2, 3) * 2 - 1).astype(np.float32)
+        return np.concatenate([base, base], 1)[:, r.permutation(2 * (n // 2))]
+    raise ValueError(kind)
+
+
+def take(points, idx):
+    """numpy gather: points (B,N,C), idx (B,...) -> (B,...,C)"""
+    b = points.shape[0]
+    flat = idx.reshape(b, -1).astype(np.int64)
+    out = np.take_along_axis(points, flat[..., None].repeat(points.shape[2], -1), 1)
+    return out.reshape(*idx.shape, points.shape[2])
