@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — point-clouds/sec, forward+backward, RepSurf-U 1024-pt classifier @ B=32 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic clouds already resident in HBM:
+zero_grad -> Model.forward (umbrella constructor, 3 SurfaceAbstractionCD stages, head) ->
+SmoothClsLoss -> backward (+ the RCCL gradient all-reduce when N > 1) -> optimizer step
+(BASELINE.md's definition stops at backward; the Adam step is kept inside the timed region so no
+part of a training step is skipped — `--no-optim` reproduces the BASELINE.md definition exactly).
+Batches shard across ranks (one process per GPU, weak scaling: B=32 per rank), gradients are
+averaged by DistributedDataParallel over RCCL/xGMI in one bucket.
+
+Rank 0 prints ONE JSON line with the driver's contract fields plus
+  "roofline":     the dominant instrumented HIP kernel, timed live with HIP events on the launch stream,
+  "cpu_baseline": the CPU oracle (oracle/torch_ref.py + oracle/geom_oracle.c) on the same workload,
+                  timed on this host (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "repsurf_amd", "classification")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_F32_MFMA_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--model", default="repsurf_ssg_umb")
+    ap.add_argument("--no-optim", action="store_true", help="stop the step at backward (BASELINE.md definition)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--breakdown", default="", help="write a per-kernel timing breakdown JSON here")
+    return ap.parse_args()
+
+
+def model_args():
+    return argparse.Namespace(num_point=1024, return_dist=True, return_center=True, return_polar=True,
+                              group_size=8, umb_pool="sum", cuda_ops=True, num_class=15)
+
+
+def synthetic_batch(seed, b, n, device):
+    g = torch.Generator().manual_seed(seed)
+    xyz = (torch.rand(b, n, 3, generator=g) * 2 - 1)
+    label = torch.randint(0, 15, (b,), generator=g)
+    return xyz.permute(0, 2, 1).contiguous().to(device), label.to(device)
+
+
+def cpu_baseline(args, state):
+    """The CPU oracle on the same workload: B x points clouds, forward + loss + backward."""
+    from oracle import geom_oracle, torch_ref
+    geom_oracle.build()
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(123)
+    xyz = (torch.rand(args.batch, args.points, 3, generator=g) * 2 - 1).numpy()
+    label = torch.randint(0, 15, (args.batch,), generator=g).numpy()
+    starts = [np.zeros(args.batch, np.int32)] * 3
+    times = []
+    for i in range(1 + args.cpu_steps):
+        t0 = time.perf_counter()
+        torch_ref.step(state, xyz, label, None, starts, arch=args.model)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.mean(times[1:]))
+    cpu = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(args.batch / dt, 3), "unit": "clouds/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{args.cpu_steps} steps (after 1 warm-up) of the same B={args.batch}x{args.points} "
+                      f"fwd+loss+bwd workload; dense ops torch {torch.__version__} CPU on {threads} threads, "
+                      f"geometry single-threaded C; host CPU: {cpu}",
+            "s_per_step": round(dt, 4)}
+
+
+def algorithmic_cost(name, dims):
+    """(unit, amount) of algorithmic work of one launch of an instrumented ABI call."""
+    if name == "rs_ballquery":
+        b, n, m, ns = dims
+        return "bytes", 4.0 * (3 * b * n + 3 * b * m + b * m * ns)
+    if name == "rs_mlp_gemm":
+        rows, cin, cout = dims
+        return "flops", 2.0 * rows * cin * cout
+    return None, 0.0
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+
+    import importlib
+    from repsurf_amd import _lib, mlp, ops
+    from util.utils import SmoothClsLoss
+    Model = importlib.import_module(f"models.repsurf.{args.model}").Model
+
+    torch.manual_seed(0)                     # identical initial weights on every rank
+    model = Model(model_args()).to(device).train()
+    cpu_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True,
+            broadcast_buffers=False, find_unused_parameters=False)
+    criterion = SmoothClsLoss()
+    optim = None if args.no_optim else torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    points, label = synthetic_batch(1000 + rank, args.batch, args.points, device)
+    torch.manual_seed(100 + rank)            # CPU generator: FPS starts / normal flips differ per rank
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss = criterion(net(points), label)
+        loss.backward()
+        if optim is not None:
+            optim.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_timing:
+        _lib.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = _lib.profile_collect()            # {abi name: [(ms, dims), ...]} from HIP events on the launch stream
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        roofline = None
+        table = []
+        for name, recs in prof.items():
+            by_dims = {}
+            for t_ms, dims in recs:
+                by_dims.setdefault(dims, []).append(t_ms)
+            for dims, ts in by_dims.items():
+                unit, amount = algorithmic_cost(name, dims)
+                table.append({"kernel": name, "dims": list(dims), "launches": len(ts), "avg_us": float(np.mean(ts)) * 1e3,
+                              "total_ms_per_step": float(np.sum(ts)) / args.steps, "unit": unit, "amount": amount})
+        table.sort(key=lambda r: -r["total_ms_per_step"])
+        for row in table:
+            if row["unit"] is None:
+                continue
+            sec = row["avg_us"] * 1e-6
+            if row["unit"] == "flops":
+                ach = row["amount"] / sec / 1e12
+                roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "mfma", "achieved": round(ach, 2),
+                            "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TF, 4)}
+            else:
+                ach = row["amount"] / sec / 1e9
+                roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "hbm", "achieved": round(ach, 2),
+                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5)}
+            roofline["avg_launch_us"] = round(row["avg_us"], 2)
+            roofline["traffic"] = traffic_from_profiles(row["kernel"])
+            break
+        if args.breakdown:
+            os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
+            json.dump({"ms_per_step": ms, "kernels": table}, open(args.breakdown, "w"), indent=1)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, cpu_state)
+        out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U 1024-pt cls @ B=32 per GPU", "value": round(value, 2),
+               "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic uniform [-1,1]^3 clouds, random-init weights",
+               "config": {"workload": f"configs[1]: RepSurf-U ({args.model}) classifier, B={args.batch}x{args.points} pts "
+                                      "per GPU, fp32, full encoder + head, fwd+loss+bwd"
+                                      + ("" if args.no_optim else "+Adam step"),
+                          "global_batch": args.batch * world, "points": args.points,
+                          "parallelism": f"dp{world}", "mlp_backend": mlp.BACKEND,
+                          "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5)},
+               "roofline": roofline, "cpu_baseline": cpu}
+        if cpu:
+            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def traffic_from_profiles(kernel):
+    """HBM bytes per launch from the PMC passes summarised under profiles/ (None until collected)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path)).get(kernel)
+        except (OSError, ValueError):
+            return None
+    return None
+
+
+if __name__ == "__main__":
+    main()

@@ -110,7 +110,7 @@ int rs_knnquery_offset(int m, int nsample, const float *xyz, const float *new_xy
  * build the triangle fan, emit per triangle [centre(3), polar(3), normal(3), pos(1)].
  * inv_sign: (b) floats of +-1 (the per-cloud random inversion drawn by the host
  * from the CPU generator, recons_utils.py:50) or NULL.  knn_idx (b, n, k) int32 is
- * optional (NULL to skip).  feat: (b, n, k-1, 10).  3 <= k <= 16. */
+ * optional (NULL to skip).  feat: (b, n, k-1, 10).  k in {5, 9, 13, 17} (group_size 4/8/12/16). */
 int rs_umbrella_features(int b, int n, int k, const float *xyz, const float *inv_sign,
                          int *knn_idx, float *feat, void *stream);
 
@@ -157,41 +157,6 @@ int rs_three_interpolate(int b, int c, int m, int n, const float *points, const 
 int rs_three_interpolate_backward(int b, int c, int n, int m, const float *grad_out,
                                   const int *idx, const float *weight, float *grad_points,
                                   void *stream);
-
-/* ---- shared MLP (1x1 conv + BatchNorm(train) + ReLU [+ max over nsample]) ----
- * The reference runs nn.Conv2d(1x1) -> nn.BatchNorm2d -> F.relu as three framework
- * calls per layer (classification/modules/repsurface_utils.py:236-244).  Here one
- * fp32-MFMA GEMM kernel per layer does
- *     y[rows, cout] = act(x)[rows, cin] . w[cout, cin]^T + bias
- * where act() optionally applies the previous layer's BatchNorm affine + ReLU
- * while loading (x_scale/x_shift per input channel; NULL = identity), and the
- * epilogue accumulates the per-channel sum / sum of squares that the next call
- * of rs_bn_finalize turns into batch statistics.
- * stats: (2, cout) floats, zeroed by the caller, accumulated with atomics. */
-int rs_mlp_gemm_fwd(int rows, int cin, int cout, const float *x, int ldx,
-                    const float *x_scale, const float *x_shift, int x_relu,
-                    const float *w, const float *bias, float *y, int ldy,
-                    float *stats, void *stream);
-
-/* BatchNorm statistics -> affine.  From stats (sum, sumsq over `rows` rows) computes
- * mean/var (biased), scale = gamma / sqrt(var + eps), shift = beta - scale * mean,
- * writes save_mean / save_invstd (for backward) and, when running_mean != NULL,
- * updates the running statistics with `momentum` and the unbiased variance like
- * nn.BatchNorm2d in training mode. */
-int rs_bn_finalize(int c, int rows, const float *stats, const float *gamma, const float *beta,
-                   float eps, float momentum, float *scale, float *shift, float *save_mean,
-                   float *save_invstd, float *running_mean, float *running_var, void *stream);
-
-/* out[g, c] = max_j relu(scale[c] * y[g*nsample + j, c] + shift[c]); arg[g, c] = winning j
- * (torch.max(new_feature, 2)[0], repsurface_utils.py:244, fused with the last BN+ReLU).
- * With scale2/shift2/y2 non-NULL the pre-activation is the sum of two BN outputs
- * (bn_l0(mlp_l0) + bn_f0(mlp_f0), repsurface_utils.py:236-239). */
-int rs_bn_relu_maxpool(int groups, int nsample, int c, const float *y, const float *scale,
-                       const float *shift, float *out, int *arg, void *stream);
-
-/* z = relu(scale*y + shift [+ scale2*y2 + shift2]) elementwise, rows x c. */
-int rs_bn_relu(int rows, int c, const float *y, const float *scale, const float *shift,
-               const float *y2, const float *scale2, const float *shift2, float *z, void *stream);
 
 #ifdef __cplusplus
 }

@@ -71,10 +71,44 @@ def load():
     return lib
 
 
+_profile = None   # None = off; else list of (name, dims, start_event, end_event)
+
+
+def profile_enable(on):
+    """Per-launch timing of ABI calls with HIP events recorded on the launch stream (torch's
+    current stream, the one every operator passes down).  Used by bench.py for the live
+    `roofline` numbers; off by default (two event records per call)."""
+    global _profile, _frozen
+    if on:
+        _profile = []
+    elif _profile is not None:
+        _frozen, _profile = _profile, None
+
+
+_frozen = []
+
+
+def profile_collect():
+    """-> {abi name: [(milliseconds, (int dims...)), ...]}; call after a device synchronise."""
+    out = {}
+    for name, dims, e0, e1 in _frozen:
+        out.setdefault(name, []).append((e0.elapsed_time(e1), dims))
+    return out
+
+
 def call(name, *args):
     """Invoke an ABI function; non-zero return -> RepSurfHipError with the library's message."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if _profile is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        dims = tuple(a for a, t in zip(args, SIGNATURES[name]) if t is c_int)
+        _profile.append((name, dims, e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.rs_last_error()
         raise RepSurfHipError(f"{name} failed (code {rc}): {msg.decode() if msg else '?'}")

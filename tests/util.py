@@ -65,3 +65,13 @@ def take(points, idx):
     flat = idx.reshape(b, -1).astype(np.int64)
     out = np.take_along_axis(points, flat[..., None].repeat(points.shape[2], -1), 1)
     return out.reshape(*idx.shape, points.shape[2])
+
+
+def is_pre_bn_bias(name):
+    """Biases added right before a BatchNorm: their gradient is analytically zero."""
+    if not name.endswith(".bias"):
+        return False
+    return (".mlp_l0." in name or ".mlp_f0." in name or ".mlp_convs." in name
+            # mlps.6.bias shifts every normal channel by a constant, which each stage's bn_f0 removes
+            or name in ("surface_constructor.mlps.3.bias", "surface_constructor.mlps.6.bias",
+                        "classfier.0.bias", "classfier.4.bias"))
