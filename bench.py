@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--no-optim", action="store_true", help="stop the step at backward (BASELINE.md definition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8, help="clouds in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--breakdown", default="", help="write a per-kernel timing breakdown JSON here")
     return ap.parse_args()
 
@@ -69,12 +71,13 @@ def cpu_baseline(args, state):
     """The CPU oracle on the same workload: B x points clouds, forward + loss + backward."""
     from oracle import geom_oracle, torch_ref
     geom_oracle.build()
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, args.cpu_threads)
     torch.set_num_threads(threads)
+    nb = min(args.batch, args.cpu_batch)       # bounded sample: same per-cloud workload, fewer clouds
     g = torch.Generator().manual_seed(123)
-    xyz = (torch.rand(args.batch, args.points, 3, generator=g) * 2 - 1).numpy()
-    label = torch.randint(0, 15, (args.batch,), generator=g).numpy()
-    starts = [np.zeros(args.batch, np.int32)] * 3
+    xyz = (torch.rand(nb, args.points, 3, generator=g) * 2 - 1).numpy()
+    label = torch.randint(0, 15, (nb,), generator=g).numpy()
+    starts = [np.zeros(nb, np.int32)] * 3
     times = []
     for i in range(1 + args.cpu_steps):
         t0 = time.perf_counter()
@@ -89,10 +92,11 @@ def cpu_baseline(args, state):
                 break
     except OSError:
         pass
-    return {"value": round(args.batch / dt, 3), "unit": "clouds/s", "cores": torch.get_num_threads(),
+    return {"value": round(nb / dt, 3), "unit": "clouds/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"{args.cpu_steps} steps (after 1 warm-up) of the same B={args.batch}x{args.points} "
-                      f"fwd+loss+bwd workload; dense ops torch {torch.__version__} CPU on {threads} threads, "
+            "sample": f"{args.cpu_steps} steps (after 1 warm-up) of B={nb}x{args.points} clouds through the same "
+                      f"fwd+loss+bwd workload (per-cloud work identical to the B={args.batch} GPU batch); "
+                      f"dense ops torch {torch.__version__} CPU on {threads} threads, "
                       f"geometry single-threaded C; host CPU: {cpu}",
             "s_per_step": round(dt, 4)}
 
@@ -102,9 +106,12 @@ def algorithmic_cost(name, dims):
     if name == "rs_ballquery":
         b, n, m, ns = dims
         return "bytes", 4.0 * (3 * b * n + 3 * b * m + b * m * ns)
-    if name == "rs_mlp_gemm":
-        rows, cin, cout = dims
-        return "flops", 2.0 * rows * cin * cout
+    if name == "rs_mlp_gemm_rows":
+        rows, kdim, cols = dims[:3]
+        return "flops", 2.0 * rows * kdim * cols
+    if name == "rs_mlp_wgrad":
+        rows, ncols, kcols = dims[:3]
+        return "flops", 2.0 * rows * ncols * kcols
     return None, 0.0
 
 

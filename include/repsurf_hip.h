@@ -158,6 +158,82 @@ int rs_three_interpolate_backward(int b, int c, int n, int m, const float *grad_
                                   const int *idx, const float *weight, float *grad_points,
                                   void *stream);
 
+/* ---- shared MLP (1x1 conv + BatchNorm(train) + ReLU [+ pool over nsample]) on fp32 MFMA ----
+ * The reference runs nn.Conv2d(1x1) -> nn.BatchNorm2d -> F.relu as three framework calls per layer
+ * (classification/modules/repsurface_utils.py:236-244, 296-305).  Here a layer is one row-GEMM whose
+ * operand is assembled on the fly (previous BatchNorm affine + ReLU in forward, BatchNorm-backward
+ * affine in backward) and whose epilogue produces the BatchNorm sums; see repsurf_amd/csrc/mlp.hip.
+ * All matrices are row-major (rows, channels) with explicit leading dimensions. */
+
+/* E[r][c] built while loading (a, b row-major with leading dimensions lda, ldb; s*, t* per column): */
+enum {
+  RS_OP_ID = 0,     /* E = a[r][c]                                                                  */
+  RS_OP_RELU1 = 1,  /* E = relu(s1*a + t1)                       BatchNorm + ReLU of a conv output   */
+  RS_OP_RELU2 = 2,  /* E = relu(s1*a + t1 + s2*b + t2)           bn_l0(mlp_l0) + bn_f0(mlp_f0), :236-239 */
+  RS_OP_AFF2 = 3,   /* E = s1*a + s2*b + t1                      BatchNorm backward: a = dz, b = y   */
+  RS_OP_POOLED = 4, /* dz = arg[g][c]==r%ns ? a[g][c] : 0, g=r/ns; E = s1*dz + s2*b[r][c] + t1
+                       (gradient through torch.max over nsample, :244; a/arg have leading dim lda)  */
+  RS_OP_BCAST = 5   /* E = a[r/ns][c]                            gradient through a sum over ns, :305 */
+};
+typedef struct rs_row_operand {
+  const float *a; long long lda;
+  const float *b; long long ldb;
+  const float *s1, *t1, *s2, *t2;
+  const int *arg; int ns;
+  int mode;
+} rs_row_operand;
+
+enum {
+  RS_EPI_STORE = 0, /* out = acc + bias                                                              */
+  RS_EPI_STATS = 1, /* + per-column {sum y, sum y^2} -> partial[block][2][cols]      (BN forward)     */
+  RS_EPI_MASK = 2   /* out = (ms1*my1+mt1 [+ ms2*my2+mt2] > 0) ? acc : 0;  partial[block][2|3][cols] =
+                       {sum out, sum out*yhat1 [, sum out*yhat2]}, yhat = (my - mean)*invstd (BN backward) */
+};
+typedef struct rs_mlp_epilogue {
+  const float *bias; float *out; long long ldo; int mode;
+  const float *my1; long long ldm1; const float *ms1, *mt1, *mean1, *invstd1;
+  const float *my2; long long ldm2; const float *ms2, *mt2, *mean2, *invstd2;
+  double *partial; int partial_blocks;   /* rows of the partial buffer (unused ones are zeroed) */
+} rs_mlp_epilogue;
+
+/* out[rows, cols] = E[rows, kdim] . B,  B[k][n] = w[n*ldw + k] (w_is_k_by_n = 0: conv weight (cout, cin))
+ *                                               or w[k*ldw + n] (w_is_k_by_n = 1: data gradient dY . W) */
+int rs_mlp_gemm_rows(long long rows, int kdim, int cols, const rs_row_operand *x, const float *w, int ldw,
+                     int w_is_k_by_n, const rs_mlp_epilogue *epi, void *stream);
+
+/* Weight gradient dw[ncols][kcols] = sum_r P[r][n] * Q[r][k]; rows are split into `chunks` workgroup
+ * slabs whose partial products land in partial (chunks, ncols*kcols) and are summed in a fixed order. */
+int rs_mlp_wgrad(long long rows, int ncols, int kcols, const rs_row_operand *p, const rs_row_operand *q,
+                 float *partial, int chunks, float *dw, void *stream);
+
+/* BatchNorm statistics -> affine: from partial (nblk, 2, c) {sum, sumsq} over `rows` rows:
+ * mean, biased var, scale = gamma/sqrt(var+eps), shift = beta - mean*scale; saves mean/invstd and,
+ * when running_mean != NULL, updates running stats with `momentum` and the unbiased variance
+ * (nn.BatchNorm2d training semantics). */
+int rs_bn_finalize(int c, long long rows, int nblk, const double *partial, const float *gamma,
+                   const float *beta, float eps, float momentum, float *scale, float *shift,
+                   float *save_mean, float *save_invstd, float *running_mean, float *running_var,
+                   void *stream);
+
+/* BatchNorm backward sums -> coefficients of dy = p*dz + q*y + r (RS_OP_AFF2 / RS_OP_POOLED operands)
+ * from partial (nblk, nstat, c): row 0 = sum dz, row `which` = sum dz*yhat.  dgamma/dbeta optional. */
+int rs_bn_backward_finalize(int c, long long rows, int nblk, int nstat, int which, const double *partial,
+                            const float *scale, const float *mean, const float *invstd, float *p,
+                            float *q, float *r, float *dgamma, float *dbeta, void *stream);
+
+/* out[g][c] = max_k f(scale*y[g*nsample+k][c] + shift), f = relu when `relu` != 0, arg = first k
+ * attaining it (torch.max(new_feature, 2)[0] fused with the last BatchNorm + ReLU, :243-244);
+ * scale/shift may be NULL (identity). */
+int rs_pool_max(long long groups, int nsample, int c, int relu, const float *y, const float *scale,
+                const float *shift, float *out, int *arg, void *stream);
+/* v = dout * (out > 0) and the BatchNorm-backward sums of the pooled layer from (groups, c) data only:
+ * partial (partial_blocks, 2, c) = {sum v, sum v * yhat[arg row]}. */
+int rs_pool_max_backward(long long groups, int nsample, int c, const float *dout, const float *out,
+                         const int *arg, const float *y, const float *mean, const float *invstd,
+                         float *v, double *partial, int partial_blocks, void *stream);
+/* out[g][c] = sum_k y[g*nsample+k][c]   (umbrella aggregation 'sum', :305) */
+int rs_pool_sum(long long groups, int nsample, int c, const float *y, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,8 +34,8 @@ def _bn_train(y, w, b, eps=1e-5):
     layout reduces with a cascade sum that is accurate to ~2e-6; F.batch_norm on a 2-D (rows, C)
     tensor uses a plain running sum that drifts by 1e-4 at 5e5 rows (probed), so the statistics
     are restated here in float64 and applied as y*alpha + beta like the CPU kernel does."""
-    mean = y.double().mean(0)
-    var = y.double().var(0, unbiased=False)
+    mean = y.mean(0, dtype=torch.float64)                       # fp64 accumulation, no fp64 copy of y
+    var = ((y * y).mean(0, dtype=torch.float64) - mean * mean).clamp_min(0)
     alpha = (w.double() / torch.sqrt(var + eps)).float()
     beta = (b.double() - mean * (w.double() / torch.sqrt(var + eps))).float()
     return y * alpha + beta

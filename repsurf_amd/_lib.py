@@ -9,9 +9,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librepsurf_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
 
 # name -> argtypes (restype is always int unless listed in _SPECIAL)
@@ -32,6 +32,13 @@ SIGNATURES = {
     "rs_three_nn": [c_int, c_int, c_int, P, P, P, P, P],
     "rs_three_interpolate": [c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_three_interpolate_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "rs_mlp_gemm_rows": [c_ll, c_int, c_int, P, P, c_int, c_int, P, P],
+    "rs_mlp_wgrad": [c_ll, c_int, c_int, P, P, P, c_int, P, P],
+    "rs_bn_finalize": [c_int, c_ll, c_int, P, P, P, c_float, c_float, P, P, P, P, P, P, P],
+    "rs_bn_backward_finalize": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P],
+    "rs_pool_max": [c_ll, c_int, c_int, c_int, P, P, P, P, P, P],
+    "rs_pool_max_backward": [c_ll, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P],
+    "rs_pool_sum": [c_ll, c_int, c_int, P, P, P],
 }
 _SPECIAL = {
     "rs_last_error": ([], ctypes.c_char_p),
@@ -105,7 +112,7 @@ def call(name, *args):
         e0.record()
         rc = getattr(lib, name)(*args)
         e1.record()
-        dims = tuple(a for a, t in zip(args, SIGNATURES[name]) if t is c_int)
+        dims = tuple(a for a, t in zip(args, SIGNATURES[name]) if t is c_int or t is c_ll)
         _profile.append((name, dims, e0, e1))
     else:
         rc = getattr(lib, name)(*args)

@@ -1,0 +1,347 @@
+"""HIP executor of the grouped shared-MLP stacks (product path of repsurf_amd.mlp).
+
+Orchestrates the kernels of repsurf_amd/csrc/mlp.hip through the C ABI:
+  forward  per layer: rs_mlp_gemm_rows (previous BN+ReLU fused into the operand load, BN sums in the
+           epilogue) -> rs_bn_finalize;  last layer -> rs_pool_max (BN+ReLU+max over nsample)
+  backward per layer: rs_mlp_wgrad + rs_mlp_gemm_rows (BN-backward affine fused into the operand
+           load, ReLU mask + BN-backward sums in the epilogue) -> rs_bn_backward_finalize
+Only the pre-BatchNorm conv outputs and per-channel vectors are saved for backward; the gradient
+through the max-pool is never materialised (RS_OP_POOLED operand).
+
+Gradients of conv biases that feed a BatchNorm are returned as exact zeros: BatchNorm removes any
+per-channel constant, so the analytic gradient is 0 (the reference's autograd produces rounding
+noise of 1e-7..1e-3 there).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+c_int, c_ll, P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
+OP_ID, OP_RELU1, OP_RELU2, OP_AFF2, OP_POOLED, OP_BCAST = range(6)
+EPI_STORE, EPI_STATS, EPI_MASK = range(3)
+PARTIAL_BLOCKS = 512      # rows of the BatchNorm partial-sum buffers (>= persistent workgroups)
+WGRAD_CHUNKS = 256        # row slabs of the weight-gradient reduction
+
+
+class RowOperand(ctypes.Structure):          # rs_row_operand
+    _fields_ = [("a", P), ("lda", c_ll), ("b", P), ("ldb", c_ll), ("s1", P), ("t1", P), ("s2", P), ("t2", P),
+                ("arg", P), ("ns", c_int), ("mode", c_int)]
+
+
+class Epilogue(ctypes.Structure):            # rs_mlp_epilogue
+    _fields_ = [("bias", P), ("out", P), ("ldo", c_ll), ("mode", c_int),
+                ("my1", P), ("ldm1", c_ll), ("ms1", P), ("mt1", P), ("mean1", P), ("invstd1", P),
+                ("my2", P), ("ldm2", c_ll), ("ms2", P), ("mt2", P), ("mean2", P), ("invstd2", P),
+                ("partial", P), ("partial_blocks", c_int)]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, offset=0):
+    return None if t is None else t.data_ptr() + 4 * offset
+
+
+def operand(mode, a, lda, b=None, ldb=0, s1=None, t1=None, s2=None, t2=None, arg=None, ns=1, a_off=0):
+    return RowOperand(_ptr(a, a_off), lda, _ptr(b), ldb, _ptr(s1), _ptr(t1), _ptr(s2), _ptr(t2),
+                      None if arg is None else arg.data_ptr(), ns, mode)
+
+
+class BNVec:
+    """Per-channel vectors of one BatchNorm for one forward pass."""
+    __slots__ = ("scale", "shift", "mean", "invstd")
+
+    def __init__(self, c, device):
+        buf = torch.empty((4, c), dtype=torch.float32, device=device)
+        self.scale, self.shift, self.mean, self.invstd = buf[0], buf[1], buf[2], buf[3]
+
+
+def _w2d(w):
+    return w.detach().reshape(w.shape[0], -1).contiguous()
+
+
+def gemm_rows(rows, kdim, cols, x_op, w, ldw, k_by_n, epi):
+    _lib.call("rs_mlp_gemm_rows", rows, kdim, cols, ctypes.byref(x_op), _ptr(w), ldw, int(k_by_n),
+              ctypes.byref(epi), _stream())
+
+
+def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device):
+    """y = E . W^T + bias with BN statistics; returns (y, BNVec)."""
+    cout = w2d.shape[0]
+    y = torch.empty((rows, cout), dtype=torch.float32, device=device)
+    vec = BNVec(cout, device)
+    if training:
+        part = torch.empty((PARTIAL_BLOCKS, 2, cout), dtype=torch.float64, device=device)
+        epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STATS, partial=part.data_ptr(),
+                       partial_blocks=PARTIAL_BLOCKS)
+        gemm_rows(rows, kdim, cols=cout, x_op=x_op, w=w2d, ldw=w2d.shape[1], k_by_n=False, epi=epi)
+        track = bn_mod.track_running_stats and bn_mod.running_mean is not None
+        if track:
+            bn_mod.num_batches_tracked.add_(1)
+        mom = bn_mod.momentum if bn_mod.momentum is not None else 0.1
+        _lib.call("rs_bn_finalize", cout, rows, PARTIAL_BLOCKS, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
+                  float(bn_mod.eps), float(mom), _ptr(vec.scale), _ptr(vec.shift), _ptr(vec.mean), _ptr(vec.invstd),
+                  _ptr(bn_mod.running_mean) if track else None, _ptr(bn_mod.running_var) if track else None, _stream())
+    else:
+        epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STORE)
+        gemm_rows(rows, kdim, cols=cout, x_op=x_op, w=w2d, ldw=w2d.shape[1], k_by_n=False, epi=epi)
+        with torch.no_grad():
+            invstd = torch.rsqrt(bn_mod.running_var + bn_mod.eps)
+            vec.invstd.copy_(invstd)
+            vec.mean.copy_(bn_mod.running_mean)
+            vec.scale.copy_(bn_mod.weight * invstd)
+            vec.shift.copy_(bn_mod.bias - bn_mod.running_mean * bn_mod.weight * invstd)
+    return y, vec
+
+
+def wgrad(rows, ncols, kcols, p_op, q_op, device):
+    part = torch.empty((WGRAD_CHUNKS, ncols * kcols), dtype=torch.float32, device=device)
+    dw = torch.empty((ncols, kcols), dtype=torch.float32, device=device)
+    _lib.call("rs_mlp_wgrad", rows, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), WGRAD_CHUNKS,
+              _ptr(dw), _stream())
+    return dw
+
+
+def bwd_coeffs(c, rows, part, nstat, which, vec, device):
+    """BN backward sums -> (p, q, r, dgamma, dbeta)."""
+    buf = torch.empty((5, c), dtype=torch.float32, device=device)
+    _lib.call("rs_bn_backward_finalize", c, rows, PARTIAL_BLOCKS, nstat, which, part.data_ptr(), _ptr(vec.scale),
+              _ptr(vec.mean), _ptr(vec.invstd), _ptr(buf[0]), _ptr(buf[1]), _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]),
+              _stream())
+    return buf[0], buf[1], buf[2], buf[3], buf[4]
+
+
+def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=None):
+    """dz_prev = (P . W) * relu'(z_prev) and the BN-backward sums of the previous layer(s)."""
+    dz = torch.empty((rows, cols), dtype=torch.float32, device=device)
+    nstat = 3 if y2 is not None else 2
+    part = torch.empty((PARTIAL_BLOCKS, nstat, cols), dtype=torch.float64, device=device)
+    epi = Epilogue(bias=None, out=_ptr(dz), ldo=cols, mode=EPI_MASK,
+                   my1=_ptr(y1), ldm1=cols, ms1=_ptr(v1.scale), mt1=_ptr(v1.shift), mean1=_ptr(v1.mean), invstd1=_ptr(v1.invstd),
+                   partial=part.data_ptr(), partial_blocks=PARTIAL_BLOCKS)
+    if y2 is not None:
+        epi.my2, epi.ldm2 = _ptr(y2), cols
+        epi.ms2, epi.mt2, epi.mean2, epi.invstd2 = _ptr(v2.scale), _ptr(v2.shift), _ptr(v2.mean), _ptr(v2.invstd)
+    gemm_rows(rows, kdim, cols, p_op, w2d, w2d.shape[1], True, epi)
+    return dz, part, nstat
+
+
+# ------------------------------------------------------------------------------------------- SA stacks
+class _SAStack(Function):
+    """[two-branch | single] first layer -> [conv, BN, ReLU]* -> max over nsample.
+    args: x (rows, cx), meta, then flat parameters (see sa_mlp_cd / sa_mlp_plain)."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        dev = x.device
+        x = x.contiguous()
+        rows, cx = x.shape
+        ns, pos, bns, training = meta["nsample"], meta["pos"], meta["bns"], meta["training"]
+        groups = rows // ns
+        saved = {"x": x}
+        pi = 0
+        ys, vecs, w2ds = [], [], []
+        if pos > 0:      # two-branch first layer (SurfaceAbstractionCD)
+            wl, bl, wf, bf = params[0], params[1], params[4], params[5]
+            wl2, wf2 = _w2d(wl), _w2d(wf)
+            yl, vl = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev)
+            yf, vf = fwd_layer(rows, operand(OP_ID, x, cx, a_off=pos), cx - pos, wf2, bf, bns[1], training, dev)
+            saved.update(yl=yl, vl=vl, yf=yf, vf=vf, wl2=wl2, wf2=wf2)
+            prev_op = operand(OP_RELU2, yl, yl.shape[1], yf, yf.shape[1], vl.scale, vl.shift, vf.scale, vf.shift)
+            prev_c = wl2.shape[0]
+            pi, bi = 8, 2
+        else:
+            prev_op = operand(OP_ID, x, cx)
+            prev_c = cx
+            pi, bi = 0, 0
+        while pi < len(params):
+            w, b = params[pi], params[pi + 1]
+            w2 = _w2d(w)
+            y, vec = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev)
+            ys.append(y); vecs.append(vec); w2ds.append(w2)
+            prev_op = operand(OP_RELU1, y, y.shape[1], s1=vec.scale, t1=vec.shift)
+            prev_c = w2.shape[0]
+            pi += 4; bi += 1
+        if ys:
+            y_last, v_last = ys[-1], vecs[-1]
+            out = torch.empty((groups, prev_c), dtype=torch.float32, device=dev)
+            arg = torch.empty((groups, prev_c), dtype=torch.int32, device=dev)
+            _lib.call("rs_pool_max", groups, ns, prev_c, 1, _ptr(y_last), _ptr(v_last.scale), _ptr(v_last.shift),
+                      _ptr(out), arg.data_ptr(), _stream())
+        else:
+            raise NotImplementedError("a stack needs at least one layer after the first")
+        saved.update(ys=ys, vecs=vecs, w2ds=w2ds, out=out, arg=arg)
+        ctx.saved = saved
+        ctx.meta = meta
+        ctx.nparams = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s, meta = ctx.saved, ctx.meta
+        if not meta["training"]:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented in the HIP executor")
+        x = s["x"]
+        dev = x.device
+        rows, cx = x.shape
+        ns, pos = meta["nsample"], meta["pos"]
+        groups = rows // ns
+        ys, vecs, w2ds = s["ys"], s["vecs"], s["w2ds"]
+        dout = dout.contiguous()
+        grads = [None] * ctx.nparams
+        nl = len(ys)
+        first = 8 if pos > 0 else 0
+        # ---- pooled layer: BN-backward sums from (groups, c) data only
+        c_last = ys[-1].shape[1]
+        v = torch.empty_like(dout)
+        part = torch.empty((PARTIAL_BLOCKS, 2, c_last), dtype=torch.float64, device=dev)
+        _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(dout), _ptr(s["out"]), s["arg"].data_ptr(), _ptr(ys[-1]),
+                  _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(), PARTIAL_BLOCKS, _stream())
+        p, q, r, dg, db = bwd_coeffs(c_last, rows, part, 2, 1, vecs[-1], dev)
+        p_op = operand(OP_POOLED, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, arg=s["arg"], ns=ns)
+        dx = None
+        for li in range(nl - 1, -1, -1):
+            pidx = first + 4 * li
+            cout, cin = w2ds[li].shape
+            grads[pidx + 2], grads[pidx + 3] = dg, db
+            grads[pidx + 1] = torch.zeros(cout, dtype=torch.float32, device=dev)      # bias before BN: exactly 0
+            # the activation that fed this layer, rebuilt on the fly from the stored conv outputs
+            if li > 0:
+                q_op = operand(OP_RELU1, ys[li - 1], cin, s1=vecs[li - 1].scale, t1=vecs[li - 1].shift)
+            elif pos > 0:
+                q_op = operand(OP_RELU2, s["yl"], cin, s["yf"], cin, s["vl"].scale, s["vl"].shift,
+                               s["vf"].scale, s["vf"].shift)
+            else:
+                q_op = operand(OP_ID, x, cx)
+            grads[pidx] = wgrad(rows, cout, cin, p_op, q_op, dev)
+            if li > 0:      # data gradient, ReLU mask and BN-backward sums of layer li-1
+                dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], ys[li - 1], vecs[li - 1], device=dev)
+                p, q, r, dg, db = bwd_coeffs(cin, rows, part, nstat, 1, vecs[li - 1], dev)
+                p_op = operand(OP_AFF2, dz, cin, ys[li - 1], cin, s1=p, t1=r, s2=q)
+            elif pos > 0:   # two-branch first layer: one masked gradient, two BatchNorms
+                dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], s["yl"], s["vl"], s["yf"], s["vf"],
+                                               device=dev)
+                pl, ql, rl, dgl, dbl = bwd_coeffs(cin, rows, part, 3, 1, s["vl"], dev)
+                pf, qf, rf, dgf, dbf = bwd_coeffs(cin, rows, part, 3, 2, s["vf"], dev)
+                opl = operand(OP_AFF2, dz, cin, s["yl"], cin, s1=pl, t1=rl, s2=ql)
+                opf = operand(OP_AFF2, dz, cin, s["yf"], cin, s1=pf, t1=rf, s2=qf)
+                grads[0] = wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev)
+                grads[4] = wgrad(rows, cin, cx - pos, opf, operand(OP_ID, x, cx, a_off=pos), dev)
+                grads[1] = torch.zeros(cin, dtype=torch.float32, device=dev)
+                grads[5] = torch.zeros(cin, dtype=torch.float32, device=dev)
+                grads[2], grads[3], grads[6], grads[7] = dgl, dbl, dgf, dbf
+                if ctx.needs_input_grad[0]:     # only the feature channels carry a gradient
+                    dx = torch.zeros((rows, cx), dtype=torch.float32, device=dev)
+                    epi = Epilogue(bias=None, out=_ptr(dx, pos), ldo=cx, mode=EPI_STORE)
+                    gemm_rows(rows, cin, cx - pos, opf, s["wf2"], s["wf2"].shape[1], True, epi)
+            elif ctx.needs_input_grad[0]:
+                dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
+                epi = Epilogue(bias=None, out=_ptr(dx), ldo=cx, mode=EPI_STORE)
+                gemm_rows(rows, cout, cx, p_op, w2ds[li], w2ds[li].shape[1], True, epi)
+        out_grads = [None if g is None else g.reshape(shape) for g, shape in zip(grads, meta["shapes"])]
+        return (dx, None) + tuple(out_grads)
+
+
+def _flat_params(first, convs, bns):
+    params, mods = [], []
+    for conv, bn in first + list(zip(convs, bns)):
+        params += [conv.weight, conv.bias, bn.weight, bn.bias]
+        mods.append(bn)
+    return params, mods
+
+
+def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample):
+    params, mods = _flat_params([(mlp_l0, bn_l0), (mlp_f0, bn_f0)], convs, bns)
+    meta = {"nsample": nsample, "pos": pos_channel, "bns": mods, "training": mods[0].training,
+            "shapes": [p.shape for p in params]}
+    return _SAStack.apply(x, meta, *params)
+
+
+def sa_mlp_plain(x, convs, bns, nsample):
+    params, mods = _flat_params([], convs, bns)
+    meta = {"nsample": nsample, "pos": 0, "bns": mods, "training": mods[0].training,
+            "shapes": [p.shape for p in params]}
+    return _SAStack.apply(x, meta, *params)
+
+
+# ------------------------------------------------------------------------------------------- umbrella stack
+class _UmbrellaStack(Function):
+    """conv(no bias)-BN-ReLU-conv-BN-ReLU-conv, then sum | avg | max over the `group` fan triangles.
+    The input (geometric features) never needs a gradient."""
+
+    @staticmethod
+    def forward(ctx, x, meta, w0, g0, b0, w1, c1, g1, b1, w2, c2):
+        dev = x.device
+        x = x.contiguous()
+        rows, cx = x.shape
+        group, aggr, training = meta["group"], meta["aggr"], meta["training"]
+        bn0, bn1 = meta["bns"]
+        w0_, w1_, w2_ = _w2d(w0), _w2d(w1), _w2d(w2)
+        y0, v0 = fwd_layer(rows, operand(OP_ID, x, cx), cx, w0_, None, bn0, training, dev)
+        y1, v1 = fwd_layer(rows, operand(OP_RELU1, y0, y0.shape[1], s1=v0.scale, t1=v0.shift), w0_.shape[0], w1_, c1,
+                           bn1, training, dev)
+        cout = w2_.shape[0]
+        y2 = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+        epi = Epilogue(bias=_ptr(c2), out=_ptr(y2), ldo=cout, mode=EPI_STORE)
+        gemm_rows(rows, w1_.shape[0], cout, operand(OP_RELU1, y1, y1.shape[1], s1=v1.scale, t1=v1.shift), w2_, w2_.shape[1],
+                  False, epi)
+        points = rows // group
+        out = torch.empty((points, cout), dtype=torch.float32, device=dev)
+        arg = None
+        if aggr == "max":
+            arg = torch.empty((points, cout), dtype=torch.int32, device=dev)
+            _lib.call("rs_pool_max", points, group, cout, 0, _ptr(y2), None, None, _ptr(out), arg.data_ptr(), _stream())
+        else:
+            _lib.call("rs_pool_sum", points, group, cout, _ptr(y2), _ptr(out), _stream())
+            if aggr == "avg":
+                out.mul_(1.0 / group)
+        ctx.saved = dict(x=x, y0=y0, v0=v0, y1=y1, v1=v1, y2=y2, w0=w0_, w1=w1_, w2=w2_, arg=arg)
+        ctx.meta = meta
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s, meta = ctx.saved, ctx.meta
+        if not meta["training"]:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented in the HIP executor")
+        x, y0, v0, y1, v1 = s["x"], s["y0"], s["v0"], s["y1"], s["v1"]
+        dev = x.device
+        rows, cx = x.shape
+        group, aggr = meta["group"], meta["aggr"]
+        dout = dout.contiguous()
+        if aggr == "avg":
+            dout = dout * (1.0 / group)
+        c2n, c1n, c0n = s["w2"].shape[0], s["w1"].shape[0], s["w0"].shape[0]
+        if aggr == "max":
+            one = torch.ones(c2n, dtype=torch.float32, device=dev)
+            zero = torch.zeros(c2n, dtype=torch.float32, device=dev)
+            p2 = operand(OP_POOLED, dout, c2n, s["y2"], c2n, s1=one, t1=zero, s2=zero, arg=s["arg"], ns=group)
+            g_c2 = dout.sum(0)
+        else:
+            p2 = operand(OP_BCAST, dout, c2n, ns=group)
+            g_c2 = dout.sum(0) * group
+        g_w2 = wgrad(rows, c2n, c1n, p2, operand(OP_RELU1, y1, c1n, s1=v1.scale, t1=v1.shift), dev)
+        dz1, part, nstat = dgrad_masked(rows, c2n, c1n, p2, s["w2"], y1, v1, device=dev)
+        pa, qa, ra, g_g1, g_b1 = bwd_coeffs(c1n, rows, part, nstat, 1, v1, dev)
+        p1 = operand(OP_AFF2, dz1, c1n, y1, c1n, s1=pa, t1=ra, s2=qa)
+        g_w1 = wgrad(rows, c1n, c0n, p1, operand(OP_RELU1, y0, c0n, s1=v0.scale, t1=v0.shift), dev)
+        dz0, part0, nstat0 = dgrad_masked(rows, c1n, c0n, p1, s["w1"], y0, v0, device=dev)
+        pb, qb, rb, g_g0, g_b0 = bwd_coeffs(c0n, rows, part0, nstat0, 1, v0, dev)
+        p0 = operand(OP_AFF2, dz0, c0n, y0, c0n, s1=pb, t1=rb, s2=qb)
+        g_w0 = wgrad(rows, c0n, cx, p0, operand(OP_ID, x, cx), dev)
+        shp = meta["shapes"]
+        g_c1 = torch.zeros(c1n, dtype=torch.float32, device=dev)          # bias before BN: exactly 0
+        return (None, None, g_w0.reshape(shp[0]), g_g0, g_b0, g_w1.reshape(shp[1]), g_c1, g_g1, g_b1,
+                g_w2.reshape(shp[2]), g_c2)
+
+
+def umbrella_mlp(x, mlps, group, aggr):
+    conv0, bn0, _, conv1, bn1, _, conv2 = mlps
+    meta = {"group": group, "aggr": aggr, "bns": (bn0, bn1), "training": bn0.training,
+            "shapes": [conv0.weight.shape, conv1.weight.shape, conv2.weight.shape]}
+    return _UmbrellaStack.apply(x, meta, conv0.weight, bn0.weight, bn0.bias, conv1.weight, conv1.bias, bn1.weight,
+                                bn1.bias, conv2.weight, conv2.bias)

@@ -1,0 +1,134 @@
+"""The fp32-MFMA shared-MLP kernels (repsurf_amd/csrc/mlp.hip via repsurf_amd.mlp_hip) against a
+plain PyTorch fp32 reference of the same op (repsurf_amd.mlp "torch" executor: F.linear /
+F.batch_norm / relu / max): forward activations and every gradient.  Tolerance: 1e-5 of the
+tensor's scale for activations (north-star), 2e-4 for gradients (BatchNorm-backward cancellation
+in fp32 on both sides; the fp64 check below shows the HIP path is the closer of the two)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def make_cd(pos, feat, mlp, seed):
+    torch.manual_seed(seed)
+    m = nn.Module()
+    m.mlp_l0, m.mlp_f0 = nn.Conv2d(pos, mlp[0], 1), nn.Conv2d(feat, mlp[0], 1)
+    m.bn_l0, m.bn_f0 = nn.BatchNorm2d(mlp[0]), nn.BatchNorm2d(mlp[0])
+    m.convs = nn.ModuleList([nn.Conv2d(a, b, 1) for a, b in zip(mlp[:-1], mlp[1:])])
+    m.bns = nn.ModuleList([nn.BatchNorm2d(b) for b in mlp[1:]])
+    for bn in [m.bn_l0, m.bn_f0] + list(m.bns):
+        nn.init.uniform_(bn.weight, 0.5, 1.5)
+        nn.init.uniform_(bn.bias, -0.3, 0.3)
+    return m.cuda().train()
+
+
+def run_cd(mod, x, ns, pos, backend, w):
+    from repsurf_amd import mlp
+    mlp.set_backend(backend)
+    mod.zero_grad()
+    x = x.clone().requires_grad_()
+    out = mlp.sa_mlp_cd(x, pos, mod.mlp_l0, mod.bn_l0, mod.mlp_f0, mod.bn_f0, mod.convs, mod.bns, ns)
+    (out * w).sum().backward()
+    grads = {n: p.grad.clone() for n, p in mod.named_parameters()}
+    grads["x"] = x.grad.clone()
+    return out.detach(), grads
+
+
+def rel(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+CASES = [  # groups, nsample, pos, feat, mlp
+    (96, 32, 6, 10, [64, 64, 128]),        # sa1 shape
+    (40, 64, 6, 138, [128, 128, 256]),     # sa2 shape
+    (4, 128, 6, 266, [256, 512, 1024]),    # sa3 (group_all) shape
+    (37, 24, 6, 10, [128, 128, 256]),      # 2x model: rows not a multiple of the tile, nsample 24
+    (5, 7, 3, 5, [16, 40]),                # odd everything
+]
+
+
+@pytest.mark.parametrize("groups,ns,pos,feat,widths", CASES)
+def test_sa_cd_stack_matches_torch(groups, ns, pos, feat, widths):
+    mod = make_cd(pos, feat, widths, 1)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(groups * ns, pos + feat, generator=g).cuda()
+    w = torch.randn(groups, widths[-1], generator=g).cuda()
+    ref_mod = copy.deepcopy(mod)
+    out_t, g_t = run_cd(ref_mod, x, ns, pos, "torch", w)
+    out_h, g_h = run_cd(mod, x, ns, pos, "hip", w)
+    assert rel(out_h, out_t) < 2e-5, rel(out_h, out_t)
+    for name in g_t:
+        if name.endswith("0.bias") and ("mlp_" in name or "convs" in name):
+            continue
+        if ".bias" in name and ("mlp_l0" in name or "mlp_f0" in name or "convs" in name):
+            assert g_h[name].abs().max() == 0          # analytic zero
+            continue
+        assert rel(g_h[name], g_t[name]) < 5e-4, (name, rel(g_h[name], g_t[name]))
+    # running statistics follow nn.BatchNorm2d
+    for a, b in zip([mod.bn_l0, mod.bn_f0] + list(mod.bns), [ref_mod.bn_l0, ref_mod.bn_f0] + list(ref_mod.bns)):
+        assert torch.allclose(a.running_mean, b.running_mean, atol=1e-5)
+        assert torch.allclose(a.running_var, b.running_var, rtol=1e-4, atol=1e-6)
+        assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
+
+
+def test_sa_cd_stack_against_fp64():
+    """who is right when hip and torch-fp32 disagree in the 5th digit: compare both with fp64"""
+    groups, ns, pos, feat, widths = 64, 32, 6, 10, [64, 64, 128]
+    mod = make_cd(pos, feat, widths, 3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(groups * ns, pos + feat, generator=g).cuda()
+    w = torch.randn(groups, widths[-1], generator=g).cuda()
+    out_h, g_h = run_cd(copy.deepcopy(mod), x, ns, pos, "hip", w)
+    out_t, g_t = run_cd(copy.deepcopy(mod), x, ns, pos, "torch", w)
+    out_d, g_d = run_cd(copy.deepcopy(mod).double(), x.double(), ns, pos, "torch", w.double())
+    assert rel(out_h.double(), out_d) < 1e-5
+    for name in ("mlp_l0.weight", "mlp_f0.weight", "convs.0.weight", "convs.1.weight", "bns.1.weight", "x"):
+        eh, et = rel(g_h[name].double(), g_d[name]), rel(g_t[name].double(), g_d[name])
+        assert eh < 1e-4, (name, eh, et)
+
+
+@pytest.mark.parametrize("aggr", ["sum", "max", "avg"])
+def test_umbrella_stack_matches_torch(aggr):
+    from repsurf_amd import mlp
+    torch.manual_seed(5)
+    mlps = nn.Sequential(nn.Conv2d(10, 10, 1, bias=False), nn.BatchNorm2d(10), nn.ReLU(True), nn.Conv2d(10, 10, 1),
+                         nn.BatchNorm2d(10), nn.ReLU(True), nn.Conv2d(10, 10, 1)).cuda().train()
+    x = torch.randn(300 * 8, 10).cuda()
+    w = torch.randn(300, 10).cuda()
+    res = {}
+    for backend in ("torch", "hip"):
+        mlp.set_backend(backend)
+        m = copy.deepcopy(mlps)
+        out = mlp.umbrella_mlp(x, m, 8, aggr)
+        (out * w).sum().backward()
+        res[backend] = (out.detach(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    assert rel(res["hip"][0], res["torch"][0]) < 2e-5
+    for name, gt in res["torch"][1].items():
+        if name == "3.bias":
+            continue
+        assert rel(res["hip"][1][name], gt) < 5e-4, name
+
+
+def test_plain_stack_matches_torch():
+    from repsurf_amd import mlp
+    torch.manual_seed(6)
+    convs = nn.ModuleList([nn.Conv2d(19, 32, 1), nn.Conv2d(32, 64, 1)]).cuda()
+    bns = nn.ModuleList([nn.BatchNorm2d(32), nn.BatchNorm2d(64)]).cuda().train()
+    x0 = torch.randn(50 * 16, 19).cuda()
+    w = torch.randn(50, 64).cuda()
+    res = {}
+    for backend in ("torch", "hip"):
+        mlp.set_backend(backend)
+        c, b = copy.deepcopy(convs), copy.deepcopy(bns)
+        x = x0.clone().requires_grad_()
+        out = mlp.sa_mlp_plain(x, c, b, 16)
+        (out * w).sum().backward()
+        res[backend] = (out.detach(), x.grad.clone(), [p.grad.clone() for p in c.parameters()])
+    assert rel(res["hip"][0], res["torch"][0]) < 2e-5
+    assert rel(res["hip"][1], res["torch"][1]) < 5e-4
+    for gh, gt in zip(res["hip"][2][::2], res["torch"][2][::2]):
+        assert rel(gh, gt) < 5e-4
