@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=8, help="clouds in the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--breakdown", default="", help="write a per-kernel timing breakdown JSON here")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     return ap.parse_args()
 
 
@@ -117,9 +118,8 @@ def algorithmic_cost(name, dims):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from repsurf_amd import dist as rdist
+    rank, world, local = rdist.env()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (one rank per GPU)")
@@ -127,9 +127,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+    rdist.init(backend="nccl", device=device)                 # "nccl" is RCCL on ROCm (xGMI inside the node)
 
     import importlib
     from repsurf_amd import _lib, mlp, ops
@@ -139,15 +137,12 @@ def main():
     torch.manual_seed(0)                     # identical initial weights on every rank
     model = Model(model_args()).to(device).train()
     cpu_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(
-            model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True,
-            broadcast_buffers=False, find_unused_parameters=False)
+    net = rdist.wrap(model, device)                           # one 64 MB bucket: a single gradient all-reduce
     criterion = SmoothClsLoss()
-    optim = None if args.no_optim else torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
-    points, label = synthetic_batch(1000 + rank, args.batch, args.points, device)
-    torch.manual_seed(100 + rank)            # CPU generator: FPS starts / normal flips differ per rank
+    use_graph = (world == 1) and not args.no_graph
+    optim = None if args.no_optim else torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=use_graph)
+    points, label = synthetic_batch(rdist.rank_seed(125, rank), args.batch, args.points, device)
+    torch.manual_seed(rdist.rank_seed(13, rank))   # CPU generator: FPS starts / normal flips differ per rank
 
     def step():
         for p in model.parameters():
@@ -161,12 +156,37 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            rdist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    if not args.no_kernel_timing:
+    mode = "eager"
+    timing = not args.no_kernel_timing
+    if use_graph:
+        # Per-launch HIP events cannot be recorded inside a replayed graph: the kernel timings for `roofline`
+        # come from a short eager pass first, the throughput from graph replay of the identical step.
+        try:
+            from repsurf_amd.graph import GraphedStep
+            if timing:
+                for _ in range(2):
+                    step()
+                _lib.profile_enable(True)
+                for _ in range(min(args.steps, 5)):
+                    step()
+                torch.cuda.synchronize()
+                _lib.profile_enable(False)
+                args.timed_steps = min(args.steps, 5)
+                timing = False
+            graphed = GraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
+            step = graphed
+            mode = "hipgraph"
+        except Exception as e:  # noqa: BLE001 - fall back to eager launches, still a valid measurement
+            print(f"[bench] graph capture failed ({e!r}); running eagerly", file=sys.stderr)
+            use_graph = False
+    if not use_graph:
+        for _ in range(args.warmup):
+            step()
+    if timing:
+        args.timed_steps = args.steps
         _lib.profile_enable(True)
     fence()
     t0 = time.perf_counter()
@@ -174,11 +194,9 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    _lib.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    if timing:
+        _lib.profile_enable(False)
+    dt = rdist.max_over_ranks(dt, device)
     prof = _lib.profile_collect()            # {abi name: [(ms, dims), ...]} from HIP events on the launch stream
 
     if rank == 0:
@@ -193,7 +211,7 @@ def main():
             for dims, ts in by_dims.items():
                 unit, amount = algorithmic_cost(name, dims)
                 table.append({"kernel": name, "dims": list(dims), "launches": len(ts), "avg_us": float(np.mean(ts)) * 1e3,
-                              "total_ms_per_step": float(np.sum(ts)) / args.steps, "unit": unit, "amount": amount})
+                              "total_ms_per_step": float(np.sum(ts)) / max(1, getattr(args, "timed_steps", args.steps)), "unit": unit, "amount": amount})
         table.sort(key=lambda r: -r["total_ms_per_step"])
         for row in table:
             if row["unit"] is None:
@@ -224,14 +242,13 @@ def main():
                                       "per GPU, fp32, full encoder + head, fwd+loss+bwd"
                                       + ("" if args.no_optim else "+Adam step"),
                           "global_batch": args.batch * world, "points": args.points,
-                          "parallelism": f"dp{world}", "mlp_backend": mlp.BACKEND,
+                          "parallelism": f"dp{world}", "mlp_backend": mlp.BACKEND, "launch": mode,
                           "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5)},
                "roofline": roofline, "cpu_baseline": cpu}
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    rdist.finish()
 
 
 def traffic_from_profiles(kernel):

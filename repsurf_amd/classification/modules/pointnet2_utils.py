@@ -9,7 +9,7 @@ Index tensors are int32 (the reference's CUDA path; its CPU path returns int64).
 """
 import torch
 
-from repsurf_amd import ops
+from repsurf_amd import ops, rng
 
 
 def square_distance(src, dst):
@@ -34,8 +34,9 @@ def farthest_point_sample(xyz, npoint, cuda=False, start=None):
     """xyz (B,N,3) -> (B,npoint) int32 sampled indices (reference :47-75).
     `start` (optional, (B,) ints) overrides the random first pick."""
     if start is None:
-        start = draw_fps_start(xyz.shape[0], xyz.shape[1])
-    start = start.to(device=xyz.device, dtype=torch.int32, non_blocking=True)
+        start = rng.draw("fps", xyz.shape[0], xyz.shape[1], xyz.device)
+    else:
+        start = start.to(device=xyz.device, dtype=torch.int32, non_blocking=True)
     return ops.furthestsampling(xyz, npoint, start)
 
 

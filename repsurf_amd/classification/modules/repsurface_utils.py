@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from repsurf_amd import mlp as _mlp
-from repsurf_amd import ops
+from repsurf_amd import ops, rng
 from modules.pointnet2_utils import farthest_point_sample, index_points, query_knn_point, query_ball_point
 from modules.polar_utils import xyz2sphere
 
@@ -165,7 +165,7 @@ class UmbrellaSurfaceConstructor(nn.Module):
         b, n, _ = xyz.shape
         flip = None
         if self.random_inv:   # per-cloud sign, CPU generator, same call as recons_utils.py:50
-            flip = (torch.randint(0, 2, (b, 1, 1)).float() * 2. - 1.).view(b).to(xyz.device, non_blocking=True)
+            flip = rng.draw("flip", b, 2, xyz.device)
         feat = ops.umbrella_features(xyz, self.k, flip)           # (B,N,k-1,10) = [centre, polar, normal, pos]
         if not self.return_dist:
             feat = feat[..., :9]

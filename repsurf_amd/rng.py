@@ -1,0 +1,65 @@
+"""Host random draws of the hot path, and their static-buffer form for hipGraph replay.
+
+The reference's CPU path draws two things per forward from the CPU default generator:
+the per-cloud normal flip (classification/modules/recons_utils.py:50) and one FPS start index per
+sampling stage (classification/modules/pointnet2_utils.py:66).  Eagerly we make the same calls and
+copy the few bytes to the device.  A captured step cannot contain host work, so under
+`StaticDraws` every draw is served from a device buffer that lives as long as the graph; `refill()`
+repeats the same CPU-generator calls in the same order before each replay and overwrites the buffers.
+"""
+import torch
+
+_active = None
+
+
+def _cpu_draw(kind, b, n):
+    if kind == "flip":      # same call as recons_utils.py:50
+        return (torch.randint(0, 2, (b, 1, 1)).float() * 2. - 1.).view(b)
+    return torch.randint(0, n, (b,), dtype=torch.long).to(torch.int32)   # pointnet2_utils.py:66
+
+
+class StaticDraws:
+    """Context manager: record the draws made while capturing, replay them with fresh numbers later."""
+
+    def __init__(self, device):
+        self.device = device
+        self.slots = []        # (kind, b, n, device tensor)
+        self.cursor = None     # not None while re-running the same code path (warm-up iterations)
+
+    def __enter__(self):
+        global _active
+        _active = self
+        return self
+
+    def __exit__(self, *exc):
+        global _active
+        _active = None
+
+    def begin_pass(self):
+        self.cursor = 0
+
+    def draw(self, kind, b, n):
+        if self.cursor is not None and self.cursor < len(self.slots):
+            k, bb, nn, buf = self.slots[self.cursor]
+            assert (k, bb, nn) == (kind, b, n), "draw order changed between passes"
+            self.cursor += 1
+            return buf
+        dtype = torch.float32 if kind == "flip" else torch.int32
+        buf = torch.empty((b,), dtype=dtype, device=self.device)
+        buf.copy_(_cpu_draw(kind, b, n))          # first use: a real draw (never run a kernel on garbage)
+        self.slots.append((kind, b, n, buf))
+        if self.cursor is not None:
+            self.cursor += 1
+        return buf
+
+    def refill(self):
+        """Fresh CPU-generator draws, in forward order, into the static buffers (async H2D on the current stream)."""
+        for kind, b, n, buf in self.slots:
+            buf.copy_(_cpu_draw(kind, b, n), non_blocking=True)
+
+
+def draw(kind, b, n, device):
+    """kind: "flip" -> (b,) float +-1;  "fps" -> (b,) int32 in [0, n)."""
+    if _active is not None:
+        return _active.draw(kind, b, n)
+    return _cpu_draw(kind, b, n).to(device, non_blocking=True)

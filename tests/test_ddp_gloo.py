@@ -1,0 +1,66 @@
+"""The N>1 plumbing of bench.py / repsurf_amd.dist on CPU: world_size 2, gloo backend, 127.0.0.1.
+(The model itself has no CPU path, so a small stand-in module carries the gradients; what is
+under test is rank discovery, per-rank data, the single-bucket gradient averaging and the
+max-over-ranks timing — the same calls bench.py makes with backend "nccl" on the GPUs.)"""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from tests.util import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from repsurf_amd import dist as rdist
+    r, w = rdist.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)                                   # identical initial weights on every rank
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    net = rdist.wrap(model)
+    g = torch.Generator().manual_seed(rdist.rank_seed(5, rank))   # rank-specific batch
+    x = torch.randn(32, 8, generator=g)
+    net(x).pow(2).mean().backward()
+    grads = torch.cat([p.grad.flatten() for p in model.parameters()])
+    # local (un-averaged) gradient of this rank's batch, for the mean check
+    ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    ref.load_state_dict(model.state_dict())
+    ref(x).pow(2).mean().backward()
+    local = torch.cat([p.grad.flatten() for p in ref.parameters()])
+    slow = rdist.max_over_ranks(1.0 + rank)
+    rdist.barrier()
+    out[rank] = (grads, local, slow, float(x.sum()))
+    rdist.finish()
+
+
+def test_two_rank_gradient_average_and_timing():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        (g0, l0, s0, x0), (g1, l1, s1, x1) = out[0], out[1]
+    assert torch.allclose(g0, g1)                           # all-reduced: same on both ranks
+    assert torch.allclose(g0, (l0 + l1) / 2, atol=1e-6)     # = mean of the per-rank gradients
+    assert s0 == s1 == 2.0                                  # job time = slowest rank
+    assert x0 != x1                                         # ranks saw different data
+
+
+def test_single_process_defaults():
+    from repsurf_amd import dist as rdist
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    assert rdist.env() == (0, 1, 0)
+    m = torch.nn.Linear(2, 2)
+    assert rdist.wrap(m) is m and rdist.max_over_ranks(3.5) == 3.5
