@@ -162,39 +162,45 @@ def main():
     mode = "eager"
     timing = not args.no_kernel_timing
     if use_graph:
-        # Per-launch HIP events cannot be recorded inside a replayed graph: the kernel timings for `roofline`
-        # come from a short eager pass first, the throughput from graph replay of the identical step.
-        try:
-            from repsurf_amd.graph import GraphedStep
-            if timing:
-                for _ in range(2):
-                    step()
-                _lib.profile_enable(True)
-                for _ in range(min(args.steps, 5)):
-                    step()
-                torch.cuda.synchronize()
-                _lib.profile_enable(False)
-                args.timed_steps = min(args.steps, 5)
-                timing = False
-            graphed = GraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
-            step = graphed
-            mode = "hipgraph"
-        except Exception as e:  # noqa: BLE001 - fall back to eager launches, still a valid measurement
-            print(f"[bench] graph capture failed ({e!r}); running eagerly", file=sys.stderr)
-            use_graph = False
-    if not use_graph:
+        # Capture FIRST (an eager step on the default stream before capture leaves AccumulateGrad nodes on
+        # the wrong stream and the capture faults).  Per-launch HIP events cannot be recorded inside a
+        # replayed graph, so the kernel timings for `roofline` come from a short eager pass on a copy of
+        # the model AFTER the timed region; the throughput comes from graph replay of the identical step.
+        from repsurf_amd.graph import GraphedStep
+        step = GraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
+        mode = "hipgraph"
+    else:
         for _ in range(args.warmup):
             step()
-    if timing:
-        args.timed_steps = args.steps
-        _lib.profile_enable(True)
+        if timing:
+            args.timed_steps = args.steps
+            _lib.profile_enable(True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    if timing:
+    if timing and not use_graph:
+        _lib.profile_enable(False)
+    if timing and use_graph:
+        import copy
+        twin = copy.deepcopy(model)
+        topt = None if args.no_optim else torch.optim.Adam(twin.parameters(), lr=1e-3, fused=True)
+
+        def eager_step():
+            for p in twin.parameters():
+                p.grad = None
+            criterion(twin(points), label).backward()
+            if topt is not None:
+                topt.step()
+        for _ in range(2):
+            eager_step()
+        args.timed_steps = min(args.steps, 5)
+        _lib.profile_enable(True)
+        for _ in range(args.timed_steps):
+            eager_step()
+        torch.cuda.synchronize()
         _lib.profile_enable(False)
     dt = rdist.max_over_ranks(dt, device)
     prof = _lib.profile_collect()            # {abi name: [(ms, dims), ...]} from HIP events on the launch stream

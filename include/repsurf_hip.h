@@ -235,6 +235,32 @@ int rs_pool_max_backward(long long groups, int nsample, int c, const float *dout
 /* out[g][c] = sum_k y[g*nsample+k][c]   (umbrella aggregation 'sum', :305) */
 int rs_pool_sum(long long groups, int nsample, int c, const float *y, float *out, void *stream);
 
+/* out[e] = sum_b partial[b][e], b ascending (deterministic reduction of fp32 workgroup partials). */
+int rs_reduce_partials(int nblk, long long n, const float *partial, float *out, void *stream);
+
+/* ---- fused 10-channel MLP of UmbrellaSurfaceConstructor ---------------------------------------
+ * self.mlps = Conv2d(10,10,bias=False)-BN-ReLU-Conv2d(10,10)-BN-ReLU-Conv2d(10,10) + sum/avg over the fan
+ * (classification/modules/repsurface_utils.py:266-274, 296-305) as six register-resident passes over the
+ * (rows, 10) geometric features; nothing but BatchNorm vectors is stored between passes
+ * (repsurf_amd/csrc/umbrella_mlp.hip).  Each pass is one launch of `nblk` workgroups:
+ *   0: stat_partial (nblk,2,10) = {sum y0, sum y0^2}                      -> rs_bn_finalize -> bn0
+ *   1: same for y1 (needs bn0)                                             -> rs_bn_finalize -> bn1
+ *   2: out (rows/group, 10) = out_scale * sum over the group of y2        (needs bn0, bn1)
+ *   3: dw_partial (nblk,110) = {dW2 (10x10), db2 (10)}, stat_partial = {sum dz1, sum dz1*yhat1}
+ *   4: dw_partial = {dW1, 0}, stat_partial = {sum dz0, sum dz0*yhat0}     (needs c1 = p,q,r of BN1 backward)
+ *   5: dw_partial = {dW0, 0}                                               (needs c0)
+ * bn0/bn1: (4,10) = scale, shift, mean, invstd as written by rs_bn_finalize; c0/c1: (>=3,10) = p,q,r as
+ * written by rs_bn_backward_finalize.  dout: (rows/group, 10), already scaled for 'avg'. */
+typedef struct rs_umbrella_mlp {
+  const float *x; long long rows; int group;
+  const float *w0, *w1, *b1, *w2, *b2;
+  const float *bn0, *bn1;
+  const float *c0, *c1;
+  const float *dout;
+} rs_umbrella_mlp;
+int rs_umbrella_mlp_pass(int pass, const rs_umbrella_mlp *m, float out_scale, float *out,
+                         double *stat_partial, float *dw_partial, int nblk, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

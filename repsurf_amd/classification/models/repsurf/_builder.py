@@ -10,6 +10,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from modules.repsurface_utils import SurfaceAbstractionCD, UmbrellaSurfaceConstructor
+from repsurf_amd import rng
+from repsurf_amd.geometry import GeometryPlan
 
 REPSURF_CHANNEL = 10
 
@@ -26,6 +28,8 @@ class UmbrellaClassifier(nn.Module):
             cuda=args.cuda_ops)
         width = 0
         self._stage_names = []
+        self._sampling = [(st["npoint"], st["radius"], st["nsample"]) for st in stages[:-1]]
+        self.overlap_geometry = True      # FPS / ball query of every stage on a side stream (repsurf_amd.geometry)
         for i, st in enumerate(stages, 1):
             last = i == len(stages)
             sa = SurfaceAbstractionCD(
@@ -44,9 +48,18 @@ class UmbrellaClassifier(nn.Module):
 
     def forward(self, points):
         center = points[:, :3, :]
-        normal = self.surface_constructor(center)
+        plan = None
+        if self.overlap_geometry:
+            # same CPU-generator order as the reference: the constructor's flip first, then one FPS start per stage
+            sc = self.surface_constructor
+            flip = rng.draw("flip", center.shape[0], 2, center.device) if sc.random_inv else None
+            plan = GeometryPlan(center.permute(0, 2, 1).contiguous(), self._sampling)
+            normal = sc(center, flip=flip)
+        else:
+            normal = self.surface_constructor(center)
         feature = None
-        for name in self._stage_names:
-            center, normal, feature = getattr(self, name)(center, normal, feature)
+        for i, name in enumerate(self._stage_names):
+            geo = plan.stage(i) if (plan is not None and i < len(self._sampling)) else None
+            center, normal, feature = getattr(self, name)(center, normal, feature, geometry=geo)
         logits = self.classfier(feature.reshape(-1, self.head_in))
         return F.log_softmax(logits, -1)

@@ -21,13 +21,17 @@ from modules.polar_utils import xyz2sphere
 
 
 def sample_and_group(npoint, radius, nsample, center, normal, feature, return_normal=True, return_polar=False,
-                     cuda=False):
+                     cuda=False, geometry=None):
     """center (B,N,3), normal (B,N,Cn), feature (B,N,C)|None ->
-    new_center (B,S,3), new_normal (B,S,Cn), new_feature (B,S,nsample,C')   (reference :15-59)."""
-    fps_idx = farthest_point_sample(center, npoint)
-    new_center = index_points(center, fps_idx)
+    new_center (B,S,3), new_normal (B,S,Cn), new_feature (B,S,nsample,C')   (reference :15-59).
+    geometry: optional precomputed (fps_idx, new_center, idx) of this stage (repsurf_amd.geometry)."""
+    if geometry is None:
+        fps_idx = farthest_point_sample(center, npoint)
+        new_center = index_points(center, fps_idx)
+        idx = query_ball_point(radius, nsample, center, new_center)
+    else:
+        fps_idx, new_center, idx = geometry.fps_idx, geometry.new_center, geometry.idx
     new_normal = index_points(normal, fps_idx)
-    idx = query_ball_point(radius, nsample, center, new_center)
     b, s = fps_idx.shape
     if return_normal:
         rows = ops.group_features(center, new_center, normal, feature, idx, polar=return_polar)
@@ -122,7 +126,7 @@ class SurfaceAbstractionCD(nn.Module):
             self.mlp_bns.append(nn.BatchNorm2d(width))
             last = width
 
-    def forward(self, center, normal, feature):
+    def forward(self, center, normal, feature, geometry=None):
         center, normal = center.permute(0, 2, 1), normal.permute(0, 2, 1)
         feature = None if feature is None else feature.permute(0, 2, 1)
         if self.group_all:
@@ -131,7 +135,7 @@ class SurfaceAbstractionCD(nn.Module):
         else:
             new_center, new_normal, grouped = sample_and_group(
                 self.npoint, self.radius, self.nsample, center, normal, feature,
-                return_normal=self.return_normal, return_polar=self.return_polar)
+                return_normal=self.return_normal, return_polar=self.return_polar, geometry=geometry)
         b, s, ns, c = grouped.shape
         pooled = _mlp.sa_mlp_cd(grouped.reshape(b * s * ns, c), self.pos_channel, self.mlp_l0, self.bn_l0,
                                 self.mlp_f0, self.bn_f0, self.mlp_convs, self.mlp_bns, ns)
@@ -160,11 +164,10 @@ class UmbrellaSurfaceConstructor(nn.Module):
             nn.Conv2d(in_channel, in_channel, 1, bias=True),
         )
 
-    def forward(self, center):
+    def forward(self, center, flip=None):
         xyz = center.permute(0, 2, 1).contiguous()
         b, n, _ = xyz.shape
-        flip = None
-        if self.random_inv:   # per-cloud sign, CPU generator, same call as recons_utils.py:50
+        if self.random_inv and flip is None:   # per-cloud sign, CPU generator, same call as recons_utils.py:50
             flip = rng.draw("flip", b, 2, xyz.device)
         feat = ops.umbrella_features(xyz, self.k, flip)           # (B,N,k-1,10) = [centre, polar, normal, pos]
         if not self.return_dist:

@@ -721,6 +721,17 @@ extern "C" int rs_mlp_wgrad(long long rows, int ncols, int kcols, const rs_row_o
   return RS_OK;
 }
 
+extern "C" int rs_reduce_partials(int nblk, long long n, const float *partial, float *out, void *stream) {
+  RS_REQUIRE(nblk > 0 && n >= 0, "rs_reduce_partials: bad size");
+  if (n == 0) return RS_OK;
+  RS_REQUIRE(partial && out, "rs_reduce_partials: null pointer");
+  long long rb = (n + GM_THREADS - 1) / GM_THREADS;
+  if (rb > 1024) rb = 1024;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)rb), dim3(GM_THREADS), 0, (hipStream_t)stream, nblk, n, partial, out);
+  RS_CHECK_LAUNCH("rs_reduce_partials");
+  return RS_OK;
+}
+
 extern "C" int rs_bn_finalize(int c, long long rows, int nblk, const double *partial, const float *gamma,
                               const float *beta, float eps, float momentum, float *scale, float *shift,
                               float *save_mean, float *save_invstd, float *running_mean, float *running_var,

@@ -1,0 +1,79 @@
+"""Sampling/grouping geometry of all abstraction stages, issued ahead of time on a second HIP stream.
+
+FPS and ball query of every stage depend only on the input coordinates (stage i samples the centres
+stage i-1 picked), never on learned features, while the umbrella constructor (kNN + fan features +
+its MLP) also depends only on the coordinates.  FPS is a 511-step latency chain that occupies one
+workgroup per cloud — 32 of 256 CUs at B=32 — so it is launched on a side stream and runs underneath
+the constructor instead of in front of the first abstraction stage.  Under hipGraph capture the
+fork/join becomes two parallel branches of the graph.
+"""
+import torch
+
+from . import _lib, rng
+
+_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _streams:
+        _streams[key] = torch.cuda.Stream(device=device)
+    return _streams[key]
+
+
+class StageGeometry:
+    __slots__ = ("fps_idx", "new_center", "idx")
+
+    def __init__(self, fps_idx, new_center, idx):
+        self.fps_idx, self.new_center, self.idx = fps_idx, new_center, idx
+
+
+class GeometryPlan:
+    """plan = GeometryPlan(xyz (B,N,3), [(npoint, radius, nsample), ...]); plan.stage(i) joins the side stream
+    on first use and returns that stage's (fps_idx, new_center, ball idx)."""
+
+    def __init__(self, xyz, stages):
+        self.stages = []
+        self.main = torch.cuda.current_stream()
+        side = _side_stream(xyz.device)
+        b, dev = xyz.shape[0], xyz.device
+        # FPS start indices are drawn here, in stage order — after the constructor's flip, which the
+        # caller draws first — so the CPU-generator sequence is the reference's.
+        sizes = self._sizes(xyz.shape[1], stages)
+        starts = [rng.draw("fps", b, n, dev) for n in sizes]
+        # Outputs are allocated on the MAIN stream (the allocator then orders their reuse against the
+        # consumers); only the kernels run on the side stream, between a fork and a join event.
+        for (npoint, radius, nsample) in stages:
+            self.stages.append(StageGeometry(torch.empty((b, npoint), dtype=torch.int32, device=dev),
+                                             torch.empty((b, npoint, 3), dtype=torch.float32, device=dev),
+                                             torch.empty((b, npoint, nsample), dtype=torch.int32, device=dev)))
+        side.wait_stream(self.main)
+        with torch.cuda.stream(side):
+            st_ptr = side.cuda_stream
+            center, n = xyz, xyz.shape[1]
+            for (npoint, radius, nsample), start, g in zip(stages, starts, self.stages):
+                r2 = torch.tensor(float(radius) ** 2, dtype=torch.float32).item()
+                _lib.call("rs_furthestsampling", b, n, npoint, center.data_ptr(), start.data_ptr(), None,
+                          g.fps_idx.data_ptr(), st_ptr)
+                _lib.call("rs_gather_rows", b, n, npoint, 3, center.data_ptr(), g.fps_idx.data_ptr(),
+                          g.new_center.data_ptr(), st_ptr)
+                _lib.call("rs_ballquery", b, n, npoint, r2, nsample, g.new_center.data_ptr(), center.data_ptr(),
+                          g.idx.data_ptr(), st_ptr)
+                center, n = g.new_center, npoint
+            self.event = side.record_event()
+        self.keep = (xyz, starts)
+        self.joined = False
+
+    @staticmethod
+    def _sizes(n, stages):
+        out = []
+        for npoint, _, _ in stages:
+            out.append(n)
+            n = npoint
+        return out
+
+    def stage(self, i):
+        if not self.joined:
+            self.main.wait_event(self.event)
+            self.joined = True
+        return self.stages[i]

@@ -22,6 +22,7 @@ from . import _lib
 c_int, c_ll, P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
 OP_ID, OP_RELU1, OP_RELU2, OP_AFF2, OP_POOLED, OP_BCAST = range(6)
 EPI_STORE, EPI_STATS, EPI_MASK = range(3)
+FUSED_UMBRELLA = True     # 10-channel constructor MLP through csrc/umbrella_mlp.hip (False: generic row-GEMM path)
 DEBUG = None              # set to a dict to capture backward intermediates (tools/mlp_debug.py)
 PARTIAL_BLOCKS = 512      # rows of the BatchNorm partial-sum buffers (>= persistent workgroups)
 WGRAD_CHUNKS = 512        # workgroups of one weight-gradient launch (row slabs x output blocks)
@@ -366,9 +367,84 @@ class _UmbrellaStack(Function):
                 g_w2.reshape(shp[2]), g_c2)
 
 
+class UmbrellaMLPDesc(ctypes.Structure):      # rs_umbrella_mlp
+    _fields_ = [("x", P), ("rows", c_ll), ("group", c_int), ("w0", P), ("w1", P), ("b1", P), ("w2", P), ("b2", P),
+                ("bn0", P), ("bn1", P), ("c0", P), ("c1", P), ("dout", P)]
+
+
+UMB_BLOCKS = 512
+
+
+class _UmbrellaFused(Function):
+    """The 10-channel constructor MLP as six register-resident passes (csrc/umbrella_mlp.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, meta, w0, g0, b0, w1, c1, g1, b1, w2, c2):
+        dev = x.device
+        x = x.contiguous()
+        rows = x.shape[0]
+        group, aggr = meta["group"], meta["aggr"]
+        bn0, bn1 = meta["bns"]
+        w0_, w1_, w2_ = _w2d(w0), _w2d(w1), _w2d(w2)
+        c1_, c2_ = c1.detach().contiguous(), c2.detach().contiguous()
+        v0, v1 = BNVec(10, dev), BNVec(10, dev)
+        desc = UmbrellaMLPDesc(x=_ptr(x), rows=rows, group=group, w0=_ptr(w0_), w1=_ptr(w1_), b1=_ptr(c1_), w2=_ptr(w2_),
+                               b2=_ptr(c2_), bn0=_ptr(v0.scale), bn1=_ptr(v1.scale))
+        part = torch.empty((UMB_BLOCKS, 2, 10), dtype=torch.float64, device=dev)
+        for pas, bn_mod, vec in ((0, bn0, v0), (1, bn1, v1)):
+            _lib.call("rs_umbrella_mlp_pass", pas, ctypes.byref(desc), 1.0, None, part.data_ptr(), None, UMB_BLOCKS, _stream())
+            track = bn_mod.track_running_stats and bn_mod.running_mean is not None
+            if track:
+                bn_mod.num_batches_tracked.add_(1)
+            mom = bn_mod.momentum if bn_mod.momentum is not None else 0.1
+            _lib.call("rs_bn_finalize", 10, rows, UMB_BLOCKS, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
+                      float(bn_mod.eps), float(mom), _ptr(vec.scale), _ptr(vec.shift), _ptr(vec.mean), _ptr(vec.invstd),
+                      _ptr(bn_mod.running_mean) if track else None, _ptr(bn_mod.running_var) if track else None, _stream())
+        out = torch.empty((rows // group, 10), dtype=torch.float32, device=dev)
+        scale = 1.0 / group if aggr == "avg" else 1.0
+        _lib.call("rs_umbrella_mlp_pass", 2, ctypes.byref(desc), scale, _ptr(out), None, None, UMB_BLOCKS, _stream())
+        ctx.saved = dict(x=x, w0=w0_, w1=w1_, w2=w2_, c1=c1_, c2=c2_, v0=v0, v1=v1)
+        ctx.meta = meta
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s, meta = ctx.saved, ctx.meta
+        x, v0, v1 = s["x"], s["v0"], s["v1"]
+        dev = x.device
+        rows, group = x.shape[0], meta["group"]
+        dout = dout.contiguous()
+        if meta["aggr"] == "avg":
+            dout = dout * (1.0 / group)
+        desc = UmbrellaMLPDesc(x=_ptr(x), rows=rows, group=group, w0=_ptr(s["w0"]), w1=_ptr(s["w1"]), b1=_ptr(s["c1"]),
+                               w2=_ptr(s["w2"]), b2=_ptr(s["c2"]), bn0=_ptr(v0.scale), bn1=_ptr(v1.scale), dout=_ptr(dout))
+        part = torch.empty((UMB_BLOCKS, 2, 10), dtype=torch.float64, device=dev)
+        dwp = torch.empty((UMB_BLOCKS, 110), dtype=torch.float32, device=dev)
+        res = torch.empty((3, 110), dtype=torch.float32, device=dev)
+
+        def run(pas, slot):
+            _lib.call("rs_umbrella_mlp_pass", pas, ctypes.byref(desc), 1.0, None, part.data_ptr(), _ptr(dwp), UMB_BLOCKS, _stream())
+            _lib.call("rs_reduce_partials", UMB_BLOCKS, 110, _ptr(dwp), _ptr(res[slot]), _stream())
+
+        run(3, 2)
+        p1, q1, r1, g_g1, g_b1 = bwd_coeffs(10, rows, part, 2, 1, v1, dev)
+        desc.c1 = _ptr(p1)
+        run(4, 1)
+        p0, q0, r0, g_g0, g_b0 = bwd_coeffs(10, rows, part, 2, 1, v0, dev)
+        desc.c0 = _ptr(p0)
+        run(5, 0)
+        shp = meta["shapes"]
+        g_c1 = torch.zeros(10, dtype=torch.float32, device=dev)             # bias before BN: exactly 0
+        return (None, None, res[0, :100].reshape(shp[0]), g_g0, g_b0, res[1, :100].reshape(shp[1]), g_c1, g_g1, g_b1,
+                res[2, :100].reshape(shp[2]), res[2, 100:])
+
+
 def umbrella_mlp(x, mlps, group, aggr):
     conv0, bn0, _, conv1, bn1, _, conv2 = mlps
     meta = {"group": group, "aggr": aggr, "bns": (bn0, bn1), "training": bn0.training,
             "shapes": [conv0.weight.shape, conv1.weight.shape, conv2.weight.shape]}
-    return _UmbrellaStack.apply(x, meta, conv0.weight, bn0.weight, bn0.bias, conv1.weight, conv1.bias, bn1.weight,
-                                bn1.bias, conv2.weight, conv2.bias)
+    fused = (x.shape[1] == 10 and conv0.weight.shape[:2] == (10, 10) and conv1.weight.shape[:2] == (10, 10)
+             and conv2.weight.shape[:2] == (10, 10) and aggr in ("sum", "avg") and bn0.training and FUSED_UMBRELLA)
+    fn = _UmbrellaFused if fused else _UmbrellaStack
+    return fn.apply(x, meta, conv0.weight, bn0.weight, bn0.bias, conv1.weight, conv1.bias, bn1.weight,
+                    bn1.bias, conv2.weight, conv2.bias)
