@@ -194,6 +194,10 @@ typedef struct rs_mlp_epilogue {
   const float *my1; long long ldm1; const float *ms1, *mt1, *mean1, *invstd1;
   const float *my2; long long ldm2; const float *ms2, *mt2, *mean2, *invstd2;
   double *partial; int partial_blocks;   /* rows of the partial buffer (unused ones are zeroed) */
+  /* optional fused max-pool over groups of pool_ns consecutive rows (0 = off): raw extremes of `out`
+   * per (group, column) and their positions, resolved by rs_pool_select once BatchNorm's scale is known.
+   * pool_ns must divide 64 / 32 / 16 for cols > 64 / > 32 / <= 32. */
+  int pool_ns; float *pool_max, *pool_min; int *pool_amax, *pool_amin;
 } rs_mlp_epilogue;
 
 /* out[rows, cols] = E[rows, kdim] . B,  B[k][n] = w[k*ldw + n]: weights are passed k-major (the conv
@@ -227,6 +231,10 @@ int rs_bn_backward_finalize(int c, long long rows, int nblk, int nstat, int whic
  * scale/shift may be NULL (identity). */
 int rs_pool_max(long long groups, int nsample, int c, int relu, const float *y, const float *scale,
                 const float *shift, float *out, int *arg, void *stream);
+/* Resolves the fused pooling of rs_mlp_gemm_rows: out = relu(scale * (scale >= 0 ? ymax : ymin) + shift),
+ * arg = the matching position. */
+int rs_pool_select(long long groups, int c, const float *ymax, const float *ymin, const int *amax,
+                   const int *amin, const float *scale, const float *shift, float *out, int *arg, void *stream);
 /* v = dout * (out > 0) and the BatchNorm-backward sums of the pooled layer from (groups, c) data only:
  * partial (partial_blocks, 2, c) = {sum v, sum v * yhat[arg row]}. */
 int rs_pool_max_backward(long long groups, int nsample, int c, const float *dout, const float *out,

@@ -102,18 +102,33 @@ group_tail_kernel(long long rows, int per_cloud_rows, int n, int cf, int c0, int
   }
 }
 
-// backward of the gathered channels [c0, c0+cw) of a (rows, ctot) gradient tile
+// backward of the gathered channels [c0, c0+cw) of a (rows, ctot) gradient tile.
+// A ball-query row lists its real neighbours once (ascending indices) and then repeats the FIRST one
+// up to nsample (classification/modules/pointnet2_utils.py:92-94) — 70-90 % of the slots at the model's radii.
+// One thread owns (group, channel): gradients of all slots that point at the first neighbour are summed in
+// a register and leave as ONE atomic; only the remaining distinct neighbours cost an atomic each.
 __global__ void __launch_bounds__(GR_THREADS)
-group_scatter_kernel(long long rows, int per_cloud_rows, int n, int cw, int c0, int ctot,
+group_scatter_kernel(long long groups, int nsample, int groups_per_cloud, int n, int cw, int c0, int ctot,
                      const float *__restrict__ grad_out, const int *__restrict__ idx,
                      float *__restrict__ grad_src) {
-  const long long total = rows * cw;
+  const long long total = groups * cw;
   for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total;
        e += (long long)gridDim.x * GR_THREADS) {
-    const long long r = e / cw;
-    const int ch = (int)(e - r * cw);
-    const long long cloud = r / per_cloud_rows;
-    atomicAdd(grad_src + (cloud * n + idx[r]) * cw + ch, grad_out[r * ctot + c0 + ch]);
+    const long long g = e / cw;
+    const int ch = (int)(e - g * cw);
+    const long long cloud = g / groups_per_cloud;
+    const int *row = idx + g * nsample;
+    const float *go = grad_out + g * nsample * ctot + c0 + ch;
+    float *dst = grad_src + cloud * n * cw + ch;
+    const int first = row[0];
+    float acc = go[0];
+    for (int k = 1; k < nsample; ++k) {
+      const int p = row[k];
+      const float v = go[(long long)k * ctot];
+      if (p == first) acc += v;
+      else atomicAdd(dst + (long long)p * cw, v);
+    }
+    atomicAdd(dst + (long long)first * cw, acc);
   }
 }
 
@@ -224,12 +239,13 @@ extern "C" int rs_group_features_backward(int b, int n, int m, int nsample, int 
   RS_REQUIRE(grad_out && idx, "rs_group_features_backward: null pointer");
   const int cpos = polar ? 6 : 3, ctot = cpos + cn + cf;
   hipStream_t st = (hipStream_t)stream;
+  const long long groups = (long long)b * m;
   if (grad_normal && cn > 0)
-    hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(rows * cn)), dim3(GR_THREADS), 0, st, rows,
-                       m * nsample, n, cn, cpos, ctot, grad_out, idx, grad_normal);
+    hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(groups * cn)), dim3(GR_THREADS), 0, st, groups, nsample,
+                       m, n, cn, cpos, ctot, grad_out, idx, grad_normal);
   if (grad_feature && cf > 0)
-    hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(rows * cf)), dim3(GR_THREADS), 0, st, rows,
-                       m * nsample, n, cf, cpos + cn, ctot, grad_out, idx, grad_feature);
+    hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(groups * cf)), dim3(GR_THREADS), 0, st, groups, nsample,
+                       m, n, cf, cpos + cn, ctot, grad_out, idx, grad_feature);
   RS_CHECK_LAUNCH("rs_group_features_backward");
   return RS_OK;
 }

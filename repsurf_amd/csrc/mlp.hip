@@ -305,6 +305,27 @@ gemm_rows_kernel(long long rows, int kdim, int cols, RowOperand E, const float *
         st[0][e] += (double)s0[e]; st[1][e] += (double)s1[e]; st[2][e] += (double)s2[e];
       }
     }
+    if (ep.pool_ns > 0) {
+      // Max-pool over nsample folded into the producing GEMM: BatchNorm's scale is not known yet (its
+      // statistics are still being summed), so keep the raw extremes of y per (group, column) — the
+      // pooled activation is relu(scale * (scale >= 0 ? max : min) + shift), resolved by rs_pool_select.
+      constexpr int TPC = GM_THREADS / BN, RPT = GM_BM / TPC;     // threads per column, rows per thread
+      const int c = tid % BN, part = tid / BN, col = n0 + c;
+      if (col < cols) {
+        const float bb = ep.bias ? ep.bias[col] : 0.f;
+        for (int g0 = part * RPT; g0 < (part + 1) * RPT && r0 + g0 < rows; g0 += ep.pool_ns) {
+          float mx = -INFINITY, mn = INFINITY;
+          int ax = 0, an = 0;
+          for (int k = 0; k < ep.pool_ns; ++k) {
+            const float v = Cs[(g0 + k) * BN + c] + bb;
+            if (v > mx) { mx = v; ax = k; }
+            if (v < mn) { mn = v; an = k; }
+          }
+          const long long o = ((r0 + g0) / ep.pool_ns) * cols + col;
+          ep.pool_max[o] = mx; ep.pool_min[o] = mn; ep.pool_amax[o] = ax; ep.pool_amin[o] = an;
+        }
+      }
+    }
     __syncthreads();   // C tile consumed before the next tile's staging overwrites it
   }
 
@@ -440,13 +461,34 @@ wgrad_kernel(long long rows, int ncols, int kcols, RowOperand P, RowOperand Q, l
     }
 }
 
-// out[e] = sum_c partial[c][e]   (deterministic order)
+// out[e] = sum_c partial[c][e]   (deterministic order).  32 outputs x 8 chunk slices per workgroup:
+// consecutive lanes read consecutive outputs (coalesced), each thread sums every 8th chunk with
+// independent loads in flight, slices are combined in a fixed order through LDS.
 __global__ void __launch_bounds__(GM_THREADS)
 reduce_partials_kernel(int chunks, long long n, const float *__restrict__ partial, float *__restrict__ out) {
-  for (long long e = (long long)blockIdx.x * GM_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * GM_THREADS) {
+  __shared__ float red[8][32];
+  const int ex = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (long long e0 = (long long)blockIdx.x * 32; e0 < n; e0 += (long long)gridDim.x * 32) {
+    const long long e = e0 + ex;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += partial[(long long)c * n + e];
-    out[e] = s;
+    if (e < n) {
+      int c = sl;
+      for (; c + 24 < chunks; c += 32) {
+        const float a0 = partial[(long long)c * n + e], a1 = partial[(long long)(c + 8) * n + e];
+        const float a2 = partial[(long long)(c + 16) * n + e], a3 = partial[(long long)(c + 24) * n + e];
+        s += (a0 + a1) + (a2 + a3);
+      }
+      for (; c < chunks; c += 8) s += partial[(long long)c * n + e];
+    }
+    red[sl][ex] = s;
+    __syncthreads();
+    if (sl == 0 && e < n) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k][ex];
+      out[e] = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -529,6 +571,21 @@ pool_max_kernel(long long groups, int ns, int c, int relu, const float *__restri
       if (z > best) { best = z; bi = k; }
     }
     out[e] = best; arg[e] = bi;
+  }
+}
+
+// out = relu(scale * (scale >= 0 ? ymax : ymin) + shift), arg = matching index (resolves the fused pooling)
+__global__ void __launch_bounds__(GM_THREADS)
+pool_select_kernel(long long groups, int c, const float *__restrict__ ymax, const float *__restrict__ ymin,
+                   const int *__restrict__ amax, const int *__restrict__ amin, const float *__restrict__ scale,
+                   const float *__restrict__ shift, float *__restrict__ out, int *__restrict__ arg) {
+  const long long total = groups * c;
+  for (long long e = (long long)blockIdx.x * GM_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GM_THREADS) {
+    const int ch = (int)(e % c);
+    const float s = scale[ch];
+    const bool up = s >= 0.f;
+    out[e] = fmaxf(fmaf(s, up ? ymax[e] : ymin[e], shift[ch]), 0.f);
+    arg[e] = up ? amax[e] : amin[e];
   }
 }
 
@@ -672,6 +729,12 @@ extern "C" int rs_mlp_gemm_rows(long long rows, int kdim, int cols, const rs_row
   if (epi_mode == EPI_MASK) RS_REQUIRE(ep.my1 && ep.ms1 && ep.mt1 && ep.mean1 && ep.invstd1, "rs_mlp_gemm_rows: mask epilogue needs the producing layer's y/scale/shift/mean/invstd");
   if (epi_mode == EPI_MASK && ep.my2) RS_REQUIRE(ep.ms2 && ep.mt2 && ep.mean2 && ep.invstd2, "rs_mlp_gemm_rows: second mask branch incomplete");
   if (epi_mode != EPI_MASK) { ep.my1 = nullptr; ep.my2 = nullptr; }
+  if (ep.pool_ns > 0) {
+    RS_REQUIRE(ep.pool_max && ep.pool_min && ep.pool_amax && ep.pool_amin, "rs_mlp_gemm_rows: fused pooling needs its four outputs");
+    const int rpt = GM_BM / (GM_THREADS / (cols <= 32 ? 32 : (cols <= 64 ? 64 : 128)));
+    RS_REQUIRE(rows % ep.pool_ns == 0 && rpt % ep.pool_ns == 0,
+               "rs_mlp_gemm_rows: fused pooling needs nsample (%d) to divide %d rows per thread", ep.pool_ns, rpt);
+  }
   const int nstat = (epi_mode == EPI_MASK && ep.my2) ? 3 : 2;
   const long long tiles = (rows + GM_BM - 1) / GM_BM;
   const int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
@@ -714,8 +777,8 @@ extern "C" int rs_mlp_wgrad(long long rows, int ncols, int kcols, const rs_row_o
     launch_wgrad<4, 1, 1, 1>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, ncols, kcols, P, Q, rpc, partial);
   }
   const long long n = (long long)ncols * kcols;
-  long long rb = (n + GM_THREADS - 1) / GM_THREADS;
-  if (rb > 1024) rb = 1024;
+  long long rb = (n + 31) / 32;
+  if (rb > 2048) rb = 2048;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)rb), dim3(GM_THREADS), 0, st, chunks, n, partial, dw);
   RS_CHECK_LAUNCH("rs_mlp_wgrad");
   return RS_OK;
@@ -725,8 +788,8 @@ extern "C" int rs_reduce_partials(int nblk, long long n, const float *partial, f
   RS_REQUIRE(nblk > 0 && n >= 0, "rs_reduce_partials: bad size");
   if (n == 0) return RS_OK;
   RS_REQUIRE(partial && out, "rs_reduce_partials: null pointer");
-  long long rb = (n + GM_THREADS - 1) / GM_THREADS;
-  if (rb > 1024) rb = 1024;
+  long long rb = (n + 31) / 32;
+  if (rb > 2048) rb = 2048;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)rb), dim3(GM_THREADS), 0, (hipStream_t)stream, nblk, n, partial, out);
   RS_CHECK_LAUNCH("rs_reduce_partials");
   return RS_OK;
@@ -767,6 +830,20 @@ extern "C" int rs_pool_max(long long groups, int nsample, int c, int relu, const
   hipLaunchKernelGGL(pool_max_kernel, dim3((int)blocks), dim3(GM_THREADS), 0, (hipStream_t)stream, groups, nsample, c,
                      relu, y, scale, shift, out, arg);
   RS_CHECK_LAUNCH("rs_pool_max");
+  return RS_OK;
+}
+
+extern "C" int rs_pool_select(long long groups, int c, const float *ymax, const float *ymin, const int *amax,
+                              const int *amin, const float *scale, const float *shift, float *out, int *arg,
+                              void *stream) {
+  RS_REQUIRE(groups >= 0 && c >= 0, "rs_pool_select: bad size");
+  if (groups == 0 || c == 0) return RS_OK;
+  RS_REQUIRE(ymax && ymin && amax && amin && scale && shift && out && arg, "rs_pool_select: null pointer");
+  long long blocks = (groups * c + GM_THREADS - 1) / GM_THREADS;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pool_select_kernel, dim3((int)blocks), dim3(GM_THREADS), 0, (hipStream_t)stream, groups, c, ymax, ymin,
+                     amax, amin, scale, shift, out, arg);
+  RS_CHECK_LAUNCH("rs_pool_select");
   return RS_OK;
 }
 

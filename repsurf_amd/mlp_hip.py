@@ -37,20 +37,36 @@ class Epilogue(ctypes.Structure):            # rs_mlp_epilogue
     _fields_ = [("bias", P), ("out", P), ("ldo", c_ll), ("mode", c_int),
                 ("my1", P), ("ldm1", c_ll), ("ms1", P), ("mt1", P), ("mean1", P), ("invstd1", P),
                 ("my2", P), ("ldm2", c_ll), ("ms2", P), ("mt2", P), ("mean2", P), ("invstd2", P),
-                ("partial", P), ("partial_blocks", c_int)]
+                ("partial", P), ("partial_blocks", c_int),
+                ("pool_ns", c_int), ("pool_max", P), ("pool_min", P), ("pool_amax", P), ("pool_amin", P)]
 
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _ptr(t, offset=0):
-    return None if t is None else t.data_ptr() + 4 * offset
+class _ZeroPool:
+    """Exact-zero gradients of the biases that feed a BatchNorm: one fill kernel per backward, sliced
+    (distinct memory per parameter, so an in-place gradient op downstream cannot alias)."""
+
+    def __init__(self, total, device):
+        self.buf = torch.zeros(total, dtype=torch.float32, device=device)
+        self.used = 0
+
+    def take(self, n):
+        out = self.buf[self.used:self.used + n]
+        self.used += n
+        return out
 
 
-def operand(mode, a, lda, b=None, ldb=0, s1=None, t1=None, s2=None, t2=None, arg=None, ns=1, a_off=0):
-    return RowOperand(_ptr(a, a_off), lda, _ptr(b), ldb, _ptr(s1), _ptr(t1), _ptr(s2), _ptr(t2),
-                      None if arg is None else arg.data_ptr(), ns, mode)
+_pending_counters = []
+
+
+def _flush_counters():
+    """num_batches_tracked += 1 for every BatchNorm of the stack in ONE multi-tensor kernel."""
+    if _pending_counters:
+        torch._foreach_add_(_pending_counters, 1)
+        _pending_counters.clear()
 
 
 class BNVec:
@@ -83,23 +99,46 @@ def gemm_rows(rows, kdim, cols, x_op, wk, epi):
               ctypes.byref(epi), _stream())
 
 
-def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device):
-    """y = E . W^T + bias with BN statistics; returns (y, BNVec)."""
+def fused_pool_ok(cout, nsample):
+    """the row GEMM can fold the max over nsample into its epilogue when whole groups sit in one thread's rows"""
+    rows_per_thread = 128 // (256 // (32 if cout <= 32 else (64 if cout <= 64 else 128)))
+    return rows_per_thread % nsample == 0
+
+
+def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0):
+    """y = E . W^T + bias with BN statistics; returns (y, BNVec[, pooled (out, arg)])."""
     cout = w2d.shape[0]
     y = torch.empty((rows, cout), dtype=torch.float32, device=device)
     vec = BNVec(cout, device)
+    pool = None
     if training:
         part = torch.empty((PARTIAL_BLOCKS, 2, cout), dtype=torch.float64, device=device)
         epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STATS, partial=part.data_ptr(),
                        partial_blocks=PARTIAL_BLOCKS)
+        if pool_ns:
+            groups = rows // pool_ns
+            ext = torch.empty((2, groups, cout), dtype=torch.float32, device=device)
+            pos = torch.empty((2, groups, cout), dtype=torch.int32, device=device)
+            epi.pool_ns = pool_ns
+            epi.pool_max, epi.pool_min = _ptr(ext[0]), _ptr(ext[1])
+            epi.pool_amax, epi.pool_amin = pos[0].data_ptr(), pos[1].data_ptr()
+            pool = (ext, pos)
         gemm_rows(rows, kdim, cout, x_op, _kmajor(w2d), epi)
         track = bn_mod.track_running_stats and bn_mod.running_mean is not None
         if track:
-            bn_mod.num_batches_tracked.add_(1)
+            _pending_counters.append(bn_mod.num_batches_tracked)
         mom = bn_mod.momentum if bn_mod.momentum is not None else 0.1
         _lib.call("rs_bn_finalize", cout, rows, PARTIAL_BLOCKS, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
                   float(bn_mod.eps), float(mom), _ptr(vec.scale), _ptr(vec.shift), _ptr(vec.mean), _ptr(vec.invstd),
                   _ptr(bn_mod.running_mean) if track else None, _ptr(bn_mod.running_var) if track else None, _stream())
+        if pool is not None:
+            ext, pos = pool
+            groups = rows // pool_ns
+            out = torch.empty((groups, cout), dtype=torch.float32, device=device)
+            arg = torch.empty((groups, cout), dtype=torch.int32, device=device)
+            _lib.call("rs_pool_select", groups, cout, _ptr(ext[0]), _ptr(ext[1]), pos[0].data_ptr(), pos[1].data_ptr(),
+                      _ptr(vec.scale), _ptr(vec.shift), _ptr(out), arg.data_ptr(), _stream())
+            return y, vec, (out, arg)
     else:
         epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STORE)
         gemm_rows(rows, kdim, cout, x_op, _kmajor(w2d), epi)
@@ -182,15 +221,22 @@ class _SAStack(Function):
             prev_op = operand(OP_ID, x, cx)
             prev_c = cx
             pi, bi = 0, 0
+        pooled = None
         while pi < len(params):
             w, b = params[pi], params[pi + 1]
             w2 = _w2d(w)
-            y, vec = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev)
+            last = pi + 4 >= len(params)
+            if last and training and fused_pool_ok(w2.shape[0], ns):
+                y, vec, pooled = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, pool_ns=ns)
+            else:
+                y, vec = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev)
             ys.append(y); vecs.append(vec); w2ds.append(w2)
             prev_op = operand(OP_RELU1, y, y.shape[1], s1=vec.scale, t1=vec.shift)
             prev_c = w2.shape[0]
             pi += 4; bi += 1
-        if ys:
+        if pooled is not None:
+            out, arg = pooled
+        elif ys:
             y_last, v_last = ys[-1], vecs[-1]
             out = torch.empty((groups, prev_c), dtype=torch.float32, device=dev)
             arg = torch.empty((groups, prev_c), dtype=torch.int32, device=dev)
@@ -199,6 +245,7 @@ class _SAStack(Function):
         else:
             raise NotImplementedError("a stack needs at least one layer after the first")
         saved.update(ys=ys, vecs=vecs, w2ds=w2ds, out=out, arg=arg)
+        _flush_counters()
         ctx.saved = saved
         ctx.meta = meta
         ctx.nparams = len(params)
@@ -218,6 +265,7 @@ class _SAStack(Function):
         dout = dout.contiguous()
         grads = [None] * ctx.nparams
         nl = len(ys)
+        zeros = _ZeroPool(sum(w.shape[0] for w in w2ds) + (2 * s["wl2"].shape[0] if pos > 0 else 0), dev)
         first = 8 if pos > 0 else 0
         # ---- pooled layer: BN-backward sums from (groups, c) data only
         c_last = ys[-1].shape[1]
@@ -232,7 +280,7 @@ class _SAStack(Function):
             pidx = first + 4 * li
             cout, cin = w2ds[li].shape
             grads[pidx + 2], grads[pidx + 3] = dg, db
-            grads[pidx + 1] = torch.zeros(cout, dtype=torch.float32, device=dev)      # bias before BN: exactly 0
+            grads[pidx + 1] = zeros.take(cout)      # bias before BN: exactly 0
             # the activation that fed this layer, rebuilt on the fly from the stored conv outputs
             if li > 0:
                 q_op = operand(OP_RELU1, ys[li - 1], cin, s1=vecs[li - 1].scale, t1=vecs[li - 1].shift)
@@ -260,8 +308,8 @@ class _SAStack(Function):
                 opf = operand(OP_AFF2, dz, cin, s["yf"], cin, s1=pf, t1=rf, s2=qf)
                 grads[0] = wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev)
                 grads[4] = wgrad(rows, cin, cx - pos, opf, operand(OP_ID, x, cx, a_off=pos), dev)
-                grads[1] = torch.zeros(cin, dtype=torch.float32, device=dev)
-                grads[5] = torch.zeros(cin, dtype=torch.float32, device=dev)
+                grads[1] = zeros.take(cin)
+                grads[5] = zeros.take(cin)
                 grads[2], grads[3], grads[6], grads[7] = dgl, dbl, dgf, dbf
                 if ctx.needs_input_grad[0]:     # only the feature channels carry a gradient
                     dx = torch.zeros((rows, cx), dtype=torch.float32, device=dev)
@@ -329,6 +377,7 @@ class _UmbrellaStack(Function):
                 out.mul_(1.0 / group)
         ctx.saved = dict(x=x, y0=y0, v0=v0, y1=y1, v1=v1, y2=y2, w0=w0_, w1=w1_, w2=w2_, arg=arg)
         ctx.meta = meta
+        _flush_counters()
         return out
 
     @staticmethod
@@ -395,7 +444,7 @@ class _UmbrellaFused(Function):
             _lib.call("rs_umbrella_mlp_pass", pas, ctypes.byref(desc), 1.0, None, part.data_ptr(), None, UMB_BLOCKS, _stream())
             track = bn_mod.track_running_stats and bn_mod.running_mean is not None
             if track:
-                bn_mod.num_batches_tracked.add_(1)
+                _pending_counters.append(bn_mod.num_batches_tracked)
             mom = bn_mod.momentum if bn_mod.momentum is not None else 0.1
             _lib.call("rs_bn_finalize", 10, rows, UMB_BLOCKS, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
                       float(bn_mod.eps), float(mom), _ptr(vec.scale), _ptr(vec.shift), _ptr(vec.mean), _ptr(vec.invstd),
@@ -405,6 +454,7 @@ class _UmbrellaFused(Function):
         _lib.call("rs_umbrella_mlp_pass", 2, ctypes.byref(desc), scale, _ptr(out), None, None, UMB_BLOCKS, _stream())
         ctx.saved = dict(x=x, w0=w0_, w1=w1_, w2=w2_, c1=c1_, c2=c2_, v0=v0, v1=v1)
         ctx.meta = meta
+        _flush_counters()
         return out
 
     @staticmethod
