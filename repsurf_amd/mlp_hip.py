@@ -45,6 +45,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _ptr(t, offset=0):
+    return None if t is None else t.data_ptr() + 4 * offset
+
+
+def operand(mode, a, lda, b=None, ldb=0, s1=None, t1=None, s2=None, t2=None, arg=None, ns=1, a_off=0):
+    return RowOperand(_ptr(a, a_off), lda, _ptr(b), ldb, _ptr(s1), _ptr(t1), _ptr(s2), _ptr(t2),
+                      None if arg is None else arg.data_ptr(), ns, mode)
+
+
 class _ZeroPool:
     """Exact-zero gradients of the biases that feed a BatchNorm: one fill kernel per backward, sliced
     (distinct memory per parameter, so an in-place gradient op downstream cannot alias)."""
