@@ -81,8 +81,10 @@ int rs_gather_rows_backward(int b, int n, int m, int c, const float *grad_out, c
  * first nsample inside points in ascending index order, padded with the first.
  * A centre with an empty ball gets zeros (the CUDA kernel's pre-zeroed rows;
  * the CPU path would index out of range).  idx: (b, m, nsample) int32. */
+/* cnt (optional, (b, m) int32): number of DISTINCT neighbours in each row, min(hits, nsample), at least 1;
+ * slots [cnt, nsample) are the padding copies of slot 0 (input of rs_group_features_compact). */
 int rs_ballquery(int b, int n, int m, float radius2, int nsample, const float *new_xyz,
-                 const float *xyz, int *idx, void *stream);
+                 const float *xyz, int *idx, int *cnt, void *stream);
 
 /* ---- kNN ----------------------------------------------------------------
  * Replaces knnquery_cuda_launcher(b,n,m,nsample,xyz,new_xyz,idx,dist2,stream)
@@ -132,6 +134,22 @@ int rs_group_features(int b, int n, int m, int nsample, int cn, int cf, int pola
 int rs_group_features_backward(int b, int n, int m, int nsample, int cn, int cf, int polar,
                                const float *grad_out, const int *idx, float *grad_normal,
                                float *grad_feature, void *stream);
+/* Compacted form of rs_group_features: a ball-query row is cnt distinct neighbours followed by copies of the
+ * first one (classification/modules/pointnet2_utils.py:92-94) and the shared MLP maps equal rows to equal outputs, so
+ * only the distinct slots are materialised.  rows of group g = [offsets[g], offsets[g+1]) with
+ * offsets = exclusive scan of cnt (rs_exclusive_scan; offsets[b*m] = total rows, consumed on the device).
+ * Outputs (capacity b*m*nsample rows): out (rows, ctot), mult[row] = copies the row stands for
+ * (nsample-cnt+1 for slot 0, else 1), grp[row], slot[row], src[row] = cloud*n + idx (gather/scatter address). */
+int rs_exclusive_scan(int n, const int *in, int *out, void *stream);
+int rs_group_features_compact(int b, int n, int m, int nsample, int cn, int cf, int polar,
+                              const float *center, const float *new_center, const float *normal,
+                              const float *feature, const int *idx, const int *cnt, const int *offsets,
+                              float *out, float *mult, int *grp, int *slot, int *src, void *stream);
+/* grad_normal / grad_feature [src[row], :] += grad_out[row, gathered channels] for row < *rows_dev
+ * (gradients of the copies are already summed per row: one atomic per distinct neighbour). */
+int rs_group_features_compact_backward(long long capacity, const int *rows_dev, int cn, int cf, int polar,
+                                       const float *grad_out, const int *src, float *grad_normal,
+                                       float *grad_feature, void *stream);
 /* group_all variant (sample_and_group_all, repsurface_utils.py:62-88):
  * row (b, j) = [center (3), polar of center (3, if polar), normal (cn), feature (cf)]. */
 int rs_group_all_features(int b, int n, int cn, int cf, int polar, const float *center,
@@ -181,6 +199,11 @@ typedef struct rs_row_operand {
   const float *s1, *t1, *s2, *t2;
   const int *arg; int ns;
   int mode;
+  /* Compacted groups (duplicate ball-query slots removed, see rs_group_features_compact):
+   * mult[r] = number of identical copies row r stands for (NULL = 1): RS_OP_AFF2 / RS_OP_POOLED become
+   * E = s1*dz + mult*(s2*b + t1) with dz the gradient already summed over the copies;
+   * grp[r], slot[r] = group and position of row r (RS_OP_POOLED with ragged groups; NULL = r/ns, r%ns). */
+  const float *mult; const int *grp; const int *slot;
 } rs_row_operand;
 
 enum {
@@ -198,18 +221,21 @@ typedef struct rs_mlp_epilogue {
    * per (group, column) and their positions, resolved by rs_pool_select once BatchNorm's scale is known.
    * pool_ns must divide 64 / 32 / 16 for cols > 64 / > 32 / <= 32. */
   int pool_ns; float *pool_max, *pool_min; int *pool_amax, *pool_amin;
+  const float *row_mult;   /* RS_EPI_STATS: per-row weight of the sums (copies a compacted row stands for; NULL = 1) */
 } rs_mlp_epilogue;
 
 /* out[rows, cols] = E[rows, kdim] . B,  B[k][n] = w[k*ldw + n]: weights are passed k-major (the conv
  * weight transposed for forward, as stored for the data gradient dY . W), base 16-byte aligned,
  * ldw % 4 == 0, columns [cols, ldw) zero. */
-int rs_mlp_gemm_rows(long long rows, int kdim, int cols, const rs_row_operand *x, const float *w, int ldw,
-                     const rs_mlp_epilogue *epi, void *stream);
+/* rows_dev (optional, device int): actual row count of a compacted operand — read by the kernel, never by the
+ * host; `rows` is then the capacity of the buffers. */
+int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
+                     const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream);
 
 /* Weight gradient dw[ncols][kcols] = sum_r P[r][n] * Q[r][k]; rows are split into `chunks` workgroup
  * slabs whose partial products land in partial (chunks, ncols*kcols) and are summed in a fixed order. */
-int rs_mlp_wgrad(long long rows, int ncols, int kcols, const rs_row_operand *p, const rs_row_operand *q,
-                 float *partial, int chunks, float *dw, void *stream);
+int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
+                 const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream);
 
 /* BatchNorm statistics -> affine: from partial (nblk, 2, c) {sum, sumsq} over `rows` rows:
  * mean, biased var, scale = gamma/sqrt(var+eps), shift = beta - mean*scale; saves mean/invstd and,
@@ -229,16 +255,18 @@ int rs_bn_backward_finalize(int c, long long rows, int nblk, int nstat, int whic
 /* out[g][c] = max_k f(scale*y[g*nsample+k][c] + shift), f = relu when `relu` != 0, arg = first k
  * attaining it (torch.max(new_feature, 2)[0] fused with the last BatchNorm + ReLU, :243-244);
  * scale/shift may be NULL (identity). */
-int rs_pool_max(long long groups, int nsample, int c, int relu, const float *y, const float *scale,
-                const float *shift, float *out, int *arg, void *stream);
+/* offsets (optional, (groups+1) int32): ragged groups of a compacted row set (rows [offsets[g], offsets[g+1]));
+ * NULL = dense groups of nsample rows. */
+int rs_pool_max(long long groups, int nsample, int c, int relu, const int *offsets, const float *y,
+                const float *scale, const float *shift, float *out, int *arg, void *stream);
 /* Resolves the fused pooling of rs_mlp_gemm_rows: out = relu(scale * (scale >= 0 ? ymax : ymin) + shift),
  * arg = the matching position. */
 int rs_pool_select(long long groups, int c, const float *ymax, const float *ymin, const int *amax,
                    const int *amin, const float *scale, const float *shift, float *out, int *arg, void *stream);
 /* v = dout * (out > 0) and the BatchNorm-backward sums of the pooled layer from (groups, c) data only:
  * partial (partial_blocks, 2, c) = {sum v, sum v * yhat[arg row]}. */
-int rs_pool_max_backward(long long groups, int nsample, int c, const float *dout, const float *out,
-                         const int *arg, const float *y, const float *mean, const float *invstd,
+int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout,
+                         const float *out, const int *arg, const float *y, const float *mean, const float *invstd,
                          float *v, double *partial, int partial_blocks, void *stream);
 /* out[g][c] = sum_k y[g*nsample+k][c]   (umbrella aggregation 'sum', :305) */
 int rs_pool_sum(long long groups, int nsample, int c, const float *y, float *out, void *stream);

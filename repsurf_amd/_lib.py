@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librepsurf_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -20,24 +20,27 @@ SIGNATURES = {
     "rs_furthestsampling_offset": [c_int, c_int, P, P, P, P, P, P],
     "rs_gather_rows": [c_int, c_int, c_int, c_int, P, P, P, P],
     "rs_gather_rows_backward": [c_int, c_int, c_int, c_int, P, P, P, P],
-    "rs_ballquery": [c_int, c_int, c_int, c_float, c_int, P, P, P, P],
+    "rs_ballquery": [c_int, c_int, c_int, c_float, c_int, P, P, P, P, P],
     "rs_knnquery": [c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_knnquery_offset": [c_int, c_int, P, P, P, P, c_int, P, P, P],
     "rs_umbrella_features": [c_int, c_int, c_int, P, P, P, P, P],
     "rs_group_features": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
     "rs_group_features_backward": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_group_all_features": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "rs_exclusive_scan": [c_int, P, P, P],
+    "rs_group_features_compact": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "rs_group_features_compact_backward": [c_ll, P, c_int, c_int, c_int, P, P, P, P, P],
     "rs_group_rows": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "rs_group_rows_backward": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "rs_three_nn": [c_int, c_int, c_int, P, P, P, P, P],
     "rs_three_interpolate": [c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_three_interpolate_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P],
-    "rs_mlp_gemm_rows": [c_ll, c_int, c_int, P, P, c_int, P, P],
-    "rs_mlp_wgrad": [c_ll, c_int, c_int, P, P, P, c_int, P, P],
+    "rs_mlp_gemm_rows": [c_ll, P, c_int, c_int, P, P, c_int, P, P],
+    "rs_mlp_wgrad": [c_ll, P, c_int, c_int, P, P, P, c_int, P, P],
     "rs_bn_finalize": [c_int, c_ll, c_int, P, P, P, c_float, c_float, P, P, P, P, P, P, P],
     "rs_bn_backward_finalize": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P],
-    "rs_pool_max": [c_ll, c_int, c_int, c_int, P, P, P, P, P, P],
-    "rs_pool_max_backward": [c_ll, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P],
+    "rs_pool_max": [c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P],
+    "rs_pool_max_backward": [c_ll, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, P],
     "rs_pool_sum": [c_ll, c_int, c_int, P, P, P],
     "rs_pool_select": [c_ll, c_int, P, P, P, P, P, P, P, P, P],
     "rs_reduce_partials": [c_int, c_ll, P, P, P],

@@ -129,6 +129,9 @@ class SurfaceAbstractionCD(nn.Module):
     def forward(self, center, normal, feature, geometry=None):
         center, normal = center.permute(0, 2, 1), normal.permute(0, 2, 1)
         feature = None if feature is None else feature.permute(0, 2, 1)
+        if (not self.group_all and self.return_normal and _mlp.COMPACT_GROUPS and _mlp.BACKEND == "hip"
+                and self.bn_l0.training):
+            return self._forward_compact(center, normal, feature, geometry)
         if self.group_all:
             new_center, new_normal, grouped = sample_and_group_all(
                 center, normal, feature, return_normal=self.return_normal, return_polar=self.return_polar)
@@ -140,6 +143,25 @@ class SurfaceAbstractionCD(nn.Module):
         pooled = _mlp.sa_mlp_cd(grouped.reshape(b * s * ns, c), self.pos_channel, self.mlp_l0, self.bn_l0,
                                 self.mlp_f0, self.bn_f0, self.mlp_convs, self.mlp_bns, ns)
         return new_center.permute(0, 2, 1), new_normal.permute(0, 2, 1), pooled.view(b, s, -1).permute(0, 2, 1)
+
+
+def _sa_forward_compact(self, center, normal, feature, geometry):
+    """sample_and_group + shared MLP on the distinct ball-query slots only (ops.CompactGroups)."""
+    if geometry is None:
+        fps_idx = farthest_point_sample(center, self.npoint)
+        new_center = index_points(center, fps_idx)
+        idx, cnt = ops.ballquery(self.radius, self.nsample, center, new_center, return_count=True)
+    else:
+        fps_idx, new_center, idx, cnt = geometry.fps_idx, geometry.new_center, geometry.idx, geometry.cnt
+    new_normal = index_points(normal, fps_idx)
+    groups = ops.group_features_compact(center, new_center, normal, feature, idx, cnt, polar=self.return_polar)
+    pooled = _mlp.sa_mlp_cd(groups.x, self.pos_channel, self.mlp_l0, self.bn_l0, self.mlp_f0, self.bn_f0,
+                            self.mlp_convs, self.mlp_bns, self.nsample, compact=groups)
+    b, s = fps_idx.shape
+    return new_center.permute(0, 2, 1), new_normal.permute(0, 2, 1), pooled.view(b, s, -1).permute(0, 2, 1)
+
+
+SurfaceAbstractionCD._forward_compact = _sa_forward_compact
 
 
 class UmbrellaSurfaceConstructor(nn.Module):

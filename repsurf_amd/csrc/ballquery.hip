@@ -34,7 +34,7 @@ template <bool USE_LDS>
 __global__ void __launch_bounds__(BQ_THREADS)
 ballquery_kernel(int b, int n, int m, float radius2, int nsample, int qpw, int blocks_per_cloud,
                  const float *__restrict__ new_xyz, const float *__restrict__ xyz,
-                 int *__restrict__ idx) {
+                 int *__restrict__ idx, int *__restrict__ cnt_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *sx = lds, *sy = lds + n, *sz = lds + 2 * n, *sp = lds + 3 * n;
 
@@ -105,6 +105,8 @@ ballquery_kernel(int b, int n, int m, float radius2, int nsample, int qpw, int b
       const int filled = min(cnt[i], nsample);
       int *row = idx + ((size_t)cloud * m + (q0 + i)) * nsample;
       for (int s = filled + lane; s < nsample; s += 64) row[s] = first[i];
+      // distinct neighbours in the row (the rest is padding with the first one); an empty ball counts as one slot
+      if (cnt_out && lane == 0) cnt_out[(size_t)cloud * m + (q0 + i)] = filled > 0 ? filled : 1;
     }
   }
 }
@@ -112,7 +114,7 @@ ballquery_kernel(int b, int n, int m, float radius2, int nsample, int qpw, int b
 }  // namespace
 
 extern "C" int rs_ballquery(int b, int n, int m, float radius2, int nsample, const float *new_xyz,
-                            const float *xyz, int *idx, void *stream) {
+                            const float *xyz, int *idx, int *cnt, void *stream) {
   RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "rs_ballquery: negative size");
   if (b == 0 || m == 0 || nsample == 0) return RS_OK;
   RS_REQUIRE(n > 0, "rs_ballquery: empty cloud");
@@ -125,10 +127,10 @@ extern "C" int rs_ballquery(int b, int n, int m, float radius2, int nsample, con
   hipStream_t st = (hipStream_t)stream;
   if (n <= BQ_LDS_POINTS) {
     hipLaunchKernelGGL(ballquery_kernel<true>, grid, block, (size_t)n * 16, st, b, n, m, radius2, nsample,
-                       qpw, blocks_per_cloud, new_xyz, xyz, idx);
+                       qpw, blocks_per_cloud, new_xyz, xyz, idx, cnt);
   } else {
     hipLaunchKernelGGL(ballquery_kernel<false>, grid, block, 0, st, b, n, m, radius2, nsample, qpw,
-                       blocks_per_cloud, new_xyz, xyz, idx);
+                       blocks_per_cloud, new_xyz, xyz, idx, cnt);
   }
   RS_CHECK_LAUNCH("rs_ballquery");
   return RS_OK;

@@ -161,6 +161,98 @@ group_all_kernel(long long rows, int cn, int cf, int cpos, int ctot, const float
   }
 }
 
+// ---- compacted groups ---------------------------------------------------------------------------
+// A ball-query row holds cnt[g] distinct neighbours followed by nsample - cnt[g] copies of the first one
+// (classification/modules/pointnet2_utils.py:92-94).  The shared MLP maps identical rows to identical
+// outputs, so the grouped operand is built for the DISTINCT slots only; slot 0 carries the multiplicity
+// nsample - cnt + 1 for the BatchNorm sums.  Rows of group g live at [offsets[g], offsets[g+1]); the total
+// stays on the device (offsets[groups]) and is read by the consuming kernels, never by the host.
+
+// single-workgroup exclusive scan: out[i] = sum_{j<i} in[j], out[n] = total
+__global__ void __launch_bounds__(1024)
+exclusive_scan_kernel(int n, const int *__restrict__ in, int *__restrict__ out) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(n, t * per), hi = min(n, lo + per);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += in[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {        // Hillis-Steele inclusive scan of the 1024 partials
+    const int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;                             // exclusive prefix of this thread's chunk
+  for (int i = lo; i < hi; ++i) { out[i] = run; run += in[i]; }
+  if (t == 1023) out[n] = part[1023];
+}
+
+__global__ void __launch_bounds__(GR_THREADS)
+compact_index_kernel(long long groups, int nsample, int groups_per_cloud, int n, const int *__restrict__ idx,
+                     const int *__restrict__ cnt, const int *__restrict__ offsets, int *__restrict__ grp,
+                     int *__restrict__ slot, int *__restrict__ src, float *__restrict__ mult) {
+  const long long total = groups * nsample;
+  for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GR_THREADS) {
+    const long long g = e / nsample;
+    const int k = (int)(e - g * nsample);
+    const int c = cnt[g];
+    if (k >= c) continue;
+    const long long u = offsets[g] + k;
+    grp[u] = (int)g;
+    slot[u] = k;
+    src[u] = (int)((g / groups_per_cloud) * n + idx[e]);
+    mult[u] = (k == 0) ? (float)(nsample - c + 1) : 1.f;
+  }
+}
+
+// X[u, :] = [center[src]-new_center[g] (3), polar (3)?, normal[src] (cn), feature[src] (cf)] for u < *rows_dev
+__global__ void __launch_bounds__(GR_THREADS)
+compact_features_kernel(const int *__restrict__ rows_dev, int cn, int cf, int cpos, int ctot,
+                        const float *__restrict__ center, const float *__restrict__ new_center,
+                        const float *__restrict__ normal, const float *__restrict__ feature,
+                        const int *__restrict__ grp, const int *__restrict__ src, float *__restrict__ out) {
+  const long long total = (long long)(*rows_dev) * ctot;
+  for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GR_THREADS) {
+    const long long u = e / ctot;
+    const int ch = (int)(e - u * ctot);
+    const long long sp = src[u];
+    float v;
+    if (ch < cpos) {
+      const long long g = grp[u];
+      const float dx = center[sp * 3 + 0] - new_center[g * 3 + 0];
+      const float dy = center[sp * 3 + 1] - new_center[g * 3 + 1];
+      const float dz = center[sp * 3 + 2] - new_center[g * 3 + 2];
+      if (ch < 3) v = (ch == 0) ? dx : (ch == 1 ? dy : dz);
+      else {
+        const float rho = sqrtf(rs_sqnorm(dx, dy, dz));
+        if (ch == 3) v = rho;
+        else if (ch == 4) v = (rho == 0.f) ? 0.f : acosf(dz / rho) / RS_PI_F;
+        else v = atan2f(dy, dx) / RS_TWO_PI_F + 0.5f;
+      }
+    } else if (ch < cpos + cn) {
+      v = normal[sp * cn + (ch - cpos)];
+    } else {
+      v = feature[sp * cf + (ch - cpos - cn)];
+    }
+    out[e] = v;
+  }
+}
+
+// grad_src[src[u], :] += grad_out[u, c0 : c0+cw]   — one atomic per distinct neighbour
+__global__ void __launch_bounds__(GR_THREADS)
+compact_scatter_kernel(const int *__restrict__ rows_dev, int cw, int c0, int ctot, const float *__restrict__ grad_out,
+                       const int *__restrict__ src, float *__restrict__ grad_src) {
+  const long long total = (long long)(*rows_dev) * cw;
+  for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GR_THREADS) {
+    const long long u = e / cw;
+    const int ch = (int)(e - u * cw);
+    atomicAdd(grad_src + (long long)src[u] * cw + ch, grad_out[u * ctot + c0 + ch]);
+  }
+}
+
 inline int grid_for(long long work_items) {
   long long blocks = (work_items + GR_THREADS - 1) / GR_THREADS;
   const long long cap = 256LL * 8;     // 8 workgroups per CU, grid-stride beyond that
@@ -262,5 +354,51 @@ extern "C" int rs_group_all_features(int b, int n, int cn, int cf, int polar, co
   hipLaunchKernelGGL(group_all_kernel, dim3(grid_for(rows * ctot)), dim3(GR_THREADS), 0, (hipStream_t)stream,
                      rows, cn, cf, cpos, ctot, center, normal, feature, out);
   RS_CHECK_LAUNCH("rs_group_all_features");
+  return RS_OK;
+}
+
+extern "C" int rs_exclusive_scan(int n, const int *in, int *out, void *stream) {
+  RS_REQUIRE(n >= 0, "rs_exclusive_scan: negative size");
+  RS_REQUIRE(in && out, "rs_exclusive_scan: null pointer");
+  hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, in, out);
+  RS_CHECK_LAUNCH("rs_exclusive_scan");
+  return RS_OK;
+}
+
+extern "C" int rs_group_features_compact(int b, int n, int m, int nsample, int cn, int cf, int polar,
+                                         const float *center, const float *new_center, const float *normal,
+                                         const float *feature, const int *idx, const int *cnt, const int *offsets,
+                                         float *out, float *mult, int *grp, int *slot, int *src, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0 && cn >= 0 && cf >= 0, "rs_group_features_compact: negative size");
+  const long long groups = (long long)b * m;
+  if (groups == 0 || nsample == 0) return RS_OK;
+  RS_REQUIRE(center && new_center && idx && cnt && offsets && out && mult && grp && slot && src, "rs_group_features_compact: null pointer");
+  RS_REQUIRE(cn == 0 || normal, "rs_group_features_compact: normal is NULL but cn=%d", cn);
+  RS_REQUIRE(cf == 0 || feature, "rs_group_features_compact: feature is NULL but cf=%d", cf);
+  const int cpos = polar ? 6 : 3, ctot = cpos + cn + cf;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(groups * nsample)), dim3(GR_THREADS), 0, st, groups, nsample, m, n,
+                     idx, cnt, offsets, grp, slot, src, mult);
+  hipLaunchKernelGGL(compact_features_kernel, dim3(grid_for(groups * nsample * ctot / 4 + 1)), dim3(GR_THREADS), 0, st,
+                     offsets + groups, cn, cf, cpos, ctot, center, new_center, normal, feature, grp, src, out);
+  RS_CHECK_LAUNCH("rs_group_features_compact");
+  return RS_OK;
+}
+
+extern "C" int rs_group_features_compact_backward(long long capacity, const int *rows_dev, int cn, int cf, int polar,
+                                                  const float *grad_out, const int *src, float *grad_normal,
+                                                  float *grad_feature, void *stream) {
+  RS_REQUIRE(capacity >= 0 && cn >= 0 && cf >= 0, "rs_group_features_compact_backward: negative size");
+  if (capacity == 0) return RS_OK;
+  RS_REQUIRE(rows_dev && grad_out && src, "rs_group_features_compact_backward: null pointer");
+  const int cpos = polar ? 6 : 3, ctot = cpos + cn + cf;
+  hipStream_t st = (hipStream_t)stream;
+  if (grad_normal && cn > 0)
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(grid_for(capacity * cn / 4 + 1)), dim3(GR_THREADS), 0, st, rows_dev, cn, cpos,
+                       ctot, grad_out, src, grad_normal);
+  if (grad_feature && cf > 0)
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(grid_for(capacity * cf / 4 + 1)), dim3(GR_THREADS), 0, st, rows_dev, cf,
+                       cpos + cn, ctot, grad_out, src, grad_feature);
+  RS_CHECK_LAUNCH("rs_group_features_compact_backward");
   return RS_OK;
 }

@@ -62,7 +62,7 @@ template <int V> __device__ __forceinline__ void ldvi(const int *p, int (&d)[V])
   for (int i = 0; i < V; ++i) d[i] = f[i];
 }
 
-template <int V> struct RawVec { float a[V]; float b[V]; int g[V]; };
+template <int V> struct RawVec { float a[V]; float b[V]; int g[V]; float m; int k; };
 template <int V> struct ColCoef { float s1[V], t1[V], s2[V], t2[V]; };
 
 // MODE >= 0 fixes the operand mode at compile time (dead paths and their registers vanish);
@@ -86,27 +86,36 @@ __device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int r
   const int mode = MODE >= 0 ? MODE : o.mode;
 #pragma unroll
   for (int i = 0; i < V; ++i) { raw.a[i] = 0.f; raw.b[i] = 0.f; raw.g[i] = -1; }
+  raw.m = 1.f; raw.k = 0;
   if (!ok) return;
   const int offa = rl * (int)o.lda + c, offb = rl * (int)o.ldb + c;
   switch (mode) {
     case OPM_ID: case OPM_RELU1: ldv<V>(o.a + r0 * o.lda + offa, raw.a); break;
-    case OPM_RELU2: case OPM_AFF2: ldv<V>(o.a + r0 * o.lda + offa, raw.a); ldv<V>(o.b + r0 * o.ldb + offb, raw.b); break;
+    case OPM_RELU2: ldv<V>(o.a + r0 * o.lda + offa, raw.a); ldv<V>(o.b + r0 * o.ldb + offb, raw.b); break;
+    case OPM_AFF2:
+      ldv<V>(o.a + r0 * o.lda + offa, raw.a); ldv<V>(o.b + r0 * o.ldb + offb, raw.b);
+      if (o.mult) raw.m = o.mult[r0 + rl];
+      break;
     case OPM_POOLED: {
-      const unsigned g = (unsigned)(r0 + rl) / (unsigned)o.ns;
+      unsigned g;
+      if (o.grp) { g = (unsigned)o.grp[r0 + rl]; raw.k = o.slot[r0 + rl]; }           // compacted (ragged) groups
+      else { g = (unsigned)(r0 + rl) / (unsigned)o.ns; raw.k = (int)((unsigned)(r0 + rl) - g * (unsigned)o.ns); }
       ldv<V>(o.a + (long long)g * o.lda + c, raw.a);
       ldvi<V>(o.arg + (long long)g * o.lda + c, raw.g);
       ldv<V>(o.b + r0 * o.ldb + offb, raw.b);
+      if (o.mult) raw.m = o.mult[r0 + rl];
       break;
     }
     default: ldv<V>(o.a + (long long)((unsigned)(r0 + rl) / (unsigned)o.ns) * o.lda + c, raw.a); break;
   }
 }
 
+// The affine part (s2*b + t1) of the BatchNorm-backward operands is multiplied by the row's multiplicity:
+// a compacted row stands for `m` identical copies whose pooled/masked gradients were already summed.
 template <int V, int MODE>
 __device__ __forceinline__ void op_finish(const RowOperand &o, const ColCoef<V> &k, const RawVec<V> &raw,
                                           long long r, bool ok, float (&out)[V]) {
   const int mode = MODE >= 0 ? MODE : o.mode;
-  const int kk = (mode == OPM_POOLED) ? (int)((unsigned)r % (unsigned)o.ns) : 0;
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     float v;
@@ -114,8 +123,8 @@ __device__ __forceinline__ void op_finish(const RowOperand &o, const ColCoef<V> 
       case OPM_ID: case OPM_BCAST: v = raw.a[i]; break;
       case OPM_RELU1: v = fmaxf(fmaf(k.s1[i], raw.a[i], k.t1[i]), 0.f); break;
       case OPM_RELU2: v = fmaxf(fmaf(k.s1[i], raw.a[i], k.t1[i]) + fmaf(k.s2[i], raw.b[i], k.t2[i]), 0.f); break;
-      case OPM_AFF2: v = fmaf(k.s1[i], raw.a[i], fmaf(k.s2[i], raw.b[i], k.t1[i])); break;
-      default: v = fmaf(k.s1[i], (raw.g[i] == kk) ? raw.a[i] : 0.f, fmaf(k.s2[i], raw.b[i], k.t1[i])); break;
+      case OPM_AFF2: v = fmaf(k.s1[i], raw.a[i], raw.m * fmaf(k.s2[i], raw.b[i], k.t1[i])); break;
+      default: v = fmaf(k.s1[i], (raw.g[i] == raw.k) ? raw.a[i] : 0.f, raw.m * fmaf(k.s2[i], raw.b[i], k.t1[i])); break;
     }
     out[i] = ok ? v : 0.f;
   }
@@ -136,8 +145,10 @@ typedef rs_mlp_epilogue Epilogue;
 // two LDS buffers, one barrier per chunk.
 template <int BN, int V, int MODE>
 __global__ void __launch_bounds__(GM_THREADS, 2)     // 2 workgroups per CU: one computes while the other stages
-gemm_rows_kernel(long long rows, int kdim, int cols, RowOperand E, const float *__restrict__ w, int ldw,
-                 Epilogue ep) {
+gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim, int cols, RowOperand E,
+                 const float *__restrict__ w, int ldw, Epilogue ep) {
+  // compacted inputs carry their row count on the device (no host sync); rows_arg is then the capacity
+  const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
   constexpr int CT = BN / 32;
   constexpr int A_ELEMS = GM_BM * GM_BK / GM_THREADS;       // 16 floats of the operand tile per thread
   constexpr int A_VECS = A_ELEMS / V;
@@ -289,8 +300,9 @@ gemm_rows_kernel(long long rows, int kdim, int cols, RowOperand E, const float *
             if (my2_t) s2[e] = fmaf(y[e], (y2[e] - mu2[e]) * is2[e], s2[e]);
           }
         } else if (EPI == EPI_STATS) {
+          const float mw = ep.row_mult ? ep.row_mult[r0 + rl] : 1.f;      // copies this compacted row stands for
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { s0[e] += y[e]; s1[e] = fmaf(y[e], y[e], s1[e]); }
+          for (int e = 0; e < 4; ++e) { s0[e] = fmaf(mw, y[e], s0[e]); s1[e] = fmaf(mw * y[e], y[e], s1[e]); }
         }
         if (ep_vec) {
           *reinterpret_cast<float4 *>(out_t + (long long)rl * ep.ldo + col) = make_float4(y[0], y[1], y[2], y[3]);
@@ -358,8 +370,13 @@ constexpr int WG_BR = 32;   // rows per pipeline stage
 
 template <int WN, int WK, int TN, int TK, int VP, int VQ, int PM, int QM>
 __global__ void __launch_bounds__(GM_THREADS, 2)
-wgrad_kernel(long long rows, int ncols, int kcols, RowOperand P, RowOperand Q, long long rows_per_chunk,
-             float *__restrict__ partial) {
+wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, int kcols, RowOperand P, RowOperand Q,
+             long long rows_per_chunk_arg, float *__restrict__ partial) {
+  long long rows = rows_arg, rows_per_chunk = rows_per_chunk_arg;
+  if (rows_dev) {     // device-side row count: split what is actually there over the launched slabs
+    rows = min(rows_arg, (long long)*rows_dev);
+    rows_per_chunk = ((rows + gridDim.x - 1) / gridDim.x + WG_BR - 1) / WG_BR * WG_BR;
+  }
   constexpr int BNN = WN * TN * 32, BKK = WK * TK * 32;
   constexpr int P_VECS = WG_BR * BNN / VP / GM_THREADS, Q_VECS = (WG_BR * BKK / VQ + GM_THREADS - 1) / GM_THREADS;
   constexpr int P_TPR = BNN / VP, Q_TPR = BKK / VQ;           // threads per tile row
@@ -492,29 +509,50 @@ reduce_partials_kernel(int chunks, long long n, const float *__restrict__ partia
   }
 }
 
-// ---- BatchNorm statistics -> affine (forward): one wave per channel ------------------------------
-__device__ __forceinline__ double wave_sum_f64(double v) {
+// ---- BatchNorm statistics -> affine.  Workgroup = 32 channels x 8 slices of the partial rows: consecutive
+// lanes read consecutive channels (256-byte coalesced rows of doubles), slices are combined through LDS in a
+// fixed order (deterministic).
+template <int NS>   // number of statistics reduced together
+__device__ __forceinline__ void reduce_stat_rows(int c, int nblk, int nstat, const int (&which)[NS],
+                                                 const double *__restrict__ partial, double (&out)[NS], bool &owner) {
+  __shared__ double red[8][32][NS];
+  const int ex = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + ex;
+  double acc[NS];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+  if (ch < c)
+    for (int b = sl; b < nblk; b += 8)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] += partial[((long long)b * nstat + which[s]) * c + ch];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) red[sl][ex][s] = acc[s];
+  __syncthreads();
+  owner = (sl == 0) && (ch < c);
+  if (owner)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k][ex][s];
+      out[s] = t;
+    }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 bn_finalize_kernel(int c, long long rows, int nblk, const double *__restrict__ partial,
                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
                    float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
                    float *__restrict__ invstd_out, float *__restrict__ running_mean,
                    float *__restrict__ running_var) {
-  const int ch = blockIdx.x, lane = threadIdx.x;
-  double s = 0.0, q = 0.0;
-  for (int b = lane; b < nblk; b += 64) {
-    s += partial[((long long)b * 2 + 0) * c + ch];
-    q += partial[((long long)b * 2 + 1) * c + ch];
-  }
-  s = wave_sum_f64(s); q = wave_sum_f64(q);
-  if (lane != 0) return;
-  const double mean = s / (double)rows;
-  double var = q / (double)rows - mean * mean;
+  const int which[2] = {0, 1};
+  double sq[2];
+  bool owner;
+  reduce_stat_rows<2>(c, nblk, 2, which, partial, sq, owner);
+  if (!owner) return;
+  const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
+  const double mean = sq[0] / (double)rows;
+  double var = sq[1] / (double)rows - mean * mean;
   if (var < 0.0) var = 0.0;
   const double invstd = 1.0 / sqrt(var + (double)eps);
   const double g = gamma ? (double)gamma[ch] : 1.0, bt = beta ? (double)beta[ch] : 0.0;
@@ -531,19 +569,18 @@ bn_finalize_kernel(int c, long long rows, int nblk, const double *__restrict__ p
 
 // ---- BatchNorm backward sums -> coefficients of dy = p*dz + q*y + r ------------------------------
 // which: 1 -> dgamma from stat row 1, 2 -> from stat row 2 (second branch of the two-branch first layer)
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 bn_bwd_finalize_kernel(int c, long long rows, int nblk, int nstat, int which, const double *__restrict__ partial,
                        const float *__restrict__ scale, const float *__restrict__ mean,
                        const float *__restrict__ invstd, float *__restrict__ p, float *__restrict__ q,
                        float *__restrict__ r, float *__restrict__ dgamma, float *__restrict__ dbeta) {
-  const int ch = blockIdx.x, lane = threadIdx.x;
-  double db = 0.0, dg = 0.0;
-  for (int b = lane; b < nblk; b += 64) {
-    db += partial[((long long)b * nstat + 0) * c + ch];
-    dg += partial[((long long)b * nstat + which) * c + ch];
-  }
-  db = wave_sum_f64(db); dg = wave_sum_f64(dg);
-  if (lane != 0) return;
+  const int sel[2] = {0, which};
+  double v[2];
+  bool owner;
+  reduce_stat_rows<2>(c, nblk, nstat, sel, partial, v, owner);
+  if (!owner) return;
+  const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
+  const double db = v[0], dg = v[1];
   const double s = scale[ch], is = invstd[ch], mu = mean[ch], m = (double)rows;
   // dy = s * (dz - db/m - yhat * dg/m),  yhat = (y - mu) * is
   const double qq = -s * is * dg / m;
@@ -557,16 +594,19 @@ bn_bwd_finalize_kernel(int c, long long rows, int nblk, int nstat, int which, co
 // ---- pooling over nsample, fused with the last BatchNorm + ReLU -----------------------------------
 // out[g][c] = max_k relu(scale*y[g*ns+k][c] + shift), arg = first k attaining it
 __global__ void __launch_bounds__(GM_THREADS)
-pool_max_kernel(long long groups, int ns, int c, int relu, const float *__restrict__ y, const float *__restrict__ scale,
-                const float *__restrict__ shift, float *__restrict__ out, int *__restrict__ arg) {
+pool_max_kernel(long long groups, int ns, int c, int relu, const int *__restrict__ offsets, const float *__restrict__ y,
+                const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
+                int *__restrict__ arg) {
   const long long total = groups * c;
   for (long long e = (long long)blockIdx.x * GM_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GM_THREADS) {
     const long long g = e / c;
     const int ch = (int)(e - g * c);
     const float s = scale ? scale[ch] : 1.f, t = shift ? shift[ch] : 0.f;
     float best = -INFINITY; int bi = 0;
-    for (int k = 0; k < ns; ++k) {
-      float z = fmaf(s, y[(g * ns + k) * c + ch], t);
+    const long long base = offsets ? offsets[g] : g * ns;             // ragged (compacted) or dense groups
+    const int len = offsets ? offsets[g + 1] - offsets[g] : ns;
+    for (int k = 0; k < len; ++k) {
+      float z = fmaf(s, y[(base + k) * c + ch], t);
       if (relu) z = fmaxf(z, 0.f);
       if (z > best) { best = z; bi = k; }
     }
@@ -592,9 +632,10 @@ pool_select_kernel(long long groups, int c, const float *__restrict__ ymax, cons
 // v[g][c] = dout * (out > 0); partial sums {sum v, sum v * yhat[arg row]} per column (BatchNorm backward
 // of the pooled layer computed from G x C data only)
 __global__ void __launch_bounds__(GM_THREADS)
-pool_max_bwd_kernel(long long groups, int ns, int c, const float *__restrict__ dout, const float *__restrict__ out,
-                    const int *__restrict__ arg, const float *__restrict__ y, const float *__restrict__ mean,
-                    const float *__restrict__ invstd, float *__restrict__ v, double *__restrict__ partial) {
+pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ offsets, const float *__restrict__ dout,
+                    const float *__restrict__ out, const int *__restrict__ arg, const float *__restrict__ y,
+                    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ v,
+                    double *__restrict__ partial) {
   // one thread per column, grid-stride over group slabs: column sums stay in registers
   const int ch = blockIdx.y * GM_THREADS + threadIdx.x;
   if (ch >= c) return;
@@ -604,7 +645,7 @@ pool_max_bwd_kernel(long long groups, int ns, int c, const float *__restrict__ d
     const long long e = g * c + ch;
     const float val = out[e] > 0.f ? dout[e] : 0.f;
     v[e] = val;
-    const float yy = y[(g * ns + arg[e]) * c + ch];
+    const float yy = y[((offsets ? (long long)offsets[g] : g * ns) + arg[e]) * c + ch];
     s0 += (double)val;
     s1 += (double)(val * ((yy - mu) * is));
   }
@@ -655,17 +696,17 @@ int check_operand(const char *who, const RowOperand *o, long long rows) {
   if (o->mode == OPM_RELU1) RS_REQUIRE(o->s1 && o->t1, "%s: RELU1 operand needs scale/shift", who);
   if (o->mode == OPM_RELU2) RS_REQUIRE(o->b && o->s1 && o->t1 && o->s2 && o->t2, "%s: RELU2 operand needs two tensors and two scale/shift pairs", who);
   if (o->mode == OPM_AFF2) RS_REQUIRE(o->b && o->s1 && o->t1 && o->s2, "%s: AFF2 operand needs dz, y and p/q/r", who);
-  if (o->mode == OPM_POOLED) RS_REQUIRE(o->b && o->s1 && o->t1 && o->s2 && o->arg && o->ns > 0, "%s: POOLED operand needs v, arg, y, p/q/r, nsample", who);
+  if (o->mode == OPM_POOLED) RS_REQUIRE(o->b && o->s1 && o->t1 && o->s2 && o->arg && (o->ns > 0 || (o->grp && o->slot)), "%s: POOLED operand needs v, arg, y, p/q/r and nsample or (grp, slot)", who);
   if (o->mode == OPM_BCAST) RS_REQUIRE(o->ns > 0, "%s: BCAST operand needs nsample", who);
   if (o->mode == OPM_POOLED || o->mode == OPM_BCAST) RS_REQUIRE(rows < 2147483647LL, "%s: pooled operands need rows < 2^31", who);
   return RS_OK;
 }
 
 template <int BN, int V>
-void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, int kdim, int cols, const RowOperand &E,
+void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                    const float *w, int ldw, const Epilogue &ep) {
   const size_t lds = sizeof(float) * (2 * GM_BK * GM_LDA + 2 * GM_BK * BN);
-#define RS_G(M_) hipLaunchKernelGGL((gemm_rows_kernel<BN, V, M_>), grid, dim3(GM_THREADS), lds, st, rows, kdim, cols, E, w, ldw, ep)
+#define RS_G(M_) hipLaunchKernelGGL((gemm_rows_kernel<BN, V, M_>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, kdim, cols, E, w, ldw, ep)
   if (V == 1) { RS_G(-1); return; }                 // odd sizes: one generic (runtime-mode) kernel
   switch (E.mode) {
     case OPM_ID: RS_G(OPM_ID); break;
@@ -678,18 +719,18 @@ void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, int kdim, int cols
 #undef RS_G
 }
 template <int BN>
-void launch_gemm(int v, dim3 grid, hipStream_t st, long long rows, int kdim, int cols, const RowOperand &E,
+void launch_gemm(int v, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                  const float *w, int ldw, const Epilogue &ep) {
-  if (v == 4) launch_gemm_m<BN, 4>(grid, st, rows, kdim, cols, E, w, ldw, ep);
-  else if (v == 2) launch_gemm_m<BN, 2>(grid, st, rows, kdim, cols, E, w, ldw, ep);
-  else launch_gemm_m<BN, 1>(grid, st, rows, kdim, cols, E, w, ldw, ep);
+  if (v == 4) launch_gemm_m<BN, 4>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else if (v == 2) launch_gemm_m<BN, 2>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else launch_gemm_m<BN, 1>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
 }
 
 template <int WN, int WK, int TN, int TK, int VP, int VQ>
-void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, int ncols, int kcols, const RowOperand &P,
+void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
                     const RowOperand &Q, long long rpc, float *partial) {
   const size_t lds = sizeof(float) * 2 * WG_BR * (WN * TN * 32 + WK * TK * 32);
-#define RS_WG(PM_, QM_) hipLaunchKernelGGL((wgrad_kernel<WN, WK, TN, TK, VP, VQ, PM_, QM_>), grid, dim3(GM_THREADS), lds, st, rows, ncols, kcols, P, Q, rpc, partial)
+#define RS_WG(PM_, QM_) hipLaunchKernelGGL((wgrad_kernel<WN, WK, TN, TK, VP, VQ, PM_, QM_>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial)
 #define RS_WGQ(PM_) do { if (Q.mode == OPM_ID) RS_WG(PM_, OPM_ID); else if (Q.mode == OPM_RELU1) RS_WG(PM_, OPM_RELU1); else if (Q.mode == OPM_RELU2) RS_WG(PM_, OPM_RELU2); else RS_WG(-1, -1); } while (0)
   if (VP == 1 || VQ == 1) { RS_WG(-1, -1); return; }
   if (P.mode == OPM_AFF2) RS_WGQ(OPM_AFF2);
@@ -700,18 +741,18 @@ void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, int ncols, int kc
 #undef RS_WG
 }
 template <int WN, int WK, int TN, int TK>
-void launch_wgrad(int vp, int vq, dim3 grid, hipStream_t st, long long rows, int ncols, int kcols, const RowOperand &P,
+void launch_wgrad(int vp, int vq, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
                   const RowOperand &Q, long long rpc, float *partial) {
-  if (vp == 1 || vq == 1) launch_wgrad_m<WN, WK, TN, TK, 1, 1>(grid, st, rows, ncols, kcols, P, Q, rpc, partial);
-  else if (vp == 4 && vq == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 4>(grid, st, rows, ncols, kcols, P, Q, rpc, partial);
-  else if (vp == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 2>(grid, st, rows, ncols, kcols, P, Q, rpc, partial);
-  else launch_wgrad_m<WN, WK, TN, TK, 2, 2>(grid, st, rows, ncols, kcols, P, Q, rpc, partial);   // (2,4) runs as (2,2)
+  if (vp == 1 || vq == 1) launch_wgrad_m<WN, WK, TN, TK, 1, 1>(grid, st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
+  else if (vp == 4 && vq == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 4>(grid, st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
+  else if (vp == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 2>(grid, st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
+  else launch_wgrad_m<WN, WK, TN, TK, 2, 2>(grid, st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);   // (2,4) runs as (2,2)
 }
 
 }  // namespace
 
-extern "C" int rs_mlp_gemm_rows(long long rows, int kdim, int cols, const rs_row_operand *x, const float *w, int ldw,
-                                const rs_mlp_epilogue *epi, void *stream) {
+extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
+                                const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
   RS_REQUIRE(rows >= 0 && kdim >= 0 && cols >= 0, "rs_mlp_gemm_rows: negative size");
   if (rows == 0 || cols == 0) return RS_OK;
   RS_REQUIRE(kdim > 0, "rs_mlp_gemm_rows: empty reduction dimension");
@@ -730,6 +771,7 @@ extern "C" int rs_mlp_gemm_rows(long long rows, int kdim, int cols, const rs_row
   if (epi_mode == EPI_MASK && ep.my2) RS_REQUIRE(ep.ms2 && ep.mt2 && ep.mean2 && ep.invstd2, "rs_mlp_gemm_rows: second mask branch incomplete");
   if (epi_mode != EPI_MASK) { ep.my1 = nullptr; ep.my2 = nullptr; }
   if (ep.pool_ns > 0) {
+    RS_REQUIRE(!rows_dev, "rs_mlp_gemm_rows: fused pooling needs dense groups (not a compacted row set)");
     RS_REQUIRE(ep.pool_max && ep.pool_min && ep.pool_amax && ep.pool_amin, "rs_mlp_gemm_rows: fused pooling needs its four outputs");
     const int rpt = GM_BM / (GM_THREADS / (cols <= 32 ? 32 : (cols <= 64 ? 64 : 128)));
     RS_REQUIRE(rows % ep.pool_ns == 0 && rpt % ep.pool_ns == 0,
@@ -746,15 +788,15 @@ extern "C" int rs_mlp_gemm_rows(long long rows, int kdim, int cols, const rs_row
   if (epi_mode != EPI_STORE && gx < ep.partial_blocks)   // unused partial rows must read as zero
     (void)hipMemsetAsync(ep.partial + (long long)gx * nstat * cols, 0, sizeof(double) * (size_t)(ep.partial_blocks - gx) * nstat * cols, st);
   const int v = pick_vec(E, kdim);
-  if (bn == 32) launch_gemm<32>(v, grid, st, rows, kdim, cols, E, w, ldw, ep);
-  else if (bn == 64) launch_gemm<64>(v, grid, st, rows, kdim, cols, E, w, ldw, ep);
-  else launch_gemm<128>(v, grid, st, rows, kdim, cols, E, w, ldw, ep);
+  if (bn == 32) launch_gemm<32>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else if (bn == 64) launch_gemm<64>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else launch_gemm<128>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
   RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
   return RS_OK;
 }
 
-extern "C" int rs_mlp_wgrad(long long rows, int ncols, int kcols, const rs_row_operand *p, const rs_row_operand *q,
-                            float *partial, int chunks, float *dw, void *stream) {
+extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
+                            const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
   RS_REQUIRE(rows >= 0 && ncols >= 0 && kcols >= 0 && chunks > 0, "rs_mlp_wgrad: bad size");
   if (ncols == 0 || kcols == 0) return RS_OK;
   RS_REQUIRE(partial && dw, "rs_mlp_wgrad: null pointer");
@@ -770,11 +812,11 @@ extern "C" int rs_mlp_wgrad(long long rows, int ncols, int kcols, const rs_row_o
   hipStream_t st = (hipStream_t)stream;
   const int vp = pick_vec(P, ncols), vq = pick_vec(Q, kcols);
   if (kcols > 64) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
-    launch_wgrad<2, 2, 2, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, ncols, kcols, P, Q, rpc, partial);
+    launch_wgrad<2, 2, 2, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
   } else if (kcols > 32) {   // 128 x 64: waves 4 x 1, 1 x 2 tiles
-    launch_wgrad<4, 1, 1, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, ncols, kcols, P, Q, rpc, partial);
+    launch_wgrad<4, 1, 1, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
   } else {                   // 128 x 32: waves 4 x 1, 1 x 1 tile
-    launch_wgrad<4, 1, 1, 1>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, ncols, kcols, P, Q, rpc, partial);
+    launch_wgrad<4, 1, 1, 1>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
   }
   const long long n = (long long)ncols * kcols;
   long long rb = (n + 31) / 32;
@@ -802,7 +844,7 @@ extern "C" int rs_bn_finalize(int c, long long rows, int nblk, const double *par
   RS_REQUIRE(c >= 0 && rows > 0 && nblk > 0, "rs_bn_finalize: bad size");
   if (c == 0) return RS_OK;
   RS_REQUIRE(partial && scale && shift && save_mean && save_invstd, "rs_bn_finalize: null pointer");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, c, rows, nblk,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(rs_cdiv(c, 32)), dim3(256), 0, (hipStream_t)stream, c, rows, nblk,
                      partial, gamma, beta, eps, momentum, scale, shift, save_mean, save_invstd, running_mean, running_var);
   RS_CHECK_LAUNCH("rs_bn_finalize");
   return RS_OK;
@@ -814,21 +856,21 @@ extern "C" int rs_bn_backward_finalize(int c, long long rows, int nblk, int nsta
   RS_REQUIRE(c >= 0 && rows > 0 && nblk > 0 && nstat >= 2 && which >= 1 && which < nstat, "rs_bn_backward_finalize: bad size");
   if (c == 0) return RS_OK;
   RS_REQUIRE(partial && scale && mean && invstd && p && q && r, "rs_bn_backward_finalize: null pointer");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, c, rows, nblk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rs_cdiv(c, 32)), dim3(256), 0, (hipStream_t)stream, c, rows, nblk,
                      nstat, which, partial, scale, mean, invstd, p, q, r, dgamma, dbeta);
   RS_CHECK_LAUNCH("rs_bn_backward_finalize");
   return RS_OK;
 }
 
-extern "C" int rs_pool_max(long long groups, int nsample, int c, int relu, const float *y, const float *scale,
-                           const float *shift, float *out, int *arg, void *stream) {
+extern "C" int rs_pool_max(long long groups, int nsample, int c, int relu, const int *offsets, const float *y,
+                           const float *scale, const float *shift, float *out, int *arg, void *stream) {
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0, "rs_pool_max: bad size");
   if (groups == 0 || c == 0) return RS_OK;
   RS_REQUIRE(y && out && arg, "rs_pool_max: null pointer");
   long long blocks = (groups * c + GM_THREADS - 1) / GM_THREADS;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(pool_max_kernel, dim3((int)blocks), dim3(GM_THREADS), 0, (hipStream_t)stream, groups, nsample, c,
-                     relu, y, scale, shift, out, arg);
+                     relu, offsets, y, scale, shift, out, arg);
   RS_CHECK_LAUNCH("rs_pool_max");
   return RS_OK;
 }
@@ -847,9 +889,9 @@ extern "C" int rs_pool_select(long long groups, int c, const float *ymax, const 
   return RS_OK;
 }
 
-extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const float *dout, const float *out,
-                                    const int *arg, const float *y, const float *mean, const float *invstd,
-                                    float *v, double *partial, int partial_blocks, void *stream) {
+extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout,
+                                    const float *out, const int *arg, const float *y, const float *mean,
+                                    const float *invstd, float *v, double *partial, int partial_blocks, void *stream) {
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0 && partial_blocks > 0, "rs_pool_max_backward: bad size");
   if (groups == 0 || c == 0) return RS_OK;
   RS_REQUIRE(dout && out && arg && y && mean && invstd && v && partial, "rs_pool_max_backward: null pointer");
@@ -858,7 +900,7 @@ extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const 
   if (gx < partial_blocks)
     (void)hipMemsetAsync(partial + (long long)gx * 2 * c, 0, sizeof(double) * (size_t)(partial_blocks - gx) * 2 * c, st);
   hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(gx, rs_cdiv(c, GM_THREADS)), dim3(GM_THREADS), 0, st, groups, nsample, c,
-                     dout, out, arg, y, mean, invstd, v, partial);
+                     offsets, dout, out, arg, y, mean, invstd, v, partial);
   RS_CHECK_LAUNCH("rs_pool_max_backward");
   return RS_OK;
 }

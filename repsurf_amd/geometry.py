@@ -22,10 +22,10 @@ def _side_stream(device):
 
 
 class StageGeometry:
-    __slots__ = ("fps_idx", "new_center", "idx")
+    __slots__ = ("fps_idx", "new_center", "idx", "cnt")
 
-    def __init__(self, fps_idx, new_center, idx):
-        self.fps_idx, self.new_center, self.idx = fps_idx, new_center, idx
+    def __init__(self, fps_idx, new_center, idx, cnt=None):
+        self.fps_idx, self.new_center, self.idx, self.cnt = fps_idx, new_center, idx, cnt
 
 
 class GeometryPlan:
@@ -46,7 +46,8 @@ class GeometryPlan:
         for (npoint, radius, nsample) in stages:
             self.stages.append(StageGeometry(torch.empty((b, npoint), dtype=torch.int32, device=dev),
                                              torch.empty((b, npoint, 3), dtype=torch.float32, device=dev),
-                                             torch.empty((b, npoint, nsample), dtype=torch.int32, device=dev)))
+                                             torch.empty((b, npoint, nsample), dtype=torch.int32, device=dev),
+                                             torch.empty((b, npoint), dtype=torch.int32, device=dev)))
         side.wait_stream(self.main)
         with torch.cuda.stream(side):
             st_ptr = side.cuda_stream
@@ -58,7 +59,7 @@ class GeometryPlan:
                 _lib.call("rs_gather_rows", b, n, npoint, 3, center.data_ptr(), g.fps_idx.data_ptr(),
                           g.new_center.data_ptr(), st_ptr)
                 _lib.call("rs_ballquery", b, n, npoint, r2, nsample, g.new_center.data_ptr(), center.data_ptr(),
-                          g.idx.data_ptr(), st_ptr)
+                          g.idx.data_ptr(), g.cnt.data_ptr(), st_ptr)
                 center, n = g.new_center, npoint
             self.event = side.record_event()
         self.keep = (xyz, starts)

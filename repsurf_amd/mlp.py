@@ -18,6 +18,9 @@ import torch
 import torch.nn.functional as F
 
 BACKEND = os.environ.get("REPSURF_MLP", "hip")
+# Build the grouped operand for the DISTINCT ball-query slots only (padding copies of the first neighbour are
+# carried as a per-row multiplicity): exact, and 3-7x fewer rows at the model's radii.  HIP executor only.
+COMPACT_GROUPS = os.environ.get("REPSURF_COMPACT", "1") != "0"
 
 
 def set_backend(name):
@@ -71,14 +74,15 @@ def _torch_umbrella(x, mlps, group, aggr):
 
 
 # ------------------------------------------------------------------ dispatch
-def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample):
+def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample, compact=None):
     """SurfaceAbstractionCD body (classification/modules/repsurface_utils.py:236-244):
     relu(bn_l0(mlp_l0(x[:, :pos])) + bn_f0(mlp_f0(x[:, pos:]))) -> [conv, bn, relu]* -> max over nsample.
     x (G*nsample, pos+feat) -> (G, mlp[-1])."""
     if BACKEND == "torch":
+        assert compact is None, "the torch reference executor works on dense groups"
         return _torch_sa_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample)
     from . import mlp_hip
-    return mlp_hip.sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample)
+    return mlp_hip.sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample, compact=compact)
 
 
 def sa_mlp_plain(x, convs, bns, nsample):

@@ -30,7 +30,7 @@ WGRAD_CHUNKS = 512        # workgroups of one weight-gradient launch (row slabs 
 
 class RowOperand(ctypes.Structure):          # rs_row_operand
     _fields_ = [("a", P), ("lda", c_ll), ("b", P), ("ldb", c_ll), ("s1", P), ("t1", P), ("s2", P), ("t2", P),
-                ("arg", P), ("ns", c_int), ("mode", c_int)]
+                ("arg", P), ("ns", c_int), ("mode", c_int), ("mult", P), ("grp", P), ("slot", P)]
 
 
 class Epilogue(ctypes.Structure):            # rs_mlp_epilogue
@@ -38,7 +38,8 @@ class Epilogue(ctypes.Structure):            # rs_mlp_epilogue
                 ("my1", P), ("ldm1", c_ll), ("ms1", P), ("mt1", P), ("mean1", P), ("invstd1", P),
                 ("my2", P), ("ldm2", c_ll), ("ms2", P), ("mt2", P), ("mean2", P), ("invstd2", P),
                 ("partial", P), ("partial_blocks", c_int),
-                ("pool_ns", c_int), ("pool_max", P), ("pool_min", P), ("pool_amax", P), ("pool_amin", P)]
+                ("pool_ns", c_int), ("pool_max", P), ("pool_min", P), ("pool_amax", P), ("pool_amin", P),
+                ("row_mult", P)]
 
 
 def _stream():
@@ -49,9 +50,28 @@ def _ptr(t, offset=0):
     return None if t is None else t.data_ptr() + 4 * offset
 
 
-def operand(mode, a, lda, b=None, ldb=0, s1=None, t1=None, s2=None, t2=None, arg=None, ns=1, a_off=0):
-    return RowOperand(_ptr(a, a_off), lda, _ptr(b), ldb, _ptr(s1), _ptr(t1), _ptr(s2), _ptr(t2),
-                      None if arg is None else arg.data_ptr(), ns, mode)
+def operand(mode, a, lda, b=None, ldb=0, s1=None, t1=None, s2=None, t2=None, arg=None, ns=1, a_off=0, rs=None):
+    """rs: RowSet — attaches the per-row multiplicity / ragged group maps of a compacted row set."""
+    op = RowOperand(_ptr(a, a_off), lda, _ptr(b), ldb, _ptr(s1), _ptr(t1), _ptr(s2), _ptr(t2),
+                    None if arg is None else arg.data_ptr(), ns, mode)
+    if rs is not None and rs.mult is not None and mode in (OP_AFF2, OP_POOLED):
+        op.mult = _ptr(rs.mult)
+        if mode == OP_POOLED:
+            op.grp, op.slot = rs.grp.data_ptr(), rs.slot.data_ptr()
+    return op
+
+
+class RowSet:
+    """The rows a stack works on: dense (cap rows, all valid) or compacted (valid count on the device)."""
+    __slots__ = ("cap", "dev", "full", "mult", "grp", "slot", "offsets")
+
+    def __init__(self, cap, compact=None):
+        self.cap = cap
+        if compact is None:
+            self.dev, self.full, self.mult, self.grp, self.slot, self.offsets = None, cap, None, None, None, None
+        else:
+            self.dev, self.full = compact["rows_dev"], compact["rows_full"]
+            self.mult, self.grp, self.slot, self.offsets = compact["mult"], compact["grp"], compact["slot"], compact["offsets"]
 
 
 class _ZeroPool:
@@ -102,9 +122,9 @@ def _kmajor(w2d):
     return _pad4(w2d.t()).contiguous()
 
 
-def gemm_rows(rows, kdim, cols, x_op, wk, epi):
+def gemm_rows(rows, kdim, cols, x_op, wk, epi, rows_dev=None):
     """out[rows, cols] = E[rows, kdim] . wk[:kdim, :cols]   (wk k-major, ld % 4 == 0)"""
-    _lib.call("rs_mlp_gemm_rows", rows, kdim, cols, ctypes.byref(x_op), _ptr(wk), wk.shape[1],
+    _lib.call("rs_mlp_gemm_rows", rows, rows_dev, kdim, cols, ctypes.byref(x_op), _ptr(wk), wk.shape[1],
               ctypes.byref(epi), _stream())
 
 
@@ -114,9 +134,12 @@ def fused_pool_ok(cout, nsample):
     return rows_per_thread % nsample == 0
 
 
-def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0):
-    """y = E . W^T + bias with BN statistics; returns (y, BNVec[, pooled (out, arg)])."""
+def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, rs=None):
+    """y = E . W^T + bias with BN statistics; returns (y, BNVec[, pooled (out, arg)]).
+    rs: RowSet of a compacted operand (device row count, per-row weights of the statistics)."""
     cout = w2d.shape[0]
+    rows_dev = rs.dev if rs is not None else None
+    bn_rows = rs.full if rs is not None else rows
     y = torch.empty((rows, cout), dtype=torch.float32, device=device)
     vec = BNVec(cout, device)
     pool = None
@@ -124,6 +147,8 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0):
         part = torch.empty((PARTIAL_BLOCKS, 2, cout), dtype=torch.float64, device=device)
         epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STATS, partial=part.data_ptr(),
                        partial_blocks=PARTIAL_BLOCKS)
+        if rs is not None and rs.mult is not None:
+            epi.row_mult = _ptr(rs.mult)
         if pool_ns:
             groups = rows // pool_ns
             ext = torch.empty((2, groups, cout), dtype=torch.float32, device=device)
@@ -132,12 +157,12 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0):
             epi.pool_max, epi.pool_min = _ptr(ext[0]), _ptr(ext[1])
             epi.pool_amax, epi.pool_amin = pos[0].data_ptr(), pos[1].data_ptr()
             pool = (ext, pos)
-        gemm_rows(rows, kdim, cout, x_op, _kmajor(w2d), epi)
+        gemm_rows(rows, kdim, cout, x_op, _kmajor(w2d), epi, rows_dev)
         track = bn_mod.track_running_stats and bn_mod.running_mean is not None
         if track:
             _pending_counters.append(bn_mod.num_batches_tracked)
         mom = bn_mod.momentum if bn_mod.momentum is not None else 0.1
-        _lib.call("rs_bn_finalize", cout, rows, PARTIAL_BLOCKS, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
+        _lib.call("rs_bn_finalize", cout, bn_rows, PARTIAL_BLOCKS, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
                   float(bn_mod.eps), float(mom), _ptr(vec.scale), _ptr(vec.shift), _ptr(vec.mean), _ptr(vec.invstd),
                   _ptr(bn_mod.running_mean) if track else None, _ptr(bn_mod.running_var) if track else None, _stream())
         if pool is not None:
@@ -150,7 +175,7 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0):
             return y, vec, (out, arg)
     else:
         epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STORE)
-        gemm_rows(rows, kdim, cout, x_op, _kmajor(w2d), epi)
+        gemm_rows(rows, kdim, cout, x_op, _kmajor(w2d), epi, rows_dev)
         with torch.no_grad():
             invstd = torch.rsqrt(bn_mod.running_var + bn_mod.eps)
             vec.invstd.copy_(invstd)
@@ -169,11 +194,11 @@ def wgrad_chunks(rows, ncols, kcols):
     return max(1, min(chunks, cap))
 
 
-def wgrad(rows, ncols, kcols, p_op, q_op, device):
+def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None):
     chunks = wgrad_chunks(rows, ncols, kcols)
     part = torch.empty((chunks, ncols * kcols), dtype=torch.float32, device=device)
     dw = torch.empty((ncols, kcols), dtype=torch.float32, device=device)
-    _lib.call("rs_mlp_wgrad", rows, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), chunks,
+    _lib.call("rs_mlp_wgrad", rows, rows_dev, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), chunks,
               _ptr(dw), _stream())
     return dw
 
@@ -187,7 +212,7 @@ def bwd_coeffs(c, rows, part, nstat, which, vec, device):
     return buf[0], buf[1], buf[2], buf[3], buf[4]
 
 
-def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=None):
+def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=None, rows_dev=None):
     """dz_prev = (P . W) * relu'(z_prev) and the BN-backward sums of the previous layer(s)."""
     dz = torch.empty((rows, cols), dtype=torch.float32, device=device)
     nstat = 3 if y2 is not None else 2
@@ -198,7 +223,7 @@ def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=N
     if y2 is not None:
         epi.my2, epi.ldm2 = _ptr(y2), cols
         epi.ms2, epi.mt2, epi.mean2, epi.invstd2 = _ptr(v2.scale), _ptr(v2.shift), _ptr(v2.mean), _ptr(v2.invstd)
-    gemm_rows(rows, kdim, cols, p_op, _pad4(w2d), epi)      # (cout, cin) is already k-major for dY . W
+    gemm_rows(rows, kdim, cols, p_op, _pad4(w2d), epi, rows_dev)      # (cout, cin) is already k-major for dY . W
     return dz, part, nstat
 
 
@@ -213,15 +238,16 @@ class _SAStack(Function):
         x = x.contiguous()
         rows, cx = x.shape
         ns, pos, bns, training = meta["nsample"], meta["pos"], meta["bns"], meta["training"]
-        groups = rows // ns
-        saved = {"x": x}
+        rs = RowSet(rows, meta.get("compact"))
+        groups = rs.full // ns
+        saved = {"x": x, "rs": rs}
         pi = 0
         ys, vecs, w2ds = [], [], []
         if pos > 0:      # two-branch first layer (SurfaceAbstractionCD)
             wl, bl, wf, bf = params[0], params[1], params[4], params[5]
             wl2, wf2 = _w2d(wl), _w2d(wf)
-            yl, vl = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev)
-            yf, vf = fwd_layer(rows, operand(OP_ID, x, cx, a_off=pos), cx - pos, wf2, bf, bns[1], training, dev)
+            yl, vl = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev, rs=rs)
+            yf, vf = fwd_layer(rows, operand(OP_ID, x, cx, a_off=pos), cx - pos, wf2, bf, bns[1], training, dev, rs=rs)
             saved.update(yl=yl, vl=vl, yf=yf, vf=vf, wl2=wl2, wf2=wf2)
             prev_op = operand(OP_RELU2, yl, yl.shape[1], yf, yf.shape[1], vl.scale, vl.shift, vf.scale, vf.shift)
             prev_c = wl2.shape[0]
@@ -235,10 +261,10 @@ class _SAStack(Function):
             w, b = params[pi], params[pi + 1]
             w2 = _w2d(w)
             last = pi + 4 >= len(params)
-            if last and training and fused_pool_ok(w2.shape[0], ns):
+            if last and training and rs.dev is None and fused_pool_ok(w2.shape[0], ns):
                 y, vec, pooled = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, pool_ns=ns)
             else:
-                y, vec = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev)
+                y, vec = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, rs=rs)
             ys.append(y); vecs.append(vec); w2ds.append(w2)
             prev_op = operand(OP_RELU1, y, y.shape[1], s1=vec.scale, t1=vec.shift)
             prev_c = w2.shape[0]
@@ -249,8 +275,8 @@ class _SAStack(Function):
             y_last, v_last = ys[-1], vecs[-1]
             out = torch.empty((groups, prev_c), dtype=torch.float32, device=dev)
             arg = torch.empty((groups, prev_c), dtype=torch.int32, device=dev)
-            _lib.call("rs_pool_max", groups, ns, prev_c, 1, _ptr(y_last), _ptr(v_last.scale), _ptr(v_last.shift),
-                      _ptr(out), arg.data_ptr(), _stream())
+            _lib.call("rs_pool_max", groups, ns, prev_c, 1, _ptr(rs.offsets), _ptr(y_last), _ptr(v_last.scale),
+                      _ptr(v_last.shift), _ptr(out), arg.data_ptr(), _stream())
         else:
             raise NotImplementedError("a stack needs at least one layer after the first")
         saved.update(ys=ys, vecs=vecs, w2ds=w2ds, out=out, arg=arg)
@@ -269,7 +295,8 @@ class _SAStack(Function):
         dev = x.device
         rows, cx = x.shape
         ns, pos = meta["nsample"], meta["pos"]
-        groups = rows // ns
+        rs = s["rs"]
+        groups, full, rdev = rs.full // ns, rs.full, rs.dev
         ys, vecs, w2ds = s["ys"], s["vecs"], s["w2ds"]
         dout = dout.contiguous()
         grads = [None] * ctx.nparams
@@ -280,10 +307,11 @@ class _SAStack(Function):
         c_last = ys[-1].shape[1]
         v = torch.empty_like(dout)
         part = torch.empty((PARTIAL_BLOCKS, 2, c_last), dtype=torch.float64, device=dev)
-        _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(dout), _ptr(s["out"]), s["arg"].data_ptr(), _ptr(ys[-1]),
-                  _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(), PARTIAL_BLOCKS, _stream())
-        p, q, r, dg, db = bwd_coeffs(c_last, rows, part, 2, 1, vecs[-1], dev)
-        p_op = operand(OP_POOLED, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, arg=s["arg"], ns=ns)
+        _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), _ptr(s["out"]),
+                  s["arg"].data_ptr(), _ptr(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
+                  PARTIAL_BLOCKS, _stream())
+        p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev)
+        p_op = operand(OP_POOLED, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, arg=s["arg"], ns=ns, rs=rs)
         dx = None
         for li in range(nl - 1, -1, -1):
             pidx = first + 4 * li
@@ -298,36 +326,37 @@ class _SAStack(Function):
                                s["vf"].scale, s["vf"].shift)
             else:
                 q_op = operand(OP_ID, x, cx)
-            grads[pidx] = wgrad(rows, cout, cin, p_op, q_op, dev)
+            grads[pidx] = wgrad(rows, cout, cin, p_op, q_op, dev, rdev)
             if li > 0:      # data gradient, ReLU mask and BN-backward sums of layer li-1
-                dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], ys[li - 1], vecs[li - 1], device=dev)
-                p, q, r, dg, db = bwd_coeffs(cin, rows, part, nstat, 1, vecs[li - 1], dev)
+                dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], ys[li - 1], vecs[li - 1], device=dev,
+                                               rows_dev=rdev)
+                p, q, r, dg, db = bwd_coeffs(cin, full, part, nstat, 1, vecs[li - 1], dev)
                 if DEBUG is not None:
                     DEBUG["layer%d" % li] = dict(dz=dz, part=part, p=p, q=q, r=r, dg=dg, db=db, y=ys[li - 1], vec=vecs[li - 1])
-                p_op = operand(OP_AFF2, dz, cin, ys[li - 1], cin, s1=p, t1=r, s2=q)
+                p_op = operand(OP_AFF2, dz, cin, ys[li - 1], cin, s1=p, t1=r, s2=q, rs=rs)
             elif pos > 0:   # two-branch first layer: one masked gradient, two BatchNorms
                 dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], s["yl"], s["vl"], s["yf"], s["vf"],
-                                               device=dev)
-                pl, ql, rl, dgl, dbl = bwd_coeffs(cin, rows, part, 3, 1, s["vl"], dev)
-                pf, qf, rf, dgf, dbf = bwd_coeffs(cin, rows, part, 3, 2, s["vf"], dev)
+                                               device=dev, rows_dev=rdev)
+                pl, ql, rl, dgl, dbl = bwd_coeffs(cin, full, part, 3, 1, s["vl"], dev)
+                pf, qf, rf, dgf, dbf = bwd_coeffs(cin, full, part, 3, 2, s["vf"], dev)
                 if DEBUG is not None:
                     DEBUG.update(dz0=dz, part0=part, pl=pl, ql=ql, rl=rl, pf=pf, qf=qf, rf=rf, dgl=dgl, dbl=dbl,
                                  dgf=dgf, dbf=dbf, yl=s["yl"], yf=s["yf"], vl=s["vl"], vf=s["vf"])
-                opl = operand(OP_AFF2, dz, cin, s["yl"], cin, s1=pl, t1=rl, s2=ql)
-                opf = operand(OP_AFF2, dz, cin, s["yf"], cin, s1=pf, t1=rf, s2=qf)
-                grads[0] = wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev)
-                grads[4] = wgrad(rows, cin, cx - pos, opf, operand(OP_ID, x, cx, a_off=pos), dev)
+                opl = operand(OP_AFF2, dz, cin, s["yl"], cin, s1=pl, t1=rl, s2=ql, rs=rs)
+                opf = operand(OP_AFF2, dz, cin, s["yf"], cin, s1=pf, t1=rf, s2=qf, rs=rs)
+                grads[0] = wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev, rdev)
+                grads[4] = wgrad(rows, cin, cx - pos, opf, operand(OP_ID, x, cx, a_off=pos), dev, rdev)
                 grads[1] = zeros.take(cin)
                 grads[5] = zeros.take(cin)
                 grads[2], grads[3], grads[6], grads[7] = dgl, dbl, dgf, dbf
                 if ctx.needs_input_grad[0]:     # only the feature channels carry a gradient
                     dx = torch.zeros((rows, cx), dtype=torch.float32, device=dev)
                     epi = Epilogue(bias=None, out=_ptr(dx, pos), ldo=cx, mode=EPI_STORE)
-                    gemm_rows(rows, cin, cx - pos, opf, _pad4(s["wf2"]), epi)
+                    gemm_rows(rows, cin, cx - pos, opf, _pad4(s["wf2"]), epi, rdev)
             elif ctx.needs_input_grad[0]:
                 dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
                 epi = Epilogue(bias=None, out=_ptr(dx), ldo=cx, mode=EPI_STORE)
-                gemm_rows(rows, cout, cx, p_op, _pad4(w2ds[li]), epi)
+                gemm_rows(rows, cout, cx, p_op, _pad4(w2ds[li]), epi, rdev)
         out_grads = [None if g is None else g.reshape(shape) for g, shape in zip(grads, meta["shapes"])]
         return (dx, None) + tuple(out_grads)
 
@@ -340,10 +369,14 @@ def _flat_params(first, convs, bns):
     return params, mods
 
 
-def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample):
+def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample, compact=None):
+    """compact: ops.CompactGroups whose .x is `x` (duplicate ball-query slots removed) or None (dense rows)."""
     params, mods = _flat_params([(mlp_l0, bn_l0), (mlp_f0, bn_f0)], convs, bns)
     meta = {"nsample": nsample, "pos": pos_channel, "bns": mods, "training": mods[0].training,
             "shapes": [p.shape for p in params]}
+    if compact is not None:
+        meta["compact"] = {"rows_dev": compact.rows_dev_ptr, "rows_full": compact.rows_full, "mult": compact.mult,
+                           "grp": compact.grp, "slot": compact.slot, "offsets": compact.offsets}
     return _SAStack.apply(x, meta, *params)
 
 
@@ -379,7 +412,7 @@ class _UmbrellaStack(Function):
         arg = None
         if aggr == "max":
             arg = torch.empty((points, cout), dtype=torch.int32, device=dev)
-            _lib.call("rs_pool_max", points, group, cout, 0, _ptr(y2), None, None, _ptr(out), arg.data_ptr(), _stream())
+            _lib.call("rs_pool_max", points, group, cout, 0, None, _ptr(y2), None, None, _ptr(out), arg.data_ptr(), _stream())
         else:
             _lib.call("rs_pool_sum", points, group, cout, _ptr(y2), _ptr(out), _stream())
             if aggr == "avg":

@@ -100,18 +100,19 @@ def gather_rows(points, idx):
 
 
 # ----------------------------------------------------------------------------- neighbour search
-def ballquery(radius, nsample, xyz, new_xyz):
-    """-> (B,S,nsample) int32; query_ball_point(cuda=False) semantics (pointnet2_utils.py:78-99).
-    The threshold is float32(radius**2) with the square taken in double, as torch's
-    tensor-vs-Python-scalar comparison does."""
+def ballquery(radius, nsample, xyz, new_xyz, return_count=False):
+    """-> (B,S,nsample) int32 [, (B,S) distinct-neighbour counts]; query_ball_point(cuda=False) semantics
+    (pointnet2_utils.py:78-99).  The threshold is float32(radius**2) with the square taken in double, as
+    torch's tensor-vs-Python-scalar comparison does."""
     _need_gpu(xyz, new_xyz)
     xyz, new_xyz = _f32c(xyz), _f32c(new_xyz)
     b, n, _ = xyz.shape
     m = new_xyz.shape[1]
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz.device) if return_count else None
     r2 = torch.tensor(float(radius) ** 2, dtype=torch.float32).item()
-    _lib.call("rs_ballquery", b, n, m, r2, nsample, _p(new_xyz), _p(xyz), _p(idx), _stream())
-    return idx
+    _lib.call("rs_ballquery", b, n, m, r2, nsample, _p(new_xyz), _p(xyz), _p(idx), _p(cnt), _stream())
+    return (idx, cnt) if return_count else idx
 
 
 def knnquery(nsample, xyz, new_xyz=None, return_dist=False):
@@ -192,6 +193,71 @@ def group_features(center, new_center, normal, feature, idx, polar=True):
     -> (B*S*ns, 3+3*polar+Cn+Cf) rows [offset, polar(offset), normal[idx], feature[idx]];
     differentiable w.r.t. normal and feature."""
     return _GroupFeatures.apply(center, new_center, normal, feature, idx, polar)
+
+
+class CompactGroups:
+    """Grouped shared-MLP operand with the padding copies of ball-query rows removed.
+    x (capacity, C): rows [offsets[g], offsets[g+1]) belong to group g, offsets[groups] rows are valid (a
+    device-side count: no host sync); mult[row] = number of dense rows it stands for."""
+    __slots__ = ("x", "mult", "grp", "slot", "src", "offsets", "groups", "nsample", "rows_full")
+
+    def __init__(self, x, mult, grp, slot, src, offsets, groups, nsample):
+        self.x, self.mult, self.grp, self.slot, self.src, self.offsets = x, mult, grp, slot, src, offsets
+        self.groups, self.nsample = groups, nsample
+        self.rows_full = groups * nsample        # what BatchNorm statistics are taken over
+
+    @property
+    def rows_dev_ptr(self):
+        return self.offsets.data_ptr() + 4 * self.groups
+
+
+class _GroupFeaturesCompact(Function):
+    @staticmethod
+    def forward(ctx, center, new_center, normal, feature, idx, cnt, polar):
+        _need_gpu(center, new_center, normal, feature, idx, cnt)
+        center, new_center, normal = _f32c(center), _f32c(new_center), _f32c(normal)
+        idx, cnt = _i32c(idx), _i32c(cnt)
+        feature = None if feature is None else _f32c(feature)
+        b, n, _ = center.shape
+        _, m, ns = idx.shape
+        cn = normal.shape[2]
+        cf = 0 if feature is None else feature.shape[2]
+        ctot = (6 if polar else 3) + cn + cf
+        dev = center.device
+        groups, cap = b * m, b * m * ns
+        offsets = torch.empty((groups + 1,), dtype=torch.int32, device=dev)
+        _lib.call("rs_exclusive_scan", groups, _p(cnt), _p(offsets), _stream())
+        out = torch.empty((cap, ctot), dtype=torch.float32, device=dev)
+        mult = torch.empty((cap,), dtype=torch.float32, device=dev)
+        meta = torch.empty((3, cap), dtype=torch.int32, device=dev)
+        grp, slot, src = meta[0], meta[1], meta[2]
+        _lib.call("rs_group_features_compact", b, n, m, ns, cn, cf, int(polar), _p(center), _p(new_center),
+                  _p(normal), _p(feature), _p(idx), _p(cnt), _p(offsets), _p(out), _p(mult), _p(grp), _p(slot),
+                  _p(src), _stream())
+        ctx.save_for_backward(src, offsets)
+        ctx.dims = (b, n, cn, cf, int(polar), cap, groups)
+        ctx.need = (ctx.needs_input_grad[2], feature is not None and ctx.needs_input_grad[3])
+        ctx.mark_non_differentiable(mult, grp, slot, src, offsets)
+        return out, mult, grp, slot, src, offsets
+
+    @staticmethod
+    def backward(ctx, grad_out, *unused):
+        src, offsets = ctx.saved_tensors
+        b, n, cn, cf, polar, cap, groups = ctx.dims
+        grad_out = _f32c(grad_out)
+        dev = grad_out.device
+        gn = torch.zeros((b, n, cn), dtype=torch.float32, device=dev) if ctx.need[0] else None
+        gf = torch.zeros((b, n, cf), dtype=torch.float32, device=dev) if ctx.need[1] else None
+        if gn is not None or gf is not None:
+            _lib.call("rs_group_features_compact_backward", cap, offsets.data_ptr() + 4 * groups, cn, cf, polar,
+                      _p(grad_out), _p(src), _p(gn), _p(gf), _stream())
+        return None, None, gn, gf, None, None, None
+
+
+def group_features_compact(center, new_center, normal, feature, idx, cnt, polar=True):
+    """Compacted grouped operand (see CompactGroups); differentiable w.r.t. normal and feature."""
+    out, mult, grp, slot, src, offsets = _GroupFeaturesCompact.apply(center, new_center, normal, feature, idx, cnt, polar)
+    return CompactGroups(out, mult, grp, slot, src, offsets, idx.shape[0] * idx.shape[1], idx.shape[2])
 
 
 def group_all_features(center, normal, feature, polar=True):

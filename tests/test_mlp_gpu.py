@@ -136,3 +136,47 @@ def test_plain_stack_matches_torch():
     assert rel_l2(res["hip"][1], res["torch"][1]) < 3e-3
     for gh, gt in zip(res["hip"][2][::2], res["torch"][2][::2]):
         assert rel_l2(gh, gt) < 3e-3
+
+
+@pytest.mark.parametrize("radius,ns", [(0.25, 16), (0.5, 32), (2.0, 8)])
+def test_compacted_groups_match_dense(radius, ns):
+    """The compacted operand (distinct ball-query slots + multiplicities) gives the same stage output and the
+    same gradients as the dense one: padding copies are exact duplicates, so this is an identity, not an
+    approximation.  radius 2.0 fills every ball (no padding at all), 0.25 leaves mostly padding."""
+    from repsurf_amd import mlp, ops
+    from tests.util import cloud
+    mlp.set_backend("hip")
+    b, n, s, cn, cf = 2, 256, 64, 10, 12
+    xyz = torch.from_numpy(cloud(77, b, n)).cuda()
+    fps = ops.furthestsampling(xyz, s)
+    centres = ops.gather_rows(xyz, fps)
+    idx, cnt = ops.ballquery(radius, ns, xyz, centres, return_count=True)
+    assert ((idx[:, :, 1:] == idx[:, :, :1]).sum(-1) == ns - cnt).all()      # cnt = distinct slots
+    g = torch.Generator().manual_seed(3)
+    normal0, feature0 = torch.randn(b, n, cn, generator=g).cuda(), torch.randn(b, n, cf, generator=g).cuda()
+    w = torch.randn(b * s, 48, generator=g).cuda()
+    mod = make_cd(6, cn + cf, [32, 32, 48], 9)
+    res = {}
+    for kind in ("dense", "compact"):
+        m = copy.deepcopy(mod)
+        normal, feature = normal0.clone().requires_grad_(), feature0.clone().requires_grad_()
+        if kind == "dense":
+            x = ops.group_features(xyz, centres, normal, feature, idx, polar=True)
+            out = mlp.sa_mlp_cd(x, 6, m.mlp_l0, m.bn_l0, m.mlp_f0, m.bn_f0, m.convs, m.bns, ns)
+        else:
+            cg = ops.group_features_compact(xyz, centres, normal, feature, idx, cnt, polar=True)
+            assert int(cg.offsets[-1]) == int(cnt.sum())
+            out = mlp.sa_mlp_cd(cg.x, 6, m.mlp_l0, m.bn_l0, m.mlp_f0, m.bn_f0, m.convs, m.bns, ns, compact=cg)
+        (out * w).sum().backward()
+        res[kind] = (out.detach(), normal.grad.clone(), feature.grad.clone(),
+                     {k: p.grad.clone() for k, p in m.named_parameters()},
+                     [bn.running_var.clone() for bn in [m.bn_l0, m.bn_f0] + list(m.bns)])
+    d, c = res["dense"], res["compact"]
+    assert rel(c[0], d[0]) < 2e-5
+    assert rel_l2(c[1], d[1]) < 3e-3 and rel_l2(c[2], d[2]) < 3e-3
+    for k in d[3]:
+        if ".bias" in k and ("mlp_l0" in k or "mlp_f0" in k or "convs" in k):
+            continue
+        assert rel_l2(c[3][k], d[3][k]) < 3e-3, k
+    for a, bb in zip(c[4], d[4]):
+        assert torch.allclose(a, bb, rtol=1e-4, atol=1e-6)
