@@ -509,20 +509,20 @@ reduce_partials_kernel(int chunks, long long n, const float *__restrict__ partia
   }
 }
 
-// ---- BatchNorm statistics -> affine.  Workgroup = 32 channels x 8 slices of the partial rows: consecutive
-// lanes read consecutive channels (256-byte coalesced rows of doubles), slices are combined through LDS in a
+// ---- BatchNorm statistics -> affine.  Workgroup = 8 channels x 32 slices of the partial rows: consecutive
+// lanes read consecutive channels (64-byte rows of doubles), slices are combined through LDS in a
 // fixed order (deterministic).
 template <int NS>   // number of statistics reduced together
 __device__ __forceinline__ void reduce_stat_rows(int c, int nblk, int nstat, const int (&which)[NS],
                                                  const double *__restrict__ partial, double (&out)[NS], bool &owner) {
-  __shared__ double red[8][32][NS];
-  const int ex = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int ch = blockIdx.x * 32 + ex;
+  __shared__ double red[32][8][NS];
+  const int ex = threadIdx.x & 7, sl = threadIdx.x >> 3;      // 8 channels (64 contiguous bytes) x 32 slices
+  const int ch = blockIdx.x * 8 + ex;
   double acc[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = 0.0;
   if (ch < c)
-    for (int b = sl; b < nblk; b += 8)
+    for (int b = sl; b < nblk; b += 32)
 #pragma unroll
       for (int s = 0; s < NS; ++s) acc[s] += partial[((long long)b * nstat + which[s]) * c + ch];
 #pragma unroll
@@ -534,7 +534,7 @@ __device__ __forceinline__ void reduce_stat_rows(int c, int nblk, int nstat, con
     for (int s = 0; s < NS; ++s) {
       double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += red[k][ex][s];
+      for (int k = 0; k < 32; ++k) t += red[k][ex][s];
       out[s] = t;
     }
 }
@@ -550,7 +550,7 @@ bn_finalize_kernel(int c, long long rows, int nblk, const double *__restrict__ p
   bool owner;
   reduce_stat_rows<2>(c, nblk, 2, which, partial, sq, owner);
   if (!owner) return;
-  const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
   const double mean = sq[0] / (double)rows;
   double var = sq[1] / (double)rows - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -579,7 +579,7 @@ bn_bwd_finalize_kernel(int c, long long rows, int nblk, int nstat, int which, co
   bool owner;
   reduce_stat_rows<2>(c, nblk, nstat, sel, partial, v, owner);
   if (!owner) return;
-  const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
   const double db = v[0], dg = v[1];
   const double s = scale[ch], is = invstd[ch], mu = mean[ch], m = (double)rows;
   // dy = s * (dz - db/m - yhat * dg/m),  yhat = (y - mu) * is
@@ -636,21 +636,29 @@ pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ off
                     const float *__restrict__ out, const int *__restrict__ arg, const float *__restrict__ y,
                     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ v,
                     double *__restrict__ partial) {
-  // one thread per column, grid-stride over group slabs: column sums stay in registers
-  const int ch = blockIdx.y * GM_THREADS + threadIdx.x;
-  if (ch >= c) return;
-  const float mu = mean[ch], is = invstd[ch];
+  // workgroup = 64 columns x 4 group lanes; column sums stay in registers over the group loop and are
+  // combined across the 4 lanes through LDS (fixed order)
+  __shared__ double red[4][64][2];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int ch = blockIdx.y * 64 + tx;
   double s0 = 0.0, s1 = 0.0;
-  for (long long g = blockIdx.x; g < groups; g += gridDim.x) {
-    const long long e = g * c + ch;
-    const float val = out[e] > 0.f ? dout[e] : 0.f;
-    v[e] = val;
-    const float yy = y[((offsets ? (long long)offsets[g] : g * ns) + arg[e]) * c + ch];
-    s0 += (double)val;
-    s1 += (double)(val * ((yy - mu) * is));
+  if (ch < c) {
+    const float mu = mean[ch], is = invstd[ch];
+    for (long long g = (long long)blockIdx.x * 4 + ty; g < groups; g += (long long)gridDim.x * 4) {
+      const long long e = g * c + ch;
+      const float val = out[e] > 0.f ? dout[e] : 0.f;
+      v[e] = val;
+      const float yy = y[((offsets ? (long long)offsets[g] : g * ns) + arg[e]) * c + ch];
+      s0 += (double)val;
+      s1 += (double)(val * ((yy - mu) * is));
+    }
   }
-  partial[((long long)blockIdx.x * 2 + 0) * c + ch] = s0;
-  partial[((long long)blockIdx.x * 2 + 1) * c + ch] = s1;
+  red[ty][tx][0] = s0; red[ty][tx][1] = s1;
+  __syncthreads();
+  if (ty == 0 && ch < c) {
+    partial[((long long)blockIdx.x * 2 + 0) * c + ch] = (red[0][tx][0] + red[1][tx][0]) + (red[2][tx][0] + red[3][tx][0]);
+    partial[((long long)blockIdx.x * 2 + 1) * c + ch] = (red[0][tx][1] + red[1][tx][1]) + (red[2][tx][1] + red[3][tx][1]);
+  }
 }
 
 // out[g][c] = sum_k y[g*ns+k][c]   (umbrella aggregation 'sum')
@@ -773,13 +781,14 @@ extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, i
   if (ep.pool_ns > 0) {
     RS_REQUIRE(!rows_dev, "rs_mlp_gemm_rows: fused pooling needs dense groups (not a compacted row set)");
     RS_REQUIRE(ep.pool_max && ep.pool_min && ep.pool_amax && ep.pool_amin, "rs_mlp_gemm_rows: fused pooling needs its four outputs");
-    const int rpt = GM_BM / (GM_THREADS / (cols <= 32 ? 32 : (cols <= 64 ? 64 : 128)));
+    const int rpt = GM_BM / (GM_THREADS / (cols <= 32 ? 32 : (cols <= 64 ? 64 : 128)));   // (pooling keeps 128-wide tiles)
     RS_REQUIRE(rows % ep.pool_ns == 0 && rpt % ep.pool_ns == 0,
                "rs_mlp_gemm_rows: fused pooling needs nsample (%d) to divide %d rows per thread", ep.pool_ns, rpt);
   }
   const int nstat = (epi_mode == EPI_MASK && ep.my2) ? 3 : 2;
   const long long tiles = (rows + GM_BM - 1) / GM_BM;
-  const int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
+  int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
+  if (bn == 128 && tiles * rs_cdiv(cols, 128) < 256 && ep.pool_ns == 0) bn = 64;   // few rows (group_all stage): 2x the workgroups
   const int tiles_n = rs_cdiv(cols, bn);
   int gx = persistent_blocks(tiles, tiles_n);
   if (epi_mode != EPI_STORE) gx = gx < ep.partial_blocks ? gx : ep.partial_blocks;
@@ -844,7 +853,7 @@ extern "C" int rs_bn_finalize(int c, long long rows, int nblk, const double *par
   RS_REQUIRE(c >= 0 && rows > 0 && nblk > 0, "rs_bn_finalize: bad size");
   if (c == 0) return RS_OK;
   RS_REQUIRE(partial && scale && shift && save_mean && save_invstd, "rs_bn_finalize: null pointer");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(rs_cdiv(c, 32)), dim3(256), 0, (hipStream_t)stream, c, rows, nblk,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(rs_cdiv(c, 8)), dim3(256), 0, (hipStream_t)stream, c, rows, nblk,
                      partial, gamma, beta, eps, momentum, scale, shift, save_mean, save_invstd, running_mean, running_var);
   RS_CHECK_LAUNCH("rs_bn_finalize");
   return RS_OK;
@@ -856,7 +865,7 @@ extern "C" int rs_bn_backward_finalize(int c, long long rows, int nblk, int nsta
   RS_REQUIRE(c >= 0 && rows > 0 && nblk > 0 && nstat >= 2 && which >= 1 && which < nstat, "rs_bn_backward_finalize: bad size");
   if (c == 0) return RS_OK;
   RS_REQUIRE(partial && scale && mean && invstd && p && q && r, "rs_bn_backward_finalize: null pointer");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rs_cdiv(c, 32)), dim3(256), 0, (hipStream_t)stream, c, rows, nblk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rs_cdiv(c, 8)), dim3(256), 0, (hipStream_t)stream, c, rows, nblk,
                      nstat, which, partial, scale, mean, invstd, p, q, r, dgamma, dbeta);
   RS_CHECK_LAUNCH("rs_bn_backward_finalize");
   return RS_OK;
@@ -895,11 +904,12 @@ extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const 
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0 && partial_blocks > 0, "rs_pool_max_backward: bad size");
   if (groups == 0 || c == 0) return RS_OK;
   RS_REQUIRE(dout && out && arg && y && mean && invstd && v && partial, "rs_pool_max_backward: null pointer");
-  int gx = (int)(groups < partial_blocks ? groups : partial_blocks);
+  const long long want = (groups + 3) / 4;
+  int gx = (int)(want < partial_blocks ? want : partial_blocks);
   hipStream_t st = (hipStream_t)stream;
   if (gx < partial_blocks)
     (void)hipMemsetAsync(partial + (long long)gx * 2 * c, 0, sizeof(double) * (size_t)(partial_blocks - gx) * 2 * c, st);
-  hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(gx, rs_cdiv(c, GM_THREADS)), dim3(GM_THREADS), 0, st, groups, nsample, c,
+  hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(gx, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, st, groups, nsample, c,
                      offsets, dout, out, arg, y, mean, invstd, v, partial);
   RS_CHECK_LAUNCH("rs_pool_max_backward");
   return RS_OK;
