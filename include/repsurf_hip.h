@@ -271,6 +271,16 @@ int rs_pool_max_backward(long long groups, int nsample, int c, const int *offset
 /* out[g][c] = sum_k y[g*nsample+k][c]   (umbrella aggregation 'sum', :305) */
 int rs_pool_sum(long long groups, int nsample, int c, const float *y, float *out, void *stream);
 
+/* k-major, zero-padded copies (the layout rs_mlp_gemm_rows reads) of up to RS_PACK_MAX conv weights
+ * (cout, cin) in one launch: dst[k*ld + j] = src[j*cin + k] for j < cout, 0 for cout <= j < ld. */
+#define RS_PACK_MAX 8
+typedef struct rs_pack_weights_args {
+  const float *src[RS_PACK_MAX]; float *dst[RS_PACK_MAX];
+  int cout[RS_PACK_MAX], cin[RS_PACK_MAX], ld[RS_PACK_MAX];
+  int n;
+} rs_pack_weights_args;
+int rs_pack_weights(const rs_pack_weights_args *args, void *stream);
+
 /* out[e] = sum_b partial[b][e], b ascending (deterministic reduction of fp32 workgroup partials). */
 int rs_reduce_partials(int nblk, long long n, const float *partial, float *out, void *stream);
 

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librepsurf_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -44,6 +44,7 @@ SIGNATURES = {
     "rs_pool_sum": [c_ll, c_int, c_int, P, P, P],
     "rs_pool_select": [c_ll, c_int, P, P, P, P, P, P, P, P, P],
     "rs_reduce_partials": [c_int, c_ll, P, P, P],
+    "rs_pack_weights": [P, P],
     "rs_umbrella_mlp_pass": [c_int, P, c_float, P, P, P, c_int, P],
 }
 _SPECIAL = {

@@ -78,10 +78,88 @@ __device__ __forceinline__ void knn_scan(const float *__restrict__ pts, int n, f
   }
 }
 
+// ---- 4 lanes per query ----------------------------------------------------------------------------
+// One thread per query leaves the scan a 1024-step serial chain per wave.  Here 4 adjacent lanes share a
+// query: lane `sub` scans candidates sub, sub+4, ... (the 4 lanes of a query read one contiguous 64-byte
+// LDS span per step), then the four sorted lists are merged by two butterfly rounds of shuffles.  Order is
+// lexicographic in (distance, index) everywhere, so the result is the sequential scan's, bit for bit.
+constexpr int KNN_QPB = KNN_THREADS / 4;   // queries per workgroup
+
+template <int K>
+__device__ __forceinline__ void knn_insert_lex(float (&bd)[K], int (&bi)[K], float d, int p) {
+  if (d < bd[K - 1] || (d == bd[K - 1] && p < bi[K - 1])) {
+    bd[K - 1] = d; bi[K - 1] = p;
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+      const bool sw = bd[j] < bd[j - 1] || (bd[j] == bd[j - 1] && bi[j] < bi[j - 1]);
+      const float td = bd[j]; const int ti = bi[j];
+      bd[j] = sw ? bd[j - 1] : td; bi[j] = sw ? bi[j - 1] : ti;
+      bd[j - 1] = sw ? td : bd[j - 1]; bi[j - 1] = sw ? ti : bi[j - 1];
+    }
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void knn_scan4(const float *__restrict__ pts, int n, float4 *tile,
+                                          float qx, float qy, float qz, float (&bd)[K], int (&bi)[K]) {
+  const int sub = threadIdx.x & 3;
+  const float qq = rs_sqnorm(qx, qy, qz);
+#pragma unroll
+  for (int j = 0; j < K; ++j) { bd[j] = INFINITY; bi[j] = 0x7fffffff; }
+  for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
+    const int tn = min(KNN_TILE, n - t0);
+    __syncthreads();
+    for (int p = threadIdx.x; p < tn; p += KNN_THREADS) {
+      const float x = pts[(t0 + p) * 3 + 0], y = pts[(t0 + p) * 3 + 1], z = pts[(t0 + p) * 3 + 2];
+      tile[p] = make_float4(x, y, z, rs_sqnorm(x, y, z));
+    }
+    __syncthreads();
+    for (int p = sub; p < tn; p += 4) {
+      const float4 c = tile[p];
+      const float d = rs_sqdist_expanded(qx, qy, qz, qq, c.x, c.y, c.z, c.w);
+      knn_insert<K>(bd, bi, d, t0 + p);        // candidates of one lane arrive in ascending index order
+    }
+  }
+  // butterfly merge of the 4 partial lists: afterwards every lane of the query holds the K best of the union
+#pragma unroll
+  for (int mask = 1; mask <= 2; mask <<= 1) {
+    float od[K]; int oi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { od[j] = __shfl_xor(bd[j], mask, 64); oi[j] = __shfl_xor(bi[j], mask, 64); }
+#pragma unroll
+    for (int j = 0; j < K; ++j) knn_insert_lex<K>(bd, bi, od[j], oi[j]);
+  }
+}
+
 template <int K>
 __global__ void __launch_bounds__(KNN_THREADS)
 knn_kernel(int b, int n, int m, int nsample, int blocks_per_cloud, const float *__restrict__ xyz,
            const float *__restrict__ new_xyz, int *__restrict__ idx, float *__restrict__ dist2) {
+  __shared__ float4 tile[KNN_TILE];
+  int cloud, chunk;
+  rs_xcd_remap(blockIdx.x, b, blocks_per_cloud, cloud, chunk);
+  const int q = chunk * KNN_QPB + (threadIdx.x >> 2);
+  const int qc = min(q, m - 1);
+  const float *c = new_xyz + ((size_t)cloud * m + qc) * 3;
+  float bd[K]; int bi[K];
+  knn_scan4<K>(xyz + (size_t)cloud * n * 3, n, tile, c[0], c[1], c[2], bd, bi);
+  if (q < m && (threadIdx.x & 3) == 0) {
+    int *orow = idx + ((size_t)cloud * m + q) * nsample;
+#pragma unroll
+    for (int j = 0; j < K; ++j) if (j < nsample) orow[j] = bi[j];
+    if (dist2) {
+      float *drow = dist2 + ((size_t)cloud * m + q) * nsample;
+#pragma unroll
+      for (int j = 0; j < K; ++j) if (j < nsample) drow[j] = bd[j];
+    }
+  }
+}
+
+// one thread per query: for large K, where the unrolled butterfly merge (K*K compare-swaps) does not pay
+template <int K>
+__global__ void __launch_bounds__(KNN_THREADS)
+knn_kernel1(int b, int n, int m, int nsample, int blocks_per_cloud, const float *__restrict__ xyz,
+            const float *__restrict__ new_xyz, int *__restrict__ idx, float *__restrict__ dist2) {
   __shared__ float4 tile[KNN_TILE];
   int cloud, chunk;
   rs_xcd_remap(blockIdx.x, b, blocks_per_cloud, cloud, chunk);
@@ -122,13 +200,26 @@ umbrella_kernel(int b, int n, int blocks_per_cloud, const float *__restrict__ xy
   int cloud, chunk;
   rs_xcd_remap(blockIdx.x, b, blocks_per_cloud, cloud, chunk);
   const float *pts = xyz + (size_t)cloud * n * 3;
-  const int q = chunk * KNN_THREADS + threadIdx.x;
-  const int qc = min(q, n - 1);
-  const float qx = pts[qc * 3 + 0], qy = pts[qc * 3 + 1], qz = pts[qc * 3 + 2];
-
-  float bd[K]; int bi[K];
-  knn_scan<K>(pts, n, tile, qx, qy, qz, bd, bi);
+  int bi[K];
+  {   // phase 1: kNN, 4 lanes per query (64 queries per workgroup)
+    const int q4 = min(chunk * KNN_QPB + (threadIdx.x >> 2), n - 1);
+    float bd[K];
+    knn_scan4<K>(pts, n, tile, pts[q4 * 3 + 0], pts[q4 * 3 + 1], pts[q4 * 3 + 2], bd, bi);
+  }
+  // phase 2: one lane per query.  The lists travel through LDS so that wave 0 works with all 64 lanes.
+  __syncthreads();
+  int *lists = reinterpret_cast<int *>(tile);
+  if ((threadIdx.x & 3) == 0) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) lists[(threadIdx.x >> 2) * K + j] = bi[j];
+  }
+  __syncthreads();
+  if (threadIdx.x >= KNN_QPB) return;
+  const int q = chunk * KNN_QPB + threadIdx.x;
   if (q >= n) return;
+#pragma unroll
+  for (int j = 0; j < K; ++j) bi[j] = lists[threadIdx.x * K + j];
+  const float qx = pts[q * 3 + 0], qy = pts[q * 3 + 1], qz = pts[q * 3 + 2];
 
   if (knn_idx) {
     int *orow = knn_idx + ((size_t)cloud * n + q) * K;
@@ -207,16 +298,23 @@ umbrella_kernel(int b, int n, int blocks_per_cloud, const float *__restrict__ xy
 }
 
 template <int K>
+void launch_knn1(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx,
+                 float *dist2, hipStream_t st) {
+  const int bpc = rs_cdiv(m, KNN_THREADS);
+  hipLaunchKernelGGL(knn_kernel1<K>, dim3(b * bpc), dim3(KNN_THREADS), 0, st, b, n, m, nsample, bpc, xyz,
+                     new_xyz, idx, dist2);
+}
+template <int K>
 void launch_knn(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx,
                 float *dist2, hipStream_t st) {
-  const int bpc = rs_cdiv(m, KNN_THREADS);
+  const int bpc = rs_cdiv(m, KNN_QPB);
   hipLaunchKernelGGL(knn_kernel<K>, dim3(b * bpc), dim3(KNN_THREADS), 0, st, b, n, m, nsample, bpc, xyz,
                      new_xyz, idx, dist2);
 }
 template <int K>
 void launch_umb(int b, int n, const float *xyz, const float *inv_sign, int *knn_idx, float *feat,
                 hipStream_t st) {
-  const int bpc = rs_cdiv(n, KNN_THREADS);
+  const int bpc = rs_cdiv(n, KNN_QPB);
   hipLaunchKernelGGL(umbrella_kernel<K>, dim3(b * bpc), dim3(KNN_THREADS), 0, st, b, n, bpc, xyz, inv_sign,
                      knn_idx, feat);
 }
@@ -234,8 +332,8 @@ extern "C" int rs_knnquery(int b, int n, int m, int nsample, const float *xyz, c
   if (nsample <= 4) launch_knn<4>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
   else if (nsample <= 9) launch_knn<9>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
   else if (nsample <= 16) launch_knn<16>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
-  else if (nsample <= 32) launch_knn<32>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
-  else launch_knn<64>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
+  else if (nsample <= 32) launch_knn1<32>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
+  else launch_knn1<64>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
   RS_CHECK_LAUNCH("rs_knnquery");
   return RS_OK;
 }

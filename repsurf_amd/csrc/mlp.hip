@@ -835,6 +835,37 @@ extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int 
   return RS_OK;
 }
 
+// ---- k-major copies of up to RS_PACK_MAX conv weights in one launch --------------------------------
+// dst[k*ld + j] = src[j*cin + k] (j < cout), zero for cout <= j < ld: the layout rs_mlp_gemm_rows reads.
+__global__ void __launch_bounds__(GM_THREADS)
+pack_weights_kernel(rs_pack_weights_args a) {
+  const int e = blockIdx.y;
+  const int cout = a.cout[e], cin = a.cin[e], ld = a.ld[e];
+  const float *__restrict__ src = a.src[e];
+  float *__restrict__ dst = a.dst[e];
+  const int total = cin * ld;
+  for (int i = blockIdx.x * GM_THREADS + threadIdx.x; i < total; i += gridDim.x * GM_THREADS) {
+    const int k = i / ld, j = i - k * ld;
+    dst[i] = j < cout ? src[j * cin + k] : 0.f;
+  }
+}
+
+extern "C" int rs_pack_weights(const rs_pack_weights_args *args, void *stream) {
+  RS_REQUIRE(args && args->n >= 0 && args->n <= RS_PACK_MAX, "rs_pack_weights: bad descriptor count");
+  if (args->n == 0) return RS_OK;
+  int biggest = 0;
+  for (int e = 0; e < args->n; ++e) {
+    RS_REQUIRE(args->src[e] && args->dst[e] && args->ld[e] >= args->cout[e] && args->ld[e] % 4 == 0,
+               "rs_pack_weights: entry %d invalid (ld=%d cout=%d)", e, args->ld[e], args->cout[e]);
+    biggest = max(biggest, args->cin[e] * args->ld[e]);
+  }
+  int gx = rs_cdiv(biggest, GM_THREADS);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(gx, args->n), dim3(GM_THREADS), 0, (hipStream_t)stream, *args);
+  RS_CHECK_LAUNCH("rs_pack_weights");
+  return RS_OK;
+}
+
 extern "C" int rs_reduce_partials(int nblk, long long n, const float *partial, float *out, void *stream) {
   RS_REQUIRE(nblk > 0 && n >= 0, "rs_reduce_partials: bad size");
   if (n == 0) return RS_OK;

@@ -122,6 +122,34 @@ def _kmajor(w2d):
     return _pad4(w2d.t()).contiguous()
 
 
+PACK_MAX = 8
+
+
+class PackArgs(ctypes.Structure):            # rs_pack_weights_args
+    _fields_ = [("src", P * PACK_MAX), ("dst", P * PACK_MAX), ("cout", c_int * PACK_MAX), ("cin", c_int * PACK_MAX),
+                ("ld", c_int * PACK_MAX), ("n", c_int)]
+
+
+def pack_kmajor(w2ds, device):
+    """k-major zero-padded copies of several (cout, cin) weights with ONE launch per 8 weights."""
+    lds = [(-(-w.shape[0] // 4)) * 4 for w in w2ds]
+    sizes = [w.shape[1] * ld for w, ld in zip(w2ds, lds)]
+    flat = torch.empty((sum(-(-sz // 4) * 4 for sz in sizes),), dtype=torch.float32, device=device)
+    outs, off = [], 0
+    for w, ld, sz in zip(w2ds, lds, sizes):
+        outs.append(flat[off:off + sz].view(w.shape[1], ld))
+        off += -(-sz // 4) * 4                      # keep every copy 16-byte aligned
+    for i in range(0, len(w2ds), PACK_MAX):
+        a = PackArgs()
+        chunk = list(zip(w2ds[i:i + PACK_MAX], outs[i:i + PACK_MAX], lds[i:i + PACK_MAX]))
+        for j, (w, o, ld) in enumerate(chunk):
+            a.src[j], a.dst[j] = w.data_ptr(), o.data_ptr()
+            a.cout[j], a.cin[j], a.ld[j] = w.shape[0], w.shape[1], ld
+        a.n = len(chunk)
+        _lib.call("rs_pack_weights", ctypes.byref(a), _stream())
+    return outs
+
+
 def gemm_rows(rows, kdim, cols, x_op, wk, epi, rows_dev=None):
     """out[rows, cols] = E[rows, kdim] . wk[:kdim, :cols]   (wk k-major, ld % 4 == 0)"""
     _lib.call("rs_mlp_gemm_rows", rows, rows_dev, kdim, cols, ctypes.byref(x_op), _ptr(wk), wk.shape[1],
@@ -134,7 +162,7 @@ def fused_pool_ok(cout, nsample):
     return rows_per_thread % nsample == 0
 
 
-def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, rs=None):
+def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, rs=None, wk=None):
     """y = E . W^T + bias with BN statistics; returns (y, BNVec[, pooled (out, arg)]).
     rs: RowSet of a compacted operand (device row count, per-row weights of the statistics)."""
     cout = w2d.shape[0]
@@ -157,7 +185,7 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
             epi.pool_max, epi.pool_min = _ptr(ext[0]), _ptr(ext[1])
             epi.pool_amax, epi.pool_amin = pos[0].data_ptr(), pos[1].data_ptr()
             pool = (ext, pos)
-        gemm_rows(rows, kdim, cout, x_op, _kmajor(w2d), epi, rows_dev)
+        gemm_rows(rows, kdim, cout, x_op, wk if wk is not None else _kmajor(w2d), epi, rows_dev)
         track = bn_mod.track_running_stats and bn_mod.running_mean is not None
         if track:
             _pending_counters.append(bn_mod.num_batches_tracked)
@@ -175,7 +203,7 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
             return y, vec, (out, arg)
     else:
         epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STORE)
-        gemm_rows(rows, kdim, cout, x_op, _kmajor(w2d), epi, rows_dev)
+        gemm_rows(rows, kdim, cout, x_op, wk if wk is not None else _kmajor(w2d), epi, rows_dev)
         with torch.no_grad():
             invstd = torch.rsqrt(bn_mod.running_var + bn_mod.eps)
             vec.invstd.copy_(invstd)
@@ -195,7 +223,9 @@ def wgrad_chunks(rows, ncols, kcols):
 
 
 def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None):
-    chunks = wgrad_chunks(rows, ncols, kcols)
+    # a compacted row set fills a fraction of its capacity (the count is on the device): size the slab split
+    # for a quarter of it so that slabs keep several pipeline stages and fewer partials need reducing
+    chunks = wgrad_chunks(rows if rows_dev is None else max(rows // 4, 256), ncols, kcols)
     part = torch.empty((chunks, ncols * kcols), dtype=torch.float32, device=device)
     dw = torch.empty((ncols, kcols), dtype=torch.float32, device=device)
     _lib.call("rs_mlp_wgrad", rows, rows_dev, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), chunks,
@@ -243,11 +273,14 @@ class _SAStack(Function):
         saved = {"x": x, "rs": rs}
         pi = 0
         ys, vecs, w2ds = [], [], []
+        all_w2d = [_w2d(params[i]) for i in range(0, len(params), 4)]
+        wks = pack_kmajor(all_w2d, dev)            # one launch for every layer's k-major weight copy
         if pos > 0:      # two-branch first layer (SurfaceAbstractionCD)
             wl, bl, wf, bf = params[0], params[1], params[4], params[5]
-            wl2, wf2 = _w2d(wl), _w2d(wf)
-            yl, vl = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev, rs=rs)
-            yf, vf = fwd_layer(rows, operand(OP_ID, x, cx, a_off=pos), cx - pos, wf2, bf, bns[1], training, dev, rs=rs)
+            wl2, wf2 = all_w2d[0], all_w2d[1]
+            yl, vl = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev, rs=rs, wk=wks[0])
+            yf, vf = fwd_layer(rows, operand(OP_ID, x, cx, a_off=pos), cx - pos, wf2, bf, bns[1], training, dev, rs=rs,
+                               wk=wks[1])
             saved.update(yl=yl, vl=vl, yf=yf, vf=vf, wl2=wl2, wf2=wf2)
             prev_op = operand(OP_RELU2, yl, yl.shape[1], yf, yf.shape[1], vl.scale, vl.shift, vf.scale, vf.shift)
             prev_c = wl2.shape[0]
@@ -259,12 +292,12 @@ class _SAStack(Function):
         pooled = None
         while pi < len(params):
             w, b = params[pi], params[pi + 1]
-            w2 = _w2d(w)
+            w2, wk = all_w2d[pi // 4], wks[pi // 4]
             last = pi + 4 >= len(params)
             if last and training and rs.dev is None and fused_pool_ok(w2.shape[0], ns):
-                y, vec, pooled = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, pool_ns=ns)
+                y, vec, pooled = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, pool_ns=ns, wk=wk)
             else:
-                y, vec = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, rs=rs)
+                y, vec = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, rs=rs, wk=wk)
             ys.append(y); vecs.append(vec); w2ds.append(w2)
             prev_op = operand(OP_RELU1, y, y.shape[1], s1=vec.scale, t1=vec.shift)
             prev_c = w2.shape[0]
@@ -349,8 +382,10 @@ class _SAStack(Function):
                 grads[1] = zeros.take(cin)
                 grads[5] = zeros.take(cin)
                 grads[2], grads[3], grads[6], grads[7] = dgl, dbl, dgf, dbf
-                if ctx.needs_input_grad[0]:     # only the feature channels carry a gradient
-                    dx = torch.zeros((rows, cx), dtype=torch.float32, device=dev)
+                if ctx.needs_input_grad[0]:
+                    # Only the feature channels [pos:] carry a gradient (coordinates are inputs); the grouping
+                    # backward reads nothing else, so the position columns are left unwritten (no 150 MB memset).
+                    dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
                     epi = Epilogue(bias=None, out=_ptr(dx, pos), ldo=cx, mode=EPI_STORE)
                     gemm_rows(rows, cin, cx - pos, opf, _pad4(s["wf2"]), epi, rdev)
             elif ctx.needs_input_grad[0]:
