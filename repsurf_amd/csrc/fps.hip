@@ -57,8 +57,8 @@ __device__ __forceinline__ FpsSeg fps_segment(int blk, int n, int m, const int *
   return s;
 }
 
-template <int PPT>
-__global__ void __launch_bounds__(1024)
+template <int PPT, int NW>     // points per thread, waves per workgroup (blockDim.x == 64 * NW)
+__global__ void __launch_bounds__(64 * NW)
 fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *__restrict__ start,
                const int *__restrict__ offset, const int *__restrict__ new_offset,
                int *__restrict__ idx_out) {
@@ -74,7 +74,6 @@ fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *_
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int nwaves = blockDim.x >> 6;
 
   float px[PPT], py[PPT], pz[PPT], md[PPT];
 #pragma unroll
@@ -129,7 +128,7 @@ fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *_
     const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), wl));
     const int widx = (wave * 64 + wl) * PPT + wslot;
 
-    if (nwaves == 1) {
+    if (NW == 1) {
       cur = widx; cx = wx; cy = wy; cz = wz;
     } else {
       const int par = it & 1;
@@ -138,14 +137,17 @@ fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *_
         red_xyz[par][wave] = make_float4(wx, wy, wz, 0.f);
       }
       __syncthreads();
-      unsigned bkey = 0u; int bidx = 0; float bx = 0.f, by = 0.f, bz = 0.f;
-      for (int w = 0; w < nwaves; ++w) {     // ascending waves + strict '>' keeps the lowest index on ties
-        const uint2 k = red_key[par][w];
-        const float4 c = red_xyz[par][w];
-        const bool better = (w == 0) || (k.x > bkey);
-        bkey = better ? k.x : bkey;
-        bidx = better ? (int)k.y : bidx;
-        bx = better ? c.x : bx; by = better ? c.y : by; bz = better ? c.z : bz;
+      // all NW candidates are fetched with independent LDS reads (one wait), then compared in registers
+      uint2 k[NW]; float4 c[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { k[w] = red_key[par][w]; c[w] = red_xyz[par][w]; }
+      unsigned bkey = k[0].x; int bidx = (int)k[0].y; float bx = c[0].x, by = c[0].y, bz = c[0].z;
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {         // ascending waves + strict '>' keeps the lowest index on ties
+        const bool better = k[w].x > bkey;
+        bkey = better ? k[w].x : bkey;
+        bidx = better ? (int)k[w].y : bidx;
+        bx = better ? c[w].x : bx; by = better ? c[w].y : by; bz = better ? c[w].z : bz;
       }
       cur = bidx; cx = bx; cy = by; cz = bz;
       // the other parity buffer is only rewritten after the NEXT barrier, so no second barrier
@@ -208,33 +210,47 @@ int env_int(const char *name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-template <int PPT>
-void launch_reg(int blocks, int threads, int n, int m, const float *xyz, const int *start,
-                const int *offset, const int *new_offset, int *idx, hipStream_t st) {
-  hipLaunchKernelGGL(fps_reg_kernel<PPT>, dim3(blocks), dim3(threads), 0, st, n, m, xyz, start, offset,
+template <int PPT, int NW>
+void launch_reg2(int blocks, int n, int m, const float *xyz, const int *start, const int *offset,
+                 const int *new_offset, int *idx, hipStream_t st) {
+  hipLaunchKernelGGL((fps_reg_kernel<PPT, NW>), dim3(blocks), dim3(64 * NW), 0, st, n, m, xyz, start, offset,
                      new_offset, idx);
+}
+template <int PPT>
+void launch_reg(int blocks, int waves, int n, int m, const float *xyz, const int *start,
+                const int *offset, const int *new_offset, int *idx, hipStream_t st) {
+  switch (waves) {
+    case 1: launch_reg2<PPT, 1>(blocks, n, m, xyz, start, offset, new_offset, idx, st); break;
+    case 2: launch_reg2<PPT, 2>(blocks, n, m, xyz, start, offset, new_offset, idx, st); break;
+    case 4: launch_reg2<PPT, 4>(blocks, n, m, xyz, start, offset, new_offset, idx, st); break;
+    case 8: launch_reg2<PPT, 8>(blocks, n, m, xyz, start, offset, new_offset, idx, st); break;
+    default: launch_reg2<PPT, 16>(blocks, n, m, xyz, start, offset, new_offset, idx, st); break;
+  }
 }
 
 // n_max: the largest cloud a workgroup can meet
 int fps_dispatch(int blocks, int n_max, int n, int m, const float *xyz, const int *start,
                  const int *offset, const int *new_offset, float *temp, int *idx, hipStream_t st) {
-  // waves per workgroup: fewer waves = more register work per lane but cheaper cross-wave step.
+  // Waves per workgroup: the loop is a latency chain, so fewer waves (no cross-wave hop, or a short one)
+  // win as long as the per-lane point count stays small: measured best 1 wave up to 512 points, 2 waves
+  // at 1024 (profiles/: RS_FPS_WAVES sweep).
   int waves = env_int("RS_FPS_WAVES", 0);
-  if (waves <= 0) waves = n_max <= 256 ? 1 : (n_max <= 2048 ? 4 : (n_max <= 8192 ? 8 : 16));
-  if (waves > 16) waves = 16;
-  int threads = waves * 64;
-  int ppt = (n_max + threads - 1) / threads;
-  while (ppt > 16 && threads < 1024) { threads *= 2; ppt = (n_max + threads - 1) / threads; }
+  if (waves <= 0) waves = n_max <= 512 ? 1 : (n_max <= 1024 ? 2 : (n_max <= 4096 ? 4 : (n_max <= 8192 ? 8 : 16)));
+  int w = 1;
+  while (w < waves && w < 16) w <<= 1;       // power of two
+  waves = w;
+  int ppt = (n_max + waves * 64 - 1) / (waves * 64);
+  while (ppt > 16 && waves < 16) { waves *= 2; ppt = (n_max + waves * 64 - 1) / (waves * 64); }
   if (ppt > 16) {   // > 16384 points per cloud: distances no longer fit the register file
     if (!temp) { rs_set_error("rs_furthestsampling: n=%d needs the `temp` scratch (b*n floats)", n_max); return RS_ERR_ARG; }
     hipLaunchKernelGGL(fps_global_kernel, dim3(blocks), dim3(1024), 0, st, n, m, xyz, start, offset, new_offset, temp, idx);
     return RS_OK;
   }
-  if (ppt <= 1) launch_reg<1>(blocks, threads, n, m, xyz, start, offset, new_offset, idx, st);
-  else if (ppt <= 2) launch_reg<2>(blocks, threads, n, m, xyz, start, offset, new_offset, idx, st);
-  else if (ppt <= 4) launch_reg<4>(blocks, threads, n, m, xyz, start, offset, new_offset, idx, st);
-  else if (ppt <= 8) launch_reg<8>(blocks, threads, n, m, xyz, start, offset, new_offset, idx, st);
-  else launch_reg<16>(blocks, threads, n, m, xyz, start, offset, new_offset, idx, st);
+  if (ppt <= 1) launch_reg<1>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, st);
+  else if (ppt <= 2) launch_reg<2>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, st);
+  else if (ppt <= 4) launch_reg<4>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, st);
+  else if (ppt <= 8) launch_reg<8>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, st);
+  else launch_reg<16>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, st);
   return RS_OK;
 }
 

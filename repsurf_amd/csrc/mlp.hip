@@ -522,9 +522,16 @@ __device__ __forceinline__ void reduce_stat_rows(int c, int nblk, int nstat, con
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = 0.0;
   if (ch < c)
-    for (int b = sl; b < nblk; b += 32)
+    for (int b = sl; b < nblk; b += 128) {     // 4 partial rows per trip: the loads are independent and overlap
+      double v[4][NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) acc[s] += partial[((long long)b * nstat + which[s]) * c + ch];
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          v[u][s] = (b + 32 * u < nblk) ? partial[((long long)(b + 32 * u) * nstat + which[s]) * c + ch] : 0.0;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] += (v[0][s] + v[1][s]) + (v[2][s] + v[3][s]);
+    }
 #pragma unroll
   for (int s = 0; s < NS; ++s) red[sl][ex][s] = acc[s];
   __syncthreads();

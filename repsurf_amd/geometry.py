@@ -34,6 +34,7 @@ class GeometryPlan:
 
     def __init__(self, xyz, stages):
         self.stages = []
+        self.events = []
         self.main = torch.cuda.current_stream()
         side = _side_stream(xyz.device)
         b, dev = xyz.shape[0], xyz.device
@@ -61,9 +62,9 @@ class GeometryPlan:
                 _lib.call("rs_ballquery", b, n, npoint, r2, nsample, g.new_center.data_ptr(), center.data_ptr(),
                           g.idx.data_ptr(), g.cnt.data_ptr(), st_ptr)
                 center, n = g.new_center, npoint
-            self.event = side.record_event()
+                self.events.append(side.record_event())      # stage i is usable as soon as ITS kernels are done
         self.keep = (xyz, starts)
-        self.joined = False
+        self.joined = [False] * len(self.stages)
 
     @staticmethod
     def _sizes(n, stages):
@@ -74,7 +75,7 @@ class GeometryPlan:
         return out
 
     def stage(self, i):
-        if not self.joined:
-            self.main.wait_event(self.event)
-            self.joined = True
+        if not self.joined[i]:
+            self.main.wait_event(self.events[i])
+            self.joined[i] = True
         return self.stages[i]
