@@ -107,6 +107,8 @@ def algorithmic_cost(name, dims):
     if name == "rs_ballquery":
         b, n, m, ns = dims
         return "bytes", 4.0 * (3 * b * n + 3 * b * m + b * m * ns)
+    if dims and isinstance(dims[-1], str):
+        return None, 0.0           # compacted operand: the launch's row count is device-side, no static cost
     if name == "rs_mlp_gemm_rows":
         rows, kdim, cols = dims[:3]
         return "flops", 2.0 * rows * kdim * cols
@@ -137,9 +139,11 @@ def main():
     torch.manual_seed(0)                     # identical initial weights on every rank
     model = Model(model_args()).to(device).train()
     cpu_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    net = rdist.wrap(model, device)                           # one 64 MB bucket: a single gradient all-reduce
+    use_graph = not args.no_graph
+    # eager launches: DistributedDataParallel (one 64 MB bucket = a single gradient all-reduce);
+    # graph replay: the model itself, gradients in one flat buffer, one explicit all-reduce per step
+    net = model if use_graph else rdist.wrap(model, device)
     criterion = SmoothClsLoss()
-    use_graph = (world == 1) and not args.no_graph
     optim = None if args.no_optim else torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=use_graph)
     points, label = synthetic_batch(rdist.rank_seed(125, rank), args.batch, args.points, device)
     torch.manual_seed(rdist.rank_seed(13, rank))   # CPU generator: FPS starts / normal flips differ per rank
@@ -166,9 +170,25 @@ def main():
         # the wrong stream and the capture faults).  Per-launch HIP events cannot be recorded inside a
         # replayed graph, so the kernel timings for `roofline` come from a short eager pass on a copy of
         # the model AFTER the timed region; the throughput comes from graph replay of the identical step.
-        from repsurf_amd.graph import GraphedStep
-        step = GraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
-        mode = "hipgraph"
+        from repsurf_amd.graph import GraphedStep, ShardedGraphedStep
+        if world == 1:
+            step = GraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
+            mode = "hipgraph"
+        else:
+            try:
+                step = ShardedGraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
+                mode = "hipgraph x2 + rccl all-reduce"
+            except Exception as e:  # noqa: BLE001 - keep the scaling run alive: eager DDP is slower but equivalent
+                print(f"[bench rank {rank}] graph capture failed ({e!r}); falling back to eager DDP", file=sys.stderr)
+                for p in model.parameters():
+                    p.grad = None
+                net = rdist.wrap(model, device)
+                use_graph = False
+                for _ in range(args.warmup):
+                    step()
+                if timing:
+                    args.timed_steps = args.steps
+                    _lib.profile_enable(True)
     else:
         for _ in range(args.warmup):
             step()
@@ -183,7 +203,7 @@ def main():
     dt = time.perf_counter() - t0
     if timing and not use_graph:
         _lib.profile_enable(False)
-    if timing and use_graph:
+    if timing and use_graph and rank == 0:
         import copy
         twin = copy.deepcopy(model)
         topt = None if args.no_optim else torch.optim.Adam(twin.parameters(), lr=1e-3, fused=True)

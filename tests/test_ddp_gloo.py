@@ -64,3 +64,39 @@ def test_single_process_defaults():
     assert rdist.env() == (0, 1, 0)
     m = torch.nn.Linear(2, 2)
     assert rdist.wrap(m) is m and rdist.max_over_ranks(3.5) == 3.5
+
+
+def _flat_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from repsurf_amd import dist as rdist
+    from repsurf_amd.graph import attach_flat_grads
+    rdist.init(backend="gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    flat = attach_flat_grads(list(model.parameters()))
+    g = torch.Generator().manual_seed(rdist.rank_seed(5, rank))
+    x = torch.randn(32, 8, generator=g)
+    for _ in range(2):                         # second pass checks the zero_() + in-place accumulation cycle
+        flat.zero_()
+        model(x).pow(2).mean().backward()
+    local = flat.clone()
+    assert all(p.grad.data_ptr() >= flat.data_ptr() for p in model.parameters())   # still views of the buffer
+    dist.all_reduce(flat)
+    flat.div_(world)
+    out[rank] = (flat.clone(), local, torch.cat([p.grad.flatten() for p in model.parameters()]))
+    rdist.finish()
+
+
+def test_flat_gradient_buffer_allreduce():
+    """the gradient path of ShardedGraphedStep (flat buffer + one all-reduce) on 2 gloo ranks"""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_flat_worker, args=(world, port, out), nprocs=world, join=True)
+        (f0, l0, g0), (f1, l1, g1) = out[0], out[1]
+    assert torch.allclose(f0, f1) and torch.allclose(f0, (l0 + l1) / 2, atol=1e-6)
+    assert torch.equal(g0, f0)                 # parameters see the averaged gradient through their views

@@ -47,3 +47,34 @@ def test_graphed_step_matches_eager():
     assert (g_g - g_e).norm() / g_e.norm() < 5e-2 or True     # draws differ by one pass offset at most; see loss check
     l4 = step().item()
     assert np.isfinite(l4)
+
+
+def test_sharded_step_single_rank_process_group():
+    """ShardedGraphedStep (graph A -> all-reduce -> graph B) with a 1-rank RCCL process group."""
+    import os
+    import torch.distributed as dist
+    from models.repsurf.repsurf_ssg_umb import Model
+    from repsurf_amd import mlp
+    from repsurf_amd.graph import ShardedGraphedStep
+    from util.utils import SmoothClsLoss
+    mlp.set_backend("hip")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        m = Model(ref_args())
+        name_seeded_init(m)
+        m = m.cuda().train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True, capturable=True)
+        pts = torch.from_numpy(cloud(3, 8, 1024)).cuda().permute(0, 2, 1).contiguous()
+        lab = torch.arange(8).cuda() % 15
+        w0 = m.classfier[8].weight.detach().clone()
+        step = ShardedGraphedStep(m, SmoothClsLoss(), opt, pts, lab, warmup=2)
+        l1 = step().item()
+        l2 = step().item()
+        assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1 + 0.5
+        assert not torch.equal(w0, m.classfier[8].weight)          # the optimizer graph ran
+        assert step.flat.abs().sum() > 0
+    finally:
+        dist.destroy_process_group()
