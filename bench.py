@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=8, help="clouds in the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--breakdown", default="", help="write a per-kernel timing breakdown JSON here")
+    ap.add_argument("--launch-log", default="", help="write the ordered (abi call, sizes) list of the timing pass "
+                                                     "(tools/traffic_from_pmc.py matches it to a rocprofv3 --pmc run)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     return ap.parse_args()
 
@@ -107,8 +109,11 @@ def algorithmic_cost(name, dims):
     if name == "rs_ballquery":
         b, n, m, ns = dims
         return "bytes", 4.0 * (3 * b * n + 3 * b * m + b * m * ns)
-    if dims and isinstance(dims[-1], str):
-        return None, 0.0           # compacted operand: the launch's row count is device-side, no static cost
+    # compacted launches: dims[0] is the capacity, the rows really processed come as a trailing "rows=<mean>" note
+    notes = [d for d in dims if isinstance(d, str)]
+    dims = [d for d in dims if not isinstance(d, str)]
+    if notes:
+        dims[0] = float(notes[0].split("=")[1])
     if name == "rs_mlp_gemm_rows":
         rows, kdim, cols = dims[:3]
         return "flops", 2.0 * rows * kdim * cols
@@ -232,9 +237,16 @@ def main():
         table = []
         for name, recs in prof.items():
             by_dims = {}
+            rows_of = {}
             for t_ms, dims in recs:
-                by_dims.setdefault(dims, []).append(t_ms)
+                static = tuple(d for d in dims if not isinstance(d, str))
+                by_dims.setdefault(static, []).append(t_ms)
+                for d in dims:
+                    if isinstance(d, str):       # "rows=<n>": row count of a compacted launch (varies a little per step)
+                        rows_of.setdefault(static, []).append(int(d.split("=")[1]))
             for dims, ts in by_dims.items():
+                if dims in rows_of:
+                    dims = dims + (f"rows={float(np.mean(rows_of[dims])):.1f}",)
                 unit, amount = algorithmic_cost(name, dims)
                 table.append({"kernel": name, "dims": list(dims), "launches": len(ts), "avg_us": float(np.mean(ts)) * 1e3,
                               "total_ms_per_step": float(np.sum(ts)) / max(1, getattr(args, "timed_steps", args.steps)), "unit": unit, "amount": amount})
@@ -252,8 +264,19 @@ def main():
                 roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "hbm", "achieved": round(ach, 2),
                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5)}
             roofline["avg_launch_us"] = round(row["avg_us"], 2)
-            roofline["traffic"] = traffic_from_profiles(row["kernel"])
+            roofline["launches_per_step"] = row["launches"] // max(1, getattr(args, "timed_steps", args.steps))
+            roofline["traffic"] = traffic_from_profiles(row["kernel"], row["dims"])
             break
+        # every MFMA launch of the step together (all shared-MLP GEMMs + weight-gradient GEMMs)
+        fl = sum(r["amount"] * r["launches"] for r in table if r["unit"] == "flops")
+        tm = sum(r["avg_us"] * r["launches"] for r in table if r["unit"] == "flops") * 1e-6
+        if roofline is not None and tm > 0:
+            roofline["all_mfma_launches"] = {"achieved": round(fl / tm / 1e12, 2), "unit": "TFLOP/s",
+                                             "frac": round(fl / tm / 1e12 / PEAK_F32_MFMA_TF, 4),
+                                             "ms_per_step": round(tm * 1e3 / max(1, getattr(args, "timed_steps", args.steps)), 4)}
+        if args.launch_log:
+            os.makedirs(os.path.dirname(os.path.abspath(args.launch_log)), exist_ok=True)
+            json.dump([[n, list(d)] for n, d in _lib.profile_sequence()], open(args.launch_log, "w"))
         if args.breakdown:
             os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
             json.dump({"ms_per_step": ms, "kernels": table}, open(args.breakdown, "w"), indent=1)
@@ -277,13 +300,20 @@ def main():
     rdist.finish()
 
 
-def traffic_from_profiles(kernel):
-    """HBM bytes per launch from the PMC passes summarised under profiles/ (None until collected)."""
+def traffic_key(kernel, dims):
+    return kernel + "|" + ",".join(str(d) for d in dims if not isinstance(d, str))
+
+
+def traffic_from_profiles(kernel, dims):
+    """HBM bytes per launch of this ABI call at these sizes, from the rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 FETCH_SIZE x2 correction) that
+    tools/traffic_from_pmc.py summarises into profiles/traffic.json; None until collected."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(path):
         try:
-            return json.load(open(path)).get(kernel)
-        except (OSError, ValueError):
+            rec = json.load(open(path)).get(traffic_key(kernel, dims))
+            return rec["hbm_bytes"] if rec else None
+        except (OSError, ValueError, KeyError):
             return None
     return None
 

@@ -110,6 +110,30 @@ def profile_collect():
     return out
 
 
+_hip = None
+
+
+def _read_device_int(ptr):
+    """Blocking 4-byte device->host copy (profiling only; orders after the work queued so far)."""
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [c_void_p, c_void_p, ctypes.c_size_t, c_int]
+        _hip.hipMemcpy.restype = c_int
+    import torch
+    torch.cuda.current_stream().synchronize()
+    host = c_int(0)
+    rc = _hip.hipMemcpy(ctypes.byref(host), ptr, 4, 2)        # 2 = hipMemcpyDeviceToHost
+    if rc != 0:
+        raise RepSurfHipError(f"hipMemcpy of a device row count failed (hip error {rc})")
+    return int(host.value)
+
+
+def profile_sequence():
+    """-> [(abi name, dims), ...] in launch order for the last profiled region."""
+    return [(name, dims) for name, dims, _, _ in _frozen]
+
+
 def call(name, *args):
     """Invoke an ABI function; non-zero return -> RepSurfHipError with the library's message."""
     lib = load()
@@ -121,7 +145,9 @@ def call(name, *args):
         e1.record()
         dims = tuple(a for a, t in zip(args, SIGNATURES[name]) if t is c_int or t is c_ll)
         if name in ("rs_mlp_gemm_rows", "rs_mlp_wgrad") and args[1] is not None:
-            dims = dims + ("compacted: rows is the capacity",)     # true row count lives on the device
+            # compacted operand: args[0] is only the capacity, the launch's row count lives on the device.
+            # Profiling mode may synchronise: read it back so the cost model sees the rows really processed.
+            dims = dims + (f"rows={_read_device_int(args[1])}",)      # dims[0] stays the (static) capacity
         _profile.append((name, dims, e0, e1))
     else:
         rc = getattr(lib, name)(*args)

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 PMC passes of tools/gpu_profile.sh into one CSV (profiles/<tag>/pmc_summary.csv):
+per kernel instance + grid: launches, FETCH_SIZE/WRITE_SIZE (KB as reported, and HBM MB with the gfx950 x2 read
+correction), MFMA-busy cycles, GRBM_GUI_ACTIVE, and the MFMA utilisation
+    mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD * 256 CU) / (GRBM_GUI_ACTIVE / 8 XCD)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+d = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(os.path.join(d, "pmc_*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][-80:] + " grid=" + r["Grid_Size"]
+        a = agg[k][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"] or 0)
+        a[1] += 1
+rows = []
+for k, c in agg.items():
+    def avg(n):
+        return c[n][0] / c[n][1] if n in c and c[n][1] else 0.0
+    n = max(v[1] for v in c.values())
+    gui = avg("GRBM_GUI_ACTIVE")
+    mf = avg("SQ_VALU_MFMA_BUSY_CYCLES")
+    util = mf / 1024.0 / (gui / 8.0) if gui else 0.0
+    rows.append((gui * n, k, n, avg("FETCH_SIZE"), avg("FETCH_SIZE") * 2 / 1024, avg("WRITE_SIZE"), avg("WRITE_SIZE") / 1024,
+                 mf, gui, util))
+rows.sort(reverse=True)
+w = csv.writer(open(os.path.join(d, "pmc_summary.csv"), "w"))
+w.writerow(["kernel", "launches", "FETCH_SIZE_KB_avg", "hbm_read_MB_corrected(2x)", "WRITE_SIZE_KB_avg", "hbm_write_MB",
+            "SQ_VALU_MFMA_BUSY_CYCLES_avg", "GRBM_GUI_ACTIVE_avg(8 XCD sum)", "mfma_util"])
+for _, k, n, f, fm, wr, wm, mf, gui, util in rows:
+    if "rocclr" in k or "at::native" in k or "elementwise" in k:
+        continue
+    w.writerow([k, n, round(f, 1), round(fm, 1), round(wr, 1), round(wm, 1), int(mf), int(gui), round(util, 3)])
+print("rows", len(rows))

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of each instrumented ABI call, from rocprofv3 PMC passes.
+
+Inputs (all produced by tools/gpu_profile.sh on the GPU box):
+  * one launch log per PMC pass -- `bench.py --no-graph --launch-log X.json` writes the ordered list of
+    (abi call, sizes) of its timed steps;
+  * the matching `*_counter_collection.csv` of `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+    (separate passes: the TCC counters do not fit in one, MI355X_MICROARCH.md "HBM").
+Counter collection serialises dispatches and keeps their order, and every ABI call below launches exactly
+one kernel of its family, so the last L dispatches of a family line up 1:1 with the L log entries.
+
+Corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE is reported in KB and, on gfx950, counts 64 B per
+128-B request for wide coalesced reads -> x2.  WRITE_SIZE (KB) is used as reported (uncalibrated).
+Output: profiles/traffic.json  {"<abi>|<sizes>": {"hbm_bytes", "read_bytes", "write_bytes", "launches",
+"kernel"}} -- bench.py's roofline.traffic looks its dominant launch up here.
+"""
+import argparse
+import collections
+import csv
+import json
+
+FAMILY = {
+    "rs_mlp_gemm_rows": "gemm_rows_kernel",
+    "rs_mlp_wgrad": "wgrad_kernel",
+    "rs_ballquery": "ballquery_kernel",
+    "rs_furthestsampling": "fps_",
+    "rs_umbrella_features": "umbrella_kernel",
+    "rs_pool_max": "pool_max_kernel",
+    "rs_pool_max_backward": "pool_max_bwd_kernel",
+    "rs_group_features_compact": "compact_features_kernel",
+    "rs_group_features_compact_backward": "compact_scatter_kernel",
+}
+
+
+def key(name, dims):
+    return name + "|" + ",".join(str(d) for d in dims if not isinstance(d, str))
+
+
+def per_family(csv_path, counter):
+    fam = collections.defaultdict(list)
+    with open(csv_path) as f:
+        rows = [r for r in csv.DictReader(f) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
+        for abi, sub in FAMILY.items():
+            if sub in r["Kernel_Name"]:
+                fam[abi].append((float(r["Counter_Value"]), r["Kernel_Name"].split("(")[0]))
+    return fam
+
+
+def collect(log_path, csv_path, counter):
+    log = json.load(open(log_path))
+    fam = per_family(csv_path, counter)
+    out = collections.defaultdict(list)
+    for abi in FAMILY:
+        calls = [(n, d) for n, d in log if n == abi]
+        disp = fam.get(abi, [])
+        if not calls or len(disp) < len(calls):
+            continue
+        for (n, d), (v, kname) in zip(calls, disp[-len(calls):]):
+            out[key(n, d)].append((v, kname))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fetch-log", required=True)
+    ap.add_argument("--fetch-csv", required=True)
+    ap.add_argument("--write-log", required=True)
+    ap.add_argument("--write-csv", required=True)
+    ap.add_argument("--out", default="profiles/traffic.json")
+    a = ap.parse_args()
+    rd = collect(a.fetch_log, a.fetch_csv, "FETCH_SIZE")
+    wr = collect(a.write_log, a.write_csv, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(rd) | set(wr)):
+        r = [v for v, _ in rd.get(k, [])]
+        w = [v for v, _ in wr.get(k, [])]
+        read_b = 2.0 * 1024.0 * sum(r) / len(r) if r else None        # KB -> B, gfx950 x2
+        write_b = 1024.0 * sum(w) / len(w) if w else None
+        kname = (rd.get(k) or wr.get(k))[0][1]
+        res[k] = {"hbm_bytes": (read_b or 0.0) + (write_b or 0.0), "read_bytes": read_b, "write_bytes": write_b,
+                  "launches": max(len(r), len(w)), "kernel": kname,
+                  "note": "FETCH_SIZE KB x2 (gfx950 correction) + WRITE_SIZE KB; separate rocprofv3 --pmc passes"}
+    json.dump(res, open(a.out, "w"), indent=1, sort_keys=True)
+    print(f"{len(res)} launch classes -> {a.out}")
+
+
+if __name__ == "__main__":
+    main()
