@@ -103,6 +103,23 @@ int rs_knnquery_offset(int m, int nsample, const float *xyz, const float *new_xy
                        const int *offset, const int *new_offset, int b,
                        int *idx, float *dist2, void *stream);
 
+/* Segmentation umbrella fan: everything UmbrellaSurfaceConstructor.forward computes between the kNN and
+ * self.mlps (segmentation/modules/repsurface_utils.py:77-98 group_by_umbrella_v2 / :101-122 group_by_umbrella,
+ * :305-321; segmentation/modules/recons_utils.py:10-45,48-57,84-100,128-151; polar_utils.py:10-31).
+ * knn_idx (m, k) are the global rows of the k nearest neighbours of each query INCLUDING the query itself
+ * (the segmentation variant does not drop it), new_offset (b) the running query ends per cloud, inv_sign (b)
+ * the per-cloud +-1 of cal_normal(random_inv) (recons_utils.py:28-43) or NULL, rotate != 0 selects sort='fix'
+ * (azimuth after _fixed_rotate, :71-74).  feat (m, k, 10) = [polar(3), normal(3), const(1), centroid(3)]
+ * per fan triangle (:320).  k in {5, 9, 13, 17}. */
+int rs_umbrella_fan_offset(int m, int k, int b, int rotate, const float *xyz, const float *new_xyz,
+                           const int *knn_idx, const int *new_offset, const float *inv_sign,
+                           float *feat, void *stream);
+
+/* Inverse-distance interpolation weights (segmentation/modules/repsurface_utils.py:262-265,
+ * segmentation/modules/pointops/functions/pointops.py:262-265): dist2 (n, 3) squared distances of the
+ * three nearest neighbours -> weight (n, 3) = r_i / ((r_0 + r_1) + r_2), r_i = 1 / (sqrt(dist2_i) + 1e-8). */
+int rs_interp_weights(long long n, const float *dist2, float *weight, void *stream);
+
 /* ---- umbrella surface constructor ---------------------------------------
  * Fuses group_by_umbrella + cal_normal + cal_center + xyz2sphere + cal_const +
  * check_nan_umb (classification/modules/repsurface_utils.py:112-132,276-293;

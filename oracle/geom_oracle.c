@@ -127,85 +127,111 @@ void oracle_knn(int b, int n, int m, int k, const float *xyz, const float *new_x
  * feat (b, n, k-1, 10) = [centroid(3), polar(3), normal(3), const(1)];  knn_idx (b,n,k) optional;
  * near_tie (b,n) optional: 1 where two azimuth keys were closer than PHI_TIE (the order is then
  * decided by the exact cross-product sign, which PyTorch's rounding need not reproduce). */
+/* The triangle fan over g ring offsets (in kNN order), shared by the classification constructor and the
+ * segmentation one.  rotate: azimuth key after segmentation/modules/repsurface_utils.py:71-74 (_fixed_rotate;
+ * torch.matmul K=3 = fma chain, probed).  seg_order: channels [polar, normal, const, centroid]
+ * (segmentation/modules/repsurface_utils.py:320) instead of [centroid, polar, normal, const]
+ * (classification/modules/repsurface_utils.py:290).  work: 6*g + 10*g floats. */
+static int fan_features(int g, float *ox, float *oy, float *oz, float flip, int rotate, int seg_order,
+                        float *work, float *o) {
+  float *key = work, *kx = key + g, *ky = kx + g, *un = ky + g;   /* un: per triangle u(3) c(3) polar(3) pos */
+  int tie = 0;
+  for (int j = 0; j < g; ++j) {
+    if (rotate) {
+      kx[j] = fmaf(oz[j], -0.5f, fmaf(oy[j], 0.7071f, ox[j] * 0.5f));
+      ky[j] = fmaf(oz[j], 0.5f, fmaf(oy[j], 0.7071f, ox[j] * -0.5f));
+    } else { kx[j] = ox[j]; ky[j] = oy[j]; }
+    key[j] = atan2f(ky[j], kx[j]) / TWO_PI_F + 0.5f;                              /* polar_utils.py:22,29 */
+  }
+  /* stable insertion sort by azimuth (argsort; stable for <= 16 keys, probed) */
+  for (int i = 1; i < g; ++i) {
+    int j = i;
+    while (j > 0) {
+      const float diff = key[j] - key[j - 1];
+      int before;
+      if (fabsf(diff) <= PHI_TIE) {
+        const double cr = (double)kx[j - 1] * (double)ky[j] - (double)kx[j] * (double)ky[j - 1];
+        before = cr < 0.0;
+        tie = 1;
+      } else before = diff < 0.0f;
+      if (!before) break;
+      float t;
+      t = key[j]; key[j] = key[j - 1]; key[j - 1] = t;
+      t = kx[j]; kx[j] = kx[j - 1]; kx[j - 1] = t;
+      t = ky[j]; ky[j] = ky[j - 1]; ky[j - 1] = t;
+      t = ox[j]; ox[j] = ox[j - 1]; ox[j - 1] = t;
+      t = oy[j]; oy[j] = oy[j - 1]; oy[j - 1] = t;
+      t = oz[j]; oz[j] = oz[j - 1]; oz[j - 1] = t;
+      --j;
+    }
+  }
+  for (int j = 0; j < g; ++j) {
+    const int j2 = (j + 1 == g) ? 0 : j + 1;                                      /* roll(-1) */
+    const float ax = ox[j], ay = oy[j], az = oz[j], bx = ox[j2], by = oy[j2], bz = oz[j2];
+    const float nx = fmaf(ay, bz, -(az * by));                                    /* recons_utils.py cal_normal: cross */
+    const float ny = fmaf(az, bx, -(ax * bz));
+    const float nz = fmaf(ax, by, -(ay * bx));
+    const float len = sqrtf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));                /* torch.norm */
+    float *t = un + j * 10;
+    t[0] = nx / len; t[1] = ny / len; t[2] = nz / len;
+    t[3] = ((0.0f + ax) + bx) / 3.0f;                                             /* cal_center: mean of 3 vertices */
+    t[4] = ((0.0f + ay) + by) / 3.0f;
+    t[5] = ((0.0f + az) + bz) / 3.0f;
+  }
+  const float pm = (un[0] > 0.0f) ? 1.0f : -1.0f;                                 /* first triangle's x positive */
+  int first = 0, found = 0;
+  for (int j = 0; j < g; ++j) {
+    float *t = un + j * 10;
+    for (int c = 0; c < 3; ++c) t[c] = (t[c] * pm) * flip;
+    const float rho = sqrtf(sqnorm3(t[3], t[4], t[5]));                           /* polar_utils.py:19 */
+    t[6] = rho;
+    t[7] = (rho == 0.0f) ? 0.0f : acosf(t[5] / rho) / PI_F;                       /* :21,24-25,28 */
+    t[8] = atan2f(t[4], t[3]) / TWO_PI_F + 0.5f;                                  /* :22,29 */
+    t[9] = ((t[0] * t[3] + t[1] * t[4]) + t[2] * t[5]) / SQRT3_F;                 /* cal_const */
+    const int bad = isnan(t[0]) || isnan(t[1]) || isnan(t[2]);                    /* check_nan_umb mask */
+    if (!bad && !found) { first = j; found = 1; }                                 /* argmax(~mask) */
+  }
+  for (int j = 0; j < g; ++j) {
+    const float *t = un + j * 10;
+    const int bad = isnan(t[0]) || isnan(t[1]) || isnan(t[2]);
+    const float *s = bad ? un + first * 10 : t;
+    float *r = o + j * 10;
+    if (seg_order) {
+      r[0] = t[6]; r[1] = t[7]; r[2] = t[8];                                      /* polar: never patched */
+      r[3] = s[0]; r[4] = s[1]; r[5] = s[2];
+      r[6] = s[9];
+      r[7] = s[3]; r[8] = s[4]; r[9] = s[5];
+    } else {
+      r[0] = s[3]; r[1] = s[4]; r[2] = s[5];                                      /* centroid */
+      r[3] = t[6]; r[4] = t[7]; r[5] = t[8];                                      /* polar: never patched */
+      r[6] = s[0]; r[7] = s[1]; r[8] = s[2];                                      /* normal */
+      r[9] = s[9];                                                                /* const */
+    }
+  }
+  return tie;
+}
+
 void oracle_umbrella(int b, int n, int k, const float *xyz, const float *inv_sign, int *knn_idx,
                      float *feat, unsigned char *near_tie) {
   const int g = k - 1;
   int *nn = (int *)malloc(sizeof(int) * (size_t)k);
-  float *ox = (float *)malloc(sizeof(float) * 4 * (size_t)g);
-  float *oy = ox + g, *oz = oy + g, *key = oz + g;
-  float *un = (float *)malloc(sizeof(float) * 10 * (size_t)g);   /* per triangle: u(3) c(3) polar(3) pos */
+  float *ox = (float *)malloc(sizeof(float) * 19 * (size_t)g);
+  float *oy = ox + g, *oz = oy + g, *work = oz + g;
   for (int bi = 0; bi < b; ++bi) {
     const float *pts = xyz + (size_t)bi * n * 3;
     for (int q = 0; q < n; ++q) {
       oracle_knn(1, n, 1, k, pts, pts + q * 3, nn, NULL);                         /* :115 */
       if (knn_idx) memcpy(knn_idx + ((size_t)bi * n + q) * k, nn, sizeof(int) * (size_t)k);
-      int tie = 0;
-      for (int j = 0; j < g; ++j) {                                               /* :117-123 */
+      for (int j = 0; j < g; ++j) {                                               /* :117-123: drop the nearest */
         const float *p = pts + nn[j + 1] * 3;
         ox[j] = p[0] - pts[q * 3]; oy[j] = p[1] - pts[q * 3 + 1]; oz[j] = p[2] - pts[q * 3 + 2];
-        key[j] = atan2f(oy[j], ox[j]) / TWO_PI_F + 0.5f;
       }
-      /* stable insertion sort by azimuth (:124 argsort; stable for 8 keys) */
-      for (int i = 1; i < g; ++i) {
-        int j = i;
-        while (j > 0) {
-          const float diff = key[j] - key[j - 1];
-          int before;
-          if (fabsf(diff) <= PHI_TIE) {
-            const double cr = (double)ox[j - 1] * (double)oy[j] - (double)ox[j] * (double)oy[j - 1];
-            before = cr < 0.0;
-            tie = 1;
-          } else before = diff < 0.0f;
-          if (!before) break;
-          float t;
-          t = key[j]; key[j] = key[j - 1]; key[j - 1] = t;
-          t = ox[j]; ox[j] = ox[j - 1]; ox[j - 1] = t;
-          t = oy[j]; oy[j] = oy[j - 1]; oy[j - 1] = t;
-          t = oz[j]; oz[j] = oz[j - 1]; oz[j - 1] = t;
-          --j;
-        }
-      }
+      const int tie = fan_features(g, ox, oy, oz, inv_sign ? inv_sign[bi] : 1.0f, 0, 0, work,
+                                   feat + ((size_t)bi * n + q) * (size_t)(g * 10));
       if (near_tie) near_tie[(size_t)bi * n + q] = (unsigned char)tie;
-      for (int j = 0; j < g; ++j) {
-        const int j2 = (j + 1 == g) ? 0 : j + 1;                                  /* :128 roll(-1) */
-        const float ax = ox[j], ay = oy[j], az = oz[j], bx = ox[j2], by = oy[j2], bz = oz[j2];
-        const float nx = fmaf(ay, bz, -(az * by));                                /* recons_utils.py:40 */
-        const float ny = fmaf(az, bx, -(ax * bz));
-        const float nz = fmaf(ax, by, -(ay * bx));
-        const float len = sqrtf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));            /* :41 */
-        float *t = un + j * 10;
-        t[0] = nx / len; t[1] = ny / len; t[2] = nz / len;
-        t[3] = ((0.0f + ax) + bx) / 3.0f;                                         /* :89 */
-        t[4] = ((0.0f + ay) + by) / 3.0f;
-        t[5] = ((0.0f + az) + bz) / 3.0f;
-      }
-      const float pm = (un[0] > 0.0f) ? 1.0f : -1.0f;                             /* :45 */
-      const float rs = inv_sign ? inv_sign[bi] : 1.0f;                            /* :50-55 */
-      int first = 0, found = 0;
-      for (int j = 0; j < g; ++j) {
-        float *t = un + j * 10;
-        for (int c = 0; c < 3; ++c) t[c] = (t[c] * pm) * rs;
-        const float rho = sqrtf(sqnorm3(t[3], t[4], t[5]));                       /* polar_utils.py:19 */
-        t[6] = rho;
-        t[7] = (rho == 0.0f) ? 0.0f : acosf(t[5] / rho) / PI_F;                   /* :21,24-25,28 */
-        t[8] = atan2f(t[4], t[3]) / TWO_PI_F + 0.5f;                              /* :22,29 */
-        t[9] = ((t[0] * t[3] + t[1] * t[4]) + t[2] * t[5]) / SQRT3_F;             /* recons_utils.py:120-122 */
-        const int bad = isnan(t[0]) || isnan(t[1]) || isnan(t[2]);                /* :161 */
-        if (!bad && !found) { first = j; found = 1; }                             /* :162 argmax(~mask) */
-      }
-      float *o = feat + ((size_t)bi * n + q) * (size_t)(g * 10);
-      for (int j = 0; j < g; ++j) {
-        const float *t = un + j * 10;
-        const int bad = isnan(t[0]) || isnan(t[1]) || isnan(t[2]);
-        const float *s = bad ? un + first * 10 : t;                               /* :166-174 */
-        o[j * 10 + 0] = s[3]; o[j * 10 + 1] = s[4]; o[j * 10 + 2] = s[5];         /* centroid */
-        o[j * 10 + 3] = t[6]; o[j * 10 + 4] = t[7]; o[j * 10 + 5] = t[8];         /* polar: never patched */
-        o[j * 10 + 6] = s[0]; o[j * 10 + 7] = s[1]; o[j * 10 + 8] = s[2];         /* normal */
-        o[j * 10 + 9] = s[9];                                                     /* const */
-      }
     }
   }
-  free(nn); free(ox); free(un);
+  free(nn); free(ox);
 }
 
 /* sample_and_group feature assembly  classification/modules/repsurface_utils.py:36-57
@@ -331,4 +357,41 @@ void oracle_knn_offset(int m, int k, int b, const float *xyz, const float *new_x
     for (int j = 0; j < k; ++j) { idx[(size_t)q * k + j] = bi_[j]; if (dist2) dist2[(size_t)q * k + j] = bd[j]; }
   }
   free(bd); free(bi_);
+}
+
+/* Segmentation umbrella fan (segmentation/modules/repsurface_utils.py:77-98,305-321): the k nearest
+ * neighbours INCLUDING the query stay in the ring (k triangles); rotate = sort='fix'.
+ * knn_idx (m,k) global rows; new_offset (b) running query ends; inv_sign (b) or NULL.
+ * feat (m, k, 10) = [polar, normal, const, centroid].  The torch part of this function is pinned against
+ * the reference's own code run on CPU (tests/golden/make_golden_seg.py); the kNN feeding it is the
+ * restated CUDA kernel (parity unpinned). */
+void oracle_umbrella_fan_offset(int m, int k, int b, int rotate, const float *xyz, const float *new_xyz,
+                                const int *knn_idx, const int *new_offset, const float *inv_sign,
+                                float *feat, unsigned char *near_tie) {
+  float *ox = (float *)malloc(sizeof(float) * 19 * (size_t)k);
+  float *oy = ox + k, *oz = oy + k, *work = oz + k;
+  for (int q = 0; q < m; ++q) {
+    int c = 0;
+    while (c < b - 1 && q >= new_offset[c]) ++c;
+    for (int j = 0; j < k; ++j) {                                                 /* :86-88 */
+      const float *p = xyz + (size_t)knn_idx[(size_t)q * k + j] * 3;
+      ox[j] = p[0] - new_xyz[q * 3]; oy[j] = p[1] - new_xyz[q * 3 + 1]; oz[j] = p[2] - new_xyz[q * 3 + 2];
+    }
+    const int tie = fan_features(k, ox, oy, oz, inv_sign ? inv_sign[c] : 1.0f, rotate, 1, work,
+                                 feat + (size_t)q * (size_t)(k * 10));
+    if (near_tie) near_tie[q] = (unsigned char)tie;
+  }
+  free(ox);
+}
+
+/* Interpolation weights: segmentation/modules/repsurface_utils.py:262-265 (dist = sqrt(dist2),
+ * pointops.py:127; torch.sum over 3 = (a+b)+c, probed). */
+void oracle_interp_weights(long long n, const float *dist2, float *weight) {
+  for (long long r = 0; r < n; ++r) {
+    const float r0 = 1.0f / (sqrtf(dist2[r * 3]) + 1e-8f);
+    const float r1 = 1.0f / (sqrtf(dist2[r * 3 + 1]) + 1e-8f);
+    const float r2 = 1.0f / (sqrtf(dist2[r * 3 + 2]) + 1e-8f);
+    const float s = (r0 + r1) + r2;
+    weight[r * 3] = r0 / s; weight[r * 3 + 1] = r1 / s; weight[r * 3 + 2] = r2 / s;
+  }
 }

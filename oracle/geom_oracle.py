@@ -146,3 +146,22 @@ def knn_offset(k, xyz, new_xyz, offset, new_offset):
     d2 = np.empty((m, k), np.float32)
     lib().oracle_knn_offset(m, k, len(offset), _p(xyz), _p(new_xyz), _p(offset), _p(new_offset), _p(idx), _p(d2))
     return idx, d2
+
+
+def umbrella_fan_offset(xyz, new_xyz, knn_idx, new_offset, inv_sign=None, rotate=True):
+    """-> feat (m,k,10) = [polar, normal, const, centroid], near_tie (m,) bool"""
+    xyz, new_xyz, knn_idx, new_offset = _f(xyz), _f(new_xyz), _i(knn_idx), _i(new_offset)
+    m, k = knn_idx.shape
+    feat = np.empty((m, k, 10), np.float32)
+    tie = np.zeros((m,), np.uint8)
+    sg = None if inv_sign is None else _f(inv_sign)
+    lib().oracle_umbrella_fan_offset(m, k, len(new_offset), int(rotate), _p(xyz), _p(new_xyz), _p(knn_idx),
+                                     _p(new_offset), _p(sg), _p(feat), _p(tie))
+    return feat, tie.astype(bool)
+
+
+def interp_weights(dist2):
+    dist2 = _f(dist2)
+    w = np.empty_like(dist2)
+    lib().oracle_interp_weights(ctypes.c_longlong(dist2.shape[0]), _p(dist2), _p(w))
+    return w

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librepsurf_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -23,6 +23,8 @@ SIGNATURES = {
     "rs_ballquery": [c_int, c_int, c_int, c_float, c_int, P, P, P, P, P],
     "rs_knnquery": [c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_knnquery_offset": [c_int, c_int, P, P, P, P, c_int, P, P, P],
+    "rs_umbrella_fan_offset": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
+    "rs_interp_weights": [c_ll, P, P, P],
     "rs_umbrella_features": [c_int, c_int, c_int, P, P, P, P, P],
     "rs_group_features": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
     "rs_group_features_backward": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],

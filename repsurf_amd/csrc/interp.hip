@@ -1,5 +1,4 @@
-// interp.hip — three nearest neighbours + inverse-distance interpolation, and the packed-batch
-// kNN of the segmentation path (gfx950).
+// interp.hip — three nearest neighbours + inverse-distance interpolation (gfx950).
 //
 // rs_three_nn / rs_three_interpolate(+backward) replace the `nearestneighbor` / `interpolation`
 // operators of the reference (classification/modules/pointops/src/interpolation/
@@ -7,10 +6,6 @@
 // data.  Distances use direct differences ((dx*dx + dy*dy) + dz*dz, products rounded
 // separately); a candidate replaces a kept neighbour only when strictly closer, so equal
 // distances keep the lower index -- the order the reference's sequential scan produces.
-//
-// rs_knnquery_offset replaces the packed-batch knnquery of the segmentation path
-// (segmentation/modules/pointops/src/knnquery/knnquery_cuda_kernel.cu:65-108): each query scans
-// the rows [offset[i-1], offset[i]) of its own cloud; output ascending by (distance, index).
 #include "rs_common.h"
 #include <math.h>
 
@@ -90,42 +85,6 @@ interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
   }
 }
 
-template <int K>
-__global__ void __launch_bounds__(IT_THREADS)
-knn_offset_kernel(int m, int nsample, int b, const float *__restrict__ xyz,
-                  const float *__restrict__ new_xyz, const int *__restrict__ offset,
-                  const int *__restrict__ new_offset, int *__restrict__ idx, float *__restrict__ dist2) {
-  const int q = blockIdx.x * IT_THREADS + threadIdx.x;
-  if (q >= m) return;
-  // cloud of this query: first i with q < new_offset[i]   (binary search; the reference walks linearly)
-  int lo = 0, hi = b - 1;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (q < new_offset[mid]) hi = mid; else lo = mid + 1; }
-  const int start = lo ? offset[lo - 1] : 0, end = offset[lo];
-  const float qx = new_xyz[q * 3 + 0], qy = new_xyz[q * 3 + 1], qz = new_xyz[q * 3 + 2];
-  float bd[K]; int bi[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) { bd[j] = 1e10f; bi[j] = start; }   // knnquery_cuda_kernel.cu:86-87
-  for (int p = start; p < end; ++p) {
-    const float dx = qx - xyz[p * 3 + 0], dy = qy - xyz[p * 3 + 1], dz = qz - xyz[p * 3 + 2];
-    const float d = (dx * dx + dy * dy) + dz * dz;
-    if (d < bd[K - 1]) {
-      bd[K - 1] = d; bi[K - 1] = p;
-#pragma unroll
-      for (int j = K - 1; j > 0; --j) {
-        const bool sw = bd[j] < bd[j - 1];
-        const float td = bd[j]; const int ti = bi[j];
-        bd[j] = sw ? bd[j - 1] : td; bi[j] = sw ? bi[j - 1] : ti;
-        bd[j - 1] = sw ? td : bd[j - 1]; bi[j - 1] = sw ? ti : bi[j - 1];
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < K; ++j) if (j < nsample) {
-    idx[(size_t)q * nsample + j] = bi[j];
-    if (dist2) dist2[(size_t)q * nsample + j] = bd[j];
-  }
-}
-
 inline int grid_for(long long work_items) {
   long long blocks = (work_items + IT_THREADS - 1) / IT_THREADS;
   if (blocks > 2048) blocks = 2048;
@@ -173,22 +132,3 @@ extern "C" int rs_three_interpolate_backward(int b, int c, int n, int m, const f
   return RS_OK;
 }
 
-extern "C" int rs_knnquery_offset(int m, int nsample, const float *xyz, const float *new_xyz,
-                                  const int *offset, const int *new_offset, int b, int *idx,
-                                  float *dist2, void *stream) {
-  RS_REQUIRE(m >= 0 && nsample >= 0 && b >= 0, "rs_knnquery_offset: negative size");
-  if (m == 0 || nsample == 0 || b == 0) return RS_OK;
-  RS_REQUIRE(nsample <= 64, "rs_knnquery_offset: nsample=%d exceeds the supported maximum of 64", nsample);
-  RS_REQUIRE(xyz && new_xyz && offset && new_offset && idx, "rs_knnquery_offset: null pointer");
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(rs_cdiv(m, IT_THREADS)), block(IT_THREADS);
-#define RS_LAUNCH_KO(K) hipLaunchKernelGGL(knn_offset_kernel<K>, grid, block, 0, st, m, nsample, b, xyz, new_xyz, offset, new_offset, idx, dist2)
-  if (nsample <= 3) RS_LAUNCH_KO(3);
-  else if (nsample <= 9) RS_LAUNCH_KO(9);
-  else if (nsample <= 16) RS_LAUNCH_KO(16);
-  else if (nsample <= 32) RS_LAUNCH_KO(32);
-  else RS_LAUNCH_KO(64);
-#undef RS_LAUNCH_KO
-  RS_CHECK_LAUNCH("rs_knnquery_offset");
-  return RS_OK;
-}

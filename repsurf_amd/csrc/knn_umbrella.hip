@@ -27,12 +27,7 @@
 // their kNN order.  oracle/geom_oracle.c uses the same rule and reports how many points had a
 // near-tie so the parity tests can account for them.
 #include "rs_common.h"
-#include <math.h>
-
-#define RS_PHI_TIE 4.8e-7f          // 8 ulp at 1.0 in normalised-azimuth units
-#define RS_PI_F 3.14159274101257324f      // float(np.pi)
-#define RS_TWO_PI_F 6.28318548202514648f  // float(2*np.pi)
-#define RS_SQRT3_F 1.73205077648162842f   // torch.sqrt(torch.Tensor([3]))
+#include "umbrella_fan.h"
 
 namespace {
 
@@ -180,16 +175,6 @@ knn_kernel1(int b, int n, int m, int nsample, int blocks_per_cloud, const float 
   }
 }
 
-// "b goes before a" for two fan neighbours a (earlier position) and b (later position).
-__device__ __forceinline__ bool phi_before(float ka, float xa, float ya, float kb, float xb, float yb) {
-  const float diff = kb - ka;
-  if (__builtin_expect(fabsf(diff) <= RS_PHI_TIE, 0)) {
-    const double cr = (double)xa * (double)yb - (double)xb * (double)ya;   // > 0: b is counter-clockwise of a
-    return cr < 0.0;
-  }
-  return diff < 0.f;
-}
-
 template <int K>
 __global__ void __launch_bounds__(KNN_THREADS)
 umbrella_kernel(int b, int n, int blocks_per_cloud, const float *__restrict__ xyz,
@@ -228,73 +213,14 @@ umbrella_kernel(int b, int n, int blocks_per_cloud, const float *__restrict__ xy
   }
 
   // offsets of the k-1 neighbours that follow the nearest (repsurface_utils.py:119-121)
-  float ox[G], oy[G], oz[G], key[G];
+  float ox[G], oy[G], oz[G];
 #pragma unroll
   for (int j = 0; j < G; ++j) {
     const int p = bi[j + 1];
     ox[j] = pts[p * 3 + 0] - qx; oy[j] = pts[p * 3 + 1] - qy; oz[j] = pts[p * 3 + 2] - qz;
-    key[j] = atan2f(oy[j], ox[j]) / RS_TWO_PI_F + 0.5f;    // xyz2sphere(...)[..., 2]
   }
-  // stable odd-even transposition sort by azimuth (argsort, repsurface_utils.py:124)
-#pragma unroll
-  for (int round = 0; round < G; ++round) {
-#pragma unroll
-    for (int j = (round & 1); j + 1 < G; j += 2) {
-      const bool sw = phi_before(key[j], ox[j], oy[j], key[j + 1], ox[j + 1], oy[j + 1]);
-      const float tk = key[j], tx = ox[j], ty = oy[j], tz = oz[j];
-      key[j] = sw ? key[j + 1] : tk; ox[j] = sw ? ox[j + 1] : tx; oy[j] = sw ? oy[j + 1] : ty; oz[j] = sw ? oz[j + 1] : tz;
-      key[j + 1] = sw ? tk : key[j + 1]; ox[j + 1] = sw ? tx : ox[j + 1]; oy[j + 1] = sw ? ty : oy[j + 1]; oz[j + 1] = sw ? tz : oz[j + 1];
-    }
-  }
-
-  // triangle fan (origin, s_j, s_{j+1}): normal / centroid / polar / constant
-  float ux[G], uy[G], uz[G], cx[G], cy[G], cz[G], rho[G], th[G], ph[G], pos[G];
-  bool bad[G];
-#pragma unroll
-  for (int j = 0; j < G; ++j) {
-    const int j2 = (j + 1 == G) ? 0 : j + 1;
-    const float ax = ox[j], ay = oy[j], az = oz[j], bx = ox[j2], by = oy[j2], bz = oz[j2];
-    const float nx = rs_fma(ay, bz, -(az * by));     // torch.cross (contracted on the CPU build)
-    const float ny = rs_fma(az, bx, -(ax * bz));
-    const float nz = rs_fma(ax, by, -(ay * bx));
-    const float len = sqrtf(rs_fma(nz, nz, rs_fma(ny, ny, nx * nx)));   // torch.norm
-    ux[j] = nx / len; uy[j] = ny / len; uz[j] = nz / len;
-    cx[j] = ((0.f + ax) + bx) / 3.f; cy[j] = ((0.f + ay) + by) / 3.f; cz[j] = ((0.f + az) + bz) / 3.f;
-  }
-  // keep x_n of the FIRST triangle positive, then the per-cloud random flip (recons_utils.py:45-55)
-  const float pm = (ux[0] > 0.f) ? 1.f : -1.f;
-  const float rs = inv_sign ? inv_sign[cloud] : 1.f;
-#pragma unroll
-  for (int j = 0; j < G; ++j) {
-    ux[j] = (ux[j] * pm) * rs; uy[j] = (uy[j] * pm) * rs; uz[j] = (uz[j] * pm) * rs;
-    const float r = sqrtf(rs_sqnorm(cx[j], cy[j], cz[j]));
-    rho[j] = r;
-    th[j] = (r == 0.f) ? 0.f : acosf(cz[j] / r) / RS_PI_F;
-    ph[j] = atan2f(cy[j], cx[j]) / RS_TWO_PI_F + 0.5f;
-    pos[j] = ((ux[j] * cx[j] + uy[j] * cy[j]) + uz[j] * cz[j]) / RS_SQRT3_F;
-    bad[j] = (ux[j] != ux[j]) || (uy[j] != uy[j]) || (uz[j] != uz[j]);
-  }
-  // check_nan_umb: first valid triangle (0 when none) donates normal / centroid / constant
-  float fux = ux[0], fuy = uy[0], fuz = uz[0], fcx = cx[0], fcy = cy[0], fcz = cz[0], fpos = pos[0];
-  bool found = !bad[0];
-#pragma unroll
-  for (int j = 1; j < G; ++j) {
-    const bool take = !found && !bad[j];
-    fux = take ? ux[j] : fux; fuy = take ? uy[j] : fuy; fuz = take ? uz[j] : fuz;
-    fcx = take ? cx[j] : fcx; fcy = take ? cy[j] : fcy; fcz = take ? cz[j] : fcz;
-    fpos = take ? pos[j] : fpos;
-    found = found || !bad[j];
-  }
-  float *orow = feat + ((size_t)cloud * n + q) * (G * 10);
-#pragma unroll
-  for (int j = 0; j < G; ++j) {
-    const bool r = bad[j];
-    float *o = orow + j * 10;
-    o[0] = r ? fcx : cx[j]; o[1] = r ? fcy : cy[j]; o[2] = r ? fcz : cz[j];
-    o[3] = rho[j]; o[4] = th[j]; o[5] = ph[j];
-    o[6] = r ? fux : ux[j]; o[7] = r ? fuy : uy[j]; o[8] = r ? fuz : uz[j];
-    o[9] = r ? fpos : pos[j];
-  }
+  rs_fan_features<G, false, false>(ox, oy, oz, inv_sign ? inv_sign[cloud] : 1.f,
+                                   feat + ((size_t)cloud * n + q) * (G * 10));
 }
 
 template <int K>

@@ -1,0 +1,259 @@
+// seg_geom.hip — packed-batch ("offset") geometry of the segmentation path for gfx950.
+//
+// Layout: clouds are concatenated, xyz (Ntot, 3); offset (B) int32 holds the running row ends, cloud i owns
+// rows [offset[i-1], offset[i]) (segmentation/util/data_util.py:15-23 collate format).
+//
+// rs_knnquery_offset   pointops.knnquery (segmentation/modules/pointops/functions/pointops.py:114-130 ->
+//                      src/knnquery/knnquery_cuda_kernel.cu:65-108): direct-difference squared distances,
+//                      initial list (1e10, first row of the cloud), strict '<' replacement, ascending
+//                      output.  The reference runs one thread per query that re-reads the whole cloud from
+//                      global memory and keeps a 100-entry heap in scratch.  Here a workgroup stages the
+//                      cloud through LDS once for 64 queries, 4 lanes share a query (each scans every 4th
+//                      point, lists merged lexicographically in (distance, row) so the result equals the
+//                      sequential scan), and workgroups that straddle a cloud boundary walk the (at most few)
+//                      clouds their queries belong to.  Exact distance ties come out in ascending row order
+//                      (the reference's heap leaves them in heap order; parity unpinned, oracle/geom_oracle.c).
+// rs_umbrella_fan_offset  everything UmbrellaSurfaceConstructor.forward does between the kNN and self.mlps
+//                      (segmentation/modules/repsurface_utils.py:77-98,305-321): the point itself stays in the
+//                      ring (k triangles, the two that touch it are degenerate and take the first valid
+//                      triangle's normal/centroid/constant), azimuth after the fixed rotation (sort='fix').
+// rs_interp_weights    inverse-distance weights of SurfaceFeaturePropagationCD / pointops.interpolation
+//                      (repsurface_utils.py:262-265, pointops.py:262-265).
+#include "rs_common.h"
+#include "umbrella_fan.h"
+
+namespace {
+
+constexpr int SG_THREADS = 256;
+constexpr int SG_TILE = 2048;         // points per LDS tile (32 KB as float4)
+constexpr int SG_LANES = 4;           // lanes per query
+constexpr int SG_QPB = SG_THREADS / SG_LANES;
+
+// first cloud c with q < ends[c]  (the reference walks linearly: knnquery_cuda_kernel.cu:51-62)
+__device__ __forceinline__ int cloud_of(int q, const int *__restrict__ ends, int b) {
+  int lo = 0, hi = b - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (q < ends[mid]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+template <int K>
+__device__ __forceinline__ void sorted_insert(float (&bd)[K], int (&bi)[K], float d, int p) {
+  if (d < bd[K - 1]) {          // strict: an equal distance never displaces an earlier row
+    bd[K - 1] = d; bi[K - 1] = p;
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+      const bool sw = bd[j] < bd[j - 1];
+      const float td = bd[j]; const int ti = bi[j];
+      bd[j] = sw ? bd[j - 1] : td; bi[j] = sw ? bi[j - 1] : ti;
+      bd[j - 1] = sw ? td : bd[j - 1]; bi[j - 1] = sw ? ti : bi[j - 1];
+    }
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void sorted_insert_lex(float (&bd)[K], int (&bi)[K], float d, int p) {
+  if (d < bd[K - 1] || (d == bd[K - 1] && p < bi[K - 1])) {
+    bd[K - 1] = d; bi[K - 1] = p;
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+      const bool sw = bd[j] < bd[j - 1] || (bd[j] == bd[j - 1] && bi[j] < bi[j - 1]);
+      const float td = bd[j]; const int ti = bi[j];
+      bd[j] = sw ? bd[j - 1] : td; bi[j] = sw ? bi[j - 1] : ti;
+      bd[j - 1] = sw ? td : bd[j - 1]; bi[j - 1] = sw ? ti : bi[j - 1];
+    }
+  }
+}
+
+// LDS_MERGE = false: the 4 partial lists are merged by two butterfly rounds of shuffles (K*K compare-swaps
+// per round, fine up to K = 16).  LDS_MERGE = true: the lists go to LDS and lane 0 of the query does a 4-way
+// merge by head pointers (K steps) -- for K = 32/64, where the unrolled butterfly would spill.
+template <int K, bool LDS_MERGE>
+__global__ void __launch_bounds__(SG_THREADS)
+knn_packed_kernel(int m, int nsample, int b, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                  const int *__restrict__ offset, const int *__restrict__ new_offset, int *__restrict__ idx,
+                  float *__restrict__ dist2) {
+  constexpr int LIST_BYTES = LDS_MERGE ? SG_THREADS * K * 8 : 0;
+  constexpr int LDS_BYTES = (LIST_BYTES > SG_TILE * 16) ? LIST_BYTES : SG_TILE * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  float4 *tile = reinterpret_cast<float4 *>(lds);
+
+  const int sub = threadIdx.x & (SG_LANES - 1);
+  const int q0 = blockIdx.x * SG_QPB;
+  const int q = q0 + (threadIdx.x >> 2);
+  const int qc = min(q, m - 1);
+  const int mycloud = cloud_of(qc, new_offset, b);
+  const int c_lo = cloud_of(q0, new_offset, b);                        // workgroup-uniform
+  const int c_hi = cloud_of(min(q0 + SG_QPB - 1, m - 1), new_offset, b);
+  const float qx = new_xyz[qc * 3 + 0], qy = new_xyz[qc * 3 + 1], qz = new_xyz[qc * 3 + 2];
+
+  float bd[K]; int bi[K];
+  {
+    const int mystart = mycloud ? offset[mycloud - 1] : 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { bd[j] = 1e10f; bi[j] = mystart; }     // knnquery_cuda_kernel.cu:86-87
+  }
+  for (int c = c_lo; c <= c_hi; ++c) {
+    const int start = c ? offset[c - 1] : 0, end = offset[c];
+    for (int t0 = start; t0 < end; t0 += SG_TILE) {
+      const int tn = min(SG_TILE, end - t0);
+      __syncthreads();
+      for (int p = threadIdx.x; p < tn; p += SG_THREADS) {
+        const float *s = xyz + (size_t)(t0 + p) * 3;
+        tile[p] = make_float4(s[0], s[1], s[2], 0.f);
+      }
+      __syncthreads();
+      if (mycloud == c) {
+        for (int p = sub; p < tn; p += SG_LANES) {
+          const float4 v = tile[p];
+          const float dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
+          const float d = (dx * dx + dy * dy) + dz * dz;                 // :93, no contraction
+          sorted_insert<K>(bd, bi, d, t0 + p);
+        }
+      }
+    }
+  }
+
+  if (!LDS_MERGE) {
+#pragma unroll
+    for (int mask = 1; mask <= 2; mask <<= 1) {
+      float od[K]; int oi[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) { od[j] = __shfl_xor(bd[j], mask, 64); oi[j] = __shfl_xor(bi[j], mask, 64); }
+#pragma unroll
+      for (int j = 0; j < K; ++j) sorted_insert_lex<K>(bd, bi, od[j], oi[j]);
+    }
+    if (q < m && sub == 0) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) if (j < nsample) {
+        idx[(size_t)q * nsample + j] = bi[j];
+        if (dist2) dist2[(size_t)q * nsample + j] = bd[j];
+      }
+    }
+  } else {
+    __syncthreads();                       // the tile is dead: its LDS becomes the list store
+    float *ld = reinterpret_cast<float *>(lds);
+    int *li = reinterpret_cast<int *>(lds) + SG_THREADS * K;
+    // entry j of thread t at [j * 256 + t]: consecutive lanes hit consecutive banks
+#pragma unroll
+    for (int j = 0; j < K; ++j) { ld[j * SG_THREADS + threadIdx.x] = bd[j]; li[j * SG_THREADS + threadIdx.x] = bi[j]; }
+    __syncthreads();
+    if (q < m && sub == 0) {
+      int h[SG_LANES]; float hd[SG_LANES]; int hi_[SG_LANES];
+#pragma unroll
+      for (int l = 0; l < SG_LANES; ++l) { h[l] = 0; hd[l] = ld[threadIdx.x + l]; hi_[l] = li[threadIdx.x + l]; }
+      for (int j = 0; j < nsample; ++j) {
+        int best = 0;
+#pragma unroll
+        for (int l = 1; l < SG_LANES; ++l)
+          if (hd[l] < hd[best] || (hd[l] == hd[best] && hi_[l] < hi_[best])) best = l;
+        float od = hd[0]; int oi = hi_[0];
+#pragma unroll
+        for (int l = 1; l < SG_LANES; ++l) if (best == l) { od = hd[l]; oi = hi_[l]; }
+        idx[(size_t)q * nsample + j] = oi;
+        if (dist2) dist2[(size_t)q * nsample + j] = od;
+#pragma unroll
+        for (int l = 0; l < SG_LANES; ++l) if (best == l) {
+          h[l] += 1;
+          const bool live = h[l] < K;
+          hd[l] = live ? ld[h[l] * SG_THREADS + threadIdx.x + l] : INFINITY;
+          hi_[l] = live ? li[h[l] * SG_THREADS + threadIdx.x + l] : 0x7fffffff;
+        }
+      }
+    }
+  }
+}
+
+template <int K, bool ROT>
+__global__ void __launch_bounds__(SG_THREADS)
+fan_packed_kernel(int m, int b, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                  const int *__restrict__ knn_idx, const int *__restrict__ new_offset,
+                  const float *__restrict__ inv_sign, float *__restrict__ feat) {
+  const int q = blockIdx.x * SG_THREADS + threadIdx.x;
+  if (q >= m) return;
+  const float qx = new_xyz[q * 3 + 0], qy = new_xyz[q * 3 + 1], qz = new_xyz[q * 3 + 2];
+  float ox[K], oy[K], oz[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int p = knn_idx[(size_t)q * K + j];
+    ox[j] = xyz[(size_t)p * 3 + 0] - qx; oy[j] = xyz[(size_t)p * 3 + 1] - qy; oz[j] = xyz[(size_t)p * 3 + 2] - qz;
+  }
+  const float flip = inv_sign ? inv_sign[cloud_of(q, new_offset, b)] : 1.f;
+  rs_fan_features<K, ROT, true>(ox, oy, oz, flip, feat + (size_t)q * (K * 10));
+}
+
+__global__ void __launch_bounds__(SG_THREADS)
+interp_weights_kernel(long long n, const float *__restrict__ dist2, float *__restrict__ weight) {
+  const long long r = (long long)blockIdx.x * SG_THREADS + threadIdx.x;
+  if (r >= n) return;
+  // dist = sqrt(dist2) (pointops.py:127); 1/(dist + 1e-8); / sum, torch.sum over 3 = (a+b)+c (probed)
+  const float r0 = 1.0f / (sqrtf(dist2[r * 3 + 0]) + 1e-8f);
+  const float r1 = 1.0f / (sqrtf(dist2[r * 3 + 1]) + 1e-8f);
+  const float r2 = 1.0f / (sqrtf(dist2[r * 3 + 2]) + 1e-8f);
+  const float s = (r0 + r1) + r2;
+  weight[r * 3 + 0] = r0 / s; weight[r * 3 + 1] = r1 / s; weight[r * 3 + 2] = r2 / s;
+}
+
+}  // namespace
+
+extern "C" int rs_knnquery_offset(int m, int nsample, const float *xyz, const float *new_xyz,
+                                  const int *offset, const int *new_offset, int b, int *idx, float *dist2,
+                                  void *stream) {
+  RS_REQUIRE(m >= 0 && nsample >= 0 && b >= 0, "rs_knnquery_offset: negative size");
+  if (m == 0 || nsample == 0 || b == 0) return RS_OK;
+  RS_REQUIRE(nsample <= 64, "rs_knnquery_offset: nsample=%d exceeds the supported maximum of 64", nsample);
+  RS_REQUIRE(xyz && new_xyz && offset && new_offset && idx, "rs_knnquery_offset: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(rs_cdiv(m, SG_QPB)), block(SG_THREADS);
+#define RS_LAUNCH_KP(K, LM)                                                                               \
+  hipLaunchKernelGGL((knn_packed_kernel<K, LM>), grid, block, 0, st, m, nsample, b, xyz, new_xyz, offset, \
+                     new_offset, idx, dist2)
+  if (nsample <= 3) RS_LAUNCH_KP(3, false);
+  else if (nsample <= 9) RS_LAUNCH_KP(9, false);
+  else if (nsample <= 16) RS_LAUNCH_KP(16, false);
+  else if (nsample <= 32) RS_LAUNCH_KP(32, true);
+  else RS_LAUNCH_KP(64, true);
+#undef RS_LAUNCH_KP
+  RS_CHECK_LAUNCH("rs_knnquery_offset");
+  return RS_OK;
+}
+
+extern "C" int rs_umbrella_fan_offset(int m, int k, int b, int rotate, const float *xyz, const float *new_xyz,
+                                      const int *knn_idx, const int *new_offset, const float *inv_sign,
+                                      float *feat, void *stream) {
+  RS_REQUIRE(m >= 0 && b >= 0, "rs_umbrella_fan_offset: negative size");
+  if (m == 0 || b == 0) return RS_OK;
+  RS_REQUIRE(k == 5 || k == 9 || k == 13 || k == 17,
+             "rs_umbrella_fan_offset: k=%d not built (group_size+1 must be 5, 9, 13 or 17)", k);
+  RS_REQUIRE(xyz && new_xyz && knn_idx && new_offset && feat, "rs_umbrella_fan_offset: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(rs_cdiv(m, SG_THREADS)), block(SG_THREADS);
+#define RS_LAUNCH_FAN(K)                                                                                      \
+  do {                                                                                                        \
+    if (rotate) hipLaunchKernelGGL((fan_packed_kernel<K, true>), grid, block, 0, st, m, b, xyz, new_xyz,      \
+                                   knn_idx, new_offset, inv_sign, feat);                                      \
+    else hipLaunchKernelGGL((fan_packed_kernel<K, false>), grid, block, 0, st, m, b, xyz, new_xyz, knn_idx,   \
+                            new_offset, inv_sign, feat);                                                      \
+  } while (0)
+  switch (k) {
+    case 5: RS_LAUNCH_FAN(5); break;
+    case 9: RS_LAUNCH_FAN(9); break;
+    case 13: RS_LAUNCH_FAN(13); break;
+    default: RS_LAUNCH_FAN(17); break;
+  }
+#undef RS_LAUNCH_FAN
+  RS_CHECK_LAUNCH("rs_umbrella_fan_offset");
+  return RS_OK;
+}
+
+extern "C" int rs_interp_weights(long long n, const float *dist2, float *weight, void *stream) {
+  RS_REQUIRE(n >= 0, "rs_interp_weights: negative size");
+  if (n == 0) return RS_OK;
+  RS_REQUIRE(dist2 && weight, "rs_interp_weights: null pointer");
+  hipLaunchKernelGGL(interp_weights_kernel, dim3(rs_cdiv(n, SG_THREADS)), dim3(SG_THREADS), 0,
+                     (hipStream_t)stream, n, dist2, weight);
+  RS_CHECK_LAUNCH("rs_interp_weights");
+  return RS_OK;
+}

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/seg_*.npz from the REAL reference's segmentation code (hancyran/RepSurf).
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden_seg.py
+
+The reference's segmentation path is CUDA-only: `pointops_cuda.furthestsampling_cuda` / `knnquery_cuda` are
+compiled CUDA kernels and the Python side allocates with `torch.cuda.IntTensor/FloatTensor`
+(segmentation/modules/pointops/functions/pointops.py:42-44,125-127, repsurface_utils.py:22,268).  Here
+  * `pointops_cuda` is a stub module whose two kernels are oracle/geom_oracle.c's restatements of the
+    CUDA sources (the part that stays PARITY UNPINNED), and
+  * `torch.cuda.IntTensor/FloatTensor` are replaced by CPU constructors,
+so that every line of the reference's own torch code (sample_and_group, group_by_umbrella_v2, cal_normal,
+check_nan_umb, SurfaceAbstractionCD, SurfaceFeaturePropagationCD, Model.forward) executes unmodified on CPU.
+The fixtures therefore pin everything downstream of the two kernels: feature order, rotation, NaN patching,
+numpy-RNG flips, the dual first layer, interpolation weights, the decoder wiring.
+
+Fixtures:
+  seg_geom.npz    3 packed clouds of unequal size: umbrella features (pre-MLP) through the reference
+                  functions, sample_and_group outputs of one stage, interpolation weights.
+  seg_model.npz   repsurf_umb_ssg on 2 packed clouds (2048 + 1536 points): logits, loss, stage outputs
+                  (subsampled), parameter-gradient norms + subsampled gradients; name-seeded weights, dropout 0.
+"""
+import argparse
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/segmentation"
+
+from oracle import geom_oracle as G  # noqa: E402
+
+
+def install_stubs():
+    pc = types.ModuleType("pointops_cuda")
+
+    def furthestsampling_cuda(b, n_max, xyz, offset, new_offset, tmp, idx):
+        idx.copy_(torch.from_numpy(G.fps_offset(xyz.numpy(), offset.numpy(), new_offset.numpy())))
+
+    def knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
+        i, d = G.knn_offset(nsample, xyz.numpy(), new_xyz.numpy(), offset.numpy(), new_offset.numpy())
+        idx.copy_(torch.from_numpy(i))
+        dist2.copy_(torch.from_numpy(d))
+
+    pc.furthestsampling_cuda = furthestsampling_cuda
+    pc.knnquery_cuda = knnquery_cuda
+    sys.modules["pointops_cuda"] = pc
+
+    def ctor(dtype):
+        class _T:
+            def __new__(cls, *a):
+                if len(a) == 1 and isinstance(a[0], (list, tuple)):
+                    return torch.tensor(a[0], dtype=dtype)
+                return torch.empty(*a, dtype=dtype)
+        return _T
+    torch.cuda.IntTensor = ctor(torch.int32)
+    torch.cuda.FloatTensor = ctor(torch.float32)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+def name_seeded_init(model):
+    with torch.no_grad():
+        for name, p in sorted(model.named_parameters()):
+            g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+            if p.dim() >= 2:
+                v = (torch.rand(p.shape, generator=g) * 2 - 1) / p[0].numel() ** 0.5
+            elif name.endswith("weight"):
+                v = 0.75 + 0.5 * torch.rand(p.shape, generator=g)
+            else:
+                v = (torch.rand(p.shape, generator=g) * 2 - 1) * 0.1
+            p.copy_(v)
+
+
+def packed(seed, sizes):
+    g = torch.Generator().manual_seed(seed)
+    n = sum(sizes)
+    coord = (torch.rand(n, 3, generator=g) * 2 - 1).contiguous()
+    rgb = torch.rand(n, 3, generator=g).contiguous()
+    offset = torch.tensor(np.cumsum(sizes), dtype=torch.int32)
+    return coord, rgb, offset
+
+
+def sub(t, step=7):
+    return t.detach().reshape(-1)[::step].numpy().copy()
+
+
+def main():
+    install_stubs()
+    from modules import repsurface_utils as R
+    from modules.recons_utils import cal_const, cal_normal, cal_center, check_nan_umb
+    from modules.polar_utils import xyz2sphere
+    from modules.pointops.functions import pointops
+    from models.repsurf.repsurf_umb_ssg import Model
+
+    # ---------------- geometry fixture
+    coord, rgb, offset = packed(11, [300, 512, 217])
+    out = {"coord": coord.numpy(), "offset": offset.numpy()}
+    for tag, fn in (("fix", R.group_by_umbrella_v2), ("none", R.group_by_umbrella)):
+        np.random.seed(5)
+        flips = np.random.rand(3) < 0.5                      # what cal_normal will draw (recons_utils.py:29)
+        np.random.seed(5)
+        gx = fn(coord, coord, offset, offset, k=9)
+        nor = cal_normal(gx, offset, random_inv=True, is_group=True)
+        cen = cal_center(gx)
+        pol = xyz2sphere(cen)
+        pos = cal_const(nor, cen)
+        nor, cen, pos = check_nan_umb(nor, cen, pos)
+        out[f"umb_{tag}"] = torch.cat([pol, nor, pos, cen], dim=-1).numpy()
+        out[f"umb_{tag}_sign"] = np.where(flips, 1.0, -1.0).astype(np.float32)
+    normal = torch.rand(coord.shape[0], 10, generator=torch.Generator().manual_seed(3))
+    feat = torch.cat([coord, rgb], 1)
+    for polar in (False, True):
+        nc, nn_, nf, no = R.sample_and_group(4, 32, coord, normal, feat, offset, return_polar=polar, num_sector=1)
+        t = "p" if polar else "x"
+        out[f"sg_{t}_center"], out[f"sg_{t}_normal"], out[f"sg_{t}_feat"] = nc.numpy(), nn_.numpy(), nf.numpy()
+        out[f"sg_{t}_offset"] = no.numpy()
+    out["sg_normal_in"] = normal.numpy()
+    out["sg_rgb"] = rgb.numpy()
+    idx, dist = pointops.knnquery(3, nc, coord, no, offset)
+    dr = 1.0 / (dist + 1e-8)
+    out["interp_dist"] = dist.numpy()
+    out["interp_weight"] = (dr / torch.sum(dr, dim=1, keepdim=True)).numpy()
+    np.savez_compressed(os.path.join(HERE, "seg_geom.npz"), **out)
+
+    # ---------------- model fixture
+    args = argparse.Namespace(return_polar=False, in_channel=6, group_size=8, num_class=13)
+    torch.manual_seed(0)
+    model = Model(args).train()
+    name_seeded_init(model)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    coord, rgb, offset = packed(21, [2048, 1536])
+    label = torch.randint(0, 13, (coord.shape[0],), generator=torch.Generator().manual_seed(4))
+    np.random.seed(9)
+    flips = np.random.rand(2) < 0.5
+    np.random.seed(9)
+    stage = {}
+    hooks = [getattr(model, n).register_forward_hook(lambda mod, i, o, n=n: stage.__setitem__(n, list(o) if isinstance(o, list) else o))
+             for n in ("sa1", "sa2", "sa3", "sa4", "fp1", "surface_constructor")]
+    logits = model([coord, rgb, offset])
+    loss = torch.nn.functional.cross_entropy(logits, label)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    out = {"coord": coord.numpy(), "rgb": rgb.numpy(), "offset": offset.numpy(), "label": label.numpy().astype(np.int16),
+           "inv_sign": np.where(flips, 1.0, -1.0).astype(np.float32),
+           "logits": logits.detach().numpy(), "loss": np.float32(loss.item()),
+           "normal": stage["surface_constructor"].detach().numpy().astype(np.float32)}
+    for n in ("sa1", "sa2", "sa3", "sa4"):
+        out[n + "_center"] = stage[n][0].numpy()
+        out[n + "_offset"] = stage[n][3].numpy()
+        out[n + "_feat_sub"] = sub(stage[n][2])
+    out["fp1_sub"] = sub(stage["fp1"])
+    for name, p in model.named_parameters():
+        out["gnorm/" + name] = np.float32(p.grad.norm().item())
+        out["gsub/" + name] = sub(p.grad, 7 if p.numel() > 4096 else 1)
+    np.savez_compressed(os.path.join(HERE, "seg_model.npz"), **out)
+    print("wrote seg_geom.npz, seg_model.npz; loss", loss.item())
+
+
+if __name__ == "__main__":
+    main()

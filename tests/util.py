@@ -75,3 +75,66 @@ def is_pre_bn_bias(name):
             # mlps.6.bias shifts every normal channel by a constant, which each stage's bn_f0 removes
             or name in ("surface_constructor.mlps.3.bias", "surface_constructor.mlps.6.bias",
                         "classfier.0.bias", "classfier.4.bias"))
+
+
+def seg_args(**over):
+    """The flag set of segmentation/scripts/s3dis/train_repsurf_umb.sh as the model reads it."""
+    ns = argparse.Namespace(return_polar=False, in_channel=6, group_size=8, num_class=13)
+    for k, v in over.items():
+        setattr(ns, k, v)
+    return ns
+
+
+def seg_param_shapes(args=None):
+    """(name, shape) of every parameter of segmentation/models/repsurf/repsurf_umb_ssg.py:13-41."""
+    a = args or seg_args()
+    cc = 6 if a.return_polar else 3
+    out = []
+
+    def lin(name, cin, cout, conv=False):
+        out.append((name + ".weight", (cout, cin, 1) if conv else (cout, cin)))
+        out.append((name + ".bias", (cout,)))
+
+    def bn(name, c):
+        out.append((name + ".weight", (c,)))
+        out.append((name + ".bias", (c,)))
+
+    for i, (cin, mlp) in enumerate([(a.in_channel + 10, [32, 32, 64]), (64 + 10, [64, 64, 128]),
+                                    (128 + 10, [128, 128, 256]), (256 + 10, [256, 256, 512])], 1):
+        pre = f"sa{i}"
+        lin(pre + ".mlp_l0", cc, mlp[0], True); lin(pre + ".mlp_f0", cin, mlp[0], True)
+        bn(pre + ".bn_l0", mlp[0]); bn(pre + ".bn_f0", mlp[0])
+        last = mlp[0]
+        for j, w in enumerate(mlp[1:]):
+            lin(f"{pre}.mlp_convs.{j}", last, w, True); bn(f"{pre}.mlp_bns.{j}", w)
+            last = w
+    for name, prev, skip, mlp in [("fp4", 512, 256, [256, 256]), ("fp3", 256, 128, [256, 256]),
+                                  ("fp2", 256, 64, [256, 128]), ("fp1", 128, None, [128, 128, 128])]:
+        lin(name + ".mlp_f0", prev, mlp[0]); bn(name + ".norm_f0", mlp[0])
+        if skip is not None:
+            lin(name + ".mlp_s0", skip, mlp[0]); bn(name + ".norm_s0", mlp[0])
+        last = mlp[0]
+        for j, w in enumerate(mlp[1:]):
+            lin(f"{name}.mlp_convs.{j}", last, w); bn(f"{name}.mlp_bns.{j}", w)
+            last = w
+    lin("classifier.0", 128, 128); bn("classifier.1", 128); lin("classifier.4", 128, a.num_class)
+    lin("surface_constructor.mlps.0", 10, 10, True); bn("surface_constructor.mlps.1", 10)
+    lin("surface_constructor.mlps.3", 10, 10, True)
+    return out
+
+
+def seg_state(args=None):
+    """Name-seeded weights of the segmentation model as a state dict (same rule as name_seeded_init /
+    tests/golden/make_golden_seg.py), without instantiating any module."""
+    state = {}
+    for name, shape in sorted(seg_param_shapes(args)):
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+        if len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            v = (torch.rand(shape, generator=g) * 2 - 1) / fan_in ** 0.5
+        elif name.endswith("weight"):
+            v = 0.75 + 0.5 * torch.rand(shape, generator=g)
+        else:
+            v = (torch.rand(shape, generator=g) * 2 - 1) * 0.1
+        state[name] = v
+    return state
