@@ -101,3 +101,19 @@ def umbrella_mlp(x, mlps, group, aggr):
         return _torch_umbrella(x, mlps, group, aggr)
     from . import mlp_hip
     return mlp_hip.umbrella_mlp(x, mlps, group, aggr)
+
+
+def _torch_umbrella2(x, mlps, group):
+    conv0, bn0, _, conv1 = mlps
+    h = F.relu(_bn(F.linear(x, _w2d(conv0), conv0.bias), bn0))
+    return F.linear(h, _w2d(conv1), conv1.bias).view(-1, group, conv1.weight.shape[0]).sum(dim=1)
+
+
+def umbrella_mlp2(x, mlps, group):
+    """Segmentation UmbrellaSurfaceConstructor.mlps + aggregation
+    (segmentation/modules/repsurface_utils.py:298-303,323-327): conv-bn-relu-conv, sum over the `group`
+    fan triangles.  x (P*group, C) -> (P, Cout)."""
+    if BACKEND == "torch":
+        return _torch_umbrella2(x, mlps, group)
+    from . import mlp_hip
+    return mlp_hip.umbrella_mlp2(x, mlps, group)

@@ -566,6 +566,60 @@ class _UmbrellaFused(Function):
                 res[2, :100].reshape(shp[2]), res[2, 100:])
 
 
+class _UmbrellaStack2(Function):
+    """conv-BN-ReLU-conv, then the sum over the `group` fan triangles: the segmentation constructor's mlps
+    (segmentation/modules/repsurface_utils.py:298-303,323-327).  The input (geometric features) never needs a
+    gradient."""
+
+    @staticmethod
+    def forward(ctx, x, meta, w0, c0, g0, b0, w1, c1):
+        dev = x.device
+        x = x.contiguous()
+        rows, cx = x.shape
+        group, training, bn0 = meta["group"], meta["training"], meta["bn"]
+        w0_, w1_ = _w2d(w0), _w2d(w1)
+        y0, v0 = fwd_layer(rows, operand(OP_ID, x, cx), cx, w0_, c0, bn0, training, dev)
+        cout = w1_.shape[0]
+        y1 = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+        epi = Epilogue(bias=_ptr(c1), out=_ptr(y1), ldo=cout, mode=EPI_STORE)
+        gemm_rows(rows, w0_.shape[0], cout, operand(OP_RELU1, y0, y0.shape[1], s1=v0.scale, t1=v0.shift), _kmajor(w1_), epi)
+        points = rows // group
+        out = torch.empty((points, cout), dtype=torch.float32, device=dev)
+        _lib.call("rs_pool_sum", points, group, cout, _ptr(y1), _ptr(out), _stream())
+        ctx.saved = dict(x=x, y0=y0, v0=v0, w0=w0_, w1=w1_)
+        ctx.meta = meta
+        _flush_counters()
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s, meta = ctx.saved, ctx.meta
+        if not meta["training"]:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented in the HIP executor")
+        x, y0, v0 = s["x"], s["y0"], s["v0"]
+        dev = x.device
+        rows, cx = x.shape
+        group = meta["group"]
+        dout = dout.contiguous()
+        c1n, c0n = s["w1"].shape[0], s["w0"].shape[0]
+        p1 = operand(OP_BCAST, dout, c1n, ns=group)
+        g_c1 = dout.sum(0) * group
+        g_w1 = wgrad(rows, c1n, c0n, p1, operand(OP_RELU1, y0, c0n, s1=v0.scale, t1=v0.shift), dev)
+        dz0, part0, nstat0 = dgrad_masked(rows, c1n, c0n, p1, s["w1"], y0, v0, device=dev)
+        pb, qb, rb, g_g0, g_b0 = bwd_coeffs(c0n, rows, part0, nstat0, 1, v0, dev)
+        p0 = operand(OP_AFF2, dz0, c0n, y0, c0n, s1=pb, t1=rb, s2=qb)
+        g_w0 = wgrad(rows, c0n, cx, p0, operand(OP_ID, x, cx), dev)
+        shp = meta["shapes"]
+        g_c0 = torch.zeros(c0n, dtype=torch.float32, device=dev)          # bias before BN: exactly 0
+        return None, None, g_w0.reshape(shp[0]), g_c0, g_g0, g_b0, g_w1.reshape(shp[1]), g_c1
+
+
+def umbrella_mlp2(x, mlps, group):
+    conv0, bn0, _, conv1 = mlps
+    meta = {"group": group, "bn": bn0, "training": bn0.training, "shapes": [conv0.weight.shape, conv1.weight.shape]}
+    return _UmbrellaStack2.apply(x, meta, conv0.weight, conv0.bias, bn0.weight, bn0.bias, conv1.weight, conv1.bias)
+
+
 def umbrella_mlp(x, mlps, group, aggr):
     conv0, bn0, _, conv1, bn1, _, conv2 = mlps
     meta = {"group": group, "aggr": aggr, "bns": (bn0, bn1), "training": bn0.training,

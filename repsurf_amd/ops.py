@@ -56,18 +56,89 @@ def furthestsampling(xyz, m, start=None):
     return idx
 
 
+# ----------------------------------------------------------------------------- packed batches (segmentation)
+# Clouds concatenated along rows; `offset` (B,) int32 holds the running row ends (segmentation collate
+# format).  The reference reads offsets back with per-cloud `.item()` calls in every stage
+# (segmentation/modules/repsurface_utils.py:17-22, pointops.py:40-42); here the host copy is taken once per
+# offset tensor and travels with it (`_rs_host`), and derived offsets are cached by value, so a model forward
+# costs at most one device->host read and is graph-capturable once the caches are warm.
+_OFFSET_CACHE = {}
+
+
+def host_offsets(offset):
+    """Running ends of a packed batch as a tuple of ints (one device->host read per tensor object)."""
+    host = getattr(offset, "_rs_host", None)
+    if host is None:
+        host = tuple(int(v) for v in offset.tolist())
+        try:
+            offset._rs_host = host
+        except AttributeError:
+            pass
+    return host
+
+
+def offsets_tensor(host, device):
+    """Device int32 tensor of the running ends `host` (cached by value)."""
+    key = (tuple(host), str(device))
+    t = _OFFSET_CACHE.get(key)
+    if t is None:
+        if len(_OFFSET_CACHE) > 4096:
+            _OFFSET_CACHE.clear()
+        t = torch.tensor(list(host), dtype=torch.int32, device=device)
+        t._rs_host = tuple(host)
+        _OFFSET_CACHE[key] = t
+    return t
+
+
+def strided_offset(offset, stride):
+    """new_offset of the segmentation sample_and_group (repsurface_utils.py:17-22): running sum of
+    (cloud length // stride) -- NOT offset // stride."""
+    host = host_offsets(offset)
+    out, acc, last = [], 0, 0
+    for end in host:
+        acc += (end - last) // stride
+        out.append(acc)
+        last = end
+    return offsets_tensor(out, offset.device)
+
+
 def furthestsampling_offset(xyz, offset, new_offset):
-    """Packed batches (segmentation): xyz (Ntot,3), offset/new_offset (B,) int32 prefix sums -> idx (Mtot,)."""
+    """Packed batches: xyz (Ntot,3), offset/new_offset (B,) int32 running ends -> idx (Mtot,) int32 global rows;
+    first pick of each cloud = its first row (segmentation/.../sampling_cuda_kernel.cu:39)."""
     _need_gpu(xyz, offset, new_offset)
     xyz, offset, new_offset = _f32c(xyz), _i32c(offset), _i32c(new_offset)
-    b = offset.numel()
-    sizes = torch.diff(offset.cpu(), prepend=torch.zeros(1, dtype=torch.int32))
-    n_max = int(sizes.max()) if b else 0
-    m_tot = int(new_offset[-1]) if b else 0
+    host, new_host = host_offsets(offset), host_offsets(new_offset)
+    b = len(host)
+    n_max = max((e - s for s, e in zip((0,) + host[:-1], host)), default=0)
+    m_tot = new_host[-1] if b else 0
     idx = torch.empty((m_tot,), dtype=torch.int32, device=xyz.device)
     temp = torch.empty((xyz.shape[0],), dtype=torch.float32, device=xyz.device) if n_max > 16384 else None
     _lib.call("rs_furthestsampling_offset", b, n_max, _p(xyz), _p(offset), _p(new_offset), _p(temp), _p(idx), _stream())
     return idx
+
+
+def umbrella_fan_offset(xyz, new_xyz, knn_idx, new_offset, inv_sign=None, rotate=True):
+    """Segmentation umbrella fan: knn_idx (M,k) global rows of the k nearest neighbours (query included) ->
+    (M, k, 10) = [polar, normal, const, centroid] per fan triangle
+    (segmentation/modules/repsurface_utils.py:305-321; rotate = sort='fix')."""
+    _need_gpu(xyz, new_xyz, knn_idx, new_offset, inv_sign)
+    xyz, new_xyz, knn_idx, new_offset = _f32c(xyz), _f32c(new_xyz), _i32c(knn_idx), _i32c(new_offset)
+    m, k = knn_idx.shape
+    feat = torch.empty((m, k, 10), dtype=torch.float32, device=xyz.device)
+    sg = None if inv_sign is None else _f32c(inv_sign.reshape(-1))
+    _lib.call("rs_umbrella_fan_offset", m, k, new_offset.numel(), int(bool(rotate)), _p(xyz), _p(new_xyz),
+              _p(knn_idx), _p(new_offset), _p(sg), _p(feat), _stream())
+    return feat
+
+
+def interp_weights(dist2):
+    """dist2 (n,3) squared 3-NN distances -> normalised inverse-distance weights (n,3)
+    (segmentation/modules/repsurface_utils.py:262-265)."""
+    _need_gpu(dist2)
+    dist2 = _f32c(dist2)
+    w = torch.empty_like(dist2)
+    _lib.call("rs_interp_weights", dist2.shape[0], _p(dist2), _p(w), _stream())
+    return w
 
 
 class _GatherRows(Function):

@@ -1,0 +1,207 @@
+"""modules.repsurface_utils — RepSurf-U segmentation building blocks with the reference's names, signatures,
+parameter names and list-based calling convention (segmentation/modules/repsurface_utils.py), running on
+hand-written HIP kernels.
+
+Data are packed batches: rows of all clouds concatenated, `offset` (B,) int32 running row ends; everything is
+channels-last already, so no layout changes happen between modules.  Offsets are read back to the host at
+most once per forward (repsurf_amd.ops.host_offsets) instead of 2 `.item()` calls per cloud per stage
+(reference :17-22).
+
+RNG: the per-cloud normal inversion is drawn from numpy's global generator with the reference's call
+(`np.random.rand(B) < 0.5`, recons_utils.py:29), so `np.random.seed` reproduces the reference's flips.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from repsurf_amd import mlp as _mlp
+from repsurf_amd import ops
+from modules.pointops.functions import pointops
+from modules.polar_utils import xyz2sphere
+from modules.recons_utils import random_flips
+
+
+def sample_and_group(stride, nsample, center, normal, feature, offset, return_polar=False, num_sector=1,
+                     training=True):
+    """center (N,3), normal (N,Cn), feature (N,C)|None, offset (B,) ->
+    new_center (M,3), new_normal (M,Cn), new_feature (M,nsample,3(+3)+Cn+C), new_offset (B,)  (reference :15-51)."""
+    if stride > 1:
+        new_offset = ops.strided_offset(offset, stride)
+        if num_sector > 1 and training:
+            fps_idx = pointops.sectorized_fps(center, offset, new_offset, num_sector)
+        else:
+            fps_idx = pointops.furthestsampling(center, offset, new_offset)
+        new_center = ops.gather_rows(center.unsqueeze(0), fps_idx.unsqueeze(0)).squeeze(0)
+        new_normal = ops.gather_rows(normal.unsqueeze(0), fps_idx.unsqueeze(0)).squeeze(0)
+    else:
+        new_center, new_normal, new_offset = center, normal, offset
+    m = new_center.shape[0]
+    group_idx, _ = ops.knnquery_offset(nsample, center, new_center, offset, new_offset)
+    rows = ops.group_features(center.unsqueeze(0), new_center.unsqueeze(0), normal.unsqueeze(0),
+                              None if feature is None else feature.unsqueeze(0), group_idx.unsqueeze(0),
+                              polar=return_polar)
+    return new_center, new_normal, rows.view(m, nsample, -1), new_offset
+
+
+def resort_points(points, idx):
+    """points (N,G,C), idx (N,G) -> points re-ordered along G (reference :54-68)."""
+    return torch.gather(points, 1, idx.long().unsqueeze(-1).expand(-1, -1, points.shape[-1]))
+
+
+def _fixed_rotate(xyz):
+    """y-axis 45 deg then z-axis 45 deg (reference :71-74)."""
+    rot = xyz.new_tensor([[0.5, -0.5, 0.7071], [0.7071, 0.7071, 0.], [-0.5, 0.5, 0.7071]])
+    return xyz @ rot
+
+
+def _umbrella_ring(xyz, new_xyz, offset, new_offset, k, rotate):
+    idx, _ = ops.knnquery_offset(k, xyz, new_xyz, offset, new_offset)
+    ring = ops.gather_rows(xyz.unsqueeze(0), idx.unsqueeze(0)).squeeze(0) - new_xyz.unsqueeze(-2)
+    key = xyz2sphere(_fixed_rotate(ring) if rotate else ring)[..., 2]
+    ring = resort_points(ring, key.argsort(dim=-1)).unsqueeze(-2)
+    return torch.cat([torch.zeros_like(ring), ring, torch.roll(ring, -1, dims=-3)], dim=-2)
+
+
+def group_by_umbrella_v2(xyz, new_xyz, offset, new_offset, k=9):
+    """-> (N',k,3,3) fan triangles (origin, p_i, p_{i+1}), neighbours ordered by azimuth after the fixed
+    rotation; the query itself stays in the ring (reference :77-98).  The shipped constructor uses the fused
+    kernel instead; kNN and gather are HIP here, the k-element ordering runs as tensor ops."""
+    return _umbrella_ring(xyz, new_xyz, offset, new_offset, k, True)
+
+
+def group_by_umbrella(xyz, new_xyz, offset, new_offset, k=9):
+    """Same without the rotation (reference :101-122)."""
+    return _umbrella_ring(xyz, new_xyz, offset, new_offset, k, False)
+
+
+def sort_factory(s_type):
+    if s_type is None:
+        return group_by_umbrella
+    elif s_type == 'fix':
+        return group_by_umbrella_v2
+    raise Exception('No such sorting method')
+
+
+class SurfaceAbstraction(nn.Module):
+    """Set abstraction over surface features, single-branch first layer (reference :135-173)."""
+
+    def __init__(self, stride, nsample, in_channel, mlp, return_polar=True, num_sector=1):
+        super().__init__()
+        self.stride, self.nsample, self.num_sector = stride, nsample, num_sector
+        self.return_polar = return_polar
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for width in mlp:
+            self.mlp_convs.append(nn.Conv1d(last, width, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(width))
+            last = width
+
+    def forward(self, pos_nor_feat_off):
+        center, normal, feature, offset = pos_nor_feat_off
+        new_center, new_normal, grouped, new_offset = sample_and_group(
+            self.stride, self.nsample, center, normal, feature, offset, return_polar=self.return_polar,
+            num_sector=self.num_sector, training=self.training)
+        m, ns, c = grouped.shape
+        pooled = _mlp.sa_mlp_plain(grouped.reshape(m * ns, c), self.mlp_convs, self.mlp_bns, ns)
+        return [new_center, new_normal, pooled, new_offset]
+
+
+class SurfaceAbstractionCD(nn.Module):
+    """Set abstraction with the channel-de-differentiated first layer (reference :176-230): position channels
+    and feature channels get their own 1x1 conv + BatchNorm, summed before the ReLU; then [conv, BN, ReLU]*,
+    max over the nsample neighbours.  Parameter names (mlp_l0, mlp_f0, bn_l0, bn_f0, mlp_convs.i, mlp_bns.i)
+    and shapes (Conv1d) match the reference."""
+
+    def __init__(self, stride, nsample, feat_channel, pos_channel, mlp, return_normal=True, return_polar=False,
+                 num_sector=1):
+        super().__init__()
+        self.stride, self.nsample, self.num_sector = stride, nsample, num_sector
+        self.return_normal, self.return_polar = return_normal, return_polar
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        self.pos_channel = pos_channel
+        self.mlp_l0 = nn.Conv1d(self.pos_channel, mlp[0], 1)
+        self.mlp_f0 = nn.Conv1d(feat_channel, mlp[0], 1)
+        self.bn_l0 = nn.BatchNorm1d(mlp[0])
+        self.bn_f0 = nn.BatchNorm1d(mlp[0])
+        last = mlp[0]
+        for width in mlp[1:]:
+            self.mlp_convs.append(nn.Conv1d(last, width, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(width))
+            last = width
+
+    def forward(self, pos_nor_feat_off):
+        center, normal, feature, offset = pos_nor_feat_off
+        new_center, new_normal, grouped, new_offset = sample_and_group(
+            self.stride, self.nsample, center, normal, feature, offset, return_polar=self.return_polar,
+            num_sector=self.num_sector, training=self.training)
+        m, ns, c = grouped.shape
+        pooled = _mlp.sa_mlp_cd(grouped.reshape(m * ns, c), self.pos_channel, self.mlp_l0, self.bn_l0, self.mlp_f0,
+                                self.bn_f0, self.mlp_convs, self.mlp_bns, ns)
+        return [new_center, new_normal, pooled, new_offset]
+
+
+class SurfaceFeaturePropagationCD(nn.Module):
+    """Feature propagation with the channel-de-differentiated first layer (reference :233-284): coarse features
+    go through Linear+BatchNorm, are interpolated onto the fine points with inverse-distance weights over the
+    3 nearest coarse points of the same cloud, added to Linear+BatchNorm of the skip features, ReLU, then
+    [Linear, BN, ReLU]*.  3-NN search, weights and the gather-interpolation (+ its backward) are HIP kernels;
+    the plain Linear/BatchNorm1d layers on ungrouped rows are library GEMMs through PyTorch."""
+
+    def __init__(self, prev_channel, skip_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        self.skip = skip_channel is not None
+        self.mlp_f0 = nn.Linear(prev_channel, mlp[0])
+        self.norm_f0 = nn.BatchNorm1d(mlp[0])
+        if skip_channel is not None:
+            self.mlp_s0 = nn.Linear(skip_channel, mlp[0])
+            self.norm_s0 = nn.BatchNorm1d(mlp[0])
+        last = mlp[0]
+        for width in mlp[1:]:
+            self.mlp_convs.append(nn.Linear(last, width))
+            self.mlp_bns.append(nn.BatchNorm1d(width))
+            last = width
+
+    def forward(self, pos_feat_off1, pos_feat_off2):
+        xyz1, points1, offset1 = pos_feat_off1      # fine:   (N,3), (N,C)|None, (B,)
+        xyz2, points2, offset2 = pos_feat_off2      # coarse: (M,3), (M,C), (B,)
+        idx, d2 = ops.knnquery_offset(3, xyz2, xyz1, offset2, offset1)
+        weight = ops.interp_weights(d2)
+        points2 = self.norm_f0(self.mlp_f0(points2))
+        new_points = ops.three_interpolate(points2.unsqueeze(0), idx.unsqueeze(0), weight.unsqueeze(0)).squeeze(0)
+        if self.skip:
+            new_points = new_points + self.norm_s0(self.mlp_s0(points1))
+        new_points = F.relu(new_points)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            new_points = F.relu(bn(conv(new_points)))
+        return new_points
+
+
+class UmbrellaSurfaceConstructor(nn.Module):
+    """Umbrella RepSurf for packed batches (reference :287-329): per point, a fan of k triangles over its k
+    nearest neighbours (itself included) -> 10 geometric channels per triangle [polar, normal, const, centroid]
+    -> conv-BN-ReLU-conv -> sum over the fan.  `mlps` has the reference's Sequential layout (indices 0,1,3)."""
+
+    def __init__(self, k, in_channel, out_channel, random_inv=True, sort='fix'):
+        super().__init__()
+        self.k = k
+        self.random_inv = random_inv
+        self.mlps = nn.Sequential(
+            nn.Conv1d(in_channel, out_channel, 1, bias=True),
+            nn.BatchNorm1d(out_channel),
+            nn.ReLU(True),
+            nn.Conv1d(out_channel, out_channel, 1, bias=True),
+        )
+        self.sort_func = sort_factory(sort)
+        self._rotate = sort == 'fix'
+
+    def forward(self, center, offset, flip=None):
+        n = center.shape[0]
+        if self.random_inv and flip is None:      # numpy global generator, same call as recons_utils.py:29
+            flip = torch.from_numpy(random_flips(offset.shape[0])).to(center.device)
+        idx, _ = ops.knnquery_offset(self.k, center, center, offset, offset)
+        feat = ops.umbrella_fan_offset(center, center, idx, offset, flip, self._rotate)      # (N,k,10)
+        return _mlp.umbrella_mlp2(feat.reshape(n * self.k, 10), self.mlps, self.k)

@@ -160,8 +160,10 @@ def main():
         out[n + "_feat_sub"] = sub(stage[n][2])
     out["fp1_sub"] = sub(stage["fp1"])
     for name, p in model.named_parameters():
+        out["shape/" + name] = np.array(p.shape, np.int32)
         out["gnorm/" + name] = np.float32(p.grad.norm().item())
         out["gsub/" + name] = sub(p.grad, 7 if p.numel() > 4096 else 1)
+    out["buffers"] = np.array(sorted(n for n, _ in model.named_buffers()))
     np.savez_compressed(os.path.join(HERE, "seg_model.npz"), **out)
     print("wrote seg_geom.npz, seg_model.npz; loss", loss.item())
 

@@ -47,3 +47,17 @@ def test_rng_draw_order_matches_reference_cpu_path():
     s1, s2 = draw_fps_start(4, 1024), draw_fps_start(4, 512)
     assert np.array_equal(flip.view(4).numpy(), g["inv_sign"])
     assert np.array_equal(s1.numpy(), g["fps1_start"]) and np.array_equal(s2.numpy(), g["fps2_start"])
+
+
+def test_seg_state_dict_matches_reference_names():
+    """names, shapes and buffers of the segmentation model equal the reference's (fixture written from the
+    reference's own Model by tests/golden/make_golden_seg.py)."""
+    import numpy as np
+    from tests.util import seg_args, subproject
+    g = np.load(os.path.join(ROOT, "tests", "golden", "seg_model.npz"))
+    with subproject("segmentation"):
+        from models.repsurf.repsurf_umb_ssg import Model
+        model = Model(seg_args())
+    ref = {k[6:]: tuple(g[k]) for k in g.files if k.startswith("shape/")}
+    assert {n: tuple(p.shape) for n, p in model.named_parameters()} == ref
+    assert sorted(n for n, _ in model.named_buffers()) == list(g["buffers"])

@@ -1,0 +1,228 @@
+"""Segmentation path on the MI355X: packed-batch HIP kernels and the module mirror against the CPU oracle
+(oracle/geom_oracle.c, oracle/seg_ref.py) and the reference-generated fixtures (tests/golden/seg_*.npz).
+
+Bar: indices bit-exact, features / activations within 1e-5 of the tensor scale (tolerances in each test);
+gradients by relative L2 (see tests/test_oracle_seg_golden.py for the measured noise floor of this model)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geom_oracle as G
+from oracle import seg_ref
+from tests.util import GOLDEN, seg_args, seg_state, subproject
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def packed_cloud(seed, sizes, kind="uniform"):
+    r = np.random.RandomState(seed)
+    n = int(sum(sizes))
+    if kind == "uniform":
+        xyz = (r.rand(n, 3) * 2 - 1).astype(np.float32)
+    elif kind == "grid":         # lattice: many exactly equal distances (tie rule = lowest row first)
+        xyz = (r.randint(0, 6, (n, 3)) / 6.0).astype(np.float32)
+    elif kind == "dup":          # every point twice: zero distances, degenerate fan triangles
+        half = (r.rand((n + 1) // 2, 3) * 2 - 1).astype(np.float32)
+        xyz = np.concatenate([half, half])[:n][r.permutation(n)]
+    else:
+        raise ValueError(kind)
+    return xyz, np.cumsum(sizes).astype(np.int32)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from repsurf_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("k", [3, 9, 16, 32, 64])
+@pytest.mark.parametrize("kind", ["uniform", "grid", "dup"])
+def test_knnquery_offset_matches_oracle(ops, k, kind):
+    sizes = [700, 40, 1300, 5, 257, 2100]                 # clouds smaller than k (padding) and > one LDS tile
+    xyz, offset = packed_cloud(3 + k, sizes, kind)
+    new_offset = seg_ref.strided_offset(offset, 3)
+    r = np.random.RandomState(0)
+    starts = np.concatenate([[0], offset[:-1]])
+    pick = np.concatenate([np.sort(r.choice(e - s, (ne - ns_), replace=False)) + s
+                           for s, e, ns_, ne in zip(starts, offset, np.concatenate([[0], new_offset[:-1]]), new_offset)])
+    q = xyz[pick]
+    idx, d2 = ops.knnquery_offset(k, dev(xyz), dev(q), dev(offset), dev(new_offset))
+    ridx, rd2 = G.knn_offset(k, xyz, q, offset, new_offset)
+    assert np.array_equal(d2.cpu().numpy(), rd2)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+def test_knnquery_offset_self_query_config4_properties(ops):
+    """16 x 4096 points (BASELINE configs[3]): size-independent properties at full size."""
+    sizes = [4096] * 16
+    xyz, offset = packed_cloud(7, sizes)
+    x, off = dev(xyz), dev(offset)
+    idx, d2 = ops.knnquery_offset(9, x, x, off, off)
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    assert np.array_equal(idx[:, 0], np.arange(xyz.shape[0]))          # nearest neighbour of a point is itself
+    assert (d2[:, 0] == 0).all() and (np.diff(d2, axis=1) >= 0).all()  # ascending
+    assert np.array_equal(idx // 4096, np.repeat(np.arange(16), 4096)[:, None].repeat(9, 1))   # own cloud only
+    rows = np.random.RandomState(0).choice(xyz.shape[0], 512, replace=False)   # spot-check against the oracle
+    sub_off = np.arange(1, 17, dtype=np.int32) * 32
+    rows = np.sort(rows.reshape(16, 32) % 4096 + np.arange(16)[:, None] * 4096, axis=1).reshape(-1)
+    ridx, rd2 = G.knn_offset(9, xyz, xyz[rows], offset, sub_off)
+    assert np.array_equal(idx[rows], ridx) and np.array_equal(d2[rows], rd2)
+
+
+@pytest.mark.parametrize("rotate", [True, False])
+@pytest.mark.parametrize("kind", ["uniform", "dup"])
+def test_umbrella_fan_offset_matches_oracle(ops, rotate, kind):
+    xyz, offset = packed_cloud(5, [900, 333, 1500], kind)
+    sign = np.array([1, -1, -1], np.float32)
+    x, off = dev(xyz), dev(offset)
+    idx, _ = ops.knnquery_offset(9, x, x, off, off)
+    feat = ops.umbrella_fan_offset(x, x, idx, off, dev(sign), rotate).cpu().numpy()
+    ref, tie = G.umbrella_fan_offset(xyz, xyz, idx.cpu().numpy(), offset, sign, rotate)
+    assert feat.shape == (xyz.shape[0], 9, 10)
+    ok = ~tie
+    assert np.array_equal(np.isnan(feat[ok]), np.isnan(ref[ok]))
+    err = np.nan_to_num(np.abs(feat - ref)).reshape(xyz.shape[0], -1).max(-1)
+    # atan2f / acosf of ocml vs glibc differ in the last ulps: 1e-5 of O(1) features (north-star tolerance)
+    assert err[ok].max() <= 1e-5, err[ok].max()
+    assert tie.mean() < 0.01 or kind == "dup"
+
+
+def test_umbrella_fan_offset_matches_reference_fixture(ops):
+    g = np.load(os.path.join(GOLDEN, "seg_geom.npz"))
+    x, off = dev(g["coord"]), dev(g["offset"])
+    idx, _ = ops.knnquery_offset(9, x, x, off, off)
+    for tag, rotate in (("fix", True), ("none", False)):
+        feat = ops.umbrella_fan_offset(x, x, idx, off, dev(g[f"umb_{tag}_sign"]), rotate).cpu().numpy()
+        ref = g[f"umb_{tag}"]
+        _, tie = G.umbrella_fan_offset(g["coord"], g["coord"], idx.cpu().numpy(), g["offset"], g[f"umb_{tag}_sign"], rotate)
+        err = np.nan_to_num(np.abs(feat - ref)).reshape(ref.shape[0], -1).max(-1)
+        assert err[~tie].max() <= 1e-5
+
+
+def test_interp_weights_match_oracle(ops):
+    r = np.random.RandomState(1)
+    d2 = (r.rand(5000, 3) ** 2).astype(np.float32)
+    d2[:50, 0] = 0.0                                              # coincident points: weight -> 1
+    w = ops.interp_weights(dev(d2)).cpu().numpy()
+    assert np.array_equal(w, G.interp_weights(d2))
+    g = np.load(os.path.join(GOLDEN, "seg_geom.npz"))
+    nc, no = g["sg_x_center"], g["sg_x_offset"]
+    idx, d2 = ops.knnquery_offset(3, dev(nc), dev(g["coord"]), dev(no), dev(g["offset"]))
+    assert np.abs(ops.interp_weights(d2).cpu().numpy() - g["interp_weight"]).max() <= 2e-7
+
+
+def test_strided_offset_and_host_cache(ops):
+    off = dev(np.array([300, 812, 1029], np.int32))
+    new = ops.strided_offset(off, 4)
+    assert new.cpu().tolist() == [75, 203, 257] and new.dtype == torch.int32
+    assert ops.host_offsets(new) == (75, 203, 257)
+    assert ops.strided_offset(off, 4) is new                      # cached by value: no second upload
+
+
+@pytest.mark.parametrize("polar", [False, True])
+def test_sample_and_group_matches_oracle_and_fixture(ops, polar):
+    g = np.load(os.path.join(GOLDEN, "seg_geom.npz"))
+    t = "p" if polar else "x"
+    coord, offset = g["coord"], g["offset"]
+    feat = np.concatenate([coord, g["sg_rgb"]], 1)
+    with subproject("segmentation"):
+        from modules.repsurface_utils import sample_and_group
+        nc, nn_, nf, no = sample_and_group(4, 32, dev(coord), dev(g["sg_normal_in"]), dev(feat), dev(offset),
+                                           return_polar=polar)
+    assert np.array_equal(no.cpu().numpy(), g[f"sg_{t}_offset"])
+    assert np.array_equal(nc.cpu().numpy(), g[f"sg_{t}_center"])          # FPS picks (bit-exact rows)
+    assert np.array_equal(nn_.cpu().numpy(), g[f"sg_{t}_normal"])
+    ref = g[f"sg_{t}_feat"]
+    assert nf.shape == ref.shape
+    assert np.abs(nf.cpu().numpy() - ref).max() <= 1e-5
+
+
+def test_sectorized_fps_properties(ops):
+    sizes = [3000, 500, 2200]
+    xyz, offset = packed_cloud(9, sizes)
+    new_offset = seg_ref.strided_offset(offset, 4)
+    with subproject("segmentation"):
+        from modules.pointops.functions import pointops
+        x, off, noff = dev(xyz), dev(offset), dev(new_offset)
+        plain = pointops.furthestsampling(x, off, noff)
+        assert np.array_equal(plain.cpu().numpy(), G.fps_offset(xyz, offset, new_offset))
+        same = pointops.sectorized_fps(x, off, noff, 4)                   # all clouds < min_points: one sector
+        assert np.array_equal(same.cpu().numpy(), plain.cpu().numpy())
+        sect = pointops.sectorized_fps(x, off, noff, 4, min_points=1000).cpu().numpy()
+    assert sect.shape[0] == new_offset[-1]
+    lo = 0
+    for c, (s, e) in enumerate(zip(np.concatenate([[0], new_offset[:-1]]), new_offset)):
+        rows = sect[s:e]
+        hi = offset[c]
+        assert ((rows >= lo) & (rows < hi)).all()                         # picks stay inside their cloud
+        assert len(np.unique(rows)) == len(rows)                          # sectors are disjoint, FPS never repeats
+        if sizes[c] >= 1000:                                              # each angular sector got its quota
+            ang = np.arctan2(xyz[rows, 0], xyz[rows, 1])
+            quota = (e - s) // 4
+            edges = np.linspace(np.arctan2(xyz[lo:hi, 0], xyz[lo:hi, 1]).min(),
+                                np.arctan2(xyz[lo:hi, 0], xyz[lo:hi, 1]).max() + 1e-4, 5)
+            counts = np.histogram(ang, edges)[0]
+            assert np.abs(counts - np.array([quota, quota, quota, (e - s) - 3 * quota])).max() <= 2
+        lo = hi
+
+
+def _seg_model(state=None):
+    with subproject("segmentation"):
+        from models.repsurf.repsurf_umb_ssg import Model
+        model = Model(seg_args())
+    model.load_state_dict(state or seg_state(), strict=False)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return model.cuda().train()
+
+
+def test_seg_model_matches_oracle_and_reference_fixture():
+    fx = np.load(os.path.join(GOLDEN, "seg_model.npz"))
+    model = _seg_model()
+    coord, rgb, offset = dev(fx["coord"]), dev(fx["rgb"]), dev(fx["offset"])
+    label = dev(fx["label"].astype(np.int64))
+    np.random.seed(9)                                             # the fixture's numpy-RNG state: same flips
+    with subproject("segmentation"):
+        logits = model([coord, rgb, offset])
+    loss = torch.nn.functional.cross_entropy(logits, label)
+    loss.backward()
+    got = logits.detach().cpu().numpy()
+    assert np.abs(got - fx["logits"]).max() <= 2e-4               # reference's own torch code (CPU)
+    assert abs(loss.item() - float(fx["loss"])) <= 5e-5
+    ref = seg_ref.step(seg_state(), fx["coord"], fx["rgb"], fx["offset"], fx["label"].astype(np.int64), fx["inv_sign"])
+    assert np.abs(got - ref["logits"].detach().numpy()).max() <= 2e-4
+    bad = []
+    for name, p in model.named_parameters():
+        r = ref["grads"][name].numpy().reshape(-1)
+        gnorm = np.linalg.norm(r)
+        if gnorm < 1e-5:                                          # pre-BN biases: analytically zero
+            assert p.grad.norm().item() < 1e-4, name
+            continue
+        rel = np.linalg.norm(p.grad.detach().cpu().numpy().reshape(-1) - r) / gnorm
+        if rel > 3e-2:
+            bad.append((name, rel))
+    assert not bad, bad
+
+
+def test_seg_model_config4_runs_and_is_finite():
+    """BASELINE configs[3]: 16 clouds x 4096 points, xyz + rgb, 13 classes."""
+    model = _seg_model()
+    r = np.random.RandomState(0)
+    n = 16 * 4096
+    coord = dev((r.rand(n, 3) * 2 - 1).astype(np.float32))
+    rgb = dev(r.rand(n, 3).astype(np.float32))
+    offset = dev((np.arange(1, 17) * 4096).astype(np.int32))
+    label = dev(r.randint(0, 13, n).astype(np.int64))
+    with subproject("segmentation"):
+        logits = model([coord, rgb, offset])
+    assert logits.shape == (n, 13)
+    torch.nn.functional.cross_entropy(logits, label).backward()
+    assert torch.isfinite(logits).all()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())

@@ -1,6 +1,8 @@
 """Shared test helpers."""
 import argparse
+import contextlib
 import os
+import sys
 import zlib
 
 import numpy as np
@@ -138,3 +140,29 @@ def seg_state(args=None):
             v = (torch.rand(shape, generator=g) * 2 - 1) * 0.1
         state[name] = v
     return state
+
+
+_SUB_PACKAGES = ("modules", "models", "util")
+_SUB_CACHE = {}
+
+
+@contextlib.contextmanager
+def subproject(name):
+    """Import context of one of the reference's sub-projects (`classification` / `segmentation`): both ship
+    top-level packages called `modules` and `models`, resolved relative to the sub-project root on sys.path
+    (PYTHONPATH=./ in the reference's scripts), so only one can be live at a time."""
+    root = os.path.join(ROOT, "repsurf_amd", name)
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in _SUB_PACKAGES}
+    for k in saved:
+        del sys.modules[k]
+    sys.modules.update(_SUB_CACHE.setdefault(name, {}))
+    sys.path.insert(0, root)
+    try:
+        yield root
+    finally:
+        sys.path.remove(root)
+        now = {k: v for k, v in sys.modules.items() if k.split(".")[0] in _SUB_PACKAGES}
+        _SUB_CACHE[name].update(now)
+        for k in now:
+            del sys.modules[k]
+        sys.modules.update(saved)
