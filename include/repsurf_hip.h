@@ -241,9 +241,10 @@ typedef struct rs_mlp_epilogue {
   const float *row_mult;   /* RS_EPI_STATS: per-row weight of the sums (copies a compacted row stands for; NULL = 1) */
 } rs_mlp_epilogue;
 
-/* out[rows, cols] = E[rows, kdim] . B,  B[k][n] = w[k*ldw + n]: weights are passed k-major (the conv
- * weight transposed for forward, as stored for the data gradient dY . W), base 16-byte aligned,
- * ldw % 4 == 0, columns [cols, ldw) zero. */
+/* out[rows, cols] = E[rows, kdim] . W^T,  W[n][k] = w[n*ldw + k]: weights are passed n-major, i.e. a conv weight
+ * (cout, cin) as it is stored for the forward pass (in place when cin % 4 == 0) and its transpose for the data
+ * gradient dY . W (rs_pack_weights makes the padded / transposed copies); base 16-byte aligned, ldw % 4 == 0,
+ * entries k in [kdim, ldw) zero. */
 /* rows_dev (optional, device int): actual row count of a compacted operand — read by the kernel, never by the
  * host; `rows` is then the capacity of the buffers. */
 int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
@@ -288,12 +289,13 @@ int rs_pool_max_backward(long long groups, int nsample, int c, const int *offset
 /* out[g][c] = sum_k y[g*nsample+k][c]   (umbrella aggregation 'sum', :305) */
 int rs_pool_sum(long long groups, int nsample, int c, const float *y, float *out, void *stream);
 
-/* k-major, zero-padded copies (the layout rs_mlp_gemm_rows reads) of up to RS_PACK_MAX conv weights
- * (cout, cin) in one launch: dst[k*ld + j] = src[j*cin + k] for j < cout, 0 for cout <= j < ld. */
+/* Zero-padded copies of up to RS_PACK_MAX conv weights (cout, cin) in one launch, in the n-major layout
+ * rs_mlp_gemm_rows reads:  transpose[e] = 0: dst[j*ld + k] = src[j*cin + k] (0 for cin <= k < ld) -- forward operand
+ * when cin % 4 != 0;  transpose[e] = 1: dst[k*ld + j] = src[j*cin + k] (0 for cout <= j < ld) -- operand of dY . W. */
 #define RS_PACK_MAX 8
 typedef struct rs_pack_weights_args {
   const float *src[RS_PACK_MAX]; float *dst[RS_PACK_MAX];
-  int cout[RS_PACK_MAX], cin[RS_PACK_MAX], ld[RS_PACK_MAX];
+  int cout[RS_PACK_MAX], cin[RS_PACK_MAX], ld[RS_PACK_MAX], transpose[RS_PACK_MAX];
   int n;
 } rs_pack_weights_args;
 int rs_pack_weights(const rs_pack_weights_args *args, void *stream);

@@ -21,6 +21,7 @@
 // Workgroups are persistent over row tiles, so BatchNorm partial sums live in registers (fp64)
 // and leave the workgroup once, as one deterministic partial row (no atomics).
 #include "rs_common.h"
+#include <stdlib.h>
 #include <math.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -140,9 +141,46 @@ constexpr int GM_LDA = GM_BM + 1; // K-major LDS rows, +1 pad: transposing store
 enum { EPI_STORE = RS_EPI_STORE, EPI_STATS = RS_EPI_STATS, EPI_MASK = RS_EPI_MASK };
 typedef rs_mlp_epilogue Epilogue;
 
-// out[rows, cols] = E[rows, kdim] . B,  B[k][n] = w[k*ldw + n]  (weights k-major, ldw % 4 == 0, zero padded)
+// out[rows, cols] = E[rows, kdim] . W^T,  W[n][k] = w[n*ldw + k]: weights n-major (the conv weight's own
+// (cout, cin) layout), ldw % 4 == 0, entries k in [kdim, ldw) zero.
+//
 // Pipeline per 32-deep K chunk: registers(next chunk) <- global  ||  MFMA(current chunk from LDS);
-// two LDS buffers, one barrier per chunk.
+// two LDS stages, one barrier per chunk.
+//
+// LDS layout ("fragment-major"): v_mfma_f32_32x32x2_f32 wants, per k-step ks, lane (r = lane & 31, lk = lane >> 5)
+// to hold A[r][2*ks + lk].  A chunk's 16 k-steps are stored as 8 planes p = 2*(ks >> 2) + lk of [row][ks & 3]
+// float4s, so ONE ds_read_b128 per lane fetches its operand for FOUR k-steps (conflict-free: consecutive lanes,
+// consecutive 16 B), and the fragments of the next four k-steps are read while the 4 x CT MFMAs of the current
+// ones run.  (Reading one float per k-step right before its MFMAs exposed the ~100-cycle LDS latency twice per
+// k-step and capped the loop near 50 % of the matrix pipe.)  The weights use the same layout with n in the row role.
+constexpr int GM_PLANE_A = GM_BM * 4 + 8;          // +8 floats: the 4 planes one commit instruction hits land in different banks
+constexpr int GM_STAGE_A = 8 * GM_PLANE_A;
+template <int BN> struct WStage { static constexpr int PLANE = BN * 4 + 8; static constexpr int SIZE = 8 * PLANE; };
+
+// LDS offset of element k (0..31, chunk-relative) of row r inside a stage with `plane` floats per plane
+__device__ __forceinline__ int frag_off(int k, int r, int plane) {
+  const int ks = k >> 1;
+  return ((ks >> 2) * 2 + (k & 1)) * plane + r * 4 + (ks & 3);
+}
+// store V consecutive k of one row (k0 % V == 0)
+template <int V>
+__device__ __forceinline__ void frag_store(float *stage, int plane, int k0, int r, const float (&v)[V]) {
+  if constexpr (V == 4) {          // (k0, k0+2) -> plane lk=0, slots i0, i0+1;  (k0+1, k0+3) -> plane lk=1
+    float *b = stage + frag_off(k0, r, plane);
+    *reinterpret_cast<float2 *>(b) = make_float2(v[0], v[2]);
+    *reinterpret_cast<float2 *>(b + plane) = make_float2(v[1], v[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) stage[frag_off(k0 + i, r, plane)] = v[i];
+  }
+}
+
+#ifdef RS_EXP_TIMING     // experiment build only (tools/gemm_variants.sh): per-phase shader-clock sums of wave 0
+#define RS_T(i) do { const long long _n = clock64(); tacc[i] += _n - tlast; tlast = _n; } while (0)
+#else
+#define RS_T(i) do { } while (0)
+#endif
+
 template <int BN, int V, int MODE>
 __global__ void __launch_bounds__(GM_THREADS, 2)     // 2 workgroups per CU: one computes while the other stages
 gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim, int cols, RowOperand E,
@@ -154,16 +192,17 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   constexpr int A_VECS = A_ELEMS / V;
   constexpr int A_TPR = GM_BK / V;                          // threads per tile row
   constexpr int A_RPP = GM_THREADS / A_TPR;                 // rows per pass
-  constexpr int W_VECS = GM_BK * BN / 4 / GM_THREADS;       // float4 of the weight chunk per thread
+  constexpr int W_VECS = BN / 32;                           // float4 (4 k of one output column) per thread and chunk
+  constexpr int PLANE_W = WStage<BN>::PLANE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *At0 = smem, *At1 = smem + GM_BK * GM_LDA;
-  float *Wt0 = smem + 2 * GM_BK * GM_LDA;                   // 8256 floats: 16-byte aligned offset
-  float *Wt1 = Wt0 + GM_BK * BN;
+  float *As0 = smem, *As1 = smem + GM_STAGE_A;
+  float *Ws0 = smem + 2 * GM_STAGE_A, *Ws1 = Ws0 + WStage<BN>::SIZE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.y * BN;
   const long long tiles = (rows + GM_BM - 1) / GM_BM;
   const int lrow = lane & 31, lk = lane >> 5;
   const int a_kq = (tid % A_TPR) * V, a_r = tid / A_TPR;
+  const int w_kq = (tid & 7) * 4, w_n = tid >> 3;           // weights: 8 threads x float4 cover the 32 k of a column
   const int nchunks = (kdim + GM_BK - 1) / GM_BK;
 
   // epilogue geometry: the finished tile goes through LDS so that global traffic is row-major float4
@@ -182,24 +221,27 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   float4 wraw[W_VECS];
   ColCoef<V> coef;
 
-  auto prefetch = [&](long long r0, int k0) {
-    const int k = k0 + a_kq;
-    const bool kok = k < kdim;                              // kdim % V == 0: whole vector in or out
-    op_coef<V, MODE>(E, k, kok, coef);
+  // Loads are never predicated: out-of-range rows / k are CLAMPED to the last valid element (always in bounds,
+  // finite) and zeroed when the values are committed to LDS -- straight-line code, no exec-mask branches.
+  // `part` < 0 issues the whole chunk.  (Spreading the parts 0..3 over the four MFMA groups of the running chunk was
+  // measured and is worse: a load that cannot issue stalls the wave in front of its next MFMA -- in-order issue --
+  // 126 us against 116 us at 262144 x 128 x 128, weight gradient 410 us against 320 us.)
+  auto prefetch = [&](long long r0, int k0, int part) {
+    const int k = min(k0 + a_kq, kdim - V);                 // kdim % V == 0
+    const int rlast = (int)min((long long)GM_BM - 1, rows - 1 - r0);
+    if (part <= 0) op_coef<V, MODE>(E, k, true, coef);
 #pragma unroll
-    for (int p = 0; p < A_VECS; ++p) {
-      const int rl = p * A_RPP + a_r;
-      op_load<V, MODE>(E, r0, rl, k, kok && r0 + rl < rows, araw[p]);
-    }
+    for (int p = 0; p < A_VECS; ++p)
+      if (part < 0 || (p * 4) / A_VECS == part) op_load<V, MODE>(E, r0, min(p * A_RPP + a_r, rlast), k, true, araw[p]);
+    const int kw = min(k0 + w_kq, ldw - 4);
 #pragma unroll
-    for (int p = 0; p < W_VECS; ++p) {
-      const int e = p * GM_THREADS + tid;                   // float4 index inside the 32 x BN chunk
-      const int kk = e / (BN / 4), nn = (e - kk * (BN / 4)) * 4;
-      wraw[p] = (k0 + kk < kdim && n0 + nn < ldw) ? *reinterpret_cast<const float4 *>(w + (long long)(k0 + kk) * ldw + n0 + nn)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int p = 0; p < W_VECS; ++p)
+      if (part < 0 || (p * 4) / W_VECS == part) {
+        const int n = min(n0 + p * 32 + w_n, cols - 1);
+        wraw[p] = *reinterpret_cast<const float4 *>(w + (long long)n * ldw + kw);
+      }
   };
-  auto commit = [&](float *At, float *Wt, long long r0, int k0) {
+  auto commit = [&](float *As, float *Ws, long long r0, int k0) {
     const bool kok = (k0 + a_kq) < kdim;
 #pragma unroll
     for (int p = 0; p < A_VECS; ++p) {
@@ -207,16 +249,23 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       const long long r = r0 + rl;
       float v[V];
       op_finish<V, MODE>(E, coef, araw[p], r, kok && r < rows, v);
-#pragma unroll
-      for (int i = 0; i < V; ++i) At[(a_kq + i) * GM_LDA + rl] = v[i];
+      frag_store<V>(As, GM_PLANE_A, a_kq, rl, v);
     }
+    const bool wk_ok = (k0 + w_kq) < ldw;                   // [kdim, ldw) is zero in memory
 #pragma unroll
     for (int p = 0; p < W_VECS; ++p) {
-      const int e = p * GM_THREADS + tid;
-      *reinterpret_cast<float4 *>(Wt + e * 4) = wraw[p];     // row-major [k][BN]: no transposition needed
+      const int nl = p * 32 + w_n;
+      const bool ok = wk_ok && (n0 + nl < cols);
+      const float v[4] = {ok ? wraw[p].x : 0.f, ok ? wraw[p].y : 0.f, ok ? wraw[p].z : 0.f, ok ? wraw[p].w : 0.f};
+      frag_store<4>(Ws, PLANE_W, w_kq, nl, v);
     }
   };
 
+#ifdef RS_EXP_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+  const long long tstart = tlast;
+#endif
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long r0 = tile * GM_BM;
     f32x16 acc[CT];
@@ -225,25 +274,50 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
-    prefetch(r0, 0);
+    prefetch(r0, 0, -1);
+    RS_T(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-      float *At = (ch & 1) ? At1 : At0;
-      float *Wt = (ch & 1) ? Wt1 : Wt0;
-      commit(At, Wt, r0, ch * GM_BK);
-      __syncthreads();                                        // tile chunk visible; buffer ch-1 free again
-      if (ch + 1 < nchunks) prefetch(r0, (ch + 1) * GM_BK);   // loads fly under the MFMAs below
-      const int ksteps = min(GM_BK, kdim - ch * GM_BK + 1) >> 1;
-#pragma unroll 2
-      for (int ks = 0; ks < ksteps; ++ks) {
-        const float a = At[(2 * ks + lk) * GM_LDA + wave * 32 + lrow];
+      float *As = (ch & 1) ? As1 : As0;
+      float *Ws = (ch & 1) ? Ws1 : Ws0;
+      commit(As, Ws, r0, ch * GM_BK);
+      RS_T(1);
+      __syncthreads();                                        // tile chunk visible; stage ch-1 free again
+      RS_T(2);
+      if (ch + 1 < nchunks) prefetch(r0, (ch + 1) * GM_BK, -1);   // loads fly under the MFMAs below
+      RS_T(3);
+      // groups of 4 k-steps; the last chunk of a ragged K runs only the groups that hold data
+      const int ngroups = (min(GM_BK, kdim - ch * GM_BK) + 7) >> 3;
+      const float *ap = As + lk * GM_PLANE_A + (wave * 32 + lrow) * 4;
+      const float *bp = Ws + lk * PLANE_W + lrow * 4;
+      float4 af[2], bf[2][CT];
+      af[0] = *reinterpret_cast<const float4 *>(ap);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const float b = Wt[(2 * ks + lk) * BN + c * 32 + lrow];
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+      for (int c = 0; c < CT; ++c) bf[0][c] = *reinterpret_cast<const float4 *>(bp + c * 128);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < ngroups) {                                    // wave-uniform
+          if (j + 1 < 4) {                                    // fragments of the NEXT group: in flight under this group's MFMAs
+            af[(j + 1) & 1] = *reinterpret_cast<const float4 *>(ap + (j + 1) * 2 * GM_PLANE_A);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+              bf[(j + 1) & 1][c] = *reinterpret_cast<const float4 *>(bp + (j + 1) * 2 * PLANE_W + c * 128);
+          }
+          const float a4[4] = {af[j & 1].x, af[j & 1].y, af[j & 1].z, af[j & 1].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+              const float4 bq = bf[j & 1][c];
+              const float b = i == 0 ? bq.x : (i == 1 ? bq.y : (i == 2 ? bq.z : bq.w));
+              acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], b, acc[c], 0, 0, 0);
+            }
+          }
         }
       }
+      RS_T(4);
     }
     __syncthreads();   // all fragment reads of this tile done: the staging buffers become the C tile
+    RS_T(5);
 
     // ---- epilogue.  D[i][j]: j = lane & 31, i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)  ->  Cs[row][col]
     float *Cs = smem;                                         // 128 x BN floats (<= 64 KB)
@@ -339,7 +413,17 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       }
     }
     __syncthreads();   // C tile consumed before the next tile's staging overwrites it
+    RS_T(6);
   }
+#ifdef RS_EXP_TIMING
+  if (tid == 0 && ep.pool_amax) {
+    long long *o = reinterpret_cast<long long *>(ep.pool_amax) + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 10;
+    for (int i = 0; i < 7; ++i) o[i] = tacc[i];
+    o[7] = clock64() - tstart;
+    o[8] = 0;
+    o[9] = tiles;
+  }
+#endif
 
   if (ep.mode != EPI_STORE) {
     // workgroup reduction of the fp64 partial sums: E_RPP contributions per column
@@ -354,7 +438,12 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         if (tid < BN) {
           double t = 0.0;
           for (int p = 0; p < E_RPP; ++p) t += red[p * BN + tid];
-          if (n0 + tid < cols) ep.partial[((long long)blockIdx.x * nstat + s) * cols + n0 + tid] = t;
+          if (n0 + tid < cols) {
+            ep.partial[((long long)blockIdx.x * nstat + s) * cols + n0 + tid] = t;
+            // the finalize kernel sums `partial_blocks` rows: rows no workgroup owns read as zero (no memset launch)
+            for (int pb = blockIdx.x + gridDim.x; pb < ep.partial_blocks; pb += gridDim.x)
+              ep.partial[((long long)pb * nstat + s) * cols + n0 + tid] = 0.0;
+          }
         }
         __syncthreads();
       }
@@ -372,11 +461,12 @@ template <int WN, int WK, int TN, int TK, int VP, int VQ, int PM, int QM>
 __global__ void __launch_bounds__(GM_THREADS, 2)
 wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, int kcols, RowOperand P, RowOperand Q,
              long long rows_per_chunk_arg, float *__restrict__ partial) {
-  long long rows = rows_arg, rows_per_chunk = rows_per_chunk_arg;
-  if (rows_dev) {     // device-side row count: split what is actually there over the launched slabs
-    rows = min(rows_arg, (long long)*rows_dev);
-    rows_per_chunk = ((rows + gridDim.x - 1) / gridDim.x + WG_BR - 1) / WG_BR * WG_BR;
-  }
+  // Row stages (32 rows) are dealt round-robin to the gridDim.x row workgroups: at any moment the whole grid reads
+  // one contiguous window of the operands (gridDim.x * 32 rows), which keeps DRAM pages and TLB entries hot.
+  // (Contiguous per-workgroup slabs had 512 streams 0.5 MB apart: 1.2 TB/s; the partial sums do not care which
+  // rows they hold, and the order inside a partial stays fixed, so results remain deterministic.)
+  const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
+  (void)rows_per_chunk_arg;
   constexpr int BNN = WN * TN * 32, BKK = WK * TK * 32;
   constexpr int P_VECS = WG_BR * BNN / VP / GM_THREADS, Q_VECS = (WG_BR * BKK / VQ + GM_THREADS - 1) / GM_THREADS;
   constexpr int P_TPR = BNN / VP, Q_TPR = BKK / VQ;           // threads per tile row
@@ -388,8 +478,8 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
   const int wn = wave / WK, wk = wave % WK;
   const int n0 = blockIdx.y * BNN, k0 = blockIdx.z * BKK;
   const int lcol = lane & 31, lr = lane >> 5;
-  const long long rbeg = (long long)blockIdx.x * rows_per_chunk;
-  const long long rend = min(rows, rbeg + rows_per_chunk);
+  const long long rbeg = (long long)blockIdx.x * WG_BR, rstep = (long long)gridDim.x * WG_BR;
+  const long long rend = rows;
   const int p_c = (tid % P_TPR) * VP, p_r = tid / P_TPR;
   const int q_c = (tid % Q_TPR) * VQ, q_r = tid / Q_TPR;
   const bool q_active = tid < Q_TPR * Q_RPP;                  // Q tiles narrower than 256 vectors per pass
@@ -410,14 +500,17 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
   op_coef<VP, PM>(P, n0 + p_c, pc_ok, pcoef);                     // this thread's columns never change
   op_coef<VQ, QM>(Q, k0 + q_c, qc_ok, qcoef);
 
-  auto prefetch = [&](long long r0) {
+  // part 0..3: a quarter of the next stage's loads (issued between the MFMA steps, see gemm_rows_kernel); < 0: all
+  auto prefetch = [&](long long r0, int part) {
 #pragma unroll
     for (int p = 0; p < P_VECS; ++p) {
+      if (part >= 0 && (p * 4) / P_VECS != part) continue;
       const int rl = p * P_RPP + p_r;
       op_load<VP, PM>(P, r0, rl, n0 + p_c, pc_ok && r0 + rl < rend, praw[p]);
     }
 #pragma unroll
     for (int p = 0; p < Q_VECS; ++p) {
+      if (part >= 0 && (p * 4) / Q_VECS != part) continue;
       const int rl = p * Q_RPP + q_r;
       op_load<VQ, QM>(Q, r0, rl, k0 + q_c, qc_ok && rl < WG_BR && r0 + rl < rend, qraw[p]);
     }
@@ -443,26 +536,48 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
     }
   };
 
-  if (rbeg < rend) prefetch(rbeg);
+#ifdef RS_EXP_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+  const long long tstart = tlast;
+#endif
+  if (rbeg < rend) prefetch(rbeg, -1);
+  RS_T(0);
   int it = 0;
-  for (long long r0 = rbeg; r0 < rend; r0 += WG_BR, ++it) {
+  for (long long r0 = rbeg; r0 < rend; r0 += rstep, ++it) {
     float *Ps = (it & 1) ? Ps1 : Ps0;
     float *Qs = (it & 1) ? Qs1 : Qs0;
     commit(Ps, Qs, r0);
+    RS_T(1);
     __syncthreads();
-    if (r0 + WG_BR < rend) prefetch(r0 + WG_BR);
-#pragma unroll 4
+    RS_T(2);
+    if (r0 + rstep < rend) prefetch(r0 + rstep, -1);
+    RS_T(3);
+    // fragment reads of step s+1 are issued before the MFMAs of step s (two register sets, fully unrolled):
+    // the ~100-cycle LDS latency stays under the matrix pipe instead of in front of every 4 MFMAs
+    const float *pp = Ps + lr * BNN + wn * TN * 32 + lcol;
+    const float *qp = Qs + lr * BKK + wk * TK * 32 + lcol;
+    float pa[2][TN], qb[2][TK];
+#pragma unroll
+    for (int a = 0; a < TN; ++a) pa[0][a] = pp[a * 32];
+#pragma unroll
+    for (int b = 0; b < TK; ++b) qb[0][b] = qp[b * 32];
+#pragma unroll
     for (int s = 0; s < WG_BR / 2; ++s) {
-      float pa[TN], qb[TK];
+      if (s + 1 < WG_BR / 2) {
 #pragma unroll
-      for (int a = 0; a < TN; ++a) pa[a] = Ps[(2 * s + lr) * BNN + (wn * TN + a) * 32 + lcol];
+        for (int a = 0; a < TN; ++a) pa[(s + 1) & 1][a] = pp[(2 * s + 2) * BNN + a * 32];
 #pragma unroll
-      for (int b = 0; b < TK; ++b) qb[b] = Qs[(2 * s + lr) * BKK + (wk * TK + b) * 32 + lcol];
+        for (int b = 0; b < TK; ++b) qb[(s + 1) & 1][b] = qp[(2 * s + 2) * BKK + b * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep the reads above this step's MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[a], qb[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TK; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s & 1][a], qb[s & 1][b], acc[a][b], 0, 0, 0);
     }
+    RS_T(4);
   }
   float *dst = partial + (long long)blockIdx.x * ncols * kcols;
 #pragma unroll
@@ -476,6 +591,17 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
         if (n < ncols && kk < kcols) dst[(long long)n * kcols + kk] = acc[a][b][i];
       }
     }
+#ifdef RS_EXP_TIMING
+  RS_T(6);
+  if (tid == 0 && P.t2) {      // experiment build: the (unused) t2 slot of the P operand carries the debug buffer
+    long long *o = reinterpret_cast<long long *>(const_cast<float *>(P.t2)) +
+                   (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 10;
+    for (int i = 0; i < 7; ++i) o[i] = tacc[i];
+    o[7] = clock64() - tstart;
+    o[8] = it;
+    o[9] = gridDim.x * gridDim.y * gridDim.z;
+  }
+#endif
 }
 
 // out[e] = sum_c partial[c][e]   (deterministic order).  32 outputs x 8 chunk slices per workgroup:
@@ -681,8 +807,14 @@ pool_sum_kernel(long long groups, int ns, int c, const float *__restrict__ y, fl
   }
 }
 
+int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 int persistent_blocks(long long tiles, int tiles_n) {
-  long long want = 512 / (tiles_n > 0 ? tiles_n : 1);   // ~2 workgroups per CU over the whole grid
+  static const int slots = env_int("RS_GEMM_SLOTS", 512);
+  long long want = slots / (tiles_n > 0 ? tiles_n : 1);   // ~2 workgroups per CU over the whole grid
   if (want < 64) want = 64;
   return (int)(tiles < want ? tiles : want);
 }
@@ -720,7 +852,7 @@ int check_operand(const char *who, const RowOperand *o, long long rows) {
 template <int BN, int V>
 void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                    const float *w, int ldw, const Epilogue &ep) {
-  const size_t lds = sizeof(float) * (2 * GM_BK * GM_LDA + 2 * GM_BK * BN);
+  const size_t lds = sizeof(float) * (2 * GM_STAGE_A + 2 * WStage<BN>::SIZE);
 #define RS_G(M_) hipLaunchKernelGGL((gemm_rows_kernel<BN, V, M_>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, kdim, cols, E, w, ldw, ep)
   if (V == 1) { RS_G(-1); return; }                 // odd sizes: one generic (runtime-mode) kernel
   switch (E.mode) {
@@ -772,8 +904,8 @@ extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, i
   if (rows == 0 || cols == 0) return RS_OK;
   RS_REQUIRE(kdim > 0, "rs_mlp_gemm_rows: empty reduction dimension");
   RS_REQUIRE(w && epi && epi->out, "rs_mlp_gemm_rows: null pointer");
-  RS_REQUIRE(ldw % 4 == 0 && ldw >= cols && aligned_to(w, 16),
-             "rs_mlp_gemm_rows: weights must be k-major with a 16-byte aligned base and ldw %% 4 == 0 (ldw=%d, cols=%d)", ldw, cols);
+  RS_REQUIRE(ldw % 4 == 0 && ldw >= kdim && aligned_to(w, 16),
+             "rs_mlp_gemm_rows: weights must be n-major (cols x ldw) with a 16-byte aligned base and ldw %% 4 == 0 (ldw=%d, kdim=%d)", ldw, kdim);
   int rc = check_operand("rs_mlp_gemm_rows", x, rows);
   if (rc != RS_OK) return rc;
   Epilogue ep = *epi;
@@ -792,17 +924,16 @@ extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, i
     RS_REQUIRE(rows % ep.pool_ns == 0 && rpt % ep.pool_ns == 0,
                "rs_mlp_gemm_rows: fused pooling needs nsample (%d) to divide %d rows per thread", ep.pool_ns, rpt);
   }
-  const int nstat = (epi_mode == EPI_MASK && ep.my2) ? 3 : 2;
+  (void)0;
   const long long tiles = (rows + GM_BM - 1) / GM_BM;
   int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
-  if (bn == 128 && tiles * rs_cdiv(cols, 128) < 256 && ep.pool_ns == 0) bn = 64;   // few rows (group_all stage): 2x the workgroups
+  static const int bn_small = env_int("RS_GEMM_BN64_BELOW", 256);
+  if (bn == 128 && tiles * rs_cdiv(cols, 128) < bn_small && ep.pool_ns == 0) bn = 64;   // few rows (group_all stage): 2x the workgroups
   const int tiles_n = rs_cdiv(cols, bn);
   int gx = persistent_blocks(tiles, tiles_n);
   if (epi_mode != EPI_STORE) gx = gx < ep.partial_blocks ? gx : ep.partial_blocks;
   const dim3 grid(gx, tiles_n);
   hipStream_t st = (hipStream_t)stream;
-  if (epi_mode != EPI_STORE && gx < ep.partial_blocks)   // unused partial rows must read as zero
-    (void)hipMemsetAsync(ep.partial + (long long)gx * nstat * cols, 0, sizeof(double) * (size_t)(ep.partial_blocks - gx) * nstat * cols, st);
   const int v = pick_vec(E, kdim);
   if (bn == 32) launch_gemm<32>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
   else if (bn == 64) launch_gemm<64>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
@@ -842,18 +973,28 @@ extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int 
   return RS_OK;
 }
 
-// ---- k-major copies of up to RS_PACK_MAX conv weights in one launch --------------------------------
-// dst[k*ld + j] = src[j*cin + k] (j < cout), zero for cout <= j < ld: the layout rs_mlp_gemm_rows reads.
+// ---- padded copies of up to RS_PACK_MAX conv weights (cout, cin) in one launch --------------------------------
+// transpose = 0:  dst[j*ld + k] = src[j*cin + k]  (k < cin, else 0), ld >= cin    -- forward operand of rs_mlp_gemm_rows
+//                 when cin is not a multiple of 4 (otherwise the conv weight is used in place);
+// transpose = 1:  dst[k*ld + j] = src[j*cin + k]  (j < cout, else 0), ld >= cout  -- data-gradient operand (dY . W).
 __global__ void __launch_bounds__(GM_THREADS)
 pack_weights_kernel(rs_pack_weights_args a) {
   const int e = blockIdx.y;
   const int cout = a.cout[e], cin = a.cin[e], ld = a.ld[e];
   const float *__restrict__ src = a.src[e];
   float *__restrict__ dst = a.dst[e];
-  const int total = cin * ld;
-  for (int i = blockIdx.x * GM_THREADS + threadIdx.x; i < total; i += gridDim.x * GM_THREADS) {
-    const int k = i / ld, j = i - k * ld;
-    dst[i] = j < cout ? src[j * cin + k] : 0.f;
+  if (a.transpose[e]) {
+    const int total = cin * ld;
+    for (int i = blockIdx.x * GM_THREADS + threadIdx.x; i < total; i += gridDim.x * GM_THREADS) {
+      const int k = i / ld, j = i - k * ld;
+      dst[i] = j < cout ? src[j * cin + k] : 0.f;
+    }
+  } else {
+    const int total = cout * ld;
+    for (int i = blockIdx.x * GM_THREADS + threadIdx.x; i < total; i += gridDim.x * GM_THREADS) {
+      const int j = i / ld, k = i - j * ld;
+      dst[i] = k < cin ? src[j * cin + k] : 0.f;
+    }
   }
 }
 
@@ -862,9 +1003,12 @@ extern "C" int rs_pack_weights(const rs_pack_weights_args *args, void *stream) {
   if (args->n == 0) return RS_OK;
   int biggest = 0;
   for (int e = 0; e < args->n; ++e) {
-    RS_REQUIRE(args->src[e] && args->dst[e] && args->ld[e] >= args->cout[e] && args->ld[e] % 4 == 0,
-               "rs_pack_weights: entry %d invalid (ld=%d cout=%d)", e, args->ld[e], args->cout[e]);
-    biggest = max(biggest, args->cin[e] * args->ld[e]);
+    const int inner = args->transpose[e] ? args->cout[e] : args->cin[e];
+    const int outer = args->transpose[e] ? args->cin[e] : args->cout[e];
+    RS_REQUIRE(args->src[e] && args->dst[e] && args->ld[e] >= inner && args->ld[e] % 4 == 0,
+               "rs_pack_weights: entry %d invalid (ld=%d cout=%d cin=%d transpose=%d)", e, args->ld[e], args->cout[e],
+               args->cin[e], args->transpose[e]);
+    biggest = max(biggest, outer * args->ld[e]);
   }
   int gx = rs_cdiv(biggest, GM_THREADS);
   if (gx > 64) gx = 64;

@@ -117,3 +117,12 @@ def umbrella_mlp2(x, mlps, group):
         return _torch_umbrella2(x, mlps, group)
     from . import mlp_hip
     return mlp_hip.umbrella_mlp2(x, mlps, group)
+
+
+def deferred_counters():
+    """Context in which the BatchNorm `num_batches_tracked` updates of all stacks are batched into one launch."""
+    if BACKEND == "torch":
+        import contextlib
+        return contextlib.nullcontext()
+    from . import mlp_hip
+    return mlp_hip.deferred_counters()

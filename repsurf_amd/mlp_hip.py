@@ -13,6 +13,7 @@ per-channel constant, so the analytic gradient is 0 (the reference's autograd pr
 noise of 1e-7..1e-3 there).
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -91,11 +92,30 @@ class _ZeroPool:
 _pending_counters = []
 
 
-def _flush_counters():
-    """num_batches_tracked += 1 for every BatchNorm of the stack in ONE multi-tensor kernel."""
-    if _pending_counters:
+_defer_counters = 0
+
+
+def _flush_counters(force=False):
+    """num_batches_tracked += 1 for every BatchNorm of the stack in ONE multi-tensor kernel (of the whole model when
+    the caller wraps its forward in `deferred_counters()`)."""
+    if _pending_counters and (force or not _defer_counters):
         torch._foreach_add_(_pending_counters, 1)
         _pending_counters.clear()
+
+
+class deferred_counters:
+    """with deferred_counters(): ...several stacks... -> one counter update for all of them at exit."""
+
+    def __enter__(self):
+        global _defer_counters
+        _defer_counters += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _defer_counters
+        _defer_counters -= 1
+        if _defer_counters == 0:
+            _flush_counters(force=True)
 
 
 class BNVec:
@@ -117,41 +137,59 @@ def _pad4(w):
     return w if pad == 0 else torch.nn.functional.pad(w, (0, pad))
 
 
-def _kmajor(w2d):
-    """conv weight (cout, cin) -> k-major (cin, pad4(cout)) for the forward row GEMM"""
-    return _pad4(w2d.t()).contiguous()
-
-
 PACK_MAX = 8
 
 
 class PackArgs(ctypes.Structure):            # rs_pack_weights_args
     _fields_ = [("src", P * PACK_MAX), ("dst", P * PACK_MAX), ("cout", c_int * PACK_MAX), ("cin", c_int * PACK_MAX),
-                ("ld", c_int * PACK_MAX), ("n", c_int)]
+                ("ld", c_int * PACK_MAX), ("transpose", c_int * PACK_MAX), ("n", c_int)]
 
 
-def pack_kmajor(w2ds, device):
-    """k-major zero-padded copies of several (cout, cin) weights with ONE launch per 8 weights."""
-    lds = [(-(-w.shape[0] // 4)) * 4 for w in w2ds]
-    sizes = [w.shape[1] * ld for w, ld in zip(w2ds, lds)]
+def pack_weights(w2ds, transpose, device):
+    """Zero-padded copies of several (cout, cin) weights in the n-major layout the row GEMM reads, ONE launch per 8:
+    transpose=False -> (cout, pad4(cin)) for the forward GEMM, transpose=True -> (cin, pad4(cout)) for dY . W."""
+    tr = int(bool(transpose))
+    inner = [w.shape[0] if tr else w.shape[1] for w in w2ds]
+    outer = [w.shape[1] if tr else w.shape[0] for w in w2ds]
+    lds = [(-(-n // 4)) * 4 for n in inner]
+    sizes = [o * ld for o, ld in zip(outer, lds)]
     flat = torch.empty((sum(-(-sz // 4) * 4 for sz in sizes),), dtype=torch.float32, device=device)
     outs, off = [], 0
-    for w, ld, sz in zip(w2ds, lds, sizes):
-        outs.append(flat[off:off + sz].view(w.shape[1], ld))
+    for o, ld, sz in zip(outer, lds, sizes):
+        outs.append(flat[off:off + sz].view(o, ld))
         off += -(-sz // 4) * 4                      # keep every copy 16-byte aligned
     for i in range(0, len(w2ds), PACK_MAX):
         a = PackArgs()
         chunk = list(zip(w2ds[i:i + PACK_MAX], outs[i:i + PACK_MAX], lds[i:i + PACK_MAX]))
         for j, (w, o, ld) in enumerate(chunk):
             a.src[j], a.dst[j] = w.data_ptr(), o.data_ptr()
-            a.cout[j], a.cin[j], a.ld[j] = w.shape[0], w.shape[1], ld
+            a.cout[j], a.cin[j], a.ld[j], a.transpose[j] = w.shape[0], w.shape[1], ld, tr
         a.n = len(chunk)
         _lib.call("rs_pack_weights", ctypes.byref(a), _stream())
     return outs
 
 
+def fwd_weights(w2ds, device):
+    """Forward operands: the conv weights themselves where cin % 4 == 0 (and the base is 16-byte aligned), one batched
+    padded copy for the others (the first-layer branches with 6 / 10 / 138 / 266 input channels)."""
+    need = [i for i, w in enumerate(w2ds) if w.shape[1] % 4 or w.data_ptr() % 16]
+    outs = list(w2ds)
+    if need:
+        for i, c in zip(need, pack_weights([w2ds[i] for i in need], False, device)):
+            outs[i] = c
+    return outs
+
+
+def w_fwd(w2d):
+    return fwd_weights([w2d], w2d.device)[0]
+
+
+def w_bwd(w2d):
+    return pack_weights([w2d], True, w2d.device)[0]
+
+
 def gemm_rows(rows, kdim, cols, x_op, wk, epi, rows_dev=None):
-    """out[rows, cols] = E[rows, kdim] . wk[:kdim, :cols]   (wk k-major, ld % 4 == 0)"""
+    """out[rows, cols] = E[rows, kdim] . wk[:cols, :kdim]^T   (wk n-major (cols, ld), ld % 4 == 0, zero beyond kdim)"""
     _lib.call("rs_mlp_gemm_rows", rows, rows_dev, kdim, cols, ctypes.byref(x_op), _ptr(wk), wk.shape[1],
               ctypes.byref(epi), _stream())
 
@@ -185,7 +223,7 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
             epi.pool_max, epi.pool_min = _ptr(ext[0]), _ptr(ext[1])
             epi.pool_amax, epi.pool_amin = pos[0].data_ptr(), pos[1].data_ptr()
             pool = (ext, pos)
-        gemm_rows(rows, kdim, cout, x_op, wk if wk is not None else _kmajor(w2d), epi, rows_dev)
+        gemm_rows(rows, kdim, cout, x_op, wk if wk is not None else w_fwd(w2d), epi, rows_dev)
         track = bn_mod.track_running_stats and bn_mod.running_mean is not None
         if track:
             _pending_counters.append(bn_mod.num_batches_tracked)
@@ -203,7 +241,7 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
             return y, vec, (out, arg)
     else:
         epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STORE)
-        gemm_rows(rows, kdim, cout, x_op, wk if wk is not None else _kmajor(w2d), epi, rows_dev)
+        gemm_rows(rows, kdim, cout, x_op, wk if wk is not None else w_fwd(w2d), epi, rows_dev)
         with torch.no_grad():
             invstd = torch.rsqrt(bn_mod.running_var + bn_mod.eps)
             vec.invstd.copy_(invstd)
@@ -242,7 +280,7 @@ def bwd_coeffs(c, rows, part, nstat, which, vec, device):
     return buf[0], buf[1], buf[2], buf[3], buf[4]
 
 
-def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=None, rows_dev=None):
+def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=None, rows_dev=None, wt=None):
     """dz_prev = (P . W) * relu'(z_prev) and the BN-backward sums of the previous layer(s)."""
     dz = torch.empty((rows, cols), dtype=torch.float32, device=device)
     nstat = 3 if y2 is not None else 2
@@ -253,11 +291,55 @@ def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=N
     if y2 is not None:
         epi.my2, epi.ldm2 = _ptr(y2), cols
         epi.ms2, epi.mt2, epi.mean2, epi.invstd2 = _ptr(v2.scale), _ptr(v2.shift), _ptr(v2.mean), _ptr(v2.invstd)
-    gemm_rows(rows, kdim, cols, p_op, _pad4(w2d), epi, rows_dev)      # (cout, cin) is already k-major for dY . W
+    gemm_rows(rows, kdim, cols, p_op, wt if wt is not None else w_bwd(w2d), epi, rows_dev)      # dY . W: the transposed copy
     return dz, part, nstat
 
 
 # ------------------------------------------------------------------------------------------- SA stacks
+# Weight-gradient GEMMs hang off the backward chain (nothing downstream in the chain needs them), so they CAN go to a
+# second HIP stream and overlap with the data-gradient GEMMs.  Measured (hipGraph replay, B=32): 2.67 ms/step with the
+# fork against 2.64 ms without -- both kernel families are limited by the same per-CU load/store paths and matrix
+# pipe, so running them side by side only makes each slower.  Off by default; REPSURF_WGRAD_STREAM=1 enables it.
+SIDE_WGRAD = os.environ.get("REPSURF_WGRAD_STREAM", "0") != "0"
+_side_streams = {}
+
+
+class _Fork:
+    """Fork/join of side-stream launches inside one backward call.  Temporaries read by the side stream are kept
+    alive until the join (a freed block could otherwise be handed to a later main-stream allocation while the
+    side stream still reads it)."""
+
+    def __init__(self, device):
+        self.on = SIDE_WGRAD
+        self.keep = []
+        self.used = False
+        if self.on:
+            self.main = torch.cuda.current_stream(device)
+            key = (device.index, self.main.cuda_stream)
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(device=device)
+            self.side = _side_streams[key]
+
+    def run(self, fn, *alive):
+        self.keep.extend(alive)
+        if not self.on:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        self.used = True
+        return out
+
+    def join(self):
+        if self.on and self.used:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.main.wait_event(ev)
+        self.keep.clear()
+
+
 class _SAStack(Function):
     """[two-branch | single] first layer -> [conv, BN, ReLU]* -> max over nsample.
     args: x (rows, cx), meta, then flat parameters (see sa_mlp_cd / sa_mlp_plain)."""
@@ -274,7 +356,7 @@ class _SAStack(Function):
         pi = 0
         ys, vecs, w2ds = [], [], []
         all_w2d = [_w2d(params[i]) for i in range(0, len(params), 4)]
-        wks = pack_kmajor(all_w2d, dev)            # one launch for every layer's k-major weight copy
+        wks = fwd_weights(all_w2d, dev)            # conv weights in place; one batched padded copy for odd cin
         if pos > 0:      # two-branch first layer (SurfaceAbstractionCD)
             wl, bl, wf, bf = params[0], params[1], params[4], params[5]
             wl2, wf2 = all_w2d[0], all_w2d[1]
@@ -346,6 +428,16 @@ class _SAStack(Function):
         p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev)
         p_op = operand(OP_POOLED, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, arg=s["arg"], ns=ns, rs=rs)
         dx = None
+        fork = _Fork(dev)
+        fork.keep += [v, p, q, r]
+        # transposed weight copies for the data-gradient GEMMs (dY . W), one launch: layers 1.. of the chain, plus
+        # the feature branch of a two-branch first layer / the single first layer when the input needs a gradient
+        need_t = {("l", li): w2ds[li] for li in range(1, nl)}
+        if nl and (pos > 0 or ctx.needs_input_grad[0]):
+            need_t[("l", 0)] = w2ds[0]
+        if pos > 0 and ctx.needs_input_grad[0]:
+            need_t[("f", 0)] = s["wf2"]
+        wts = dict(zip(need_t.keys(), pack_weights(list(need_t.values()), True, dev))) if need_t else {}
         for li in range(nl - 1, -1, -1):
             pidx = first + 4 * li
             cout, cin = w2ds[li].shape
@@ -359,17 +451,18 @@ class _SAStack(Function):
                                s["vf"].scale, s["vf"].shift)
             else:
                 q_op = operand(OP_ID, x, cx)
-            grads[pidx] = wgrad(rows, cout, cin, p_op, q_op, dev, rdev)
+            grads[pidx] = fork.run(lambda: wgrad(rows, cout, cin, p_op, q_op, dev, rdev))
             if li > 0:      # data gradient, ReLU mask and BN-backward sums of layer li-1
                 dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], ys[li - 1], vecs[li - 1], device=dev,
-                                               rows_dev=rdev)
+                                               rows_dev=rdev, wt=wts[("l", li)])
                 p, q, r, dg, db = bwd_coeffs(cin, full, part, nstat, 1, vecs[li - 1], dev)
                 if DEBUG is not None:
                     DEBUG["layer%d" % li] = dict(dz=dz, part=part, p=p, q=q, r=r, dg=dg, db=db, y=ys[li - 1], vec=vecs[li - 1])
                 p_op = operand(OP_AFF2, dz, cin, ys[li - 1], cin, s1=p, t1=r, s2=q, rs=rs)
+                fork.keep += [dz, p, q, r]
             elif pos > 0:   # two-branch first layer: one masked gradient, two BatchNorms
                 dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], s["yl"], s["vl"], s["yf"], s["vf"],
-                                               device=dev, rows_dev=rdev)
+                                               device=dev, rows_dev=rdev, wt=wts[("l", 0)])
                 pl, ql, rl, dgl, dbl = bwd_coeffs(cin, full, part, 3, 1, s["vl"], dev)
                 pf, qf, rf, dgf, dbf = bwd_coeffs(cin, full, part, 3, 2, s["vf"], dev)
                 if DEBUG is not None:
@@ -377,8 +470,9 @@ class _SAStack(Function):
                                  dgf=dgf, dbf=dbf, yl=s["yl"], yf=s["yf"], vl=s["vl"], vf=s["vf"])
                 opl = operand(OP_AFF2, dz, cin, s["yl"], cin, s1=pl, t1=rl, s2=ql, rs=rs)
                 opf = operand(OP_AFF2, dz, cin, s["yf"], cin, s1=pf, t1=rf, s2=qf, rs=rs)
-                grads[0] = wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev, rdev)
-                grads[4] = wgrad(rows, cin, cx - pos, opf, operand(OP_ID, x, cx, a_off=pos), dev, rdev)
+                fork.keep += [dz, pl, ql, rl, pf, qf, rf]
+                grads[0] = fork.run(lambda: wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev, rdev))
+                grads[4] = fork.run(lambda: wgrad(rows, cin, cx - pos, opf, operand(OP_ID, x, cx, a_off=pos), dev, rdev))
                 grads[1] = zeros.take(cin)
                 grads[5] = zeros.take(cin)
                 grads[2], grads[3], grads[6], grads[7] = dgl, dbl, dgf, dbf
@@ -387,11 +481,12 @@ class _SAStack(Function):
                     # backward reads nothing else, so the position columns are left unwritten (no 150 MB memset).
                     dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
                     epi = Epilogue(bias=None, out=_ptr(dx, pos), ldo=cx, mode=EPI_STORE)
-                    gemm_rows(rows, cin, cx - pos, opf, _pad4(s["wf2"]), epi, rdev)
+                    gemm_rows(rows, cin, cx - pos, opf, wts[("f", 0)], epi, rdev)
             elif ctx.needs_input_grad[0]:
                 dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
                 epi = Epilogue(bias=None, out=_ptr(dx), ldo=cx, mode=EPI_STORE)
-                gemm_rows(rows, cout, cx, p_op, _pad4(w2ds[li]), epi, rdev)
+                gemm_rows(rows, cout, cx, p_op, wts[("l", 0)], epi, rdev)
+        fork.join()
         out_grads = [None if g is None else g.reshape(shape) for g, shape in zip(grads, meta["shapes"])]
         return (dx, None) + tuple(out_grads)
 
@@ -441,7 +536,7 @@ class _UmbrellaStack(Function):
         cout = w2_.shape[0]
         y2 = torch.empty((rows, cout), dtype=torch.float32, device=dev)
         epi = Epilogue(bias=_ptr(c2), out=_ptr(y2), ldo=cout, mode=EPI_STORE)
-        gemm_rows(rows, w1_.shape[0], cout, operand(OP_RELU1, y1, y1.shape[1], s1=v1.scale, t1=v1.shift), _kmajor(w2_), epi)
+        gemm_rows(rows, w1_.shape[0], cout, operand(OP_RELU1, y1, y1.shape[1], s1=v1.scale, t1=v1.shift), w_fwd(w2_), epi)
         points = rows // group
         out = torch.empty((points, cout), dtype=torch.float32, device=dev)
         arg = None
@@ -582,7 +677,7 @@ class _UmbrellaStack2(Function):
         cout = w1_.shape[0]
         y1 = torch.empty((rows, cout), dtype=torch.float32, device=dev)
         epi = Epilogue(bias=_ptr(c1), out=_ptr(y1), ldo=cout, mode=EPI_STORE)
-        gemm_rows(rows, w0_.shape[0], cout, operand(OP_RELU1, y0, y0.shape[1], s1=v0.scale, t1=v0.shift), _kmajor(w1_), epi)
+        gemm_rows(rows, w0_.shape[0], cout, operand(OP_RELU1, y0, y0.shape[1], s1=v0.scale, t1=v0.shift), w_fwd(w1_), epi)
         points = rows // group
         out = torch.empty((points, cout), dtype=torch.float32, device=dev)
         _lib.call("rs_pool_sum", points, group, cout, _ptr(y1), _ptr(out), _stream())

@@ -309,12 +309,15 @@ class _GroupFeaturesCompact(Function):
         ctx.dims = (b, n, cn, cf, int(polar), cap, groups)
         ctx.need = (ctx.needs_input_grad[2], feature is not None and ctx.needs_input_grad[3])
         ctx.mark_non_differentiable(mult, grp, slot, src, offsets)
+        ctx.set_materialize_grads(False)      # no zero-filled "gradients" for the five index/bookkeeping outputs
         return out, mult, grp, slot, src, offsets
 
     @staticmethod
     def backward(ctx, grad_out, *unused):
         src, offsets = ctx.saved_tensors
         b, n, cn, cf, polar, cap, groups = ctx.dims
+        if grad_out is None:
+            return (None,) * 7
         grad_out = _f32c(grad_out)
         dev = grad_out.device
         gn = torch.zeros((b, n, cn), dtype=torch.float32, device=dev) if ctx.need[0] else None

@@ -72,7 +72,7 @@ for (rows, kdim, cols, ns) in shapes:
     out = torch.empty(rows, cols, device=dev)
     part = torch.full((H.PARTIAL_BLOCKS, 2, cols), float("nan"), device=dev, dtype=torch.float64)
     epi = H.Epilogue(bias=H._ptr(bias), out=H._ptr(out), ldo=cols, mode=H.EPI_STATS, partial=part.data_ptr(), partial_blocks=H.PARTIAL_BLOCKS)
-    H.gemm_rows(rows, kdim, cols, E, H._kmajor(w), epi)
+    H.gemm_rows(rows, kdim, cols, E, H.w_fwd(w), epi)
     ref = Eref @ w.double().t() + bias.double()
     ps = part.sum(0)
     print("stats", rows, kdim, cols, "y", rel(out, ref), "sum", rel(ps[0], ref.sum(0)), "sumsq", rel(ps[1], (ref * ref).sum(0)), flush=True)
