@@ -16,7 +16,7 @@ class GraphedStep:
     def __init__(self, net, criterion, optimizer, points, label, warmup=3):
         self.net, self.criterion, self.optimizer = net, criterion, optimizer
         self.points, self.label = points, label
-        self.draws = rng.StaticDraws(points.device)
+        self.draws = rng.StaticDraws(label.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), self.draws:
@@ -83,7 +83,7 @@ class ShardedGraphedStep:
         self.net, self.criterion, self.optimizer = net, criterion, optimizer
         self.points, self.label = points, label
         self.flat = attach_flat_grads(list(net.parameters()))
-        self.draws = rng.StaticDraws(points.device)
+        self.draws = rng.StaticDraws(label.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), self.draws:

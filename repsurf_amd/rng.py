@@ -15,6 +15,9 @@ _active = None
 def _cpu_draw(kind, b, n):
     if kind == "flip":      # same call as recons_utils.py:50
         return (torch.randint(0, 2, (b, 1, 1)).float() * 2. - 1.).view(b)
+    if kind == "npflip":    # segmentation: numpy's global generator, segmentation/modules/recons_utils.py:29-35
+        import numpy as np
+        return torch.from_numpy(np.where(np.random.rand(b) < 0.5, 1.0, -1.0).astype(np.float32))
     return torch.randint(0, n, (b,), dtype=torch.long).to(torch.int32)   # pointnet2_utils.py:66
 
 
@@ -47,7 +50,7 @@ class StaticDraws:
 
     @staticmethod
     def _typed(words, kind):
-        return words.view(torch.float32) if kind == "flip" else words
+        return words.view(torch.float32) if kind in ("flip", "npflip") else words
 
     def draw(self, kind, b, n):
         if self.cursor is not None and self.cursor < len(self.slots):
@@ -79,7 +82,7 @@ class StaticDraws:
 
 
 def draw(kind, b, n, device):
-    """kind: "flip" -> (b,) float +-1;  "fps" -> (b,) int32 in [0, n)."""
+    """kind: "flip" / "npflip" -> (b,) float +-1 (torch / numpy generator);  "fps" -> (b,) int32 in [0, n)."""
     if _active is not None:
         return _active.draw(kind, b, n)
     return _cpu_draw(kind, b, n).to(device, non_blocking=True)

@@ -22,6 +22,9 @@ def sectorized_fps(xyz, offset, new_offset, num_sectors, min_points=10000):
     num_sectors times shorter dependency chain.  Sector sizes depend on the data, so this op reads them back
     to the host (one read per call; the reference does several per cloud)."""
     host, new_host = ops.host_offsets(offset), ops.host_offsets(new_offset)
+    if num_sectors <= 1 or all(e - s < min_points for s, e in zip((0,) + host[:-1], host)):
+        # every cloud keeps a single sector, whose point list is the cloud itself in order: plain FPS, no read-back
+        return ops.furthestsampling_offset(xyz, offset, new_offset)
     pieces, new_sizes = [], []
     last, new_last = 0, 0
     for end, new_end in zip(host, new_host):

@@ -15,10 +15,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from repsurf_amd import mlp as _mlp
-from repsurf_amd import ops
+from repsurf_amd import ops, rng
 from modules.pointops.functions import pointops
 from modules.polar_utils import xyz2sphere
-from modules.recons_utils import random_flips
 
 
 def sample_and_group(stride, nsample, center, normal, feature, offset, return_polar=False, num_sector=1,
@@ -201,7 +200,7 @@ class UmbrellaSurfaceConstructor(nn.Module):
     def forward(self, center, offset, flip=None):
         n = center.shape[0]
         if self.random_inv and flip is None:      # numpy global generator, same call as recons_utils.py:29
-            flip = torch.from_numpy(random_flips(offset.shape[0])).to(center.device)
+            flip = rng.draw("npflip", offset.shape[0], 2, center.device)
         idx, _ = ops.knnquery_offset(self.k, center, center, offset, offset)
         feat = ops.umbrella_fan_offset(center, center, idx, offset, flip, self._rotate)      # (N,k,10)
         return _mlp.umbrella_mlp2(feat.reshape(n * self.k, 10), self.mlps, self.k)
