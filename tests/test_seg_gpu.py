@@ -226,3 +226,17 @@ def test_seg_model_config4_runs_and_is_finite():
     torch.nn.functional.cross_entropy(logits, label).backward()
     assert torch.isfinite(logits).all()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_pc_median_filter_matches_oracle_knn():
+    r = np.random.RandomState(2)
+    n = 3000
+    coord = (r.rand(n, 3) * 2 - 1).astype(np.float32)
+    label = r.randint(0, 13, n).astype(np.int64)
+    with subproject("segmentation"):
+        from util.utils import pc_median_filter_gpu
+        got = pc_median_filter_gpu(dev(coord), dev(label), group_size=16)
+    off = np.array([n], np.int32)
+    idx, _ = G.knn_offset(16, coord, coord, off, off)
+    ref = torch.median(torch.from_numpy(label[idx]), 1)[0].numpy()      # lower median of 16, like the reference
+    assert np.array_equal(got, ref)
