@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import geom_oracle as G
-from tests.util import GOLDEN, cloud, take
+from tests.util import GOLDEN, ROOT, cloud, take
 
 pytestmark = pytest.mark.gpu
 
@@ -235,3 +235,35 @@ def test_full_size_properties(ops):
     assert (knn[:, :, 0] == torch.arange(n, device="cuda")).float().mean() > 0.999   # nearest is self
     # idempotence: same launch twice gives the same bits
     assert torch.equal(ops.furthestsampling(xyz, 512, start), f1)
+
+
+def test_ballquery_grid_variant_bit_exact():
+    """The cell-list variant of rs_ballquery (forced with RS_BALLQUERY_GRID=1; the selection is read once per process,
+    hence the subprocess) returns the brute-force rows bit for bit: uniform, clustered (rows overflow nsample),
+    lattice (exact distance ties at the radius) and duplicated points, both radii of the shipped model."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from repsurf_amd import ops
+from oracle import geom_oracle as G
+from tests.util import cloud
+for kind in ("uniform", "clustered", "grid", "dup"):
+    for (n, s, r, ns) in ((1024, 512, 0.2, 32), (512, 128, 0.4, 64), (1024, 512, 0.1, 24), (2048, 300, 0.15, 16)):
+        xyz = cloud(7, 3, n, kind)
+        pick = np.stack([np.random.RandomState(i).choice(xyz.shape[1], s, replace=False) for i in range(3)])
+        centres = np.take_along_axis(xyz, pick[..., None].repeat(3, -1), 1)
+        got, cnt = ops.ballquery(r, ns, torch.from_numpy(xyz).cuda(), torch.from_numpy(centres).cuda(), return_count=True)
+        ref = G.ballquery(r, ns, xyz, centres)
+        assert np.array_equal(got.cpu().numpy(), ref), (kind, n, s, r, ns)
+        distinct = np.array([[len(set(row.tolist())) for row in b_] for b_ in ref])
+        assert np.array_equal(cnt.cpu().numpy(), distinct), (kind, "count")
+far = np.full((1, 4, 3), 5.0, np.float32)
+xyz = cloud(1, 1, 256, "uniform")
+assert (ops.ballquery(0.1, 8, torch.from_numpy(xyz).cuda(), torch.from_numpy(far).cuda()).cpu().numpy() == 0).all()
+print("grid variant ok")
+''' % ROOT
+    env = dict(os.environ, RS_BALLQUERY_GRID="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "grid variant ok" in out.stdout, out.stderr[-2000:]
