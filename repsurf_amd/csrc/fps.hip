@@ -98,14 +98,30 @@ fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *_
     if (tid == 0) out[it] = cur + seg.idx_base;
     if (it == m - 1) break;
 
-    // distance update + per-lane max
+    // distance update + per-lane max.  Two points per instruction where the lane owns an even number of them:
+    // v_pk_add_f32 / v_pk_mul_f32 round each half exactly like the scalar forms (no contraction), and the update is
+    // the longest VALU stretch of a pick.
     unsigned lmax = 0u;
+    if constexpr (PPT % 2 == 0) {
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      const v2f cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
-      const float d = (dx * dx + dy * dy) + dz * dz;
-      md[j] = d < md[j] ? d : md[j];
-      lmax = max(lmax, __float_as_uint(md[j]));
+      for (int j = 0; j < PPT; j += 2) {
+        const v2f x2 = {px[j], px[j + 1]}, y2 = {py[j], py[j + 1]}, z2 = {pz[j], pz[j + 1]};
+        const v2f dx = x2 - cx2, dy = y2 - cy2, dz = z2 - cz2;
+        const v2f d = (dx * dx + dy * dy) + dz * dz;
+        md[j] = fminf(d.x, md[j]);
+        md[j + 1] = fminf(d.y, md[j + 1]);
+        lmax = max(lmax, max(__float_as_uint(md[j]), __float_as_uint(md[j + 1])));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        md[j] = d < md[j] ? d : md[j];
+        lmax = max(lmax, __float_as_uint(md[j]));
+      }
     }
     const unsigned wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)rs_wave_max_u32(lmax));
 
