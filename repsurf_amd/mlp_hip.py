@@ -26,7 +26,8 @@ EPI_STORE, EPI_STATS, EPI_MASK = range(3)
 FUSED_UMBRELLA = True     # 10-channel constructor MLP through csrc/umbrella_mlp.hip (False: generic row-GEMM path)
 DEBUG = None              # set to a dict to capture backward intermediates (tools/mlp_debug.py)
 PARTIAL_BLOCKS = 512      # rows of the BatchNorm partial-sum buffers (>= persistent workgroups)
-WGRAD_CHUNKS = 512        # workgroups of one weight-gradient launch (row slabs x output blocks)
+WGRAD_CHUNKS = int(os.environ.get("REPSURF_WGRAD_CHUNKS", "512"))        # workgroups of one weight-gradient launch (row slabs x output blocks)
+WGRAD_MIN_ROWS = int(os.environ.get("REPSURF_WGRAD_MIN_ROWS", "128"))   # rows per row-workgroup of the weight gradient, at least
 
 
 class RowOperand(ctypes.Structure):          # rs_row_operand
@@ -255,7 +256,7 @@ def wgrad_chunks(rows, ncols, kcols):
     """row slabs of the weight-gradient reduction: >= 8 pipeline stages of 32 rows each, <= 2 workgroups
     per CU per output block, partial buffer <= 64 MB"""
     out_blocks = -(-ncols // 128) * (-(-kcols // 128) if kcols > 64 else 1)
-    chunks = max(1, min(rows // 256, WGRAD_CHUNKS // out_blocks if out_blocks <= WGRAD_CHUNKS else 1))
+    chunks = max(1, min(rows // WGRAD_MIN_ROWS, WGRAD_CHUNKS // out_blocks if out_blocks <= WGRAD_CHUNKS else 1))
     cap = max(1, (64 << 20) // (4 * ncols * kcols))
     return max(1, min(chunks, cap))
 
