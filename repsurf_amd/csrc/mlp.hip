@@ -929,6 +929,8 @@ extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, i
   int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
   static const int bn_small = env_int("RS_GEMM_BN64_BELOW", 256);
   if (bn == 128 && tiles * rs_cdiv(cols, 128) < bn_small && ep.pool_ns == 0) bn = 64;   // few rows (group_all stage): 2x the workgroups
+  static const int bn32_below = env_int("RS_GEMM_BN32_BELOW", 256);
+  if (bn == 64 && cols > 64 && tiles * rs_cdiv(cols, 64) < bn32_below && ep.pool_ns == 0) bn = 32;   // still under one workgroup per CU: 4096 x 512 -> 256 runs 22 us instead of 30
   const int tiles_n = rs_cdiv(cols, bn);
   int gx = persistent_blocks(tiles, tiles_n);
   if (epi_mode != EPI_STORE) gx = gx < ep.partial_blocks ? gx : ep.partial_blocks;
