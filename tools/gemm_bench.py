@@ -158,7 +158,8 @@ if __name__ == "__main__":
                              (4096, 1024, 512, None), (4096, 512, 1024, None), (4096, 256, 512, None), (4096, 512, 256, None),
                              (4096, 272, 256, None)]:
         bench(rows, k, n, frac)
-    for rows, n, k, frac in [(262144, 256, 128, None), (262144, 256, 128, 0.184), (262144, 128, 128, 0.184),
+    for rows, n, k, frac in [(524288, 32, 16, None), (524288, 32, 3, None), (131072, 64, 74, None), (524288, 64, 10, 0.127),
+                             (262144, 256, 128, None), (262144, 256, 128, 0.184), (262144, 128, 128, 0.184),
                              (524288, 128, 64, 0.127), (524288, 64, 64, 0.127), (4096, 1024, 512, None),
                              (4096, 512, 256, None), (4096, 256, 272, None)]:
         bench_wgrad(rows, n, k, frac)
