@@ -604,6 +604,89 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
 #endif
 }
 
+// ---- narrow weight gradient: kcols <= 16 (first-layer branches: 3 / 6 / 10 / 16 input channels) ---------------------
+// dw[n][k] = sum_r P[r][n] * Q[r][k] is a pure streaming reduction here: 2 * 16 flop per byte of P.  No LDS, no
+// barriers, no matrix pipe in the loop: thread (tn, tr) owns 4 columns of P and every k for the rows tr, tr + RG, ...
+// of its workgroup's row window; its P values are used by nobody else (one float4 global load each), the <= 16 Q
+// values of a row are the same address for the 32..8 lanes that share the row (one cache line, broadcast by L1).
+// Two rows are in flight per thread.  The RG row groups are summed through LDS at the end (fixed order) and leave as
+// one partial per workgroup, reduced over workgroups by reduce_partials_kernel like the MFMA variant.
+constexpr int WS_KP = 16;
+
+template <int NB, int VP, int PM, int QM>       // NB = 32 | 64 | 128 columns of P per workgroup
+__global__ void __launch_bounds__(GM_THREADS)
+wgrad_small_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, int kcols, RowOperand P, RowOperand Q,
+                   float *__restrict__ partial) {
+  constexpr int TPN = NB / 4, RG = GM_THREADS / TPN;          // threads across columns, row groups
+  const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // RG x NB x 16 floats for the final reduction
+  const int tid = threadIdx.x, tn = tid % TPN, tr = tid / TPN;
+  const int n0 = blockIdx.y * NB + tn * 4;
+  const bool n_ok = n0 < ncols;                                  // ncols % 4 == 0 is required by the launcher
+
+  ColCoef<4> pcoef;
+  op_coef<4, PM>(P, n0, n_ok, pcoef);
+  float qs1[WS_KP], qt1[WS_KP], qs2[WS_KP], qt2[WS_KP];
+#pragma unroll
+  for (int k = 0; k < WS_KP; ++k) {
+    ColCoef<1> c;
+    op_coef<1, QM>(Q, k, k < kcols, c);
+    qs1[k] = c.s1[0]; qt1[k] = c.t1[0]; qs2[k] = c.s2[0]; qt2[k] = c.t2[0];
+  }
+  float acc[4][WS_KP];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < WS_KP; ++k) acc[i][k] = 0.f;
+
+  const long long step = (long long)gridDim.x * RG;
+  auto load_row = [&](long long r, RawVec<4> &pr, RawVec<1> (&qr)[WS_KP]) {
+    const bool ok = r < rows;
+    op_load<4, PM>(P, r, 0, n0, ok && n_ok, pr);
+#pragma unroll
+    for (int k = 0; k < WS_KP; ++k) op_load<1, QM>(Q, r, 0, k, ok && k < kcols, qr[k]);
+  };
+  auto fma_row = [&](long long r, const RawVec<4> &pr, const RawVec<1> (&qr)[WS_KP]) {
+    const bool ok = r < rows;
+    float pv[4];
+    op_finish<4, PM>(P, pcoef, pr, r, ok && n_ok, pv);
+#pragma unroll
+    for (int k = 0; k < WS_KP; ++k) {
+      ColCoef<1> c;
+      c.s1[0] = qs1[k]; c.t1[0] = qt1[k]; c.s2[0] = qs2[k]; c.t2[0] = qt2[k];
+      float qv[1];
+      op_finish<1, QM>(Q, c, qr[k], r, ok && k < kcols, qv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][k] = fmaf(pv[i], qv[0], acc[i][k]);
+    }
+  };
+  RawVec<4> pa, pb;
+  RawVec<1> qa[WS_KP], qb[WS_KP];
+  long long r = (long long)blockIdx.x * RG + tr;
+  load_row(r, pa, qa);
+  for (; r < rows; r += 2 * step) {
+    load_row(r + step, pb, qb);
+    fma_row(r, pa, qa);
+    load_row(r + 2 * step, pa, qa);
+    fma_row(r + step, pb, qb);
+  }
+
+  // sum the RG row groups in a fixed order, one partial per workgroup
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < WS_KP; ++k) smem[(tr * NB + tn * 4 + i) * WS_KP + k] = acc[i][k];
+  __syncthreads();
+  float *dst = partial + (long long)blockIdx.x * ncols * kcols;
+  for (int e = tid; e < NB * WS_KP; e += GM_THREADS) {
+    const int nl = e / WS_KP, k = e - nl * WS_KP;
+    float t = 0.f;
+    for (int g = 0; g < RG; ++g) t += smem[(g * NB + nl) * WS_KP + k];
+    const int n = blockIdx.y * NB + nl;
+    if (n < ncols && k < kcols) dst[(long long)n * kcols + k] = t;
+  }
+}
+
 // out[e] = sum_c partial[c][e]   (deterministic order).  32 outputs x 8 chunk slices per workgroup:
 // consecutive lanes read consecutive outputs (coalesced), each thread sums every 8th chunk with
 // independent loads in flight, slices are combined in a fixed order through LDS.
@@ -960,6 +1043,22 @@ extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int 
   rpc = (rpc + WG_BR - 1) / WG_BR * WG_BR;
   hipStream_t st = (hipStream_t)stream;
   const int vp = pick_vec(P, ncols), vq = pick_vec(Q, kcols);
+  static const int small_on = env_int("RS_WGRAD_SMALL", 1);
+  if (small_on && kcols <= WS_KP && vp == 4 && (Q.mode == OPM_ID || Q.mode == OPM_RELU1) &&
+      (P.mode == OPM_AFF2 || P.mode == OPM_POOLED || P.mode == OPM_BCAST || P.mode == OPM_ID)) {
+    // narrow gradient (first-layer branches): streaming kernel, no matrix pipe
+    const int nb = ncols <= 32 ? 32 : (ncols <= 64 ? 64 : 128);
+    const dim3 grid(chunks, rs_cdiv(ncols, nb));
+    const size_t lds = sizeof(float) * (size_t)(GM_THREADS / (nb / 4)) * nb * WS_KP;
+#define RS_WS(NB_, PM_, QM_) hipLaunchKernelGGL((wgrad_small_kernel<NB_, 4, PM_, QM_>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, ncols, kcols, P, Q, partial)
+#define RS_WSQ(NB_, PM_) do { if (Q.mode == OPM_ID) RS_WS(NB_, PM_, OPM_ID); else RS_WS(NB_, PM_, OPM_RELU1); } while (0)
+#define RS_WSP(NB_) do { if (P.mode == OPM_AFF2) RS_WSQ(NB_, OPM_AFF2); else if (P.mode == OPM_POOLED) RS_WSQ(NB_, OPM_POOLED); \
+                         else if (P.mode == OPM_BCAST) RS_WSQ(NB_, OPM_BCAST); else RS_WSQ(NB_, OPM_ID); } while (0)
+    if (nb == 32) RS_WSP(32); else if (nb == 64) RS_WSP(64); else RS_WSP(128);
+#undef RS_WSP
+#undef RS_WSQ
+#undef RS_WS
+  } else
   if (kcols > 64) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
     launch_wgrad<2, 2, 2, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
   } else if (kcols > 32) {   // 128 x 64: waves 4 x 1, 1 x 2 tiles
