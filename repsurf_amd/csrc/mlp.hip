@@ -604,6 +604,95 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
 #endif
 }
 
+constexpr int WS_KP = 16;          // reduction width of the narrow (streaming) kernels
+
+// ---- narrow row GEMM: kdim <= 16, plain operand (the position / first feature branches of every stack) -------------
+// out[r][n] = bias[n] + sum_k x[r][k] * w[n][k] reads 4 * kdim bytes and writes 4 * cols bytes per row: pure streaming.
+// Thread (tn, tr) keeps the weights of its 4 output columns in registers (4 x 16), walks the rows tr, tr + RG, ... of the
+// workgroup's window, reads the <= 16 operand values of a row (same address for the lanes sharing the row: broadcast),
+// writes one float4 and keeps the BatchNorm sums of its columns; the row groups are combined in fp64 at the end, in the
+// same partial layout as gemm_rows_kernel.  The 32-deep MFMA chunk of the general kernel would be >= half padding here.
+template <int NB>
+__global__ void __launch_bounds__(GM_THREADS)
+gemm_small_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim, int cols, RowOperand E,
+                  const float *__restrict__ w, int ldw, Epilogue ep) {
+  constexpr int TPN = NB / 4, RG = GM_THREADS / TPN;
+  const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
+  __shared__ double red[GM_THREADS / (NB / 4)][NB];
+  const int tid = threadIdx.x, tn = tid % TPN, tr = tid / TPN;
+  const int n0 = blockIdx.y * NB + tn * 4;
+  float wr[4][WS_KP], bias[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool nok = n0 + i < cols;
+    bias[i] = (ep.bias && nok) ? ep.bias[n0 + i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < WS_KP; ++k) wr[i][k] = (nok && k < kdim) ? w[(long long)(n0 + i) * ldw + k] : 0.f;
+  }
+  const bool stats = ep.mode == EPI_STATS;
+  const bool vec_ok = (((uintptr_t)ep.out) % 16 == 0) && (ep.ldo % 4 == 0) && (n0 + 3 < cols);
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  const long long step = (long long)gridDim.x * RG;
+  auto load_row = [&](long long r, float (&x)[WS_KP]) {
+    const long long rc = min(r, rows - 1);                        // clamped: never out of bounds, discarded below
+    const float *src = E.a + rc * E.lda;
+#pragma unroll
+    for (int k = 0; k < WS_KP; ++k) x[k] = k < kdim ? src[k] : 0.f;
+  };
+  auto do_row = [&](long long r, const float (&x)[WS_KP]) {
+    if (r >= rows) return;
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < WS_KP; ++k) t = fmaf(x[k], wr[i][k], t);
+      y[i] = t + bias[i];
+    }
+    float *o = ep.out + r * ep.ldo + n0;
+    if (vec_ok) *reinterpret_cast<float4 *>(o) = make_float4(y[0], y[1], y[2], y[3]);
+    else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (n0 + i < cols) o[i] = y[i];
+    }
+    if (stats) {
+      const float mw = ep.row_mult ? ep.row_mult[r] : 1.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s0[i] = fmaf(mw, y[i], s0[i]); s1[i] = fmaf(mw * y[i], y[i], s1[i]); }
+    }
+  };
+  if (rows > 0) {
+    float xa[WS_KP], xb[WS_KP];
+    long long r = (long long)blockIdx.x * RG + tr;
+    load_row(r, xa);
+    for (; r < rows; r += 2 * step) {
+      load_row(r + step, xb);
+      do_row(r, xa);
+      load_row(r + 2 * step, xa);
+      do_row(r + step, xb);
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[tr][tn * 4 + i] = (double)(s == 0 ? s0[i] : s1[i]);
+      __syncthreads();
+      if (tid < NB) {
+        double t = 0.0;
+        for (int g = 0; g < RG; ++g) t += red[g][tid];
+        const int col = blockIdx.y * NB + tid;
+        if (col < cols) {
+          ep.partial[((long long)blockIdx.x * 2 + s) * cols + col] = t;
+          for (int pb = blockIdx.x + gridDim.x; pb < ep.partial_blocks; pb += gridDim.x)
+            ep.partial[((long long)pb * 2 + s) * cols + col] = 0.0;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ---- narrow weight gradient: kcols <= 16 (first-layer branches: 3 / 6 / 10 / 16 input channels) ---------------------
 // dw[n][k] = sum_r P[r][n] * Q[r][k] is a pure streaming reduction here: 2 * 16 flop per byte of P.  No LDS, no
 // barriers, no matrix pipe in the loop: thread (tn, tr) owns 4 columns of P and every k for the rows tr, tr + RG, ...
@@ -611,7 +700,6 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
 // values of a row are the same address for the 32..8 lanes that share the row (one cache line, broadcast by L1).
 // Two rows are in flight per thread.  The RG row groups are summed through LDS at the end (fixed order) and leave as
 // one partial per workgroup, reduced over workgroups by reduce_partials_kernel like the MFMA variant.
-constexpr int WS_KP = 16;
 
 template <int NB, int VP, int PM, int QM>       // NB = 32 | 64 | 128 columns of P per workgroup
 __global__ void __launch_bounds__(GM_THREADS)
@@ -1007,7 +1095,24 @@ extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, i
     RS_REQUIRE(rows % ep.pool_ns == 0 && rpt % ep.pool_ns == 0,
                "rs_mlp_gemm_rows: fused pooling needs nsample (%d) to divide %d rows per thread", ep.pool_ns, rpt);
   }
-  (void)0;
+  hipStream_t st0 = (hipStream_t)stream;
+  static const int small_on = env_int("RS_GEMM_SMALL", 1);
+  // Only where the MFMA kernel would have to take its scalar-load generic instance (an odd kdim or an unaligned
+  // operand, e.g. the 3 position channels of a 19-channel row: 166 us against 29 us at 524288 rows); with float2 /
+  // float4 operands the MFMA kernel is the faster one even at kdim = 6 (14 us against 15-18 us at 66 584 rows).
+  if (small_on && kdim <= WS_KP && E.mode == OPM_ID && epi_mode != EPI_MASK && ep.pool_ns == 0 && pick_vec(E, kdim) == 1) {
+    const int nb = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
+    int gxs = (int)((rows + 63) / 64);
+    if (gxs > 512) gxs = 512;
+    if (epi_mode != EPI_STORE && gxs > ep.partial_blocks) gxs = ep.partial_blocks;
+    if (gxs < 1) gxs = 1;
+    const dim3 grid(gxs, rs_cdiv(cols, nb));
+    if (nb == 32) hipLaunchKernelGGL(gemm_small_kernel<32>, grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+    else if (nb == 64) hipLaunchKernelGGL(gemm_small_kernel<64>, grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+    else hipLaunchKernelGGL(gemm_small_kernel<128>, grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+    RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
+    return RS_OK;
+  }
   const long long tiles = (rows + GM_BM - 1) / GM_BM;
   int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
   static const int bn_small = env_int("RS_GEMM_BN64_BELOW", 256);

@@ -145,6 +145,22 @@ if __name__ == "__main__":
         frac = float(sys.argv[5]) if len(sys.argv) > 5 else None
         bench(rows, k, n, frac)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "small":       # narrow first-layer GEMMs (kdim <= 16)
+        for rows, k, n, frac in [(524288, 6, 64, 0.127), (524288, 10, 64, 0.127), (262144, 6, 128, 0.184), (4096, 6, 256, None),
+                                 (524288, 3, 32, None), (524288, 16, 32, None)]:
+            x = torch.randn(rows, 16, device=dev)
+            w = torch.randn(n, k, device=dev)
+            wk = H.w_fwd(w)
+            out = torch.empty(rows, n, device=dev)
+            part = torch.empty((H.PARTIAL_BLOCKS, 3, n), dtype=torch.float64, device=dev)
+            rd = torch.tensor([int(rows * frac)], dtype=torch.int32, device=dev) if frac else None
+            eff = int(rows * frac) if frac else rows
+            op = H.operand(H.OP_ID, x, 16)
+            ep = H.Epilogue(bias=None, out=H._ptr(out), ldo=n, mode=H.EPI_STATS, partial=part.data_ptr(), partial_blocks=H.PARTIAL_BLOCKS)
+            us = timeit(lambda: H.gemm_rows(rows, k, n, op, wk, ep, rd.data_ptr() if frac else None))
+            byt = eff * (16 + n) * 4
+            print(f"small gemm rows={eff:>7} K={k:>3} N={n:>4} ID+STATS: {us:7.1f} us  {byt / us / 1e3:7.1f} GB/s", flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cold":
         for rows, k, n, frac in [(262144, 128, 128, None), (262144, 128, 128, 0.184), (262144, 256, 128, 0.184), (262144, 128, 256, 0.184),
                                  (524288, 64, 64, 0.127), (524288, 64, 128, 0.127), (4096, 1024, 512, None), (4096, 512, 1024, None),
