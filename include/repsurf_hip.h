@@ -140,17 +140,20 @@ int rs_umbrella_features(int b, int n, int k, const float *xyz, const float *inv
  * (classification/modules/pointops/src/grouping/grouping_cuda_kernel.h:19) + subtract +
  * xyz2sphere + cat: row r = (b, s, j) of `out` (rows, 3 + 3*polar + cn + cf) is
  * [center[idx]-new_center (3), polar of that offset (3, if polar), normal[idx] (cn), feature[idx] (cf)].
- * feature may be NULL (cf = 0).  idx: (b, m, nsample). */
+ * feature may be NULL (cf = 0).  idx: (b, m, nsample).
+ * pos_pad zero channels follow the position block and rows are `ldo` floats apart (0 = tight): with 3 position
+ * channels, pos_pad = 1 and ldo % 4 == 0 keep the feature branch of the first layer 8-byte aligned, so the row GEMM
+ * and weight gradient read it with vector loads (segmentation: 3 + 10 + C channels). */
 int rs_group_features(int b, int n, int m, int nsample, int cn, int cf, int polar,
                       const float *center, const float *new_center, const float *normal,
-                      const float *feature, const int *idx, float *out, void *stream);
+                      const float *feature, const int *idx, float *out, int pos_pad, int ldo, void *stream);
 /* Backward of the gathered (normal, feature) channels: scatter-adds
  * grad_out[:, cpos:cpos+cn] into grad_normal (b,n,cn) and grad_out[:, cpos+cn:] into
  * grad_feature (b,n,cf) (either may be NULL; both pre-zeroed by the caller).
  * Replaces grouping_backward_cuda_launcher (grouping_cuda_kernel.h:17). */
 int rs_group_features_backward(int b, int n, int m, int nsample, int cn, int cf, int polar,
                                const float *grad_out, const int *idx, float *grad_normal,
-                               float *grad_feature, void *stream);
+                               float *grad_feature, int pos_pad, int ldo, void *stream);
 /* Compacted form of rs_group_features: a ball-query row is cnt distinct neighbours followed by copies of the
  * first one (classification/modules/pointnet2_utils.py:92-94) and the shared MLP maps equal rows to equal outputs, so
  * only the distinct slots are materialised.  rows of group g = [offsets[g], offsets[g+1]) with

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -26,8 +26,8 @@ SIGNATURES = {
     "rs_umbrella_fan_offset": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
     "rs_interp_weights": [c_ll, P, P, P],
     "rs_umbrella_features": [c_int, c_int, c_int, P, P, P, P, P],
-    "rs_group_features": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
-    "rs_group_features_backward": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "rs_group_features": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P],
+    "rs_group_features_backward": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P],
     "rs_group_all_features": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_exclusive_scan": [c_int, P, P, P],
     "rs_group_features_compact": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P],

@@ -50,11 +50,11 @@ gather_rows_bwd_kernel(long long rows, int per_cloud, int n, int c, const float 
 
 // Head channels [offset(3), polar(3)?, normal(cn)] : one thread per (row, channel)
 __global__ void __launch_bounds__(GR_THREADS)
-group_head_kernel(long long rows, int m, int nsample, int n, int cn, int cpos, int ctot,
+group_head_kernel(long long rows, int m, int nsample, int n, int cn, int cpos, int pw, int ldo,
                   const float *__restrict__ center, const float *__restrict__ new_center,
                   const float *__restrict__ normal, const int *__restrict__ idx,
                   float *__restrict__ out) {
-  const int ch_head = cpos + cn;
+  const int ch_head = pw + cn;                 // [offset / polar (cpos) | zero padding up to pw | normal (cn)]
   const long long total = rows * ch_head;
   for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total;
        e += (long long)gridDim.x * GR_THREADS) {
@@ -75,14 +75,15 @@ group_head_kernel(long long rows, int m, int nsample, int n, int cn, int cpos, i
         else if (ch == 4) v = (rho == 0.f) ? 0.f : acosf(dz / rho) / RS_PI_F;
         else v = atan2f(dy, dx) / RS_TWO_PI_F + 0.5f;
       }
+    } else if (ch < pw) {
+      v = 0.f;
     } else {
-      v = normal[src * cn + (ch - cpos)];
+      v = normal[src * cn + (ch - pw)];
     }
-    out[r * ctot + ch] = v;
+    out[r * ldo + ch] = v;
   }
 }
 
-// Feature channels: out[r, c0 + :] = feature[src(r), :]   VEC floats per thread
 template <int VEC>
 __global__ void __launch_bounds__(GR_THREADS)
 group_tail_kernel(long long rows, int per_cloud_rows, int n, int cf, int c0, int ctot,
@@ -298,25 +299,27 @@ extern "C" int rs_group_rows_backward(int b, int n, int m, int nsample, int c, c
 
 extern "C" int rs_group_features(int b, int n, int m, int nsample, int cn, int cf, int polar,
                                  const float *center, const float *new_center, const float *normal,
-                                 const float *feature, const int *idx, float *out, void *stream) {
-  RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0 && cn >= 0 && cf >= 0, "rs_group_features: negative size");
+                                 const float *feature, const int *idx, float *out, int pos_pad, int ldo, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0 && cn >= 0 && cf >= 0 && pos_pad >= 0, "rs_group_features: negative size");
   const long long rows = (long long)b * m * nsample;
   if (rows == 0) return RS_OK;
   RS_REQUIRE(center && new_center && idx && out, "rs_group_features: null pointer");
   RS_REQUIRE(cn == 0 || normal, "rs_group_features: normal is NULL but cn=%d", cn);
   RS_REQUIRE(cf == 0 || feature, "rs_group_features: feature is NULL but cf=%d", cf);
-  const int cpos = polar ? 6 : 3, ctot = cpos + cn + cf;
+  const int cpos = polar ? 6 : 3, pw = cpos + pos_pad, ctot = pw + cn + cf;
+  if (ldo <= 0) ldo = ctot;
+  RS_REQUIRE(ldo >= ctot, "rs_group_features: row stride %d < %d channels", ldo, ctot);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(group_head_kernel, dim3(grid_for(rows * (cpos + cn))), dim3(GR_THREADS), 0, st, rows, m,
-                     nsample, n, cn, cpos, ctot, center, new_center, normal, idx, out);
+  hipLaunchKernelGGL(group_head_kernel, dim3(grid_for(rows * (pw + cn))), dim3(GR_THREADS), 0, st, rows, m,
+                     nsample, n, cn, cpos, pw, ldo, center, new_center, normal, idx, out);
   if (cf > 0) {
-    const bool vec = (cf % 4 == 0) && ((cpos + cn) % 4 == 0) && (ctot % 4 == 0);
+    const bool vec = (cf % 4 == 0) && ((pw + cn) % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out | (uintptr_t)feature) % 16 == 0);
     if (vec)
       hipLaunchKernelGGL(group_tail_kernel<4>, dim3(grid_for(rows * (cf / 4))), dim3(GR_THREADS), 0, st, rows,
-                         m * nsample, n, cf, cpos + cn, ctot, feature, idx, out);
+                         m * nsample, n, cf, pw + cn, ldo, feature, idx, out);
     else
       hipLaunchKernelGGL(group_tail_kernel<1>, dim3(grid_for(rows * cf)), dim3(GR_THREADS), 0, st, rows,
-                         m * nsample, n, cf, cpos + cn, ctot, feature, idx, out);
+                         m * nsample, n, cf, pw + cn, ldo, feature, idx, out);
   }
   RS_CHECK_LAUNCH("rs_group_features");
   return RS_OK;
@@ -324,20 +327,22 @@ extern "C" int rs_group_features(int b, int n, int m, int nsample, int cn, int c
 
 extern "C" int rs_group_features_backward(int b, int n, int m, int nsample, int cn, int cf, int polar,
                                           const float *grad_out, const int *idx, float *grad_normal,
-                                          float *grad_feature, void *stream) {
-  RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0 && cn >= 0 && cf >= 0, "rs_group_features_backward: negative size");
+                                          float *grad_feature, int pos_pad, int ldo, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0 && cn >= 0 && cf >= 0 && pos_pad >= 0, "rs_group_features_backward: negative size");
   const long long rows = (long long)b * m * nsample;
   if (rows == 0) return RS_OK;
   RS_REQUIRE(grad_out && idx, "rs_group_features_backward: null pointer");
-  const int cpos = polar ? 6 : 3, ctot = cpos + cn + cf;
+  const int pw = (polar ? 6 : 3) + pos_pad, ctot = pw + cn + cf;
+  if (ldo <= 0) ldo = ctot;
+  RS_REQUIRE(ldo >= ctot, "rs_group_features_backward: row stride %d < %d channels", ldo, ctot);
   hipStream_t st = (hipStream_t)stream;
   const long long groups = (long long)b * m;
   if (grad_normal && cn > 0)
     hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(groups * cn)), dim3(GR_THREADS), 0, st, groups, nsample,
-                       m, n, cn, cpos, ctot, grad_out, idx, grad_normal);
+                       m, n, cn, pw, ldo, grad_out, idx, grad_normal);
   if (grad_feature && cf > 0)
     hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(groups * cf)), dim3(GR_THREADS), 0, st, groups, nsample,
-                       m, n, cf, cpos + cn, ctot, grad_out, idx, grad_feature);
+                       m, n, cf, pw + cn, ldo, grad_out, idx, grad_feature);
   RS_CHECK_LAUNCH("rs_group_features_backward");
   return RS_OK;
 }

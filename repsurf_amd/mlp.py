@@ -74,15 +74,18 @@ def _torch_umbrella(x, mlps, group, aggr):
 
 
 # ------------------------------------------------------------------ dispatch
-def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample, compact=None):
+def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample, compact=None, feat_off=None, feat_k=None):
     """SurfaceAbstractionCD body (classification/modules/repsurface_utils.py:236-244):
     relu(bn_l0(mlp_l0(x[:, :pos])) + bn_f0(mlp_f0(x[:, pos:]))) -> [conv, bn, relu]* -> max over nsample.
     x (G*nsample, pos+feat) -> (G, mlp[-1])."""
     if BACKEND == "torch":
         assert compact is None, "the torch reference executor works on dense groups"
+        if feat_off is not None:       # aligned (padded) rows: back to the tight layout for the reference executor
+            x = torch.cat([x[:, :pos_channel], x[:, feat_off:feat_off + feat_k]], dim=1)
         return _torch_sa_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample)
     from . import mlp_hip
-    return mlp_hip.sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample, compact=compact)
+    return mlp_hip.sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample, compact=compact,
+                             feat_off=feat_off, feat_k=feat_k)
 
 
 def sa_mlp_plain(x, convs, bns, nsample):

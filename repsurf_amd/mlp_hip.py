@@ -358,11 +358,12 @@ class _SAStack(Function):
         ys, vecs, w2ds = [], [], []
         all_w2d = [_w2d(params[i]) for i in range(0, len(params), 4)]
         wks = fwd_weights(all_w2d, dev)            # conv weights in place; one batched padded copy for odd cin
+        foff, fk = meta.get("feat_off", pos), meta.get("feat_k", cx - pos)   # feature branch: columns [foff, foff + fk)
         if pos > 0:      # two-branch first layer (SurfaceAbstractionCD)
             wl, bl, wf, bf = params[0], params[1], params[4], params[5]
             wl2, wf2 = all_w2d[0], all_w2d[1]
             yl, vl = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev, rs=rs, wk=wks[0])
-            yf, vf = fwd_layer(rows, operand(OP_ID, x, cx, a_off=pos), cx - pos, wf2, bf, bns[1], training, dev, rs=rs,
+            yf, vf = fwd_layer(rows, operand(OP_ID, x, cx, a_off=foff), fk, wf2, bf, bns[1], training, dev, rs=rs,
                                wk=wks[1])
             saved.update(yl=yl, vl=vl, yf=yf, vf=vf, wl2=wl2, wf2=wf2)
             prev_op = operand(OP_RELU2, yl, yl.shape[1], yf, yf.shape[1], vl.scale, vl.shift, vf.scale, vf.shift)
@@ -472,8 +473,9 @@ class _SAStack(Function):
                 opl = operand(OP_AFF2, dz, cin, s["yl"], cin, s1=pl, t1=rl, s2=ql, rs=rs)
                 opf = operand(OP_AFF2, dz, cin, s["yf"], cin, s1=pf, t1=rf, s2=qf, rs=rs)
                 fork.keep += [dz, pl, ql, rl, pf, qf, rf]
+                foff, fk = meta.get("feat_off", pos), meta.get("feat_k", cx - pos)
                 grads[0] = fork.run(lambda: wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev, rdev))
-                grads[4] = fork.run(lambda: wgrad(rows, cin, cx - pos, opf, operand(OP_ID, x, cx, a_off=pos), dev, rdev))
+                grads[4] = fork.run(lambda: wgrad(rows, cin, fk, opf, operand(OP_ID, x, cx, a_off=foff), dev, rdev))
                 grads[1] = zeros.take(cin)
                 grads[5] = zeros.take(cin)
                 grads[2], grads[3], grads[6], grads[7] = dgl, dbl, dgf, dbf
@@ -481,8 +483,8 @@ class _SAStack(Function):
                     # Only the feature channels [pos:] carry a gradient (coordinates are inputs); the grouping
                     # backward reads nothing else, so the position columns are left unwritten (no 150 MB memset).
                     dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
-                    epi = Epilogue(bias=None, out=_ptr(dx, pos), ldo=cx, mode=EPI_STORE)
-                    gemm_rows(rows, cin, cx - pos, opf, wts[("f", 0)], epi, rdev)
+                    epi = Epilogue(bias=None, out=_ptr(dx, foff), ldo=cx, mode=EPI_STORE)
+                    gemm_rows(rows, cin, fk, opf, wts[("f", 0)], epi, rdev)
             elif ctx.needs_input_grad[0]:
                 dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
                 epi = Epilogue(bias=None, out=_ptr(dx), ldo=cx, mode=EPI_STORE)
@@ -500,11 +502,14 @@ def _flat_params(first, convs, bns):
     return params, mods
 
 
-def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample, compact=None):
-    """compact: ops.CompactGroups whose .x is `x` (duplicate ball-query slots removed) or None (dense rows)."""
+def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample, compact=None, feat_off=None, feat_k=None):
+    """compact: ops.CompactGroups whose .x is `x` (duplicate ball-query slots removed) or None (dense rows).
+    feat_off / feat_k: columns of the feature branch when x uses the aligned (padded) row layout."""
     params, mods = _flat_params([(mlp_l0, bn_l0), (mlp_f0, bn_f0)], convs, bns)
     meta = {"nsample": nsample, "pos": pos_channel, "bns": mods, "training": mods[0].training,
             "shapes": [p.shape for p in params]}
+    if feat_off is not None:
+        meta["feat_off"], meta["feat_k"] = feat_off, feat_k
     if compact is not None:
         meta["compact"] = {"rows_dev": compact.rows_dev_ptr, "rows_full": compact.rows_full, "mult": compact.mult,
                            "grp": compact.grp, "slot": compact.slot, "offsets": compact.offsets}

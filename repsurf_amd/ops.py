@@ -228,7 +228,7 @@ def umbrella_features(xyz, k=9, inv_sign=None, return_knn=False):
 # ----------------------------------------------------------------------------- grouping
 class _GroupFeatures(Function):
     @staticmethod
-    def forward(ctx, center, new_center, normal, feature, idx, polar):
+    def forward(ctx, center, new_center, normal, feature, idx, polar, aligned):
         _need_gpu(center, new_center, normal, feature, idx)
         center, new_center, normal, idx = _f32c(center), _f32c(new_center), _f32c(normal), _i32c(idx)
         feature = None if feature is None else _f32c(feature)
@@ -236,34 +236,46 @@ class _GroupFeatures(Function):
         _, m, ns = idx.shape
         cn = normal.shape[2]
         cf = 0 if feature is None else feature.shape[2]
-        ctot = (6 if polar else 3) + cn + cf
-        out = torch.empty((b * m * ns, ctot), dtype=torch.float32, device=center.device)
+        cpos = 6 if polar else 3
+        pad = (-cpos) % 4 if aligned else 0                       # position block padded to a float4 boundary
+        ctot = cpos + pad + cn + cf
+        ldo = -(-ctot // 4) * 4 if aligned else ctot              # rows a multiple of 16 bytes apart
+        out = torch.empty((b * m * ns, ldo), dtype=torch.float32, device=center.device)
         _lib.call("rs_group_features", b, n, m, ns, cn, cf, int(polar), _p(center), _p(new_center),
-                  _p(normal), _p(feature), _p(idx), _p(out), _stream())
+                  _p(normal), _p(feature), _p(idx), _p(out), pad, ldo, _stream())
         ctx.save_for_backward(idx)
-        ctx.dims = (b, n, m, ns, cn, cf, int(polar))
+        ctx.dims = (b, n, m, ns, cn, cf, int(polar), pad, ldo)
         ctx.need = (ctx.needs_input_grad[2], feature is not None and ctx.needs_input_grad[3])
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
-        b, n, m, ns, cn, cf, polar = ctx.dims
+        b, n, m, ns, cn, cf, polar, pad, ldo = ctx.dims
         grad_out = _f32c(grad_out)
         dev = grad_out.device
         gn = torch.zeros((b, n, cn), dtype=torch.float32, device=dev) if ctx.need[0] else None
         gf = torch.zeros((b, n, cf), dtype=torch.float32, device=dev) if ctx.need[1] else None
         if gn is not None or gf is not None:
             _lib.call("rs_group_features_backward", b, n, m, ns, cn, cf, polar, _p(grad_out), _p(idx),
-                      _p(gn), _p(gf), _stream())
-        return None, None, gn, gf, None, None
+                      _p(gn), _p(gf), pad, ldo, _stream())
+        return None, None, gn, gf, None, None, None
 
 
-def group_features(center, new_center, normal, feature, idx, polar=True):
+def group_features(center, new_center, normal, feature, idx, polar=True, aligned=False):
     """Grouped shared-MLP input of sample_and_group (repsurface_utils.py:36-57):
     -> (B*S*ns, 3+3*polar+Cn+Cf) rows [offset, polar(offset), normal[idx], feature[idx]];
-    differentiable w.r.t. normal and feature."""
-    return _GroupFeatures.apply(center, new_center, normal, feature, idx, polar)
+    differentiable w.r.t. normal and feature.
+    aligned=True: the position block is zero-padded to 4 channels and rows to a multiple of 4 floats --
+    (rows, ld) with [offset(3|6), 0.., normal, feature, unused..]; `aligned_layout` gives the offsets."""
+    return _GroupFeatures.apply(center, new_center, normal, feature, idx, polar, aligned)
+
+
+def aligned_layout(polar, cn, cf):
+    """(feature-branch offset, feature-branch width, row stride) of group_features(aligned=True)."""
+    cpos = 6 if polar else 3
+    off = cpos + (-cpos) % 4
+    return off, cn + cf, -(-(off + cn + cf) // 4) * 4
 
 
 class CompactGroups:

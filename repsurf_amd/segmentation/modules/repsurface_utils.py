@@ -21,9 +21,10 @@ from modules.polar_utils import xyz2sphere
 
 
 def sample_and_group(stride, nsample, center, normal, feature, offset, return_polar=False, num_sector=1,
-                     training=True):
+                     training=True, aligned=False):
     """center (N,3), normal (N,Cn), feature (N,C)|None, offset (B,) ->
-    new_center (M,3), new_normal (M,Cn), new_feature (M,nsample,3(+3)+Cn+C), new_offset (B,)  (reference :15-51)."""
+    new_center (M,3), new_normal (M,Cn), new_feature (M,nsample,3(+3)+Cn+C), new_offset (B,)  (reference :15-51).
+    aligned=True (internal use by the SA modules): rows in the padded layout of ops.group_features(aligned=True)."""
     if stride > 1:
         new_offset = ops.strided_offset(offset, stride)
         if num_sector > 1 and training:
@@ -38,7 +39,7 @@ def sample_and_group(stride, nsample, center, normal, feature, offset, return_po
     group_idx, _ = ops.knnquery_offset(nsample, center, new_center, offset, new_offset)
     rows = ops.group_features(center.unsqueeze(0), new_center.unsqueeze(0), normal.unsqueeze(0),
                               None if feature is None else feature.unsqueeze(0), group_idx.unsqueeze(0),
-                              polar=return_polar)
+                              polar=return_polar, aligned=aligned)
     return new_center, new_normal, rows.view(m, nsample, -1), new_offset
 
 
@@ -134,10 +135,13 @@ class SurfaceAbstractionCD(nn.Module):
         center, normal, feature, offset = pos_nor_feat_off
         new_center, new_normal, grouped, new_offset = sample_and_group(
             self.stride, self.nsample, center, normal, feature, offset, return_polar=self.return_polar,
-            num_sector=self.num_sector, training=self.training)
+            num_sector=self.num_sector, training=self.training, aligned=True)
         m, ns, c = grouped.shape
+        # rows are [offset(3|6), pad, normal, feature, pad]: the feature branch starts on a float4 boundary, so the
+        # first-layer GEMM and weight gradient read it with vector loads (77 = 3 + 10 + 64 channels would not)
+        foff, fk, _ = ops.aligned_layout(self.return_polar, normal.shape[1], 0 if feature is None else feature.shape[1])
         pooled = _mlp.sa_mlp_cd(grouped.reshape(m * ns, c), self.pos_channel, self.mlp_l0, self.bn_l0, self.mlp_f0,
-                                self.bn_f0, self.mlp_convs, self.mlp_bns, ns)
+                                self.bn_f0, self.mlp_convs, self.mlp_bns, ns, feat_off=foff, feat_k=fk)
         return [new_center, new_normal, pooled, new_offset]
 
 
