@@ -136,7 +136,6 @@ namespace {
 constexpr int GM_THREADS = 256;
 constexpr int GM_BM = 128;        // rows per workgroup tile (4 waves x 32)
 constexpr int GM_BK = 32;         // reduction chunk per pipeline stage
-constexpr int GM_LDA = GM_BM + 1; // K-major LDS rows, +1 pad: transposing stores stay <= 2-way conflicted
 
 enum { EPI_STORE = RS_EPI_STORE, EPI_STATS = RS_EPI_STATS, EPI_MASK = RS_EPI_MASK };
 typedef rs_mlp_epilogue Epilogue;
@@ -460,13 +459,12 @@ constexpr int WG_BR = 32;   // rows per pipeline stage
 template <int WN, int WK, int TN, int TK, int VP, int VQ, int PM, int QM>
 __global__ void __launch_bounds__(GM_THREADS, 2)
 wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, int kcols, RowOperand P, RowOperand Q,
-             long long rows_per_chunk_arg, float *__restrict__ partial) {
+             float *__restrict__ partial) {
   // Row stages (32 rows) are dealt round-robin to the gridDim.x row workgroups: at any moment the whole grid reads
   // one contiguous window of the operands (gridDim.x * 32 rows), which keeps DRAM pages and TLB entries hot.
   // (Contiguous per-workgroup slabs had 512 streams 0.5 MB apart: 1.2 TB/s; the partial sums do not care which
   // rows they hold, and the order inside a partial stays fixed, so results remain deterministic.)
   const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
-  (void)rows_per_chunk_arg;
   constexpr int BNN = WN * TN * 32, BKK = WK * TK * 32;
   constexpr int P_VECS = WG_BR * BNN / VP / GM_THREADS, Q_VECS = (WG_BR * BKK / VQ + GM_THREADS - 1) / GM_THREADS;
   constexpr int P_TPR = BNN / VP, Q_TPR = BKK / VQ;           // threads per tile row
@@ -1046,9 +1044,9 @@ void launch_gemm(int v, dim3 grid, hipStream_t st, long long rows, const int *ro
 
 template <int WN, int WK, int TN, int TK, int VP, int VQ>
 void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
-                    const RowOperand &Q, long long rpc, float *partial) {
+                    const RowOperand &Q, float *partial) {
   const size_t lds = sizeof(float) * 2 * WG_BR * (WN * TN * 32 + WK * TK * 32);
-#define RS_WG(PM_, QM_) hipLaunchKernelGGL((wgrad_kernel<WN, WK, TN, TK, VP, VQ, PM_, QM_>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial)
+#define RS_WG(PM_, QM_) hipLaunchKernelGGL((wgrad_kernel<WN, WK, TN, TK, VP, VQ, PM_, QM_>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, ncols, kcols, P, Q, partial)
 #define RS_WGQ(PM_) do { if (Q.mode == OPM_ID) RS_WG(PM_, OPM_ID); else if (Q.mode == OPM_RELU1) RS_WG(PM_, OPM_RELU1); else if (Q.mode == OPM_RELU2) RS_WG(PM_, OPM_RELU2); else RS_WG(-1, -1); } while (0)
   if (VP == 1 || VQ == 1) { RS_WG(-1, -1); return; }
   if (P.mode == OPM_AFF2) RS_WGQ(OPM_AFF2);
@@ -1060,11 +1058,11 @@ void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, const int *rows_d
 }
 template <int WN, int WK, int TN, int TK>
 void launch_wgrad(int vp, int vq, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
-                  const RowOperand &Q, long long rpc, float *partial) {
-  if (vp == 1 || vq == 1) launch_wgrad_m<WN, WK, TN, TK, 1, 1>(grid, st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
-  else if (vp == 4 && vq == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 4>(grid, st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
-  else if (vp == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 2>(grid, st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
-  else launch_wgrad_m<WN, WK, TN, TK, 2, 2>(grid, st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);   // (2,4) runs as (2,2)
+                  const RowOperand &Q, float *partial) {
+  if (vp == 1 || vq == 1) launch_wgrad_m<WN, WK, TN, TK, 1, 1>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
+  else if (vp == 4 && vq == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 4>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
+  else if (vp == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 2>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
+  else launch_wgrad_m<WN, WK, TN, TK, 2, 2>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);   // (2,4) runs as (2,2)
 }
 
 }  // namespace
@@ -1144,8 +1142,6 @@ extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int 
   RowOperand P = *p, Q = *q;
   if (P.ns <= 0) P.ns = 1;
   if (Q.ns <= 0) Q.ns = 1;
-  long long rpc = (rows + chunks - 1) / chunks;
-  rpc = (rpc + WG_BR - 1) / WG_BR * WG_BR;
   hipStream_t st = (hipStream_t)stream;
   const int vp = pick_vec(P, ncols), vq = pick_vec(Q, kcols);
   static const int small_on = env_int("RS_WGRAD_SMALL", 1);
@@ -1165,11 +1161,11 @@ extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int 
 #undef RS_WS
   } else
   if (kcols > 64) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
-    launch_wgrad<2, 2, 2, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
+    launch_wgrad<2, 2, 2, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   } else if (kcols > 32) {   // 128 x 64: waves 4 x 1, 1 x 2 tiles
-    launch_wgrad<4, 1, 1, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
+    launch_wgrad<4, 1, 1, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   } else {                   // 128 x 32: waves 4 x 1, 1 x 1 tile
-    launch_wgrad<4, 1, 1, 1>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, rpc, partial);
+    launch_wgrad<4, 1, 1, 1>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   }
   const long long n = (long long)ncols * kcols;
   long long rb = (n + 31) / 32;

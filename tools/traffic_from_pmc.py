@@ -44,7 +44,8 @@ def per_family(csv_path, counter):
     for r in rows:
         for abi, sub in FAMILY.items():
             if sub in r["Kernel_Name"]:
-                fam[abi].append((float(r["Counter_Value"]), r["Kernel_Name"].split("(")[0]))
+                name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+                fam[abi].append((float(r["Counter_Value"]), name.split("(")[0]))
     return fam
 
 
