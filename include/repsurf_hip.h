@@ -306,6 +306,46 @@ int rs_pack_weights(const rs_pack_weights_args *args, void *stream);
 /* out[e] = sum_b partial[b][e], b ascending (deterministic reduction of fp32 workgroup partials). */
 int rs_reduce_partials(int nblk, long long n, const float *partial, float *out, void *stream);
 
+/* ---- classifier head on <= 64 rows (repsurf_amd/csrc/head.hip) -----------------------------------------------
+ * classfier = Linear-BN1d-ReLU-Dropout-Linear-BN1d-ReLU-Dropout-Linear + log_softmax
+ * (classification/models/repsurf/repsurf_ssg_umb.py:32-41,56-57) and SmoothClsLoss
+ * (classification/util/utils.py:55-69).  A workgroup owns 4 output columns of a layer for all rows, so the
+ * BatchNorm(train) statistics are local: one launch per hidden layer forward (Linear + BN + ReLU + Dropout) and one
+ * per hidden layer backward (data gradient from the next layer + Dropout/ReLU/BN backward + weight gradient).
+ * Dropout masks are a hash of (seed, *step, layer, element); rs_head_output_forward advances *step once per forward,
+ * backward kernels recompute the mask of `*step - step_back`. */
+typedef struct rs_head_layer {
+  const float *x; int ldx;                    /* input (R, K) */
+  const float *w, *b, *gamma, *beta;          /* (N, K), (N), (N), (N) */
+  float *running_mean, *running_var;          /* updated in place; NULL = not tracked */
+  float momentum, eps, drop_p;
+  float *y, *h, *mean, *invstd;               /* outputs: (R, N) pre-BN, (R, N) activation, (N), (N) */
+  unsigned seed; const int *step; int layer;
+  int R, K, N;
+} rs_head_layer;
+int rs_head_layer_forward(const rs_head_layer *l, void *stream);
+/* logp (R, classes) = log_softmax(h . w^T + b); *step += 1 when step is not NULL */
+int rs_head_output_forward(int rows, int k, int classes, const float *h, const float *w, const float *b,
+                           float *logp, int *step, void *stream);
+/* dlogits = dlogp - exp(logp) * rowsum(dlogp); dw (classes, k) = dlogits^T h; db = colsum(dlogits) */
+int rs_head_output_backward(int rows, int k, int classes, const float *dlogp, const float *logp, const float *h,
+                            float *dlogits, float *dw, float *db, void *stream);
+typedef struct rs_head_layer_bwd {
+  const float *dz_next; int n2; const float *w_next;      /* (R, N2) gradient at the next Linear's output, its weight (N2, N) */
+  const float *y, *mean, *invstd, *gamma, *beta;          /* saved by the forward */
+  const float *x; int ldx;                                /* this layer's input (R, K) */
+  float *dz, *dw, *dgamma, *dbeta;                        /* outputs: (R, N), (N, K), (N), (N) */
+  float drop_p; unsigned seed; const int *step; int layer; int step_back;
+  int R, K, N;
+} rs_head_layer_bwd;
+int rs_head_layer_backward(const rs_head_layer_bwd *l, void *stream);
+/* dx (R, K) = dz (R, N) . w (N, K): the gradient that leaves the head */
+int rs_head_input_backward(int rows, int n, int k, const float *dz, const float *w, float *dx, void *stream);
+/* loss[0] = -mean_r sum_j soft[r][j] logp[r][j], soft = 1-eps on target[r] and eps/(classes-1) elsewhere;
+ * dlogp (R, classes) = -soft / R (d loss / d logp). */
+int rs_smooth_cls_loss(int rows, int classes, float eps, const float *logp, const long long *target,
+                       float *loss, float *dlogp, void *stream);
+
 /* ---- fused 10-channel MLP of UmbrellaSurfaceConstructor ---------------------------------------
  * self.mlps = Conv2d(10,10,bias=False)-BN-ReLU-Conv2d(10,10)-BN-ReLU-Conv2d(10,10) + sum/avg over the fan
  * (classification/modules/repsurface_utils.py:266-274, 296-305) as six register-resident passes over the

@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from modules.repsurface_utils import SurfaceAbstractionCD, UmbrellaSurfaceConstructor
+from repsurf_amd import head as _head
 from repsurf_amd import mlp as _mlp
 from repsurf_amd import rng
 from repsurf_amd.geometry import GeometryPlan
@@ -66,5 +67,7 @@ class UmbrellaClassifier(nn.Module):
         for i, name in enumerate(self._stage_names):
             geo = plan.stage(i) if (plan is not None and i < len(self._sampling)) else None
             center, normal, feature = getattr(self, name)(center, normal, feature, geometry=geo)
-        logits = self.classfier(feature.reshape(-1, self.head_in))
-        return F.log_softmax(logits, -1)
+        x = feature.reshape(-1, self.head_in)
+        if _head.usable(self.classfier, x):            # training batches of <= 64 clouds: 3 fused launches
+            return _head.classifier_logprobs(self.classfier, x)
+        return F.log_softmax(self.classfier(x), -1)
