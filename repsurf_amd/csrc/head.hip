@@ -18,11 +18,11 @@
 
 namespace {
 
-constexpr int HD_THREADS = 256;
-constexpr int HD_CW = 4;          // columns owned by a workgroup
-constexpr int HD_RB = 32;         // rows per register block
-constexpr int HD_KC = 256;        // reduction chunk staged in LDS
-constexpr int HD_MAXR = 64;
+constexpr int HD_THREADS = 512;   // 8 waves: each takes 1/8 of the reduction dimension of the workgroup's 32-column block
+constexpr int HD_WAVES = HD_THREADS / 64;
+constexpr int HD_COLS = 32;       // columns owned by a workgroup (one MFMA tile wide)
+constexpr int HD_MAXR = 64;       // rows (batch) supported: two 32-row MFMA blocks
+typedef float hd_f16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ unsigned hd_hash(unsigned seed, unsigned step, unsigned layer, unsigned e) {
   unsigned x = e * 0x9E3779B1u ^ (seed + step * 0x7F4A7C15u + layer * 0x94D049BBu);
@@ -34,50 +34,115 @@ __device__ __forceinline__ bool hd_keep(unsigned seed, unsigned step, unsigned l
   return (float)(hd_hash(seed, step, layer, e) >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
-// y[r][c] = sum_k x[r][k] * w[n0 + c][k] for the HD_CW owned columns and all R rows -> ys[r][c] in LDS.
-// x chunks are staged transposed (xs[k][r], conflict-free), thread (r, ks) walks 32 k of the chunk.
-__device__ __forceinline__ void hd_owned_dot(int R, int K, int ncols, int n0, const float *__restrict__ x, int ldx,
-                                             const float *__restrict__ w, int ldw, float *xs, float *ws, float *red,
-                                             float *ys) {
-  const int tid = threadIdx.x, r = tid & 31, ks = tid >> 5;
-  for (int rb = 0; rb < R; rb += HD_RB) {
-    float acc[HD_CW];
+// 4 consecutive floats of a row, zero beyond `avail`; one 16-B load when the row is aligned (vec)
+__device__ __forceinline__ float4 hd_load4(const float *__restrict__ p, int avail, bool vec) {
+  if (avail <= 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec && avail >= 4) return *reinterpret_cast<const float4 *>(p);
+  float4 v;
+  v.x = p[0]; v.y = avail > 1 ? p[1] : 0.f; v.z = avail > 2 ? p[2] : 0.f; v.w = avail > 3 ? p[3] : 0.f;
+  return v;
+}
+__device__ __forceinline__ float hd_get(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+// row of accumulator register i in the 32x32 MFMA tile, for lane half h = lane >> 5 (column = lane & 31)
+__device__ __forceinline__ int hd_drow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// acc[rb] (32 rows x 32 columns) += A[rb*32 + i][k] * B[c0 + j][k] over k in [kbeg, kend): both operands k-contiguous
+// (x . W^T).  v_mfma_f32_32x32x2_f32 takes, per step, lane (i = lane & 31, h = lane >> 5) -> A[i][k_h], B[i][k_h]; the order
+// of the k's is free as long as both operands agree, so a lane reads 4 consecutive k (one 16-B load per operand) for 4 steps.
+template <int RB>
+__device__ __forceinline__ void hd_mma_nt(const float *__restrict__ A, int lda, int R, const float *__restrict__ B, int ldb,
+                                          int ncols, int c0, int K, int kbeg, int kend, hd_f16 (&acc)[RB]) {
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const bool vec = (((lda | ldb | K) & 3) == 0) && ((((size_t)A | (size_t)B) & 15) == 0);
+  const bool bok = c0 + c < ncols;
+  const float *bp = B + (long long)(bok ? c0 + c : 0) * ldb;
+  constexpr int U = 4;                               // 4 x 8 k in flight per wave: the loads of a trip are issued together
+  for (int k0 = kbeg + 4 * h; k0 < kend; k0 += 8 * U) {
+    float4 b4[U], a4[U][RB];
 #pragma unroll
-    for (int c = 0; c < HD_CW; ++c) acc[c] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += HD_KC) {
-      __syncthreads();
+    for (int u = 0; u < U; ++u) {
+      const int kq = k0 + 8 * u, avail = min(kend, K) - kq;
+      b4[u] = hd_load4(bp + kq, bok ? avail : 0, vec);
 #pragma unroll
-      for (int rr = 0; rr < HD_RB; ++rr) {                        // coalesced: thread t loads column k0 + t of row rb + rr
-        const int k = k0 + tid, row = rb + rr;
-        xs[tid * (HD_RB + 1) + rr] = (k < K && row < R) ? x[(long long)row * ldx + k] : 0.f;
-      }
-#pragma unroll
-      for (int c = 0; c < HD_CW; ++c) {
-        const int k = k0 + tid;
-        ws[c * HD_KC + tid] = (k < K && n0 + c < ncols) ? w[(long long)(n0 + c) * ldw + k] : 0.f;
-      }
-      __syncthreads();
-#pragma unroll 8
-      for (int kk = 0; kk < 32; ++kk) {
-        const int k = ks * 32 + kk;
-        const float xv = xs[k * (HD_RB + 1) + r];
-#pragma unroll
-        for (int c = 0; c < HD_CW; ++c) acc[c] = fmaf(xv, ws[c * HD_KC + k], acc[c]);
+      for (int rb = 0; rb < RB; ++rb) {
+        const int r = rb * 32 + c;
+        a4[u][rb] = hd_load4(A + (long long)(r < R ? r : 0) * lda + kq, r < R ? avail : 0, vec);
       }
     }
-    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < HD_CW; ++c) red[(ks * HD_RB + r) * HD_CW + c] = acc[c];
-    __syncthreads();
-    if (tid < HD_RB * HD_CW) {
-      const int rr = tid / HD_CW, c = tid % HD_CW;
-      float t = 0.f;
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int s = 0; s < 8; ++s) t += red[(s * HD_RB + rr) * HD_CW + c];
-      if (rb + rr < R) ys[(rb + rr) * HD_CW + c] = t;
-    }
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(hd_get(a4[u][rb], i), hd_get(b4[u], i), acc[rb], 0, 0, 0);
   }
+}
+
+// acc[rb] += A[rb*32 + i][n] * W[n][c0 + j] over n in [nbeg, nend): A n-contiguous, W column-contiguous (dz . W)
+template <int RB>
+__device__ __forceinline__ void hd_mma_nn(const float *__restrict__ A, int lda, int R, const float *__restrict__ W, int ldw,
+                                          int ncols, int c0, int N, int nbeg, int nend, hd_f16 (&acc)[RB]) {
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const bool vec = (((lda | N) & 3) == 0) && (((size_t)A & 15) == 0);
+  const bool cok = c0 + c < ncols;
+  const float *wp = W + (cok ? c0 + c : 0);
+  constexpr int U = 4;
+  for (int n0 = nbeg + 4 * h; n0 < nend; n0 += 8 * U) {
+    float b[U][4];
+    float4 a4[U][RB];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int nq = n0 + 8 * u, avail = min(nend, N) - nq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[u][i] = (cok && i < avail) ? wp[(long long)(nq + i) * ldw] : 0.f;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int r = rb * 32 + c;
+        a4[u][rb] = hd_load4(A + (long long)(r < R ? r : 0) * lda + nq, r < R ? avail : 0, vec);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(hd_get(a4[u][rb], i), b[u][i], acc[rb], 0, 0, 0);
+  }
+}
+
+// the 8 waves' partial tiles -> part[wave][row][col] in LDS
+template <int RB>
+__device__ __forceinline__ void hd_store_partials(const hd_f16 (&acc)[RB], float *part) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[(wave * HD_MAXR + rb * 32 + hd_drow(i, h)) * HD_COLS + c] = acc[rb][i];
+}
+// element (r, c) of the workgroup's block: sum of the waves' partials
+__device__ __forceinline__ float hd_block_at(const float *part, int r, int c) {
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < HD_WAVES; ++w) t += part[(w * HD_MAXR + r) * HD_COLS + c];
+  return t;
+}
+// sum over the rows of a column: thread (c = tid & 31, rg = tid >> 5) contributes `v`; all threads get the column total
+__device__ __forceinline__ float hd_col_sum(float v, float *colred) {
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
   __syncthreads();
+  colred[rg * HD_COLS + c] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int g = 0; g < HD_THREADS / 32; ++g) t += colred[g * HD_COLS + c];
+  return t;
+}
+// split [0, n) into HD_WAVES ranges that are multiples of 8
+__device__ __forceinline__ void hd_wave_range(int n, int &beg, int &end) {
+  const int per = ((n + 8 * HD_WAVES - 1) / (8 * HD_WAVES)) * 8, wave = threadIdx.x >> 6;
+  beg = min(n, wave * per); end = min(n, beg + per);
 }
 
 struct HeadLayer {
@@ -93,24 +158,45 @@ struct HeadLayer {
   int R, K, N;
 };
 
+// Linear + BatchNorm1d(train) + ReLU + Dropout for 32 owned columns and all rows: the 8 waves split K, their partial
+// MFMA tiles meet in LDS, then thread (c, rg) finishes the rows rg, rg + 16, ... of column c.
 __global__ void __launch_bounds__(HD_THREADS)
 head_layer_fwd_kernel(HeadLayer L) {
-  __shared__ float xs[HD_KC * (HD_RB + 1)];
-  __shared__ float ws[HD_CW * HD_KC];
-  __shared__ float red[8 * HD_RB * HD_CW];
-  __shared__ float ys[HD_MAXR * HD_CW];
-  const int n0 = blockIdx.x * HD_CW;
-  hd_owned_dot(L.R, L.K, L.N, n0, L.x, L.ldx, L.w, L.K, xs, ws, red, ys);
-  // one wave per owned column, lane = row: the batch statistics are a wave reduction
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = n0 + wave;
-  if (n >= L.N) return;
-  const bool rok = lane < L.R;
-  const float v = rok ? ys[lane * HD_CW + wave] + L.b[n] : 0.f;
-  const float mean = rs_wave_sum_f32(v) / (float)L.R;
-  const float d = rok ? v - mean : 0.f;
-  const float var = rs_wave_sum_f32(d * d) / (float)L.R;
+  __shared__ float part[HD_WAVES * HD_MAXR * HD_COLS];
+  __shared__ float colred[(HD_THREADS / 32) * HD_COLS];
+  const int tid = threadIdx.x, c = tid & 31, rg = tid >> 5, n0 = blockIdx.x * HD_COLS, n = n0 + c;
+  int kbeg, kend;
+  hd_wave_range(L.K, kbeg, kend);
+  if (L.R <= 32) {
+    hd_f16 acc[1] = {};
+    hd_mma_nt<1>(L.x, L.ldx, L.R, L.w, L.K, L.N, n0, L.K, kbeg, kend, acc);
+    hd_store_partials<1>(acc, part);
+  } else {
+    hd_f16 acc[2] = {};
+    hd_mma_nt<2>(L.x, L.ldx, L.R, L.w, L.K, L.N, n0, L.K, kbeg, kend, acc);
+    hd_store_partials<2>(acc, part);
+  }
+  __syncthreads();
+  const bool nok = n < L.N;
+  const float bias = nok ? L.b[n] : 0.f;
+  float v[4], s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = rg + 16 * q;
+    v[q] = (r < L.R && nok) ? hd_block_at(part, r, c) + bias : 0.f;
+    s += v[q];
+  }
+  const float mean = hd_col_sum(s, colred) / (float)L.R;
+  float d[4], s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    d[q] = (rg + 16 * q < L.R && nok) ? v[q] - mean : 0.f;
+    s2 = fmaf(d[q], d[q], s2);
+  }
+  const float var = hd_col_sum(s2, colred) / (float)L.R;
   const float invstd = 1.0f / sqrtf(var + L.eps);
-  if (lane == 0) {
+  if (!nok) return;
+  if (rg == 0) {
     L.mean[n] = mean; L.invstd[n] = invstd;
     if (L.running_mean) {       // nn.BatchNorm1d: running = (1-m) running + m batch, variance unbiased
       L.running_mean[n] = (1.f - L.momentum) * L.running_mean[n] + L.momentum * mean;
@@ -118,13 +204,17 @@ head_layer_fwd_kernel(HeadLayer L) {
       L.running_var[n] = (1.f - L.momentum) * L.running_var[n] + L.momentum * unb;
     }
   }
-  if (rok) {
-    const float z = d * invstd * L.gamma[n] + L.beta[n];
+  const float ga = L.gamma[n], be = L.beta[n];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = rg + 16 * q;
+    if (r >= L.R) continue;
+    const float z = d[q] * invstd * ga + be;
     float a = fmaxf(z, 0.f);
     if (L.drop_p > 0.f)
-      a = hd_keep(L.seed, (unsigned)*L.step, (unsigned)L.layer, (unsigned)(lane * L.N + n), L.drop_p) ? a / (1.f - L.drop_p) : 0.f;
-    L.y[(long long)lane * L.N + n] = v;
-    L.h[(long long)lane * L.N + n] = a;
+      a = hd_keep(L.seed, (unsigned)*L.step, (unsigned)L.layer, (unsigned)(r * L.N + n), L.drop_p) ? a / (1.f - L.drop_p) : 0.f;
+    L.y[(long long)r * L.N + n] = v[q];
+    L.h[(long long)r * L.N + n] = a;
   }
 }
 
@@ -218,103 +308,102 @@ struct HeadLayerBwd {
 
 __global__ void __launch_bounds__(HD_THREADS)
 head_layer_bwd_kernel(HeadLayerBwd L) {
-  extern __shared__ float sm[];                      // dz_next (R, n2+1) | owned columns of w_next (n2, 4)
-  __shared__ float dzs[HD_MAXR * HD_CW];
-  const int tid = threadIdx.x, n0 = blockIdx.x * HD_CW;
-  const int wave = tid >> 6, lane = tid & 63, n = n0 + wave;
-  const int ld2 = L.n2 + 1;
-  float *dn = sm, *wn = sm + L.R * ld2;
-  for (int e = tid; e < L.R * L.n2; e += HD_THREADS) { const int r = e / L.n2, j = e - r * L.n2; dn[r * ld2 + j] = L.dz_next[e]; }
-  for (int e = tid; e < L.n2 * HD_CW; e += HD_THREADS) {
-    const int j = e / HD_CW, c = e - j * HD_CW;
-    wn[e] = (n0 + c < L.N) ? L.w_next[(long long)j * L.N + n0 + c] : 0.f;
-  }
-  __syncthreads();
-  const bool rok = lane < L.R && n < L.N;
-  // dh for (row = lane, column = n0 + wave): reduction over the next layer's columns
-  float dh = 0.f;
-  if (rok) {
-    const float *dzr = dn + lane * ld2;
-#pragma unroll 8
-    for (int j = 0; j < L.n2; ++j) dh = fmaf(dzr[j], wn[j * HD_CW + wave], dh);
-  }
-  float yv = 0.f, xhat = 0.f, g = 0.f;
-  if (rok) {
-    yv = L.y[(long long)lane * L.N + n];
-    xhat = (yv - L.mean[n]) * L.invstd[n];
-    const float z = xhat * L.gamma[n] + L.beta[n];
-    g = dh;
-    if (L.drop_p > 0.f)
-      g = hd_keep(L.seed, (unsigned)(*L.step - L.step_back), (unsigned)L.layer, (unsigned)(lane * L.N + n), L.drop_p)
-              ? g / (1.f - L.drop_p) : 0.f;
-    g = z > 0.f ? g : 0.f;                       // gradient w.r.t. the BatchNorm output
-  }
-  const float sum_g = rs_wave_sum_f32(g), sum_gx = rs_wave_sum_f32(g * xhat);
-  if (n < L.N) {
-    if (lane == 0) { L.dgamma[n] = sum_gx; L.dbeta[n] = sum_g; }
-    const float inv_r = 1.f / (float)L.R;
-    const float dzv = rok ? L.gamma[n] * L.invstd[n] * (g - sum_g * inv_r - xhat * sum_gx * inv_r) : 0.f;
-    dzs[lane * HD_CW + wave] = dzv;
-    if (rok) L.dz[(long long)lane * L.N + n] = dzv;
+  __shared__ float part[HD_WAVES * HD_MAXR * HD_COLS];
+  __shared__ float colred[(HD_THREADS / 32) * HD_COLS];
+  __shared__ float dzs[HD_MAXR * (HD_COLS + 1)];
+  const int tid = threadIdx.x, c = tid & 31, rg = tid >> 5, n0 = blockIdx.x * HD_COLS, n = n0 + c;
+  // dh block (rows x 32 owned columns) = dz_next . w_next[:, n0 : n0 + 32]; the waves split the next layer's columns
+  int jbeg, jend;
+  hd_wave_range(L.n2, jbeg, jend);
+  if (L.R <= 32) {
+    hd_f16 acc[1] = {};
+    hd_mma_nn<1>(L.dz_next, L.n2, L.R, L.w_next, L.N, L.N, n0, L.n2, jbeg, jend, acc);
+    hd_store_partials<1>(acc, part);
   } else {
-    dzs[lane * HD_CW + wave] = 0.f;
+    hd_f16 acc[2] = {};
+    hd_mma_nn<2>(L.dz_next, L.n2, L.R, L.w_next, L.N, L.N, n0, L.n2, jbeg, jend, acc);
+    hd_store_partials<2>(acc, part);
   }
   __syncthreads();
-  // weight gradient rows n0 .. n0+3: thread per k (coalesced reads of x rows and writes of dW rows)
-  for (int k = tid; k < L.K; k += HD_THREADS) {
-    float acc[HD_CW];
+  const bool nok = n < L.N;
+  const float mean = nok ? L.mean[n] : 0.f, invstd = nok ? L.invstd[n] : 0.f;
+  const float ga = nok ? L.gamma[n] : 0.f, be = nok ? L.beta[n] : 0.f;
+  unsigned step = 0;
+  if (L.drop_p > 0.f) step = (unsigned)(*L.step - L.step_back);
+  float g[4], xh[4], sg = 0.f, sgx = 0.f;
 #pragma unroll
-    for (int c = 0; c < HD_CW; ++c) acc[c] = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < L.R; ++r) {
-      const float xv = L.x[(long long)r * L.ldx + k];
+  for (int q = 0; q < 4; ++q) {
+    const int r = rg + 16 * q;
+    g[q] = 0.f; xh[q] = 0.f;
+    if (r < L.R && nok) {
+      xh[q] = (L.y[(long long)r * L.N + n] - mean) * invstd;
+      const float z = xh[q] * ga + be;
+      float t = hd_block_at(part, r, c);
+      if (L.drop_p > 0.f) t = hd_keep(L.seed, step, (unsigned)L.layer, (unsigned)(r * L.N + n), L.drop_p) ? t / (1.f - L.drop_p) : 0.f;
+      g[q] = z > 0.f ? t : 0.f;                  // gradient w.r.t. the BatchNorm output
+    }
+    sg += g[q];
+    sgx = fmaf(g[q], xh[q], sgx);
+  }
+  const float sum_g = hd_col_sum(sg, colred), sum_gx = hd_col_sum(sgx, colred);
+  if (nok && rg == 0) { L.dgamma[n] = sum_gx; L.dbeta[n] = sum_g; }
+  const float inv_r = 1.f / (float)L.R;
 #pragma unroll
-      for (int c = 0; c < HD_CW; ++c) acc[c] = fmaf(dzs[r * HD_CW + c], xv, acc[c]);
+  for (int q = 0; q < 4; ++q) {
+    const int r = rg + 16 * q;
+    const float dzv = (r < L.R && nok) ? ga * invstd * (g[q] - sum_g * inv_r - xh[q] * sum_gx * inv_r) : 0.f;
+    dzs[r * (HD_COLS + 1) + c] = dzv;
+    if (r < L.R && nok) L.dz[(long long)r * L.N + n] = dzv;
+  }
+  __syncthreads();
+  // weight gradient rows n0 .. n0+31: tile (32 n x 32 k) = dzs^T . x over the rows; a wave takes every 8th k tile
+  const int wave = tid >> 6, lane = tid & 63, h = lane >> 5, lc = lane & 31;
+  const int steps = (L.R + 1) >> 1;
+  for (int k0 = wave * 32; k0 < L.K; k0 += HD_WAVES * 32) {
+    hd_f16 acc = {};
+    const bool kok = k0 + lc < L.K;
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = 2 * (s0 + u) + h;
+        a[u] = r < HD_MAXR ? dzs[r * (HD_COLS + 1) + lc] : 0.f;     // rows R .. 63 hold 0
+        b[u] = (kok && r < L.R) ? L.x[(long long)r * L.ldx + k0 + lc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int c = 0; c < HD_CW; ++c)
-      if (n0 + c < L.N) L.dw[(long long)(n0 + c) * L.K + k] = acc[c];
+    for (int i = 0; i < 16; ++i) {
+      const int nn = n0 + hd_drow(i, h);
+      if (kok && nn < L.N) L.dw[(long long)nn * L.K + k0 + lc] = acc[i];
+    }
   }
 }
 
 // dx[r][k] = sum_n dz[r][n] * w[n][k]: gradient that leaves the head (into the last abstraction stage).
-// Workgroup = 32 consecutive k for all rows; W and dz go through LDS in tiles of 64 n (coalesced float loads);
-// thread (kl = tid & 31, rg = tid >> 5) accumulates the rows rg, rg + 8, ...
+// Workgroup = 32 consecutive k for all rows; the 8 waves split n.
 __global__ void __launch_bounds__(HD_THREADS)
 head_dx_kernel(int R, int N, int K, const float *__restrict__ dz, const float *__restrict__ w, float *__restrict__ dx) {
-  __shared__ float wsm[64 * 33];
-  __shared__ float dzs[HD_MAXR * 65];
-  const int tid = threadIdx.x, kl = tid & 31, rg = tid >> 5;
-  const int kb = blockIdx.x * 32;
-  float acc[HD_MAXR / 8];
-#pragma unroll
-  for (int i = 0; i < HD_MAXR / 8; ++i) acc[i] = 0.f;
-  for (int nb = 0; nb < N; nb += 64) {
-    __syncthreads();
-    for (int e = tid; e < 64 * 32; e += HD_THREADS) {
-      const int nn = e >> 5, kk = e & 31;
-      wsm[nn * 33 + kk] = (nb + nn < N && kb + kk < K) ? w[(long long)(nb + nn) * K + kb + kk] : 0.f;
-    }
-    for (int e = tid; e < R * 64; e += HD_THREADS) {
-      const int r = e >> 6, nn = e & 63;
-      dzs[r * 65 + nn] = (nb + nn < N) ? dz[(long long)r * N + nb + nn] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int nn = 0; nn < 64; ++nn) {
-      const float wv = wsm[nn * 33 + kl];
-#pragma unroll
-      for (int i = 0; i < HD_MAXR / 8; ++i) {
-        const int r = rg + 8 * i;
-        acc[i] = fmaf(r < R ? dzs[r * 65 + nn] : 0.f, wv, acc[i]);
-      }
-    }
+  __shared__ float part[HD_WAVES * HD_MAXR * HD_COLS];
+  const int tid = threadIdx.x, c = tid & 31, rg = tid >> 5, kb = blockIdx.x * HD_COLS;
+  int nbeg, nend;
+  hd_wave_range(N, nbeg, nend);
+  if (R <= 32) {
+    hd_f16 acc[1] = {};
+    hd_mma_nn<1>(dz, N, R, w, K, K, kb, N, nbeg, nend, acc);
+    hd_store_partials<1>(acc, part);
+  } else {
+    hd_f16 acc[2] = {};
+    hd_mma_nn<2>(dz, N, R, w, K, K, kb, N, nbeg, nend, acc);
+    hd_store_partials<2>(acc, part);
   }
-  if (kb + kl < K)
+  __syncthreads();
+  if (kb + c < K)
 #pragma unroll
-    for (int i = 0; i < HD_MAXR / 8; ++i) {
-      const int r = rg + 8 * i;
-      if (r < R) dx[(long long)r * K + kb + kl] = acc[i];
+    for (int q = 0; q < 4; ++q) {
+      const int r = rg + 16 * q;
+      if (r < R) dx[(long long)r * K + kb + c] = hd_block_at(part, r, c);
     }
 }
 
@@ -353,7 +442,7 @@ extern "C" int rs_head_layer_forward(const rs_head_layer *l, void *stream) {
   L.momentum = l->momentum; L.eps = l->eps; L.drop_p = l->drop_p;
   L.y = l->y; L.h = l->h; L.mean = l->mean; L.invstd = l->invstd;
   L.seed = l->seed; L.step = l->step; L.layer = l->layer; L.R = l->R; L.K = l->K; L.N = l->N;
-  hipLaunchKernelGGL(head_layer_fwd_kernel, dim3(rs_cdiv(l->N, HD_CW)), dim3(HD_THREADS), 0, (hipStream_t)stream, L);
+  hipLaunchKernelGGL(head_layer_fwd_kernel, dim3(rs_cdiv(l->N, HD_COLS)), dim3(HD_THREADS), 0, (hipStream_t)stream, L);
   RS_CHECK_LAUNCH("rs_head_layer_forward");
   return RS_OK;
 }
@@ -389,9 +478,7 @@ extern "C" int rs_head_layer_backward(const rs_head_layer_bwd *l, void *stream) 
   L.gamma = l->gamma; L.beta = l->beta; L.x = l->x; L.ldx = l->ldx; L.dz = l->dz; L.dw = l->dw; L.dgamma = l->dgamma;
   L.dbeta = l->dbeta; L.drop_p = l->drop_p; L.seed = l->seed; L.step = l->step; L.layer = l->layer; L.step_back = l->step_back;
   L.R = l->R; L.K = l->K; L.N = l->N;
-  const size_t lds = sizeof(float) * ((size_t)l->R * (l->n2 + 1) + (size_t)l->n2 * HD_CW);
-  RS_REQUIRE(lds <= 120 * 1024, "rs_head_layer_backward: rows=%d x n2=%d do not fit the LDS staging", l->R, l->n2);
-  hipLaunchKernelGGL(head_layer_bwd_kernel, dim3(rs_cdiv(l->N, HD_CW)), dim3(HD_THREADS), lds, (hipStream_t)stream, L);
+  hipLaunchKernelGGL(head_layer_bwd_kernel, dim3(rs_cdiv(l->N, HD_COLS)), dim3(HD_THREADS), 0, (hipStream_t)stream, L);
   RS_CHECK_LAUNCH("rs_head_layer_backward");
   return RS_OK;
 }
@@ -399,7 +486,7 @@ extern "C" int rs_head_layer_backward(const rs_head_layer_bwd *l, void *stream) 
 extern "C" int rs_head_input_backward(int rows, int n, int k, const float *dz, const float *w, float *dx, void *stream) {
   RS_REQUIRE(rows > 0 && rows <= HD_MAXR && n > 0 && k > 0, "rs_head_input_backward: bad size");
   RS_REQUIRE(dz && w && dx, "rs_head_input_backward: null pointer");
-  hipLaunchKernelGGL(head_dx_kernel, dim3(rs_cdiv(k, 32)), dim3(HD_THREADS), 0, (hipStream_t)stream, rows, n, k, dz, w, dx);
+  hipLaunchKernelGGL(head_dx_kernel, dim3(rs_cdiv(k, HD_COLS)), dim3(HD_THREADS), 0, (hipStream_t)stream, rows, n, k, dz, w, dx);
   RS_CHECK_LAUNCH("rs_head_input_backward");
   return RS_OK;
 }
