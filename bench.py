@@ -138,6 +138,7 @@ def main():
 
     import importlib
     from repsurf_amd import _lib, mlp, ops
+    from repsurf_amd.optim import Adam
     from util.utils import SmoothClsLoss
     Model = importlib.import_module(f"models.repsurf.{args.model}").Model
 
@@ -149,7 +150,7 @@ def main():
     # graph replay: the model itself, gradients in one flat buffer, one explicit all-reduce per step
     net = model if use_graph else rdist.wrap(model, device)
     criterion = SmoothClsLoss()
-    optim = None if args.no_optim else torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=use_graph)
+    optim = None if args.no_optim else Adam(model.parameters(), lr=1e-3)
     points, label = synthetic_batch(rdist.rank_seed(125, rank), args.batch, args.points, device)
     torch.manual_seed(rdist.rank_seed(13, rank))   # CPU generator: FPS starts / normal flips differ per rank
 
@@ -211,7 +212,7 @@ def main():
     if timing and use_graph and rank == 0:
         import copy
         twin = copy.deepcopy(model)
-        topt = None if args.no_optim else torch.optim.Adam(twin.parameters(), lr=1e-3, fused=True)
+        topt = None if args.no_optim else Adam(twin.parameters(), lr=1e-3)
 
         def eager_step():
             for p in twin.parameters():

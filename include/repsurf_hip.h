@@ -346,6 +346,24 @@ int rs_head_input_backward(int rows, int n, int k, const float *dz, const float 
 int rs_smooth_cls_loss(int rows, int classes, float eps, const float *logp, const long long *target,
                        float *loss, float *dlogp, void *stream);
 
+/* ---- optimizer step -------------------------------------------------------------------------------
+ * torch.optim.Adam(lr, betas, eps, weight_decay) as the reference configures it
+ * (classification/tool/train_cls_scanobjectnn.py:179-185), for up to RS_ADAM_MAX fp32 tensors per launch:
+ *   g += wd * p;  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * hyper (device, 5 DOUBLES) = {lr, beta1, beta2, eps, weight_decay}; step (device int) = number of updates done so far,
+ * t = *step + 1; with advance != 0 the launch stores t back when its last workgroup retires (`done` = device int, 0
+ * between launches) -- pass advance = 0 on all but the last launch of one optimizer step. */
+#define RS_ADAM_MAX 40
+typedef struct rs_adam_table {
+  float *p[RS_ADAM_MAX];         /* parameters, updated in place */
+  const float *g[RS_ADAM_MAX];   /* gradients */
+  float *m[RS_ADAM_MAX];         /* exp_avg */
+  float *v[RS_ADAM_MAX];         /* exp_avg_sq */
+  int n[RS_ADAM_MAX];            /* elements */
+  int count;
+} rs_adam_table;
+int rs_adam_step(const rs_adam_table *t, const double *hyper, int *step, int *done, int advance, void *stream);
+
 /* ---- fused 10-channel MLP of UmbrellaSurfaceConstructor ---------------------------------------
  * self.mlps = Conv2d(10,10,bias=False)-BN-ReLU-Conv2d(10,10)-BN-ReLU-Conv2d(10,10) + sum/avg over the fan
  * (classification/modules/repsurface_utils.py:266-274, 296-305) as six register-resident passes over the

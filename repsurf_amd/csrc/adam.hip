@@ -1,0 +1,108 @@
+// adam.hip — torch.optim.Adam step over a list of fp32 parameter tensors in one launch per 40 tensors (gfx950).
+//
+// The reference trains with torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=decay_rate)
+// (classification/tool/train_cls_scanobjectnn.py:179-185).  The model has ~70 small parameter tensors (1.5 M floats);
+// the framework's multi-tensor Adam spends ~75 us on them (two launches whose workgroups each take one 64 K chunk of
+// one tensor).  The update is 7 streams x 6 MB = 42 MB of HBM traffic, ~8 us of bandwidth: here a workgroup takes
+// 2048 consecutive elements of one tensor (two 16-B loads per stream per thread), the table of tensors rides in the
+// kernel arguments, and hyper-parameters / step count live in device memory so a captured hipGraph follows the
+// learning-rate schedule and counts its own replays.
+#include "rs_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int AD_THREADS = 256;
+constexpr int AD_CHUNK = 2048;            // elements per workgroup
+
+struct AdamTable {
+  float *p[RS_ADAM_MAX];
+  const float *g[RS_ADAM_MAX];
+  float *m[RS_ADAM_MAX];
+  float *v[RS_ADAM_MAX];
+  int n[RS_ADAM_MAX];
+  int blk_end[RS_ADAM_MAX];               // running number of workgroups up to and including tensor i
+  int count;
+};
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float wd, float omb1, float b2, float omb2,
+                                         float eps, float step_size, float bc2_sqrt) {
+  g = fmaf(wd, p, g);                              // grad.add(param, alpha=weight_decay)
+  m = fmaf(g - m, omb1, m);                        // exp_avg.lerp_(grad, 1 - beta1)
+  v = fmaf(omb2, g * g, v * b2);                   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = fmaf(-step_size, m / denom, p);              // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ void __launch_bounds__(AD_THREADS)
+adam_kernel(AdamTable T, const double *__restrict__ hyper, int *__restrict__ step, int *__restrict__ done, int advance) {
+  int ti = 0;
+  while (ti < T.count - 1 && (int)blockIdx.x >= T.blk_end[ti]) ++ti;
+  const int blk0 = ti ? T.blk_end[ti - 1] : 0;
+  const int base = ((int)blockIdx.x - blk0) * AD_CHUNK;
+  const int n = T.n[ti];
+  float *__restrict__ p = T.p[ti];
+  const float *__restrict__ g = T.g[ti];
+  float *__restrict__ m = T.m[ti];
+  float *__restrict__ v = T.v[ti];
+
+  // hyper-parameters are doubles, like the Python floats the framework derives its scalars from: 1 - beta2 formed in
+  // fp32 from a rounded beta2 = 0.999f is off by 5e-5 relative.
+  const double lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2];
+  const float eps = (float)hyper[3], wd = (float)hyper[4];
+  const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+  const int t = *step + 1;                          // this update's step number (1-based)
+  const float step_size = (float)(lr / (1.0 - pow(beta1, (double)t)));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
+
+  const bool vec = ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0);
+#pragma unroll
+  for (int u = 0; u < AD_CHUNK / (AD_THREADS * 4); ++u) {
+    const int e = base + (u * AD_THREADS + (int)threadIdx.x) * 4;
+    if (e >= n) break;
+    if (vec && e + 4 <= n) {
+      float4 pv = *reinterpret_cast<const float4 *>(p + e), gv = *reinterpret_cast<const float4 *>(g + e);
+      float4 mv = *reinterpret_cast<const float4 *>(m + e), vv = *reinterpret_cast<const float4 *>(v + e);
+      adam_one(pv.x, gv.x, mv.x, vv.x, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
+      adam_one(pv.y, gv.y, mv.y, vv.y, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
+      adam_one(pv.z, gv.z, mv.z, vv.z, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
+      adam_one(pv.w, gv.w, mv.w, vv.w, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
+      *reinterpret_cast<float4 *>(p + e) = pv;
+      *reinterpret_cast<float4 *>(m + e) = mv;
+      *reinterpret_cast<float4 *>(v + e) = vv;
+    } else {
+      for (int i = e; i < min(e + 4, n); ++i) {
+        float pv = p[i], mv = m[i], vv = v[i];
+        adam_one(pv, g[i], mv, vv, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
+        p[i] = pv; m[i] = mv; v[i] = vv;
+      }
+    }
+  }
+  // the last workgroup to finish advances the step counter (every workgroup has read it by then)
+  if (advance) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(done, 1) == (int)gridDim.x - 1) { *done = 0; *step = t; }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int rs_adam_step(const rs_adam_table *t, const double *hyper, int *step, int *done, int advance, void *stream) {
+  RS_REQUIRE(t && hyper && step && done, "rs_adam_step: null pointer");
+  RS_REQUIRE(t->count > 0 && t->count <= RS_ADAM_MAX, "rs_adam_step: count=%d (1..%d)", t->count, RS_ADAM_MAX);
+  AdamTable T;
+  int blocks = 0;
+  for (int i = 0; i < t->count; ++i) {
+    RS_REQUIRE(t->p[i] && t->g[i] && t->m[i] && t->v[i] && t->n[i] > 0, "rs_adam_step: tensor %d: null pointer or empty", i);
+    T.p[i] = t->p[i]; T.g[i] = t->g[i]; T.m[i] = t->m[i]; T.v[i] = t->v[i]; T.n[i] = t->n[i];
+    blocks += rs_cdiv(t->n[i], AD_CHUNK);
+    T.blk_end[i] = blocks;
+  }
+  T.count = t->count;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(AD_THREADS), 0, (hipStream_t)stream, T, hyper, step, done, advance);
+  RS_CHECK_LAUNCH("rs_adam_step");
+  return RS_OK;
+}

@@ -9,6 +9,7 @@ is captured once (`torch.cuda.CUDAGraph` = hipGraph on ROCm) and replayed.
 """
 import torch
 
+from . import head as _head
 from . import rng
 
 
@@ -41,13 +42,15 @@ class GraphedStep:
             for p in self.net.parameters():
                 p.grad = None
         loss = self.criterion(self.net(self.points), self.label)
-        loss.backward()
+        loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
         if self.optimizer is not None:
             self.optimizer.step()
         return loss
 
     def __call__(self):
         self.draws.refill()        # fresh FPS starts / normal flips, same CPU-generator order as eager
+        if hasattr(self.optimizer, "sync_hyper"):
+            self.optimizer.sync_hyper()    # learning-rate schedule -> device (repsurf_amd.optim.Adam)
         self.graph.replay()
         return self.loss
 
@@ -112,7 +115,7 @@ class ShardedGraphedStep:
     def _fwd_bwd(self):
         self.flat.zero_()
         loss = self.criterion(self.net(self.points), self.label)
-        loss.backward()
+        loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
         return loss
 
     def _reduce(self):
@@ -125,5 +128,7 @@ class ShardedGraphedStep:
         self.graph_a.replay()
         self._reduce()
         if self.graph_b is not None:
+            if hasattr(self.optimizer, "sync_hyper"):
+                self.optimizer.sync_hyper()
             self.graph_b.replay()
         return self.loss

@@ -107,9 +107,11 @@ class _Head(Function):
         layer(buf1[1], w2, b2, g2, be2, bn2, p2, buf2, st2, 2)
         _lib.call("rs_head_output_forward", r, n2, nc, buf2[1].data_ptr(), w3.data_ptr(), b3.data_ptr(), logp.data_ptr(),
                   step.data_ptr(), _stream())
-        if meta["counters"]:
-            torch._foreach_add_(meta["counters"], 1)
+        if meta["counters"]:                   # joins the model's one deferred counter update when inside deferred_counters()
+            from . import mlp_hip
+            mlp_hip._pending_counters.extend(meta["counters"])
             meta["counters"].clear()
+            mlp_hip._flush_counters()
         if DEBUG is not None:
             DEBUG.update(y1=buf1[0], h1=buf1[1], y2=buf2[0], h2=buf2[1], st1=st1, st2=st2)
         ctx.save_for_backward(x, w1, g1, be1, w2, g2, be2, w3, logp)
@@ -178,7 +180,22 @@ class _SmoothLoss(Function):
     @staticmethod
     def backward(ctx, gout):
         (dlogp,) = ctx.saved_tensors
+        one = _unit.get(str(dlogp.device))
+        if one is not None and gout.data_ptr() == one.data_ptr():     # loss.backward(unit_gradient(device)): d loss = 1
+            return dlogp, None, None
         return dlogp * gout, None, None
+
+
+_unit = {}
+
+
+def unit_gradient(device):
+    """A persistent scalar 1.0 to pass as `loss.backward(unit_gradient(device))`: autograd then neither fills a fresh
+    ones tensor nor multiplies the loss gradient by it (two launches per step)."""
+    key = str(torch.device(device))
+    if key not in _unit:
+        _unit[key] = torch.ones((), dtype=torch.float32, device=device)
+    return _unit[key]
 
 
 def smooth_cls_loss(logp, target, eps):

@@ -141,6 +141,14 @@ def interp_weights(dist2):
     return w
 
 
+def _zero_pair(rows, c0, c1, lead, dev):
+    """two zero-filled (lead..., c) scatter targets out of ONE allocation / ONE fill (None where c == 0)"""
+    buf = torch.zeros((rows * (c0 + c1),), dtype=torch.float32, device=dev)
+    a = buf[:rows * c0].view(*lead, c0) if c0 else None
+    b = buf[rows * c0:].view(*lead, c1) if c1 else None
+    return a, b
+
+
 class _GatherRows(Function):
     @staticmethod
     def forward(ctx, points, idx):
@@ -254,8 +262,7 @@ class _GroupFeatures(Function):
         b, n, m, ns, cn, cf, polar, pad, ldo = ctx.dims
         grad_out = _f32c(grad_out)
         dev = grad_out.device
-        gn = torch.zeros((b, n, cn), dtype=torch.float32, device=dev) if ctx.need[0] else None
-        gf = torch.zeros((b, n, cf), dtype=torch.float32, device=dev) if ctx.need[1] else None
+        gn, gf = _zero_pair(b * n, cn if ctx.need[0] else 0, cf if ctx.need[1] else 0, (b, n), dev)
         if gn is not None or gf is not None:
             _lib.call("rs_group_features_backward", b, n, m, ns, cn, cf, polar, _p(grad_out), _p(idx),
                       _p(gn), _p(gf), pad, ldo, _stream())
@@ -332,8 +339,7 @@ class _GroupFeaturesCompact(Function):
             return (None,) * 7
         grad_out = _f32c(grad_out)
         dev = grad_out.device
-        gn = torch.zeros((b, n, cn), dtype=torch.float32, device=dev) if ctx.need[0] else None
-        gf = torch.zeros((b, n, cf), dtype=torch.float32, device=dev) if ctx.need[1] else None
+        gn, gf = _zero_pair(b * n, cn if ctx.need[0] else 0, cf if ctx.need[1] else 0, (b, n), dev)
         if gn is not None or gf is not None:
             _lib.call("rs_group_features_compact_backward", cap, offsets.data_ptr() + 4 * groups, cn, cf, polar,
                       _p(grad_out), _p(src), _p(gn), _p(gf), _stream())
