@@ -208,11 +208,6 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   constexpr int E_TPR = BN / 4;                 // threads per tile row (4 columns each)
   constexpr int E_RPP = GM_THREADS / E_TPR;     // rows per pass
   const int e_col = (tid % E_TPR) * 4, e_row = tid / E_TPR;
-  double st[3][4];
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) st[s][c] = 0.0;
   const bool ep_vec = (((uintptr_t)ep.out | (uintptr_t)ep.my1 | (uintptr_t)ep.my2) % 16 == 0) && (ep.ldo % 4 == 0) &&
                       (ep.ldm1 % 4 == 0) && (ep.ldm2 % 4 == 0) && (cols % 4 == 0);
 
@@ -326,6 +321,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       for (int i = 0; i < 16; ++i)
         Cs[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk) * BN + c * 32 + lrow] = acc[c][i];
     __syncthreads();
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // this tile's column sums
     {
       const int EPI = ep.mode;
       const int col = n0 + e_col;
@@ -340,7 +336,6 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
           if (ep.my2) { ms2[e] = ep.ms2[col + e]; mt2[e] = ep.mt2[col + e]; mu2[e] = ep.mean2[col + e]; is2[e] = ep.invstd2[col + e]; }
         }
       }
-      float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
       float *out_t = ep.out + r0 * ep.ldo;                    // wave-uniform tile bases
       const float *my1_t = ep.my1 ? ep.my1 + r0 * ep.ldm1 : nullptr;
       const float *my2_t = ep.my2 ? ep.my2 + r0 * ep.ldm2 : nullptr;
@@ -385,10 +380,6 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
             if (col + e < cols) out_t[(long long)rl * ep.ldo + col + e] = y[e];
         }
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {    // columns beyond `cols` accumulated zeros only
-        st[0][e] += (double)s0[e]; st[1][e] += (double)s1[e]; st[2][e] += (double)s2[e];
-      }
     }
     if (ep.pool_ns > 0) {
       // Max-pool over nsample folded into the producing GEMM: BatchNorm's scale is not known yet (its
@@ -411,7 +402,31 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         }
       }
     }
-    __syncthreads();   // C tile consumed before the next tile's staging overwrites it
+    __syncthreads();   // C tile consumed before the statistics / the next tile's staging overwrite it
+    if (ep.mode != EPI_STORE) {
+      // Column sums of this tile -> fp64 partial row of this workgroup.  The sums leave the registers here, per tile,
+      // instead of riding along in 24 VGPRs of fp64 accumulators: with those live across the K loop the dual-operand
+      // instances spilled operand pointers to scratch, and a scratch reload in front of a prefetch waits for every older
+      // global load (in-order vmcnt) -- the prefetch latency was exposed once per chunk.
+      double *red = reinterpret_cast<double *>(smem);         // 3 x E_RPP x BN doubles = 24 KB
+      const int nstat = (ep.mode == EPI_MASK && ep.my2) ? 3 : 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                           // columns beyond `cols` accumulated zeros only
+        red[(0 * E_RPP + e_row) * BN + e_col + e] = (double)s0[e];
+        red[(1 * E_RPP + e_row) * BN + e_col + e] = (double)s1[e];
+        if (nstat == 3) red[(2 * E_RPP + e_row) * BN + e_col + e] = (double)s2[e];
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < cols) {
+        for (int sidx = 0; sidx < nstat; ++sidx) {
+          double t = 0.0;
+          for (int p = 0; p < E_RPP; ++p) t += red[(sidx * E_RPP + p) * BN + tid];
+          double *dst = ep.partial + ((long long)blockIdx.x * nstat + sidx) * cols + n0 + tid;
+          *dst = (tile == (long long)blockIdx.x) ? t : *dst + t;    // first tile of this workgroup stores, later ones add
+        }
+      }
+      __syncthreads();
+    }
     RS_T(6);
   }
 #ifdef RS_EXP_TIMING
@@ -424,28 +439,14 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   }
 #endif
 
-  if (ep.mode != EPI_STORE) {
-    // workgroup reduction of the fp64 partial sums: E_RPP contributions per column
-    double *red = reinterpret_cast<double *>(smem);           // E_RPP x BN doubles <= 32 KB
+  if (ep.mode != EPI_STORE && tid < BN && n0 + tid < cols) {
+    // the finalize kernel sums `partial_blocks` rows: rows no workgroup owns read as zero (no memset launch);
+    // a workgroup without a tile zeroes its own row too
     const int nstat = (ep.mode == EPI_MASK && ep.my2) ? 3 : 2;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (s < nstat) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[e_row * BN + e_col + e] = st[s][e];
-        __syncthreads();
-        if (tid < BN) {
-          double t = 0.0;
-          for (int p = 0; p < E_RPP; ++p) t += red[p * BN + tid];
-          if (n0 + tid < cols) {
-            ep.partial[((long long)blockIdx.x * nstat + s) * cols + n0 + tid] = t;
-            // the finalize kernel sums `partial_blocks` rows: rows no workgroup owns read as zero (no memset launch)
-            for (int pb = blockIdx.x + gridDim.x; pb < ep.partial_blocks; pb += gridDim.x)
-              ep.partial[((long long)pb * nstat + s) * cols + n0 + tid] = 0.0;
-          }
-        }
-        __syncthreads();
-      }
+    for (int sidx = 0; sidx < nstat; ++sidx) {
+      if ((long long)blockIdx.x >= tiles) ep.partial[((long long)blockIdx.x * nstat + sidx) * cols + n0 + tid] = 0.0;
+      for (int pb = blockIdx.x + gridDim.x; pb < ep.partial_blocks; pb += gridDim.x)
+        ep.partial[((long long)pb * nstat + sidx) * cols + n0 + tid] = 0.0;
     }
   }
 }
