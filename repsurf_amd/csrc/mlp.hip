@@ -152,8 +152,7 @@ typedef rs_mlp_epilogue Epilogue;
 // consecutive 16 B), and the fragments of the next four k-steps are read while the 4 x CT MFMAs of the current
 // ones run.  (Reading one float per k-step right before its MFMAs exposed the ~100-cycle LDS latency twice per
 // k-step and capped the loop near 50 % of the matrix pipe.)  The weights use the same layout with n in the row role.
-constexpr int GM_PLANE_A = GM_BM * 4 + 8;          // +8 floats: the 4 planes one commit instruction hits land in different banks
-constexpr int GM_STAGE_A = 8 * GM_PLANE_A;
+template <int BM> struct AStage { static constexpr int PLANE = BM * 4 + 8; static constexpr int SIZE = 8 * PLANE; };   // +8 floats: the 4 planes one commit instruction hits land in different banks
 template <int BN> struct WStage { static constexpr int PLANE = BN * 4 + 8; static constexpr int SIZE = 8 * PLANE; };
 
 // LDS offset of element k (0..31, chunk-relative) of row r inside a stage with `plane` floats per plane
@@ -180,26 +179,33 @@ __device__ __forceinline__ void frag_store(float *stage, int plane, int k0, int 
 #define RS_T(i) do { } while (0)
 #endif
 
-template <int BN, int V, int MODE>
-__global__ void __launch_bounds__(GM_THREADS, 2)     // 2 workgroups per CU: one computes while the other stages
+// Tile = BM rows x BN columns, BM = 128 (4 waves stacked, each 32 rows x BN) or 64 (2 x 2 waves, each 32 rows x BN/2):
+// the short tile doubles the number of workgroups -- with ~400-1000 tiles of 128 rows on 256 CUs the last round of a
+// launch left a third of the chip idle -- and its 50 KB of LDS lets three workgroups share a CU.
+template <int BM, int BN, int V, int MODE>
+__global__ void __launch_bounds__(GM_THREADS, 2)     // >= 2 workgroups per CU: one computes while another stages
 gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim, int cols, RowOperand E,
                  const float *__restrict__ w, int ldw, Epilogue ep) {
   // compacted inputs carry their row count on the device (no host sync); rows_arg is then the capacity
   const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
-  constexpr int CT = BN / 32;
-  constexpr int A_ELEMS = GM_BM * GM_BK / GM_THREADS;       // 16 floats of the operand tile per thread
+  constexpr int WR = BM / 32, WC = 4 / WR;                  // waves along rows / columns of the tile
+  constexpr int CT = BN / 32 / WC;                          // 32-column MFMA tiles per wave
+  static_assert(CT >= 1, "tile too narrow for the wave layout");
+  constexpr int PLANE_A = AStage<BM>::PLANE;
+  constexpr int A_ELEMS = BM * GM_BK / GM_THREADS;          // floats of the operand tile per thread (16 / 8)
   constexpr int A_VECS = A_ELEMS / V;
   constexpr int A_TPR = GM_BK / V;                          // threads per tile row
   constexpr int A_RPP = GM_THREADS / A_TPR;                 // rows per pass
   constexpr int W_VECS = BN / 32;                           // float4 (4 k of one output column) per thread and chunk
   constexpr int PLANE_W = WStage<BN>::PLANE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *As0 = smem, *As1 = smem + GM_STAGE_A;
-  float *Ws0 = smem + 2 * GM_STAGE_A, *Ws1 = Ws0 + WStage<BN>::SIZE;
+  float *As0 = smem, *As1 = smem + AStage<BM>::SIZE;
+  float *Ws0 = smem + 2 * AStage<BM>::SIZE, *Ws1 = Ws0 + WStage<BN>::SIZE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.y * BN;
-  const long long tiles = (rows + GM_BM - 1) / GM_BM;
+  const long long tiles = (rows + BM - 1) / BM;
   const int lrow = lane & 31, lk = lane >> 5;
+  const int wave_r = wave % WR, wave_c = wave / WR;
   const int a_kq = (tid % A_TPR) * V, a_r = tid / A_TPR;
   const int w_kq = (tid & 7) * 4, w_n = tid >> 3;           // weights: 8 threads x float4 cover the 32 k of a column
   const int nchunks = (kdim + GM_BK - 1) / GM_BK;
@@ -222,7 +228,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   // 126 us against 116 us at 262144 x 128 x 128, weight gradient 410 us against 320 us.)
   auto prefetch = [&](long long r0, int k0, int part) {
     const int k = min(k0 + a_kq, kdim - V);                 // kdim % V == 0
-    const int rlast = (int)min((long long)GM_BM - 1, rows - 1 - r0);
+    const int rlast = (int)min((long long)BM - 1, rows - 1 - r0);
     if (part <= 0) op_coef<V, MODE>(E, k, true, coef);
 #pragma unroll
     for (int p = 0; p < A_VECS; ++p)
@@ -243,7 +249,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       const long long r = r0 + rl;
       float v[V];
       op_finish<V, MODE>(E, coef, araw[p], r, kok && r < rows, v);
-      frag_store<V>(As, GM_PLANE_A, a_kq, rl, v);
+      frag_store<V>(As, PLANE_A, a_kq, rl, v);
     }
     const bool wk_ok = (k0 + w_kq) < ldw;                   // [kdim, ldw) is zero in memory
 #pragma unroll
@@ -261,7 +267,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   const long long tstart = tlast;
 #endif
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const long long r0 = tile * GM_BM;
+    const long long r0 = tile * BM;
     f32x16 acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -281,8 +287,8 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       RS_T(3);
       // groups of 4 k-steps; the last chunk of a ragged K runs only the groups that hold data
       const int ngroups = (min(GM_BK, kdim - ch * GM_BK) + 7) >> 3;
-      const float *ap = As + lk * GM_PLANE_A + (wave * 32 + lrow) * 4;
-      const float *bp = Ws + lk * PLANE_W + lrow * 4;
+      const float *ap = As + lk * PLANE_A + (wave_r * 32 + lrow) * 4;
+      const float *bp = Ws + lk * PLANE_W + (wave_c * CT * 32 + lrow) * 4;
       float4 af[2], bf[2][CT];
       af[0] = *reinterpret_cast<const float4 *>(ap);
 #pragma unroll
@@ -291,7 +297,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       for (int j = 0; j < 4; ++j) {
         if (j < ngroups) {                                    // wave-uniform
           if (j + 1 < 4) {                                    // fragments of the NEXT group: in flight under this group's MFMAs
-            af[(j + 1) & 1] = *reinterpret_cast<const float4 *>(ap + (j + 1) * 2 * GM_PLANE_A);
+            af[(j + 1) & 1] = *reinterpret_cast<const float4 *>(ap + (j + 1) * 2 * PLANE_A);
 #pragma unroll
             for (int c = 0; c < CT; ++c)
               bf[(j + 1) & 1][c] = *reinterpret_cast<const float4 *>(bp + (j + 1) * 2 * PLANE_W + c * 128);
@@ -314,12 +320,12 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
     RS_T(5);
 
     // ---- epilogue.  D[i][j]: j = lane & 31, i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)  ->  Cs[row][col]
-    float *Cs = smem;                                         // 128 x BN floats (<= 64 KB)
+    float *Cs = smem;                                         // BM x BN floats (<= 64 KB)
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int i = 0; i < 16; ++i)
-        Cs[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk) * BN + c * 32 + lrow] = acc[c][i];
+        Cs[(wave_r * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk) * BN + (wave_c * CT + c) * 32 + lrow] = acc[c][i];
     __syncthreads();
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // this tile's column sums
     {
@@ -339,7 +345,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       float *out_t = ep.out + r0 * ep.ldo;                    // wave-uniform tile bases
       const float *my1_t = ep.my1 ? ep.my1 + r0 * ep.ldm1 : nullptr;
       const float *my2_t = ep.my2 ? ep.my2 + r0 * ep.ldm2 : nullptr;
-      for (int rl = e_row; rl < GM_BM; rl += E_RPP) {
+      for (int rl = e_row; rl < BM; rl += E_RPP) {
         if (r0 + rl >= rows || col >= cols) continue;
         const float4 cv = *reinterpret_cast<const float4 *>(Cs + rl * BN + e_col);
         float y[4] = {cv.x + bias[0], cv.y + bias[1], cv.z + bias[2], cv.w + bias[3]};
@@ -385,7 +391,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       // Max-pool over nsample folded into the producing GEMM: BatchNorm's scale is not known yet (its
       // statistics are still being summed), so keep the raw extremes of y per (group, column) — the
       // pooled activation is relu(scale * (scale >= 0 ? max : min) + shift), resolved by rs_pool_select.
-      constexpr int TPC = GM_THREADS / BN, RPT = GM_BM / TPC;     // threads per column, rows per thread
+      constexpr int TPC = GM_THREADS / BN, RPT = BM / TPC;        // threads per column, rows per thread
       const int c = tid % BN, part = tid / BN, col = n0 + c;
       if (col < cols) {
         const float bb = ep.bias ? ep.bias[col] : 0.f;
@@ -982,9 +988,10 @@ int env_int(const char *name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-int persistent_blocks(long long tiles, int tiles_n) {
-  static const int slots = env_int("RS_GEMM_SLOTS", 512);
-  long long want = slots / (tiles_n > 0 ? tiles_n : 1);   // ~2 workgroups per CU over the whole grid
+int persistent_blocks(long long tiles, int tiles_n, int bm) {
+  static const int slots128 = env_int("RS_GEMM_SLOTS", 512), slots64 = env_int("RS_GEMM_SLOTS64", 512);
+  const int slots = bm == 64 ? slots64 : slots128;
+  long long want = slots / (tiles_n > 0 ? tiles_n : 1);   // ~2 (tall tiles) / 3-4 (short tiles) workgroups per CU over the whole grid
   if (want < 64) want = 64;
   return (int)(tiles < want ? tiles : want);
 }
@@ -1019,11 +1026,11 @@ int check_operand(const char *who, const RowOperand *o, long long rows) {
   return RS_OK;
 }
 
-template <int BN, int V>
+template <int BM, int BN, int V>
 void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                    const float *w, int ldw, const Epilogue &ep) {
-  const size_t lds = sizeof(float) * (2 * GM_STAGE_A + 2 * WStage<BN>::SIZE);
-#define RS_G(M_) hipLaunchKernelGGL((gemm_rows_kernel<BN, V, M_>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, kdim, cols, E, w, ldw, ep)
+  const size_t lds = sizeof(float) * (2 * AStage<BM>::SIZE + 2 * WStage<BN>::SIZE);
+#define RS_G(M_) hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, V, M_>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, kdim, cols, E, w, ldw, ep)
   if (V == 1) { RS_G(-1); return; }                 // odd sizes: one generic (runtime-mode) kernel
   switch (E.mode) {
     case OPM_ID: RS_G(OPM_ID); break;
@@ -1035,12 +1042,12 @@ void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_de
   }
 #undef RS_G
 }
-template <int BN>
+template <int BM, int BN>
 void launch_gemm(int v, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                  const float *w, int ldw, const Epilogue &ep) {
-  if (v == 4) launch_gemm_m<BN, 4>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else if (v == 2) launch_gemm_m<BN, 2>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else launch_gemm_m<BN, 1>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  if (v == 4) launch_gemm_m<BM, BN, 4>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else if (v == 2) launch_gemm_m<BM, BN, 2>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else if constexpr (BM == 128) launch_gemm_m<BM, BN, 1>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);   // scalar operands: tall tile only
 }
 
 template <int WN, int WK, int TN, int TK, int VP, int VQ>
@@ -1112,21 +1119,27 @@ extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, i
     RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
     return RS_OK;
   }
-  const long long tiles = (rows + GM_BM - 1) / GM_BM;
+  const int v = pick_vec(E, kdim);
+  // tile height: 64-row tiles (2 x 2 waves) wherever the layout allows -- twice the workgroups, three per CU
+  static const int bm64_on = env_int("RS_GEMM_BM64", 1);
+  int bm = (bm64_on && cols > 32 && v >= 2 && ep.pool_ns == 0) ? 64 : GM_BM;
+  long long tiles = (rows + bm - 1) / bm;
   int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
-  static const int bn_small = env_int("RS_GEMM_BN64_BELOW", 256);
-  if (bn == 128 && tiles * rs_cdiv(cols, 128) < bn_small && ep.pool_ns == 0) bn = 64;   // few rows (group_all stage): 2x the workgroups
+  static const int bn_small = env_int("RS_GEMM_BN64_BELOW", 256), bn_small64 = env_int("RS_GEMM_BN64_BELOW64", 512);
+  if (bn == 128 && tiles * rs_cdiv(cols, 128) < (bm == 64 ? bn_small64 : bn_small) && ep.pool_ns == 0) bn = 64;   // few rows (group_all stage): 2x the workgroups
   static const int bn32_below = env_int("RS_GEMM_BN32_BELOW", 256);
-  if (bn == 64 && cols > 64 && tiles * rs_cdiv(cols, 64) < bn32_below && ep.pool_ns == 0) bn = 32;   // still under one workgroup per CU: 4096 x 512 -> 256 runs 22 us instead of 30
+  if (bm == GM_BM && bn == 64 && cols > 64 && tiles * rs_cdiv(cols, 64) < bn32_below && ep.pool_ns == 0) bn = 32;   // still under one workgroup per CU: 4096 x 512 -> 256 runs 22 us instead of 30
   const int tiles_n = rs_cdiv(cols, bn);
-  int gx = persistent_blocks(tiles, tiles_n);
+  int gx = persistent_blocks(tiles, tiles_n, bm);
   if (epi_mode != EPI_STORE) gx = gx < ep.partial_blocks ? gx : ep.partial_blocks;
   const dim3 grid(gx, tiles_n);
   hipStream_t st = (hipStream_t)stream;
-  const int v = pick_vec(E, kdim);
-  if (bn == 32) launch_gemm<32>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else if (bn == 64) launch_gemm<64>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else launch_gemm<128>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  if (bm == 64) {
+    if (bn == 64) launch_gemm<64, 64>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+    else launch_gemm<64, 128>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  } else if (bn == 32) launch_gemm<128, 32>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else if (bn == 64) launch_gemm<128, 64>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else launch_gemm<128, 128>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
   RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
   return RS_OK;
 }

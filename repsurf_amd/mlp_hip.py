@@ -25,7 +25,7 @@ OP_ID, OP_RELU1, OP_RELU2, OP_AFF2, OP_POOLED, OP_BCAST = range(6)
 EPI_STORE, EPI_STATS, EPI_MASK = range(3)
 FUSED_UMBRELLA = True     # 10-channel constructor MLP through csrc/umbrella_mlp.hip (False: generic row-GEMM path)
 DEBUG = None              # set to a dict to capture backward intermediates (tools/mlp_debug.py)
-PARTIAL_BLOCKS = 512      # rows of the BatchNorm partial-sum buffers (>= persistent workgroups)
+PARTIAL_BLOCKS = int(os.environ.get("REPSURF_PARTIAL_BLOCKS", "512"))      # rows of the BatchNorm partial-sum buffers (>= persistent workgroups)
 WGRAD_CHUNKS = int(os.environ.get("REPSURF_WGRAD_CHUNKS", "512"))        # workgroups of one weight-gradient launch (row slabs x output blocks)
 WGRAD_MIN_ROWS = int(os.environ.get("REPSURF_WGRAD_MIN_ROWS", "128"))   # rows per row-workgroup of the weight gradient, at least
 
@@ -272,10 +272,10 @@ def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None):
     return dw
 
 
-def bwd_coeffs(c, rows, part, nstat, which, vec, device):
-    """BN backward sums -> (p, q, r, dgamma, dbeta)."""
+def bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk=None):
+    """BN backward sums (`nblk` partial rows, default PARTIAL_BLOCKS) -> (p, q, r, dgamma, dbeta)."""
     buf = torch.empty((5, c), dtype=torch.float32, device=device)
-    _lib.call("rs_bn_backward_finalize", c, rows, PARTIAL_BLOCKS, nstat, which, part.data_ptr(), _ptr(vec.scale),
+    _lib.call("rs_bn_backward_finalize", c, rows, PARTIAL_BLOCKS if nblk is None else nblk, nstat, which, part.data_ptr(), _ptr(vec.scale),
               _ptr(vec.mean), _ptr(vec.invstd), _ptr(buf[0]), _ptr(buf[1]), _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]),
               _stream())
     return buf[0], buf[1], buf[2], buf[3], buf[4]
@@ -655,10 +655,10 @@ class _UmbrellaFused(Function):
             _lib.call("rs_reduce_partials", UMB_BLOCKS, 110, _ptr(dwp), _ptr(res[slot]), _stream())
 
         run(3, 2)
-        p1, q1, r1, g_g1, g_b1 = bwd_coeffs(10, rows, part, 2, 1, v1, dev)
+        p1, q1, r1, g_g1, g_b1 = bwd_coeffs(10, rows, part, 2, 1, v1, dev, UMB_BLOCKS)
         desc.c1 = _ptr(p1)
         run(4, 1)
-        p0, q0, r0, g_g0, g_b0 = bwd_coeffs(10, rows, part, 2, 1, v0, dev)
+        p0, q0, r0, g_g0, g_b0 = bwd_coeffs(10, rows, part, 2, 1, v0, dev, UMB_BLOCKS)
         desc.c0 = _ptr(p0)
         run(5, 0)
         shp = meta["shapes"]
