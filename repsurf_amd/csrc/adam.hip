@@ -46,6 +46,20 @@ adam_kernel(AdamTable T, const double *__restrict__ hyper, int *__restrict__ ste
   float *__restrict__ m = T.m[ti];
   float *__restrict__ v = T.v[ti];
 
+  // the operands are requested first: the bias-correction powers below (fp64, ~300 instructions) run under the loads
+  constexpr int U = AD_CHUNK / (AD_THREADS * 4);
+  const bool vec = ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0);
+  float4 pv[U], gv[U], mv[U], vv[U];
+  bool full[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int e = base + (u * AD_THREADS + (int)threadIdx.x) * 4;
+    full[u] = vec && e + 4 <= n;
+    if (full[u]) {
+      pv[u] = *reinterpret_cast<const float4 *>(p + e); gv[u] = *reinterpret_cast<const float4 *>(g + e);
+      mv[u] = *reinterpret_cast<const float4 *>(m + e); vv[u] = *reinterpret_cast<const float4 *>(v + e);
+    }
+  }
   // hyper-parameters are doubles, like the Python floats the framework derives its scalars from: 1 - beta2 formed in
   // fp32 from a rounded beta2 = 0.999f is off by 5e-5 relative.
   const double lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2];
@@ -54,27 +68,23 @@ adam_kernel(AdamTable T, const double *__restrict__ hyper, int *__restrict__ ste
   const int t = *step + 1;                          // this update's step number (1-based)
   const float step_size = (float)(lr / (1.0 - pow(beta1, (double)t)));
   const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
-
-  const bool vec = ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0);
 #pragma unroll
-  for (int u = 0; u < AD_CHUNK / (AD_THREADS * 4); ++u) {
+  for (int u = 0; u < U; ++u) {
     const int e = base + (u * AD_THREADS + (int)threadIdx.x) * 4;
     if (e >= n) break;
-    if (vec && e + 4 <= n) {
-      float4 pv = *reinterpret_cast<const float4 *>(p + e), gv = *reinterpret_cast<const float4 *>(g + e);
-      float4 mv = *reinterpret_cast<const float4 *>(m + e), vv = *reinterpret_cast<const float4 *>(v + e);
-      adam_one(pv.x, gv.x, mv.x, vv.x, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
-      adam_one(pv.y, gv.y, mv.y, vv.y, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
-      adam_one(pv.z, gv.z, mv.z, vv.z, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
-      adam_one(pv.w, gv.w, mv.w, vv.w, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
-      *reinterpret_cast<float4 *>(p + e) = pv;
-      *reinterpret_cast<float4 *>(m + e) = mv;
-      *reinterpret_cast<float4 *>(v + e) = vv;
+    if (full[u]) {
+      adam_one(pv[u].x, gv[u].x, mv[u].x, vv[u].x, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
+      adam_one(pv[u].y, gv[u].y, mv[u].y, vv[u].y, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
+      adam_one(pv[u].z, gv[u].z, mv[u].z, vv[u].z, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
+      adam_one(pv[u].w, gv[u].w, mv[u].w, vv[u].w, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
+      *reinterpret_cast<float4 *>(p + e) = pv[u];
+      *reinterpret_cast<float4 *>(m + e) = mv[u];
+      *reinterpret_cast<float4 *>(v + e) = vv[u];
     } else {
       for (int i = e; i < min(e + 4, n); ++i) {
-        float pv = p[i], mv = m[i], vv = v[i];
-        adam_one(pv, g[i], mv, vv, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
-        p[i] = pv; m[i] = mv; v[i] = vv;
+        float ps = p[i], ms = m[i], vs = v[i];
+        adam_one(ps, g[i], ms, vs, wd, omb1, b2, omb2, eps, step_size, bc2_sqrt);
+        p[i] = ps; m[i] = ms; v[i] = vs;
       }
     }
   }

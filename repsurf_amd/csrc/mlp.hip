@@ -792,6 +792,13 @@ reduce_partials_kernel(int chunks, long long n, const float *__restrict__ partia
     float s = 0.f;
     if (e < n) {
       int c = sl;
+      for (; c + 120 < chunks; c += 128) {        // 16 loads in flight: a 512-chunk reduction is 4 latencies deep, not 16
+        float a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = partial[(long long)(c + 8 * u) * n + e];
+        s += (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+             (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
+      }
       for (; c + 24 < chunks; c += 32) {
         const float a0 = partial[(long long)c * n + e], a1 = partial[(long long)(c + 8) * n + e];
         const float a2 = partial[(long long)(c + 16) * n + e], a3 = partial[(long long)(c + 24) * n + e];
@@ -824,15 +831,20 @@ __device__ __forceinline__ void reduce_stat_rows(int c, int nblk, int nstat, con
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = 0.0;
   if (ch < c)
-    for (int b = sl; b < nblk; b += 128) {     // 4 partial rows per trip: the loads are independent and overlap
-      double v[4][NS];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
+    for (int b = sl; b < nblk; b += 512) {     // 16 partial rows per trip, all loads in flight together: the kernel is
+      double v[16][NS];                         // one memory latency deep at the usual 512 rows (it sits between every
+#pragma unroll                                  // two GEMMs of a stack, so its latency is on the step's critical path)
+      for (int u = 0; u < 16; ++u)
 #pragma unroll
         for (int s = 0; s < NS; ++s)
           v[u][s] = (b + 32 * u < nblk) ? partial[((long long)(b + 32 * u) * nstat + which[s]) * c + ch] : 0.0;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) acc[s] += (v[0][s] + v[1][s]) + (v[2][s] + v[3][s]);
+      for (int s = 0; s < NS; ++s) {
+        double t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = (v[4 * q][s] + v[4 * q + 1][s]) + (v[4 * q + 2][s] + v[4 * q + 3][s]);
+        acc[s] += (t[0] + t[1]) + (t[2] + t[3]);
+      }
     }
 #pragma unroll
   for (int s = 0; s < NS; ++s) red[sl][ex][s] = acc[s];

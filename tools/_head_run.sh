@@ -1,3 +1,4 @@
-for cfg in "RS_GEMM_BM64=1" "RS_GEMM_SLOTS64=768 REPSURF_PARTIAL_BLOCKS=768" "RS_GEMM_BN64_BELOW64=256" "RS_GEMM_BN64_BELOW64=1024" "RS_GEMM_SLOTS=768 RS_GEMM_SLOTS64=768 REPSURF_PARTIAL_BLOCKS=768"; do
+python -m pytest tests/test_mlp_gpu.py tests/test_optim_gpu.py -x -q -m gpu 2>&1 | tail -2
+for cfg in "A=1" "REPSURF_WGRAD_CHUNKS=256" ; do
   env $cfg python bench.py --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', d['value'], d['ms_per_step'])"
 done
