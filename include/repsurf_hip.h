@@ -295,7 +295,7 @@ int rs_pool_sum(long long groups, int nsample, int c, const float *y, float *out
 /* Zero-padded copies of up to RS_PACK_MAX conv weights (cout, cin) in one launch, in the n-major layout
  * rs_mlp_gemm_rows reads:  transpose[e] = 0: dst[j*ld + k] = src[j*cin + k] (0 for cin <= k < ld) -- forward operand
  * when cin % 4 != 0;  transpose[e] = 1: dst[k*ld + j] = src[j*cin + k] (0 for cout <= j < ld) -- operand of dY . W. */
-#define RS_PACK_MAX 8
+#define RS_PACK_MAX 32
 typedef struct rs_pack_weights_args {
   const float *src[RS_PACK_MAX]; float *dst[RS_PACK_MAX];
   int cout[RS_PACK_MAX], cin[RS_PACK_MAX], ld[RS_PACK_MAX], transpose[RS_PACK_MAX];

@@ -52,9 +52,18 @@ class UmbrellaClassifier(nn.Module):
         with _mlp.deferred_counters():
             return self._forward(points)
 
+    def _sa_convs(self):
+        out = []
+        for name in self._stage_names:
+            sa = getattr(self, name)
+            out += [sa.mlp_l0, sa.mlp_f0] + list(sa.mlp_convs)
+        return out
+
     def _forward(self, points):
         center = points[:, :3, :]
         plan = None
+        if points.is_cuda and self.training:
+            _mlp.prepack(self._sa_convs())      # padded / transposed weight copies of all stages: one launch
         if self.overlap_geometry:
             # same CPU-generator order as the reference: the constructor's flip first, then one FPS start per stage
             sc = self.surface_constructor

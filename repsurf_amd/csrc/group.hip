@@ -191,6 +191,54 @@ exclusive_scan_kernel(int n, const int *__restrict__ in, int *__restrict__ out) 
   if (t == 1023) out[n] = part[1023];
 }
 
+// n <= 16384: every thread owns 16 consecutive counts (four 16-byte loads issued together), scans them in registers,
+// the wave scans its 64 totals with shuffles and the 16 wave totals go through LDS -- two barriers instead of the
+// twenty of the generic kernel, one memory latency instead of sixteen (22 us -> ~3 us at 16384 counts; the scan sits
+// between ball query and the first grouped GEMM on the critical path).
+__global__ void __launch_bounds__(1024)
+exclusive_scan16_kernel(int n, const int *__restrict__ in, int *__restrict__ out) {
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, base = t * 16;
+  int v[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = base + 4 * q;
+    if (i + 4 <= n) {
+      const int4 x = *reinterpret_cast<const int4 *>(in + i);
+      v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * q + e] = (i + e < n) ? in[i + e] : 0;
+    }
+  }
+  int tot = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { const int x = v[e]; v[e] = tot; tot += x; }     // exclusive inside the thread
+  int inc = tot;                                                                  // inclusive scan over the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { const int x = wsum[w]; if (w < wave) wbase += x; total += x; }
+  const int pre = wbase + inc - tot;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = base + 4 * q;
+    if (i + 4 <= n) {
+      *reinterpret_cast<int4 *>(out + i) = make_int4(pre + v[4 * q], pre + v[4 * q + 1], pre + v[4 * q + 2], pre + v[4 * q + 3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (i + e < n) out[i + e] = pre + v[4 * q + e];
+    }
+  }
+  if (t == 0) out[n] = total;
+}
+
 __global__ void __launch_bounds__(GR_THREADS)
 compact_index_kernel(long long groups, int nsample, int groups_per_cloud, int n, const int *__restrict__ idx,
                      const int *__restrict__ cnt, const int *__restrict__ offsets, int *__restrict__ grp,
@@ -365,7 +413,10 @@ extern "C" int rs_group_all_features(int b, int n, int cn, int cf, int polar, co
 extern "C" int rs_exclusive_scan(int n, const int *in, int *out, void *stream) {
   RS_REQUIRE(n >= 0, "rs_exclusive_scan: negative size");
   RS_REQUIRE(in && out, "rs_exclusive_scan: null pointer");
-  hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, in, out);
+  if (n <= 16384 && (((size_t)in | (size_t)out) & 15) == 0)
+    hipLaunchKernelGGL(exclusive_scan16_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, in, out);
+  else
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, in, out);
   RS_CHECK_LAUNCH("rs_exclusive_scan");
   return RS_OK;
 }

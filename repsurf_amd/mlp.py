@@ -122,6 +122,13 @@ def umbrella_mlp2(x, mlps, group):
     return mlp_hip.umbrella_mlp2(x, mlps, group)
 
 
+def prepack(convs):
+    """One launch that makes every weight copy the SA stacks on these 1x1 convolutions need in this step."""
+    if BACKEND != "torch":
+        from . import mlp_hip
+        mlp_hip.prepack(convs)
+
+
 def deferred_counters():
     """Context in which the BatchNorm `num_batches_tracked` updates of all stacks are batched into one launch."""
     if BACKEND == "torch":

@@ -138,7 +138,7 @@ def _pad4(w):
     return w if pad == 0 else torch.nn.functional.pad(w, (0, pad))
 
 
-PACK_MAX = 8
+PACK_MAX = 32
 
 
 class PackArgs(ctypes.Structure):            # rs_pack_weights_args
@@ -146,12 +146,11 @@ class PackArgs(ctypes.Structure):            # rs_pack_weights_args
                 ("ld", c_int * PACK_MAX), ("transpose", c_int * PACK_MAX), ("n", c_int)]
 
 
-def pack_weights(w2ds, transpose, device):
-    """Zero-padded copies of several (cout, cin) weights in the n-major layout the row GEMM reads, ONE launch per 8:
+def _pack_items(items, device):
+    """items = [(w2d (cout, cin), transpose)] -> zero-padded n-major copies, ONE launch per 32 of them:
     transpose=False -> (cout, pad4(cin)) for the forward GEMM, transpose=True -> (cin, pad4(cout)) for dY . W."""
-    tr = int(bool(transpose))
-    inner = [w.shape[0] if tr else w.shape[1] for w in w2ds]
-    outer = [w.shape[1] if tr else w.shape[0] for w in w2ds]
+    inner = [w.shape[0] if tr else w.shape[1] for w, tr in items]
+    outer = [w.shape[1] if tr else w.shape[0] for w, tr in items]
     lds = [(-(-n // 4)) * 4 for n in inner]
     sizes = [o * ld for o, ld in zip(outer, lds)]
     flat = torch.empty((sum(-(-sz // 4) * 4 for sz in sizes),), dtype=torch.float32, device=device)
@@ -159,21 +158,65 @@ def pack_weights(w2ds, transpose, device):
     for o, ld, sz in zip(outer, lds, sizes):
         outs.append(flat[off:off + sz].view(o, ld))
         off += -(-sz // 4) * 4                      # keep every copy 16-byte aligned
-    for i in range(0, len(w2ds), PACK_MAX):
+    for i in range(0, len(items), PACK_MAX):
         a = PackArgs()
-        chunk = list(zip(w2ds[i:i + PACK_MAX], outs[i:i + PACK_MAX], lds[i:i + PACK_MAX]))
-        for j, (w, o, ld) in enumerate(chunk):
+        chunk = list(zip(items[i:i + PACK_MAX], outs[i:i + PACK_MAX], lds[i:i + PACK_MAX]))
+        for j, ((w, tr), o, ld) in enumerate(chunk):
             a.src[j], a.dst[j] = w.data_ptr(), o.data_ptr()
-            a.cout[j], a.cin[j], a.ld[j], a.transpose[j] = w.shape[0], w.shape[1], ld, tr
+            a.cout[j], a.cin[j], a.ld[j], a.transpose[j] = w.shape[0], w.shape[1], ld, int(bool(tr))
         a.n = len(chunk)
         _lib.call("rs_pack_weights", ctypes.byref(a), _stream())
+    return outs
+
+
+# Copies made ahead of time for a whole model (prepack): (weight address, transposed) -> (weight version, copy).
+# The six per-stack pack launches of a step (three forward, three backward) become one at the top of the forward.
+_prepacked = {}
+PREPACK = os.environ.get("REPSURF_PREPACK", "1") != "0"
+
+
+def _needs_copy(w):
+    return bool(w.shape[1] % 4 or w.data_ptr() % 16)
+
+
+def prepack(convs):
+    """Pack, in one launch, what the SA stacks built on these 1x1 convolutions will ask for in this step: the padded
+    forward copy of the weights whose cin is not a multiple of 4, and the transposed copy of every weight."""
+    items = []
+    if not PREPACK:
+        return
+    for conv in convs:
+        w = _w2d(conv.weight)
+        if _needs_copy(w):
+            items.append((w, False))
+        items.append((w, True))
+    if not items:
+        return
+    for (w, tr), out in zip(items, _pack_items(items, items[0][0].device)):
+        _prepacked[(w.data_ptr(), bool(tr))] = (w._version, out)
+
+
+def pack_weights(w2ds, transpose, device):
+    """Padded (transpose=False) / transposed (transpose=True) copies of several weights; copies `prepack` made of the
+    same, unchanged weights are reused, the rest share one launch."""
+    tr = bool(transpose)
+    outs, miss = [None] * len(w2ds), []
+    for i, w in enumerate(w2ds):
+        hit = _prepacked.get((w.data_ptr(), tr))
+        if hit is not None and hit[0] == w._version and hit[1].device == w.device:
+            outs[i] = hit[1]
+        else:
+            miss.append(i)
+    if miss:
+        for i, c in zip(miss, _pack_items([(w2ds[i], tr) for i in miss], device)):
+            outs[i] = c
     return outs
 
 
 def fwd_weights(w2ds, device):
     """Forward operands: the conv weights themselves where cin % 4 == 0 (and the base is 16-byte aligned), one batched
     padded copy for the others (the first-layer branches with 6 / 10 / 138 / 266 input channels)."""
-    need = [i for i, w in enumerate(w2ds) if w.shape[1] % 4 or w.data_ptr() % 16]
+    need = [i for i, w in enumerate(w2ds) if _needs_copy(w)]
     outs = list(w2ds)
     if need:
         for i, c in zip(need, pack_weights([w2ds[i] for i in need], False, device)):

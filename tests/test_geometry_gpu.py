@@ -267,3 +267,17 @@ print("grid variant ok")
     env = dict(os.environ, RS_BALLQUERY_GRID="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "grid variant ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 63, 4096, 16383, 16384, 20000])
+def test_exclusive_scan_matches_cumsum(n):
+    """offsets of the compacted groups (rs_exclusive_scan): out[i] = sum_{j<i} in[j], out[n] = total; bit-exact."""
+    from repsurf_amd import _lib
+    g = torch.Generator().manual_seed(n)
+    cnt = torch.randint(0, 65, (n,), generator=g, dtype=torch.int32).cuda()
+    out = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+    _lib.call("rs_exclusive_scan", n, cnt.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    ref = torch.zeros(n + 1, dtype=torch.int64)
+    ref[1:] = torch.cumsum(cnt.cpu().to(torch.int64), 0)
+    assert torch.equal(out.cpu().to(torch.int64), ref)

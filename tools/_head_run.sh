@@ -1,4 +1,3 @@
-python -m pytest tests/test_mlp_gpu.py tests/test_optim_gpu.py -x -q -m gpu 2>&1 | tail -2
-for cfg in "A=1" "REPSURF_WGRAD_CHUNKS=256" ; do
-  env $cfg python bench.py --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', d['value'], d['ms_per_step'])"
+for cfg in "REPSURF_PREPACK=1" "REPSURF_PREPACK=0" "REPSURF_PREPACK=1" "REPSURF_PREPACK=0"; do
+  env $cfg python bench.py --no-cpu-baseline --steps 40 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', d['value'], d['ms_per_step'])"
 done
