@@ -13,7 +13,8 @@ d = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(d, "pmc_*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-80:] + " grid=" + r["Grid_Size"]
+        nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        k = nm.split("(")[0][-80:] + " grid=" + r["Grid_Size"]
         a = agg[k][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"] or 0)
         a[1] += 1
