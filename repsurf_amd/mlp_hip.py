@@ -643,6 +643,8 @@ class UmbrellaMLPDesc(ctypes.Structure):      # rs_umbrella_mlp
 
 
 UMB_BLOCKS = 512
+# backward passes reduce 110 weight-gradient sums per workgroup: fewer, longer workgroups amortise that reduction
+UMB_BLOCKS_BWD = int(os.environ.get("REPSURF_UMB_BLOCKS_BWD", "256"))
 
 
 class _UmbrellaFused(Function):
@@ -689,19 +691,19 @@ class _UmbrellaFused(Function):
             dout = dout * (1.0 / group)
         desc = UmbrellaMLPDesc(x=_ptr(x), rows=rows, group=group, w0=_ptr(s["w0"]), w1=_ptr(s["w1"]), b1=_ptr(s["c1"]),
                                w2=_ptr(s["w2"]), b2=_ptr(s["c2"]), bn0=_ptr(v0.scale), bn1=_ptr(v1.scale), dout=_ptr(dout))
-        part = torch.empty((UMB_BLOCKS, 2, 10), dtype=torch.float64, device=dev)
-        dwp = torch.empty((UMB_BLOCKS, 110), dtype=torch.float32, device=dev)
+        part = torch.empty((UMB_BLOCKS_BWD, 2, 10), dtype=torch.float64, device=dev)
+        dwp = torch.empty((UMB_BLOCKS_BWD, 110), dtype=torch.float32, device=dev)
         res = torch.empty((3, 110), dtype=torch.float32, device=dev)
 
         def run(pas, slot):
-            _lib.call("rs_umbrella_mlp_pass", pas, ctypes.byref(desc), 1.0, None, part.data_ptr(), _ptr(dwp), UMB_BLOCKS, _stream())
-            _lib.call("rs_reduce_partials", UMB_BLOCKS, 110, _ptr(dwp), _ptr(res[slot]), _stream())
+            _lib.call("rs_umbrella_mlp_pass", pas, ctypes.byref(desc), 1.0, None, part.data_ptr(), _ptr(dwp), UMB_BLOCKS_BWD, _stream())
+            _lib.call("rs_reduce_partials", UMB_BLOCKS_BWD, 110, _ptr(dwp), _ptr(res[slot]), _stream())
 
         run(3, 2)
-        p1, q1, r1, g_g1, g_b1 = bwd_coeffs(10, rows, part, 2, 1, v1, dev, UMB_BLOCKS)
+        p1, q1, r1, g_g1, g_b1 = bwd_coeffs(10, rows, part, 2, 1, v1, dev, UMB_BLOCKS_BWD)
         desc.c1 = _ptr(p1)
         run(4, 1)
-        p0, q0, r0, g_g0, g_b0 = bwd_coeffs(10, rows, part, 2, 1, v0, dev, UMB_BLOCKS)
+        p0, q0, r0, g_g0, g_b0 = bwd_coeffs(10, rows, part, 2, 1, v0, dev, UMB_BLOCKS_BWD)
         desc.c0 = _ptr(p0)
         run(5, 0)
         shp = meta["shapes"]
