@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--model", default="repsurf_ssg_umb")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N=1 graph mode: compute each batch's geometry inside its own step instead of under the previous "
+                         "batch's network (repsurf_amd.graph.PipelinedStep)")
     ap.add_argument("--no-optim", action="store_true", help="stop the step at backward (BASELINE.md definition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events")
@@ -176,8 +179,13 @@ def main():
         # the wrong stream and the capture faults).  Per-launch HIP events cannot be recorded inside a
         # replayed graph, so the kernel timings for `roofline` come from a short eager pass on a copy of
         # the model AFTER the timed region; the throughput comes from graph replay of the identical step.
-        from repsurf_amd.graph import GraphedStep, ShardedGraphedStep
-        if world == 1:
+        from repsurf_amd.graph import GraphedStep, PipelinedStep, ShardedGraphedStep
+        if world == 1 and not args.no_pipeline and hasattr(net, "geometry"):
+            # every replay = geometry of batch s+1 (side stream) + network of batch s; the loader's next batch is the
+            # same synthetic batch here (both input buffers hold it)
+            step = PipelinedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
+            mode = "hipgraph, geometry of batch s+1 under the network of batch s"
+        elif world == 1:
             step = GraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
             mode = "hipgraph"
         else:

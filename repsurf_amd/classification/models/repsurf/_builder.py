@@ -18,6 +18,33 @@ from repsurf_amd.geometry import GeometryPlan
 REPSURF_CHANNEL = 10
 
 
+class GeoState:
+    """What a forward needs that depends on the coordinates only -- the constructor's fan features and, per sampling
+    stage, FPS picks, their coordinates, ball-query indices and distinct-neighbour counts.  `UmbrellaClassifier.geometry`
+    computes it; a training loop that knows its next batch can do that while the previous batch is still in backward
+    (repsurf_amd.graph.PipelinedStep)."""
+    __slots__ = ("feat", "stages")
+
+    def __init__(self, feat, stages):
+        self.feat, self.stages = feat, stages
+
+    def tensors(self):
+        out = [self.feat]
+        for g in self.stages:
+            out += [g.fps_idx, g.new_center, g.idx, g.cnt]
+        return out
+
+    def clone(self):
+        from repsurf_amd.geometry import StageGeometry
+        return GeoState(self.feat.clone(), [StageGeometry(g.fps_idx.clone(), g.new_center.clone(), g.idx.clone(),
+                                                          g.cnt.clone()) for g in self.stages])
+
+    def copy_(self, other):
+        for d, s_ in zip(self.tensors(), other.tensors()):
+            d.copy_(s_)
+        return self
+
+
 class UmbrellaClassifier(nn.Module):
     def __init__(self, args, stages, head_in):
         """stages: list of dicts(npoint, radius, nsample, mlp); feature widths chain automatically."""
@@ -48,9 +75,21 @@ class UmbrellaClassifier(nn.Module):
             nn.Linear(512, 256), nn.BatchNorm1d(256), nn.ReLU(True), nn.Dropout(0.4),
             nn.Linear(256, args.num_class))
 
-    def forward(self, points):
+    def forward(self, points, geo=None):
+        """points (B, C, N) -> log-probabilities; geo: `self.geometry(points)` computed ahead of time (optional)."""
         with _mlp.deferred_counters():
-            return self._forward(points)
+            return self._forward(points, geo)
+
+    def geometry(self, points, fork=True):
+        """The coordinate-only work of a forward (no learned parameter is read): constructor kNN + fan features on the
+        current stream, FPS / ball query of every stage on the side stream.  Draws the reference's CPU-generator numbers
+        in the reference's order (constructor flip, then one FPS start per stage)."""
+        center = points[:, :3, :]
+        sc = self.surface_constructor
+        flip = rng.draw("flip", center.shape[0], 2, center.device) if sc.random_inv else None
+        plan = GeometryPlan(center.permute(0, 2, 1).contiguous(), self._sampling, fork=fork)
+        feat = sc.features(center, flip)
+        return GeoState(feat, [plan.stage(i) for i in range(len(self._sampling))])
 
     def _sa_convs(self):
         out = []
@@ -59,12 +98,14 @@ class UmbrellaClassifier(nn.Module):
             out += [sa.mlp_l0, sa.mlp_f0] + list(sa.mlp_convs)
         return out
 
-    def _forward(self, points):
+    def _forward(self, points, geo=None):
         center = points[:, :3, :]
         plan = None
         if points.is_cuda and self.training:
             _mlp.prepack(self._sa_convs())      # padded / transposed weight copies of all stages: one launch
-        if self.overlap_geometry:
+        if geo is not None:
+            normal = self.surface_constructor(center, feat=geo.feat)
+        elif self.overlap_geometry:
             # same CPU-generator order as the reference: the constructor's flip first, then one FPS start per stage
             sc = self.surface_constructor
             flip = rng.draw("flip", center.shape[0], 2, center.device) if sc.random_inv else None
@@ -74,8 +115,13 @@ class UmbrellaClassifier(nn.Module):
             normal = self.surface_constructor(center)
         feature = None
         for i, name in enumerate(self._stage_names):
-            geo = plan.stage(i) if (plan is not None and i < len(self._sampling)) else None
-            center, normal, feature = getattr(self, name)(center, normal, feature, geometry=geo)
+            if i >= len(self._sampling):
+                sg = None
+            elif geo is not None:
+                sg = geo.stages[i]
+            else:
+                sg = plan.stage(i) if plan is not None else None
+            center, normal, feature = getattr(self, name)(center, normal, feature, geometry=sg)
         x = feature.reshape(-1, self.head_in)
         if _head.usable(self.classfier, x):            # training batches of <= 64 clouds: 3 fused launches
             return _head.classifier_logprobs(self.classfier, x)

@@ -186,12 +186,19 @@ class UmbrellaSurfaceConstructor(nn.Module):
             nn.Conv2d(in_channel, in_channel, 1, bias=True),
         )
 
-    def forward(self, center, flip=None):
+    def features(self, center, flip=None):
+        """The weight-free part: kNN ring, fan triangles, 10 geometric channels -> (B,N,k-1,10) (:276-293)."""
         xyz = center.permute(0, 2, 1).contiguous()
-        b, n, _ = xyz.shape
+        b = xyz.shape[0]
         if self.random_inv and flip is None:   # per-cloud sign, CPU generator, same call as recons_utils.py:50
             flip = rng.draw("flip", b, 2, xyz.device)
-        feat = ops.umbrella_features(xyz, self.k, flip)           # (B,N,k-1,10) = [centre, polar, normal, pos]
+        return ops.umbrella_features(xyz, self.k, flip)           # [centre, polar, normal, pos]
+
+    def forward(self, center, flip=None, feat=None):
+        """feat: the output of `features` for these points when it was computed ahead of time."""
+        if feat is None:
+            feat = self.features(center, flip)
+        b, n = feat.shape[0], feat.shape[1]
         if not self.return_dist:
             feat = feat[..., :9]
         g = self.k - 1

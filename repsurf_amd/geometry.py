@@ -32,11 +32,12 @@ class GeometryPlan:
     """plan = GeometryPlan(xyz (B,N,3), [(npoint, radius, nsample), ...]); plan.stage(i) joins the side stream
     on first use and returns that stage's (fps_idx, new_center, ball idx)."""
 
-    def __init__(self, xyz, stages):
+    def __init__(self, xyz, stages, fork=True):
+        """fork=False: everything on the current stream (the caller already runs this off the critical path)."""
         self.stages = []
         self.events = []
         self.main = torch.cuda.current_stream()
-        side = _side_stream(xyz.device)
+        side = _side_stream(xyz.device) if fork else self.main
         b, dev = xyz.shape[0], xyz.device
         # FPS start indices are drawn here, in stage order — after the constructor's flip, which the
         # caller draws first — so the CPU-generator sequence is the reference's.
@@ -49,7 +50,8 @@ class GeometryPlan:
                                              torch.empty((b, npoint, 3), dtype=torch.float32, device=dev),
                                              torch.empty((b, npoint, nsample), dtype=torch.int32, device=dev),
                                              torch.empty((b, npoint), dtype=torch.int32, device=dev)))
-        side.wait_stream(self.main)
+        if fork:
+            side.wait_stream(self.main)
         with torch.cuda.stream(side):
             st_ptr = side.cuda_stream
             center, n = xyz, xyz.shape[1]
@@ -62,9 +64,10 @@ class GeometryPlan:
                 _lib.call("rs_ballquery", b, n, npoint, r2, nsample, g.new_center.data_ptr(), center.data_ptr(),
                           g.idx.data_ptr(), g.cnt.data_ptr(), st_ptr)
                 center, n = g.new_center, npoint
-                self.events.append(side.record_event())      # stage i is usable as soon as ITS kernels are done
+                if fork:
+                    self.events.append(side.record_event())      # stage i is usable as soon as ITS kernels are done
         self.keep = (xyz, starts)
-        self.joined = [False] * len(self.stages)
+        self.joined = [not fork] * len(self.stages)
 
     @staticmethod
     def _sizes(n, stages):

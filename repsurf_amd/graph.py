@@ -7,6 +7,8 @@ stream it is handed, and the only host work inside a forward — the reference's
 draws — is hoisted into `rng.StaticDraws` buffers that are refilled before each replay.  So the step
 is captured once (`torch.cuda.CUDAGraph` = hipGraph on ROCm) and replayed.
 """
+import os
+
 import torch
 
 from . import head as _head
@@ -53,6 +55,98 @@ class GraphedStep:
             self.optimizer.sync_hyper()    # learning-rate schedule -> device (repsurf_amd.optim.Adam)
         self.graph.replay()
         return self.loss
+
+
+class PipelinedStep:
+    """Graphed training step with the NEXT batch's geometry computed under the CURRENT batch's network.
+
+    FPS (a 511-pick latency chain on 32 of 256 CUs), ball query and the constructor's kNN / fan features read nothing
+    but coordinates, and they head the step: ~0.26 ms during which the GEMM stack cannot start.  A training loop has
+    its next batch in hand (the loader runs ahead), so one replay does
+        main stream :  forward(batch s, geometry from the previous replay) -> loss -> backward -> optimizer
+        side stream :  geometry(batch s+1)  ->  copied into the other state set
+    and the two state sets / input buffers alternate between two captured graphs.  Every replay still performs one
+    complete geometry pass and one complete network pass; results are those of GraphedStep step for step (the CPU-
+    generator draws are requested in the same order, one step earlier).
+
+        step = PipelinedStep(net, criterion, optimizer, points0, label0)     # geometry of batch 0 runs here
+        loss0 = step(points1, label1)        # trains on batch 0, prepares batch 1
+        loss1 = step(points2, label2)        # trains on batch 1, prepares batch 2 ...
+    `net` must offer `geometry(points)` and `forward(points, geo=...)` (classification models of this package)."""
+
+    def __init__(self, net, criterion, optimizer, points, label, warmup=3):
+        self.net, self.criterion, self.optimizer = net, criterion, optimizer
+        dev = label.device
+        self.points = [points.clone(), points.clone()]
+        self.label = [label.clone(), label.clone()]
+        self.draws = rng.StaticDraws(dev)
+        # (capturing the network on a high-priority stream so that the geometry branch only fills gaps was measured:
+        # 4.16 ms/step instead of 2.04 -- the high-priority queue serialises; both streams keep the default priority)
+        self.main = torch.cuda.Stream()
+        self.side = torch.cuda.Stream()
+        cap = self.main
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap), self.draws:
+            self.draws.begin_pass()
+            self.draws.refill()
+            first = net.geometry(self.points[0])
+            self.state = [first.clone(), first.clone()]
+            for _ in range(warmup):                       # eager warm-up of the whole body on the capture stream
+                self.draws.begin_pass()
+                self.draws.refill()
+                self._body(0)
+            self.draws.begin_pass()                        # the geometry the first replay consumes (batch 0)
+            self.draws.refill()
+            self.state[0].copy_(net.geometry(self.points[0]))
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        self.graphs, self.loss = [], []
+        for p in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with self.draws:
+                self.draws.begin_pass()
+                with torch.cuda.graph(g, pool=self.graphs[0].pool() if self.graphs else None, stream=self.main):
+                    self.loss.append(self._body(p))
+            self.graphs.append(g)
+        torch.cuda.synchronize()
+        self.parity = 0
+
+    def _body(self, p):
+        main = torch.cuda.current_stream()
+        fork = os.environ.get("REPSURF_PIPE_FORK", "1") != "0"
+        if fork:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):             # geometry of the batch the NEXT replay trains on; one branch:
+                nxt = self.net.geometry(self.points[1 - p], fork=False)   # a fork inside the fork broke hipStreamEndCapture
+                self.state[1 - p].copy_(nxt)
+        else:
+            nxt = self.net.geometry(self.points[1 - p])
+            self.state[1 - p].copy_(nxt)
+        if self.optimizer is not None:
+            self.optimizer.zero_grad(set_to_none=True)
+        else:
+            for q in self.net.parameters():
+                q.grad = None
+        loss = self.criterion(self.net(self.points[p], geo=self.state[p]), self.label[p])
+        loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
+        if self.optimizer is not None:
+            self.optimizer.step()
+        if fork:
+            main.wait_stream(self.side)
+        return loss
+
+    def __call__(self, next_points=None, next_label=None):
+        p = self.parity
+        if next_points is not None:
+            self.points[1 - p].copy_(next_points, non_blocking=True)
+        if next_label is not None:
+            self.label[1 - p].copy_(next_label, non_blocking=True)
+        self.draws.refill()            # the draws of the batch whose geometry this replay computes
+        if hasattr(self.optimizer, "sync_hyper"):
+            self.optimizer.sync_hyper()
+        self.graphs[p].replay()
+        self.parity = 1 - p
+        return self.loss[p]
 
 
 def attach_flat_grads(params):
