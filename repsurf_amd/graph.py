@@ -114,21 +114,30 @@ class PipelinedStep:
     def _body(self, p):
         main = torch.cuda.current_stream()
         fork = os.environ.get("REPSURF_PIPE_FORK", "1") != "0"
-        if fork:
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):             # geometry of the batch the NEXT replay trains on; one branch:
-                nxt = self.net.geometry(self.points[1 - p], fork=False)   # a fork inside the fork broke hipStreamEndCapture
-                self.state[1 - p].copy_(nxt)
-        else:
-            nxt = self.net.geometry(self.points[1 - p])
-            self.state[1 - p].copy_(nxt)
+        at = os.environ.get("REPSURF_PIPE_AT", "start")
+
+        def geometry():
+            if fork:
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):         # geometry of the batch the NEXT replay trains on; one branch:
+                    nxt = self.net.geometry(self.points[1 - p], fork=False)   # a fork inside the fork broke hipStreamEndCapture
+                    self.state[1 - p].copy_(nxt)
+            else:
+                self.state[1 - p].copy_(self.net.geometry(self.points[1 - p]))
+
+        if at == "start":
+            geometry()
         if self.optimizer is not None:
             self.optimizer.zero_grad(set_to_none=True)
         else:
             for q in self.net.parameters():
                 q.grad = None
         loss = self.criterion(self.net(self.points[p], geo=self.state[p]), self.label[p])
+        if at == "backward":
+            geometry()
         loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
+        if at == "adam":
+            geometry()
         if self.optimizer is not None:
             self.optimizer.step()
         if fork:
