@@ -935,6 +935,47 @@ pool_max_kernel(long long groups, int ns, int c, int relu, const int *__restrict
   }
 }
 
+// Few, long, dense groups (the group_all stage: 32 groups x 128 rows x 1024 channels): one thread per (group, channel)
+// is 32 K threads walking 128 rows each -- half the chip, a 128-deep load chain (39 us for 16 MB).  Here a workgroup
+// takes 64 channels of one group, its 4 waves take every 4th row with 4 loads in flight, and the slices meet in LDS;
+// the first row attaining the maximum wins, as in the sequential scan.
+__global__ void __launch_bounds__(GM_THREADS)
+pool_max_long_kernel(int ns, int c, int relu, const float *__restrict__ y, const float *__restrict__ scale,
+                     const float *__restrict__ shift, float *__restrict__ out, int *__restrict__ arg) {
+  __shared__ float bz[4][64];
+  __shared__ int bk[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int ch = blockIdx.y * 64 + tx;
+  const long long g = blockIdx.x;
+  float best = -INFINITY; int bi = 0x7fffffff;
+  if (ch < c) {
+    const float s = scale ? scale[ch] : 1.f, t = shift ? shift[ch] : 0.f;
+    const float *col = y + g * ns * c + ch;
+    for (int k0 = ty; k0 < ns; k0 += 16) {
+      float z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) z[u] = (k0 + 4 * u < ns) ? col[(long long)(k0 + 4 * u) * c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + 4 * u >= ns) break;
+        float v = fmaf(s, z[u], t);
+        if (relu) v = fmaxf(v, 0.f);
+        if (v > best) { best = v; bi = k0 + 4 * u; }
+      }
+    }
+  }
+  bz[ty][tx] = best; bk[ty][tx] = bi;
+  __syncthreads();
+  if (ty == 0 && ch < c) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float v = bz[w][tx]; const int k = bk[w][tx];
+      if (v > best || (v == best && k < bi)) { best = v; bi = k; }
+    }
+    out[g * c + ch] = best; arg[g * c + ch] = bi == 0x7fffffff ? 0 : bi;
+  }
+}
+
 // out = relu(scale * (scale >= 0 ? ymax : ymin) + shift), arg = matching index (resolves the fused pooling)
 __global__ void __launch_bounds__(GM_THREADS)
 pool_select_kernel(long long groups, int c, const float *__restrict__ ymax, const float *__restrict__ ymin,
@@ -1286,6 +1327,12 @@ extern "C" int rs_pool_max(long long groups, int nsample, int c, int relu, const
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0, "rs_pool_max: bad size");
   if (groups == 0 || c == 0) return RS_OK;
   RS_REQUIRE(y && out && arg, "rs_pool_max: null pointer");
+  if (!offsets && nsample >= 64 && groups <= 65535 && groups * c <= (1 << 18)) {
+    hipLaunchKernelGGL(pool_max_long_kernel, dim3((int)groups, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, (hipStream_t)stream,
+                       nsample, c, relu, y, scale, shift, out, arg);
+    RS_CHECK_LAUNCH("rs_pool_max");
+    return RS_OK;
+  }
   long long blocks = (groups * c + GM_THREADS - 1) / GM_THREADS;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(pool_max_kernel, dim3((int)blocks), dim3(GM_THREADS), 0, (hipStream_t)stream, groups, nsample, c,

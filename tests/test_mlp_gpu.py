@@ -180,3 +180,25 @@ def test_compacted_groups_match_dense(radius, ns):
         assert rel_l2(c[3][k], d[3][k]) < 3e-3, k
     for a, bb in zip(c[4], d[4]):
         assert torch.allclose(a, bb, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("groups,ns,c", [(32, 128, 1024), (5, 64, 70), (3, 200, 64), (4096, 32, 128)])
+def test_pool_max_first_maximum(groups, ns, c):
+    """rs_pool_max: max over the nsample rows of a group of relu(scale*y+shift) and the FIRST row attaining it
+    (torch.max's tie rule, classification/modules/repsurface_utils.py:245); values are quantised so that ties occur.
+    Both the per-(group, channel) kernel and the sliced kernel for few long groups are hit.  Bit-exact."""
+    import ctypes
+    from repsurf_amd import _lib
+    g = torch.Generator().manual_seed(groups + ns)
+    y = (torch.randint(-3, 4, (groups * ns, c), generator=g).float() * 0.5).cuda()
+    scale = (torch.randint(-20, 44, (c,), generator=g).float() / 64).cuda()      # few mantissa bits: fma == mul + add exactly
+    shift = (torch.randint(-8, 8, (c,), generator=g).float() / 64).cuda()
+    out = torch.empty((groups, c), dtype=torch.float32, device="cuda")
+    arg = torch.empty((groups, c), dtype=torch.int32, device="cuda")
+    _lib.call("rs_pool_max", groups, ns, c, 1, None, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+              arg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    z = torch.relu(torch.addcmul(shift, y, scale)).view(groups, ns, c)      # fma(scale, y, shift) like the kernel
+    ref = z.max(dim=1)
+    assert torch.equal(out, ref.values)
+    first = (z == ref.values.unsqueeze(1)).float().argmax(dim=1)
+    assert torch.equal(arg.long(), first)
