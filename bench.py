@@ -190,8 +190,12 @@ def main():
             mode = "hipgraph"
         else:
             try:
-                step = ShardedGraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
-                mode = "hipgraph x2 + rccl all-reduce"
+                if args.no_pipeline or not hasattr(net, "geometry"):
+                    step = ShardedGraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
+                    mode = "hipgraph x2 + rccl all-reduce"
+                else:
+                    step = PipelinedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup), sharded=True)
+                    mode = "hipgraph (geometry of batch s+1 under the network of batch s) + rccl all-reduce + Adam graph"
             except Exception as e:  # noqa: BLE001 - keep the scaling run alive: eager DDP is slower but equivalent
                 print(f"[bench rank {rank}] graph capture failed ({e!r}); falling back to eager DDP", file=sys.stderr)
                 for p in model.parameters():

@@ -130,3 +130,41 @@ def test_pipelined_step_matches_eager_step_for_step(monkeypatch):
     g_e = torch.cat([p.grad.flatten() for p in eager.parameters()])
     assert np.allclose(got, want, atol=2e-5), (got, want)
     assert (g_p - g_e).norm() / g_e.norm() < 1e-3
+
+
+def test_pipelined_sharded_step_single_rank_process_group():
+    """PipelinedStep(sharded=True): graph[p] (geometry s+1 | forward/backward s into the flat gradient buffer) -> RCCL
+    all-reduce -> Adam graph, with a 1-rank process group and this package's Adam; it must train like the unsharded
+    pipelined step from the same initial state (same draws).  Both runs make 2 warm-up + 3 measured Adam updates with
+    fp32 atomics in the scatter kernels, so the trajectories drift apart slowly: losses within 2e-2."""
+    import os
+    import torch.distributed as dist
+    from models.repsurf.repsurf_ssg_umb import Model
+    from repsurf_amd import mlp
+    from repsurf_amd.graph import PipelinedStep
+    from repsurf_amd.optim import Adam
+    from util.utils import SmoothClsLoss
+    mlp.set_backend("hip")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        pts = torch.from_numpy(cloud(3, 8, 1024)).cuda().permute(0, 2, 1).contiguous()
+        lab = torch.arange(8).cuda() % 15
+        losses = {}
+        for sharded in (False, True):
+            m = Model(ref_args())
+            name_seeded_init(m)
+            disable_dropout(m)
+            m = m.cuda().train()
+            opt = Adam(m.parameters(), lr=1e-3)
+            torch.manual_seed(21)
+            step = PipelinedStep(m, SmoothClsLoss(), opt, pts, lab, warmup=2, sharded=sharded)
+            losses[sharded] = [step().item() for _ in range(3)]
+            if sharded:
+                assert step.flat.abs().sum() > 0
+        assert np.allclose(losses[True], losses[False], atol=2e-2), losses
+        assert losses[True][2] < losses[True][0] + 0.5
+    finally:
+        dist.destroy_process_group()
