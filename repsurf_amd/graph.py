@@ -128,8 +128,9 @@ class PipelinedStep:
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):             # geometry of the batch the NEXT replay trains on; a single branch:
-            nxt = self.net.geometry(self.points[1 - p], fork=False)   # a fork inside the fork broke hipStreamEndCapture
-            self.state[1 - p].copy_(nxt)
+            if os.environ.get("REPSURF_PIPE_SKIP_GEO", "0") == "0":    # (=1: measurement only -- the network alone)
+                nxt = self.net.geometry(self.points[1 - p], fork=False)   # a fork inside the fork broke hipStreamEndCapture
+                self.state[1 - p].copy_(nxt)
         # (starting the branch at the top of the replay beats starting it in front of backward: 2.031 vs 2.050 ms)
         if self.sharded:
             self.flat.zero_()
