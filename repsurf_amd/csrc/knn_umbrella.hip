@@ -109,10 +109,35 @@ __device__ __forceinline__ void knn_scan4(const float *__restrict__ pts, int n, 
       tile[p] = make_float4(x, y, z, rs_sqnorm(x, y, z));
     }
     __syncthreads();
-    for (int p = sub; p < tn; p += 4) {
-      const float4 c = tile[p];
-      const float d = rs_sqdist_expanded(qx, qy, qz, qq, c.x, c.y, c.z, c.w);
-      knn_insert<K>(bd, bi, d, t0 + p);        // candidates of one lane arrive in ascending index order
+    // 8 candidates per lane and round: all distances first, then only the candidates that beat the lane's current
+    // K-th distance are inserted, one per trip of a wave-uniform loop.  A lane inserts ~15 % of its candidates, but a
+    // wave of 64 lanes almost always has SOME lane inserting, so candidate-by-candidate the 56-instruction insertion
+    // ran for ~90 % of the candidates; batched it runs max-over-lanes(pending) times per 8 (2-3 instead of 7).
+    // Same candidates, same ascending order per lane, same comparisons: the lists are identical.
+#ifndef RS_KNN_BATCH
+#define RS_KNN_BATCH 8
+#endif
+    constexpr int U = RS_KNN_BATCH;
+    for (int p0 = sub; p0 < tn; p0 += 4 * U) {
+      float d[U];
+      unsigned pend = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = p0 + 4 * u;
+        const float4 c = tile[min(p, tn - 1)];
+        d[u] = p < tn ? rs_sqdist_expanded(qx, qy, qz, qq, c.x, c.y, c.z, c.w) : INFINITY;
+        pend |= (d[u] < bd[K - 1] ? 1u : 0u) << u;
+      }
+      while (__any(pend != 0)) {
+        if (pend) {
+          const int u = __ffs(pend) - 1;
+          pend &= pend - 1;
+          float dd = d[0];
+#pragma unroll
+          for (int v = 1; v < U; ++v) dd = (u == v) ? d[v] : dd;
+          knn_insert<K>(bd, bi, dd, t0 + p0 + 4 * u);      // re-checks against the (possibly lowered) K-th distance
+        }
+      }
     }
   }
   // butterfly merge of the 4 partial lists: afterwards every lane of the query holds the K best of the union

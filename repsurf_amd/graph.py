@@ -58,26 +58,28 @@ class GraphedStep:
 
 
 class PipelinedStep:
-    """Graphed training step with the NEXT batch's geometry computed under the CURRENT batch's network.
+    """Graphed training step with the NEXT batch's geometry computed while the CURRENT batch trains.
 
     FPS (a 511-pick latency chain on 32 of 256 CUs), ball query and the constructor's kNN / fan features read nothing
     but coordinates, and they head the step: ~0.26 ms during which the GEMM stack cannot start.  A training loop has
-    its next batch in hand (the loader runs ahead), so one replay does
-        main stream :  forward(batch s, geometry from the previous replay) -> loss -> backward -> optimizer
-        side stream :  geometry(batch s+1)  ->  copied into the other state set
-    and the two state sets / input buffers alternate between two captured graphs.  Every replay still performs one
-    complete geometry pass and one complete network pass; results are those of GraphedStep step for step (the CPU-
-    generator draws are requested in the same order, one step earlier).
+    its next batch in hand (the loader runs ahead), so one call replays TWO linear graphs on two streams:
+        stream M :  forward(batch s, geometry from the previous call) -> loss -> backward -> optimizer
+        stream S :  geometry(batch s+1)  ->  the other of two state sets
+    ordered by two events per parity.  (Putting both into ONE graph as parallel branches costs 0.165 ms per replay on
+    this runtime even when the side branch is a single 4-byte copy -- measured -- so each graph stays a plain chain.)
+    Every call still performs one complete geometry pass and one complete network pass; results are those of
+    GraphedStep step for step (the CPU-generator draws are requested in the same order, one step earlier).
 
         step = PipelinedStep(net, criterion, optimizer, points0, label0)     # geometry of batch 0 runs here
         loss0 = step(points1, label1)        # trains on batch 0, prepares batch 1
         loss1 = step(points2, label2)        # trains on batch 1, prepares batch 2 ...
-    `net` must offer `geometry(points)` and `forward(points, geo=...)` (classification models of this package)."""
+    `net` must offer `geometry(points)` and `forward(points, geo=...)` (classification models of this package).
+    The returned loss is ready on the caller's current stream."""
 
     def __init__(self, net, criterion, optimizer, points, label, warmup=3, group=None, sharded=False):
         """sharded=True (data parallel, world_size > 1): gradients go into ONE flat buffer, the optimizer leaves the
-        main graphs and every call is  graph[p] (geometry s+1 | forward/backward s) -> RCCL all-reduce -> Adam graph,
-        like ShardedGraphedStep."""
+        network graphs and every call is  network graph -> RCCL all-reduce -> Adam graph  on stream M, like
+        ShardedGraphedStep."""
         self.net, self.criterion, self.optimizer = net, criterion, optimizer
         self.sharded, self.group = sharded, group
         if sharded:
@@ -88,50 +90,59 @@ class PipelinedStep:
         self.points = [points.clone(), points.clone()]
         self.label = [label.clone(), label.clone()]
         self.draws = rng.StaticDraws(dev)
-        # (capturing the network on a high-priority stream so that the geometry branch only fills gaps was measured:
-        # 4.16 ms/step instead of 2.04 -- the high-priority queue serialises; both streams keep the default priority)
-        self.main = torch.cuda.Stream()
-        self.side = torch.cuda.Stream()
+        self.main = torch.cuda.Stream()          # M
+        self.side = torch.cuda.Stream()          # S
         self.main.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.main), self.draws:
             self.draws.begin_pass()
             self.draws.refill()
-            first = net.geometry(self.points[0])
+            first = net.geometry(self.points[0], fork=False)
             self.state = [first.clone(), first.clone()]
-            for _ in range(warmup):                       # eager warm-up of the whole step on the capture stream
+            for _ in range(warmup):                       # eager warm-up of the whole step on one stream
                 self.draws.begin_pass()
                 self.draws.refill()
-                self._body(0)
+                self._geometry(0)
+                self._network(0)
                 self._finish()
-            self.draws.begin_pass()                        # the geometry the first replay consumes (batch 0)
+            self.draws.begin_pass()                        # the geometry the first call's network consumes (batch 0)
             self.draws.refill()
-            self.state[0].copy_(net.geometry(self.points[0]))
+            self.state[0].copy_(net.geometry(self.points[0], fork=False))
+        self.side.wait_stream(self.main)
         torch.cuda.current_stream().wait_stream(self.main)
         torch.cuda.synchronize()
-        self.graphs, self.loss = [], []
+        # geometry graphs and network graphs run concurrently: separate memory pools
+        self.g_geo, self.g_net, self.loss = [], [], []
         for p in (0, 1):
             g = torch.cuda.CUDAGraph()
             with self.draws:
                 self.draws.begin_pass()
-                with torch.cuda.graph(g, pool=self.graphs[0].pool() if self.graphs else None, stream=self.main):
-                    self.loss.append(self._body(p))
-            self.graphs.append(g)
+                with torch.cuda.graph(g, pool=self.g_geo[0].pool() if self.g_geo else None, stream=self.side):
+                    self._geometry(p)
+            self.g_geo.append(g)
+        for p in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, stream=self.main):
+                self.loss.append(self._network(p))
+            self.g_net.append(g)
         self.graph_opt = None
         if sharded and optimizer is not None:
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graphs[0].pool(), stream=self.main):
+            with torch.cuda.graph(self.graph_opt, pool=self.g_net[0].pool(), stream=self.main):
                 optimizer.step()
         torch.cuda.synchronize()
+        self.geo_done = [torch.cuda.Event(), torch.cuda.Event()]    # geo_done[q]: state[q] / points[q] are ready
+        self.net_done = [torch.cuda.Event(), torch.cuda.Event()]    # net_done[q]: the network finished reading them
+        for q in (0, 1):
+            self.geo_done[q].record(self.side)
+            self.net_done[q].record(self.main)
         self.parity = 0
 
-    def _body(self, p):
-        main = torch.cuda.current_stream()
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):             # geometry of the batch the NEXT replay trains on; a single branch:
-            if os.environ.get("REPSURF_PIPE_SKIP_GEO", "0") == "0":    # (=1: measurement only -- the network alone)
-                nxt = self.net.geometry(self.points[1 - p], fork=False)   # a fork inside the fork broke hipStreamEndCapture
-                self.state[1 - p].copy_(nxt)
-        # (starting the branch at the top of the replay beats starting it in front of backward: 2.031 vs 2.050 ms)
+    def _geometry(self, p):
+        """geometry of the batch the NEXT call trains on (buffers 1 - p), as one serial chain"""
+        if os.environ.get("REPSURF_PIPE_SKIP_GEO", "0") == "0":     # (=1: measurement only -- the network alone)
+            self.state[1 - p].copy_(self.net.geometry(self.points[1 - p], fork=False))
+
+    def _network(self, p):
         if self.sharded:
             self.flat.zero_()
         elif self.optimizer is not None:
@@ -143,7 +154,6 @@ class PipelinedStep:
         loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
         if self.optimizer is not None and not self.sharded:
             self.optimizer.step()
-        main.wait_stream(self.side)
         return loss
 
     def _reduce(self):
@@ -152,7 +162,7 @@ class PipelinedStep:
             self.flat.div_(self.dist.get_world_size(self.group))
 
     def _finish(self):
-        """what follows the main graph of a step in sharded mode (eagerly during warm-up, as a graph afterwards)"""
+        """what follows the network graph in sharded mode (eagerly during warm-up, as a graph afterwards)"""
         if not self.sharded:
             return
         self._reduce()
@@ -164,15 +174,25 @@ class PipelinedStep:
 
     def __call__(self, next_points=None, next_label=None):
         p = self.parity
-        if next_points is not None:
-            self.points[1 - p].copy_(next_points, non_blocking=True)
-        if next_label is not None:
-            self.label[1 - p].copy_(next_label, non_blocking=True)
-        self.draws.refill()            # the draws of the batch whose geometry this replay computes
-        if hasattr(self.optimizer, "sync_hyper"):
-            self.optimizer.sync_hyper()
-        self.graphs[p].replay()
-        self._finish()
+        caller = torch.cuda.current_stream()
+        with torch.cuda.stream(self.side):
+            self.side.wait_stream(caller)                  # next_points / next_label were produced there
+            self.side.wait_event(self.net_done[1 - p])     # the previous call's network is done with buffers 1 - p
+            if next_points is not None:
+                self.points[1 - p].copy_(next_points, non_blocking=True)
+            if next_label is not None:
+                self.label[1 - p].copy_(next_label, non_blocking=True)
+            self.draws.refill()        # the draws of the batch whose geometry this call computes
+            self.g_geo[p].replay()
+            self.geo_done[1 - p].record(self.side)
+        with torch.cuda.stream(self.main):
+            self.main.wait_event(self.geo_done[p])         # state[p], points[p], label[p] (previous call, stream S)
+            if hasattr(self.optimizer, "sync_hyper"):
+                self.optimizer.sync_hyper()
+            self.g_net[p].replay()
+            self._finish()
+            self.net_done[p].record(self.main)
+        caller.wait_event(self.net_done[p])
         self.parity = 1 - p
         return self.loss[p]
 
