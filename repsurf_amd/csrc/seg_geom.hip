@@ -105,12 +105,33 @@ knn_packed_kernel(int m, int nsample, int b, const float *__restrict__ xyz, cons
         tile[p] = make_float4(s[0], s[1], s[2], 0.f);
       }
       __syncthreads();
-      if (mycloud == c) {
-        for (int p = sub; p < tn; p += SG_LANES) {
-          const float4 v = tile[p];
-          const float dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
-          const float d = (dx * dx + dy * dy) + dz * dz;                 // :93, no contraction
-          sorted_insert<K>(bd, bi, d, t0 + p);
+      // 8 candidates per lane and round, then one insertion per trip of a wave-uniform loop for the candidates that
+      // beat the lane's K-th distance (see knn_scan4 in knn_umbrella.hip: a wave nearly always has SOME lane inserting,
+      // so candidate-by-candidate the K-step insertion ran for ~90 % of the candidates).  Lanes of other clouds hold no
+      // pending candidates.  Same candidates, same order per lane, same comparisons.
+      constexpr int U = 8;
+      for (int p0 = sub; p0 < tn; p0 += SG_LANES * U) {
+        float d[U];
+        unsigned pend = 0;
+        if (mycloud == c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int p = p0 + SG_LANES * u;
+            const float4 v = tile[min(p, tn - 1)];
+            const float dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
+            d[u] = p < tn ? (dx * dx + dy * dy) + dz * dz : INFINITY;      // :93, no contraction
+            pend |= (d[u] < bd[K - 1] ? 1u : 0u) << u;
+          }
+        }
+        while (__any(pend != 0)) {
+          if (pend) {
+            const int u = __ffs(pend) - 1;
+            pend &= pend - 1;
+            float dd = d[0];
+#pragma unroll
+            for (int v = 1; v < U; ++v) dd = (u == v) ? d[v] : dd;
+            sorted_insert<K>(bd, bi, dd, t0 + p0 + SG_LANES * u);
+          }
         }
       }
     }
