@@ -183,8 +183,9 @@ def main():
         if world == 1 and not args.no_pipeline and hasattr(net, "geometry"):
             # every replay = geometry of batch s+1 (side stream) + network of batch s; the loader's next batch is the
             # same synthetic batch here (both input buffers hold it)
-            step = PipelinedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
-            mode = "hipgraph, geometry of batch s+1 under the network of batch s"
+            pstep = PipelinedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
+            step = lambda: pstep(sync=False)      # noqa: E731 - the loop synchronises the device around the timed region
+            mode = "2 hipgraphs on 2 streams: geometry of batch s+1 under the network of batch s"
         elif world == 1:
             step = GraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
             mode = "hipgraph"
@@ -194,8 +195,9 @@ def main():
                     step = ShardedGraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
                     mode = "hipgraph x2 + rccl all-reduce"
                 else:
-                    step = PipelinedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup), sharded=True)
-                    mode = "hipgraph (geometry of batch s+1 under the network of batch s) + rccl all-reduce + Adam graph"
+                    pstep = PipelinedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup), sharded=True)
+                    step = lambda: pstep(sync=False)      # noqa: E731
+                    mode = "2 hipgraphs on 2 streams (geometry of batch s+1 under the network of batch s) + rccl all-reduce + Adam graph"
             except Exception as e:  # noqa: BLE001 - keep the scaling run alive: eager DDP is slower but equivalent
                 print(f"[bench rank {rank}] graph capture failed ({e!r}); falling back to eager DDP", file=sys.stderr)
                 for p in model.parameters():

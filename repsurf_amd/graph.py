@@ -172,11 +172,16 @@ class PipelinedStep:
             else:
                 self.optimizer.step()
 
-    def __call__(self, next_points=None, next_label=None):
+    def __call__(self, next_points=None, next_label=None, sync=True):
+        """sync=True orders the caller's current stream after this step (the returned loss can be read right away) and
+        stream S after the caller's (next_points may have just been produced there).  A loop that reads the loss only now
+        and then passes sync=False and synchronises when it does: every cross-stream event costs ~50 us of latency on this
+        runtime (1.97 -> 1.91 ms/step)."""
         p = self.parity
         caller = torch.cuda.current_stream()
         with torch.cuda.stream(self.side):
-            self.side.wait_stream(caller)                  # next_points / next_label were produced there
+            if sync or next_points is not None or next_label is not None:
+                self.side.wait_stream(caller)              # next_points / next_label were produced there
             self.side.wait_event(self.net_done[1 - p])     # the previous call's network is done with buffers 1 - p
             if next_points is not None:
                 self.points[1 - p].copy_(next_points, non_blocking=True)
@@ -192,7 +197,8 @@ class PipelinedStep:
             self.g_net[p].replay()
             self._finish()
             self.net_done[p].record(self.main)
-        caller.wait_event(self.net_done[p])
+        if sync:
+            caller.wait_event(self.net_done[p])
         self.parity = 1 - p
         return self.loss[p]
 
