@@ -35,6 +35,7 @@ import torch.distributed as dist
 
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_MFMA_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_BF16_MFMA_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (--dtype bf16 launches only)
 
 
 def parse():
@@ -45,6 +46,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--model", default="repsurf_ssg_umb")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="arithmetic of the shared-MLP row GEMMs: fp32 MFMA (configs[1], the metric) or bf16 MFMA with fp32 "
+                         "accumulation and storage (configs[4]: use --batch 64 --points 2048)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N=1 graph mode: compute each batch's geometry inside its own step instead of under the previous "
                          "batch's network (repsurf_amd.graph.PipelinedStep)")
@@ -117,7 +121,7 @@ def algorithmic_cost(name, dims):
     dims = [d for d in dims if not isinstance(d, str)]
     if notes:
         dims[0] = float(notes[0].split("=")[1])
-    if name == "rs_mlp_gemm_rows":
+    if name in ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16"):
         rows, kdim, cols = dims[:3]
         return "flops", 2.0 * rows * kdim * cols
     if name == "rs_mlp_wgrad":
@@ -144,6 +148,7 @@ def main():
     from repsurf_amd.optim import Adam
     from util.utils import SmoothClsLoss
     Model = importlib.import_module(f"models.repsurf.{args.model}").Model
+    mlp.set_precision(args.dtype)
 
     torch.manual_seed(0)                     # identical initial weights on every rank
     model = Model(model_args()).to(device).train()
@@ -272,8 +277,9 @@ def main():
             sec = row["avg_us"] * 1e-6
             if row["unit"] == "flops":
                 ach = row["amount"] / sec / 1e12
+                peak = PEAK_BF16_MFMA_TF if row["kernel"].endswith("_bf16") else PEAK_F32_MFMA_TF
                 roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "mfma", "achieved": round(ach, 2),
-                            "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TF, 4)}
+                            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
             else:
                 ach = row["amount"] / sec / 1e9
                 roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "hbm", "achieved": round(ach, 2),
@@ -287,7 +293,8 @@ def main():
         tm = sum(r["avg_us"] * r["launches"] for r in table if r["unit"] == "flops") * 1e-6
         if roofline is not None and tm > 0:
             roofline["all_mfma_launches"] = {"achieved": round(fl / tm / 1e12, 2), "unit": "TFLOP/s",
-                                             "frac": round(fl / tm / 1e12 / PEAK_F32_MFMA_TF, 4),
+                                             # (bf16 run: row GEMMs on the bf16 pipe, weight gradients on the fp32 one -- no single peak)
+                                             "frac": round(fl / tm / 1e12 / PEAK_F32_MFMA_TF, 4) if args.dtype == "fp32" else None,
                                              "ms_per_step": round(tm * 1e3 / max(1, getattr(args, "timed_steps", args.steps)), 4)}
         if args.launch_log:
             os.makedirs(os.path.dirname(os.path.abspath(args.launch_log)), exist_ok=True)
@@ -301,9 +308,9 @@ def main():
         out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U 1024-pt cls @ B=32 per GPU", "value": round(value, 2),
                "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic uniform [-1,1]^3 clouds, random-init weights",
-               "config": {"workload": f"configs[1]: RepSurf-U ({args.model}) classifier, B={args.batch}x{args.points} pts "
-                                      "per GPU, fp32, full encoder + head, fwd+loss+bwd"
+               "dtype": "f32" if args.dtype == "fp32" else "bf16 MFMA operands, f32 accumulate/storage", "data": "synthetic uniform [-1,1]^3 clouds, random-init weights",
+               "config": {"workload": f"configs[{1 if args.dtype == 'fp32' else 4}]: RepSurf-U ({args.model}) classifier, B={args.batch}x{args.points} pts "
+                                      f"per GPU, {args.dtype}, full encoder + head, fwd+loss+bwd"
                                       + ("" if args.no_optim else "+Adam step"),
                           "global_batch": args.batch * world, "points": args.points,
                           "parallelism": f"dp{world}", "mlp_backend": mlp.BACKEND, "launch": mode,

@@ -253,6 +253,16 @@ typedef struct rs_mlp_epilogue {
 int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
                      const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream);
 
+/* Mixed precision (BASELINE configs[4]: "bf16 mixed precision on CDNA4 MFMA for shared MLPs"): the same contract
+ * and the same fp32 tensors in HBM; the operand E (after its fp32 prologue) and the weights are rounded to bf16
+ * (nearest even) when they are staged in LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+ * Bias, BatchNorm sums, masks and pooling stay fp32.  Where the layout forces scalar operand loads, or the narrow
+ * streaming kernel applies (kdim <= 16 on an unaligned operand), the fp32 instance runs.  What torch.autocast would
+ * do for the reference's nn.Conv2d 1x1 (classification/modules/repsurface_utils.py:236-244), minus the bf16
+ * rounding of the conv OUTPUT. */
+int rs_mlp_gemm_rows_bf16(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
+                          const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream);
+
 /* Weight gradient dw[ncols][kcols] = sum_r P[r][n] * Q[r][k]; rows are split into `chunks` workgroup
  * slabs whose partial products land in partial (chunks, ncols*kcols) and are summed in a fixed order. */
 int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,

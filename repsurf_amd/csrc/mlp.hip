@@ -25,6 +25,15 @@
 #include <math.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 -> one dword of two bf16 (round to nearest even: v_cvt_pk_bf16_f32), lo in bits [15:0]
+__device__ __forceinline__ float pack_bf16(float lo, float hi) {
+  const f32x2 f = {lo, hi};
+  return __builtin_bit_cast(float, __builtin_convertvector(f, bf16x2));
+}
 
 // ---- on-the-fly row operands -----------------------------------------------------------------
 // A logical matrix E[r][c] (r < rows, c < cols) assembled while loading:
@@ -182,7 +191,14 @@ __device__ __forceinline__ void frag_store(float *stage, int plane, int k0, int 
 // Tile = BM rows x BN columns, BM = 128 (4 waves stacked, each 32 rows x BN) or 64 (2 x 2 waves, each 32 rows x BN/2):
 // the short tile doubles the number of workgroups -- with ~400-1000 tiles of 128 rows on 256 CUs the last round of a
 // launch left a third of the chip idle -- and its 50 KB of LDS lets three workgroups share a CU.
-template <int BM, int BN, int V, int MODE>
+//
+// BF = true (rs_mlp_gemm_rows_bf16, BASELINE configs[4]): the operands are rounded to bf16 when they are committed to
+// LDS -- AFTER the fp32 prologue -- and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation; HBM tensors,
+// prologue, epilogue and BatchNorm sums stay fp32.  A lane (row = lane & 31, g = lane >> 5) feeds k = 16 s + 8 g .. + 7
+// of its row to MFMA step s, so a 32-deep chunk is FOUR planes p = k >> 3 of [row][4 dwords = 8 bf16]: one
+// ds_read_b128 per operand per step, two steps per chunk (16 fp32 steps otherwise); plane pad 16 dwords keeps the
+// 8-byte commit stores of a half-wave (4 rows x 4 planes x 2 halves) on distinct banks.
+template <int BM, int BN, int V, int MODE, bool BF>
 __global__ void __launch_bounds__(GM_THREADS, 2)     // >= 2 workgroups per CU: one computes while another stages
 gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim, int cols, RowOperand E,
                  const float *__restrict__ w, int ldw, Epilogue ep) {
@@ -191,13 +207,14 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   constexpr int WR = BM / 32, WC = 4 / WR;                  // waves along rows / columns of the tile
   constexpr int CT = BN / 32 / WC;                          // 32-column MFMA tiles per wave
   static_assert(CT >= 1, "tile too narrow for the wave layout");
-  constexpr int PLANE_A = AStage<BM>::PLANE;
+  static_assert(!BF || V >= 2, "bf16 staging packs pairs of k");
+  constexpr int PLANE_A = BF ? BM * 4 + 16 : AStage<BM>::PLANE;
   constexpr int A_ELEMS = BM * GM_BK / GM_THREADS;          // floats of the operand tile per thread (16 / 8)
   constexpr int A_VECS = A_ELEMS / V;
   constexpr int A_TPR = GM_BK / V;                          // threads per tile row
   constexpr int A_RPP = GM_THREADS / A_TPR;                 // rows per pass
   constexpr int W_VECS = BN / 32;                           // float4 (4 k of one output column) per thread and chunk
-  constexpr int PLANE_W = WStage<BN>::PLANE;
+  constexpr int PLANE_W = BF ? BN * 4 + 16 : WStage<BN>::PLANE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *As0 = smem, *As1 = smem + AStage<BM>::SIZE;
   float *Ws0 = smem + 2 * AStage<BM>::SIZE, *Ws1 = Ws0 + WStage<BN>::SIZE;
@@ -249,7 +266,13 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       const long long r = r0 + rl;
       float v[V];
       op_finish<V, MODE>(E, coef, araw[p], r, kok && r < rows, v);
-      frag_store<V>(As, PLANE_A, a_kq, rl, v);
+      if constexpr (BF) {                                     // k = a_kq .. a_kq + V - 1 -> plane k >> 3, dword (k & 7) >> 1
+        float *b = As + (a_kq >> 3) * PLANE_A + rl * 4 + ((a_kq & 7) >> 1);
+        if constexpr (V == 4) *reinterpret_cast<float2 *>(b) = make_float2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+        else *b = pack_bf16(v[0], v[1]);
+      } else {
+        frag_store<V>(As, PLANE_A, a_kq, rl, v);
+      }
     }
     const bool wk_ok = (k0 + w_kq) < ldw;                   // [kdim, ldw) is zero in memory
 #pragma unroll
@@ -257,7 +280,11 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       const int nl = p * 32 + w_n;
       const bool ok = wk_ok && (n0 + nl < cols);
       const float v[4] = {ok ? wraw[p].x : 0.f, ok ? wraw[p].y : 0.f, ok ? wraw[p].z : 0.f, ok ? wraw[p].w : 0.f};
-      frag_store<4>(Ws, PLANE_W, w_kq, nl, v);
+      if constexpr (BF)
+        *reinterpret_cast<float2 *>(Ws + (w_kq >> 3) * PLANE_W + nl * 4 + ((w_kq & 7) >> 1)) =
+            make_float2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      else
+        frag_store<4>(Ws, PLANE_W, w_kq, nl, v);
     }
   };
 
@@ -285,6 +312,24 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       RS_T(2);
       if (ch + 1 < nchunks) prefetch(r0, (ch + 1) * GM_BK, -1);   // loads fly under the MFMAs below
       RS_T(3);
+      if constexpr (BF) {
+        // both steps' fragments first (2 + 2 CT ds_read_b128), then 2 x CT MFMAs; k beyond kdim was committed as zero
+        const float *ap = As + lk * PLANE_A + (wave_r * 32 + lrow) * 4;
+        const float *bp = Ws + lk * PLANE_W + (wave_c * CT * 32 + lrow) * 4;
+        float4 af[2], bf[2][CT];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          af[st] = *reinterpret_cast<const float4 *>(ap + 2 * st * PLANE_A);
+#pragma unroll
+          for (int c = 0; c < CT; ++c) bf[st][c] = *reinterpret_cast<const float4 *>(bp + 2 * st * PLANE_W + c * 128);
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[st]),
+                                                             __builtin_bit_cast(bf16x8, bf[st][c]), acc[c], 0, 0, 0);
+      } else {
       // groups of 4 k-steps; the last chunk of a ragged K runs only the groups that hold data
       const int ngroups = (min(GM_BK, kdim - ch * GM_BK) + 7) >> 3;
       const float *ap = As + lk * PLANE_A + (wave_r * 32 + lrow) * 4;
@@ -313,6 +358,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
             }
           }
         }
+      }
       }
       RS_T(4);
     }
@@ -1079,11 +1125,11 @@ int check_operand(const char *who, const RowOperand *o, long long rows) {
   return RS_OK;
 }
 
-template <int BM, int BN, int V>
+template <int BM, int BN, int V, bool BF>
 void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                    const float *w, int ldw, const Epilogue &ep) {
   const size_t lds = sizeof(float) * (2 * AStage<BM>::SIZE + 2 * WStage<BN>::SIZE);
-#define RS_G(M_) hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, V, M_>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, kdim, cols, E, w, ldw, ep)
+#define RS_G(M_) hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, V, M_, BF>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, kdim, cols, E, w, ldw, ep)
   if (V == 1) { RS_G(-1); return; }                 // odd sizes: one generic (runtime-mode) kernel
   switch (E.mode) {
     case OPM_ID: RS_G(OPM_ID); break;
@@ -1096,11 +1142,13 @@ void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_de
 #undef RS_G
 }
 template <int BM, int BN>
-void launch_gemm(int v, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
+void launch_gemm(bool bf, int v, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                  const float *w, int ldw, const Epilogue &ep) {
-  if (v == 4) launch_gemm_m<BM, BN, 4>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else if (v == 2) launch_gemm_m<BM, BN, 2>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else if constexpr (BM == 128) launch_gemm_m<BM, BN, 1>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);   // scalar operands: tall tile only
+  if (bf && v == 4) launch_gemm_m<BM, BN, 4, true>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else if (bf && v == 2) launch_gemm_m<BM, BN, 2, true>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else if (v == 4) launch_gemm_m<BM, BN, 4, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else if (v == 2) launch_gemm_m<BM, BN, 2, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else if constexpr (BM == 128) launch_gemm_m<BM, BN, 1, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);   // scalar operands: tall tile only, fp32 (bf16 staging packs pairs)
 }
 
 template <int WN, int WK, int TN, int TK, int VP, int VQ>
@@ -1128,8 +1176,8 @@ void launch_wgrad(int vp, int vq, dim3 grid, hipStream_t st, long long rows, con
 
 }  // namespace
 
-extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
-                                const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
+static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
+                          const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
   RS_REQUIRE(rows >= 0 && kdim >= 0 && cols >= 0, "rs_mlp_gemm_rows: negative size");
   if (rows == 0 || cols == 0) return RS_OK;
   RS_REQUIRE(kdim > 0, "rs_mlp_gemm_rows: empty reduction dimension");
@@ -1188,13 +1236,25 @@ extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, i
   const dim3 grid(gx, tiles_n);
   hipStream_t st = (hipStream_t)stream;
   if (bm == 64) {
-    if (bn == 64) launch_gemm<64, 64>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-    else launch_gemm<64, 128>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  } else if (bn == 32) launch_gemm<128, 32>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else if (bn == 64) launch_gemm<128, 64>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else launch_gemm<128, 128>(v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+    if (bn == 64) launch_gemm<64, 64>(bf, v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+    else launch_gemm<64, 128>(bf, v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  } else if (bn == 32) launch_gemm<128, 32>(bf, v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else if (bn == 64) launch_gemm<128, 64>(bf, v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  else launch_gemm<128, 128>(bf, v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
   RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
   return RS_OK;
+}
+
+extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
+                                const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
+  return gemm_rows_impl(false, rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
+}
+// Mixed precision (BASELINE configs[4]): same contract, operands rounded to bf16 at the LDS commit, bf16 MFMA with
+// fp32 accumulation.  Launches the fp32 instance where the layout forces scalar operand loads or the narrow
+// streaming kernel applies (kdim <= 16, unaligned: no matrix pipe involved).
+extern "C" int rs_mlp_gemm_rows_bf16(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
+                                     const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
+  return gemm_rows_impl(true, rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
 }
 
 extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,

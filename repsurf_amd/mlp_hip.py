@@ -234,7 +234,8 @@ def w_bwd(w2d):
 
 def gemm_rows(rows, kdim, cols, x_op, wk, epi, rows_dev=None):
     """out[rows, cols] = E[rows, kdim] . wk[:cols, :kdim]^T   (wk n-major (cols, ld), ld % 4 == 0, zero beyond kdim)"""
-    _lib.call("rs_mlp_gemm_rows", rows, rows_dev, kdim, cols, ctypes.byref(x_op), _ptr(wk), wk.shape[1],
+    from . import mlp as _mlp      # late: mlp imports this module on first use
+    _lib.call("rs_mlp_gemm_rows_bf16" if _mlp.PRECISION == "bf16" else "rs_mlp_gemm_rows", rows, rows_dev, kdim, cols, ctypes.byref(x_op), _ptr(wk), wk.shape[1],
               ctypes.byref(epi), _stream())
 
 

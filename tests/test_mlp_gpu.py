@@ -202,3 +202,90 @@ def test_pool_max_first_maximum(groups, ns, c):
     assert torch.equal(out, ref.values)
     first = (z == ref.values.unsqueeze(1)).float().argmax(dim=1)
     assert torch.equal(arg.long(), first)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 mixed precision (BASELINE configs[4]): rs_mlp_gemm_rows_bf16 = operands rounded to bf16 at the LDS commit,
+# v_mfma_f32_32x32x16_bf16, fp32 accumulation and storage.
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("rows,k,n", [(300, 128, 128), (4096, 512, 1024), (1000, 64, 64), (777, 40, 200),
+                                      (130, 268, 256), (65, 16, 32), (512, 6, 64)])
+def test_bf16_row_gemm_is_the_rounded_operand_product(rows, k, n):
+    """The kernel's contract, exactly: out = bf16(x) . bf16(w)^T + bias accumulated in fp32.  Products of two
+    bf16 values are exact in fp32, so against the same product in fp64 only the fp32 accumulation order is left
+    (<= 1e-5 of the output scale) -- a wrong fragment layout, a dropped k-step or an unrounded operand would be O(1) / 4e-3.
+    Asymmetric random operands; ragged K (40, 268, 6), rows and columns that do not fill a tile."""
+    from repsurf_amd import mlp_hip as H, mlp
+    g = torch.Generator().manual_seed(rows + k)
+    x = torch.randn(rows, k, generator=g).cuda()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    out = torch.full((rows, n), float("nan"), device="cuda")
+    wk = H.w_fwd(w)
+    epi = H.Epilogue(bias=H._ptr(bias), out=H._ptr(out), ldo=n, mode=H.EPI_STORE)
+    mlp.set_precision("bf16")
+    try:
+        H.gemm_rows(rows, k, n, H.operand(H.OP_ID, x, k), wk, epi)
+    finally:
+        mlp.set_precision("fp32")
+    ref = _bf16_round(x) @ _bf16_round(w).T + bias.double()
+    err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-5, err
+    # and it is NOT the fp32 product (the bf16 pipe really ran), unless the layout forced the fp32 instance
+    full = x.double() @ w.double().T + bias.double()
+    if k % 2 == 0 and k > 16:
+        assert (out.double() - full).abs().max().item() / full.abs().max().item() > 1e-4
+
+
+def test_bf16_row_gemm_fused_prologue_and_statistics():
+    """BN+ReLU prologue in fp32 BEFORE the rounding, BatchNorm column sums of the fp32 output in the epilogue."""
+    from repsurf_amd import mlp_hip as H, mlp
+    rows, k, n = 5000, 128, 256
+    g = torch.Generator().manual_seed(11)
+    # few mantissa bits: s*y + t is exact in fp32 whether fused or not, so the value that gets rounded to bf16 is
+    # the same in the kernel and in the reference below
+    y = (torch.randint(-32, 33, (rows, k), generator=g).float() / 8).cuda()
+    s, t = (torch.randint(32, 96, (k,), generator=g).float() / 64).cuda(), (torch.randint(-8, 8, (k,), generator=g).float() / 64).cuda()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda()
+    out = torch.empty(rows, n, device="cuda")
+    part = torch.empty((H.PARTIAL_BLOCKS, 2, n), dtype=torch.float64, device="cuda")
+    epi = H.Epilogue(bias=None, out=H._ptr(out), ldo=n, mode=H.EPI_STATS, partial=part.data_ptr(),
+                     partial_blocks=H.PARTIAL_BLOCKS)
+    mlp.set_precision("bf16")
+    try:
+        H.gemm_rows(rows, k, n, H.operand(H.OP_RELU1, y, k, s1=s, t1=t), H.w_fwd(w), epi)
+    finally:
+        mlp.set_precision("fp32")
+    act = torch.relu(torch.addcmul(t, y, s))                       # fma(s, y, t) like the kernel
+    ref = _bf16_round(act) @ _bf16_round(w).T
+    assert (out.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+    sums = part.sum(0)
+    assert torch.allclose(sums[0], out.double().sum(0), rtol=1e-5, atol=2e-3)      # per-tile fp32 column sums, fp64 across tiles
+    assert torch.allclose(sums[1], (out.double() ** 2).sum(0), rtol=1e-5, atol=2e-3)
+
+
+@pytest.mark.parametrize("groups,ns,pos,feat,widths", CASES[:4])
+def test_bf16_sa_stack_within_restated_tolerance(groups, ns, pos, feat, widths):
+    """SURVEY.md §8(d) C5, tolerance restated against the fp32 path: pooled post-BN activations max-abs <= 2e-2
+    (they are O(1): BatchNorm-normalised), gradients cosine >= 0.999."""
+    from repsurf_amd import mlp
+    mod = make_cd(pos, feat, widths, 1)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(groups * ns, pos + feat, generator=g).cuda()
+    w = torch.randn(groups, widths[-1], generator=g).cuda()
+    out_f, g_f = run_cd(copy.deepcopy(mod), x, ns, pos, "hip", w)
+    mlp.set_precision("bf16")
+    try:
+        out_b, g_b = run_cd(copy.deepcopy(mod), x, ns, pos, "hip", w)
+    finally:
+        mlp.set_precision("fp32")
+    assert (out_b - out_f).abs().max().item() <= 2e-2 * max(1.0, out_f.abs().max().item()), (out_b - out_f).abs().max().item()
+    assert not torch.equal(out_b, out_f)
+    for name in g_f:
+        if g_f[name].abs().max() == 0:
+            continue
+        cos = torch.nn.functional.cosine_similarity(g_b[name].flatten().double(), g_f[name].flatten().double(), dim=0).item()
+        assert cos >= 0.999, (name, cos)
