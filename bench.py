@@ -124,7 +124,7 @@ def algorithmic_cost(name, dims):
     if name in ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16"):
         rows, kdim, cols = dims[:3]
         return "flops", 2.0 * rows * kdim * cols
-    if name == "rs_mlp_wgrad":
+    if name in ("rs_mlp_wgrad", "rs_mlp_wgrad_bf16"):
         rows, ncols, kcols = dims[:3]
         return "flops", 2.0 * rows * ncols * kcols
     return None, 0.0

@@ -267,6 +267,10 @@ int rs_mlp_gemm_rows_bf16(long long rows, const int *rows_dev, int kdim, int col
  * slabs whose partial products land in partial (chunks, ncols*kcols) and are summed in a fixed order. */
 int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
                  const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream);
+/* Mixed precision (see rs_mlp_gemm_rows_bf16): P and Q rounded to bf16 after their fp32 prologues, bf16 MFMA with
+ * fp32 accumulation inside a row slab; partial products and their fixed-order sum stay fp32. */
+int rs_mlp_wgrad_bf16(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
+                      const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream);
 
 /* BatchNorm statistics -> affine: from partial (nblk, 2, c) {sum, sumsq} over `rows` rows:
  * mean, biased var, scale = gamma/sqrt(var+eps), shift = beta - mean*scale; saves mean/invstd and,

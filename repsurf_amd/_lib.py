@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -40,6 +40,7 @@ SIGNATURES = {
     "rs_mlp_gemm_rows": [c_ll, P, c_int, c_int, P, P, c_int, P, P],
     "rs_mlp_gemm_rows_bf16": [c_ll, P, c_int, c_int, P, P, c_int, P, P],
     "rs_mlp_wgrad": [c_ll, P, c_int, c_int, P, P, P, c_int, P, P],
+    "rs_mlp_wgrad_bf16": [c_ll, P, c_int, c_int, P, P, P, c_int, P, P],
     "rs_bn_finalize": [c_int, c_ll, c_int, P, P, P, c_float, c_float, P, P, P, P, P, P, P],
     "rs_bn_backward_finalize": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P],
     "rs_pool_max": [c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P],
@@ -154,7 +155,7 @@ def call(name, *args):
         rc = getattr(lib, name)(*args)
         e1.record()
         dims = tuple(a for a, t in zip(args, SIGNATURES[name]) if t is c_int or t is c_ll)
-        if name in ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16", "rs_mlp_wgrad") and args[1] is not None:
+        if name in ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16", "rs_mlp_wgrad", "rs_mlp_wgrad_bf16") and args[1] is not None:
             # compacted operand: args[0] is only the capacity, the launch's row count lives on the device.
             # Profiling mode may synchronise: read it back so the cost model sees the rows really processed.
             dims = dims + (f"rows={_read_device_int(args[1])}",)      # dims[0] stays the (static) capacity

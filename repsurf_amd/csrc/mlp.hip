@@ -509,7 +509,13 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
 // Same register-prefetch / double-buffer pipeline as the row GEMM.
 constexpr int WG_BR = 32;   // rows per pipeline stage
 
-template <int WN, int WK, int TN, int TK, int VP, int VQ, int PM, int QM>
+//
+// BF = true (rs_mlp_wgrad_bf16): v_mfma_f32_32x32x16_bf16.  A lane needs 8 values of ONE column along the reduction
+// index (rows), so a stage is stored as 16 row-PAIRS t of [column] dwords, dword = bf16(row 2t) | bf16(row 2t+1) << 16:
+// a thread loads rows 2t and 2t+1 of its columns (t = u * RPP + its row slot), rounds after the fp32 prologue and
+// writes V consecutive dwords; the fragment of MFMA step s for lane (col, g) is the dwords t = 4 (2 s + g) .. + 3 of its
+// column (consecutive lanes, consecutive addresses).  Which rows meet in which k slot is free as long as P and Q agree.
+template <int WN, int WK, int TN, int TK, int VP, int VQ, int PM, int QM, bool BF>
 __global__ void __launch_bounds__(GM_THREADS, 2)
 wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, int kcols, RowOperand P, RowOperand Q,
              float *__restrict__ partial) {
@@ -534,6 +540,10 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
   const int p_c = (tid % P_TPR) * VP, p_r = tid / P_TPR;
   const int q_c = (tid % Q_TPR) * VQ, q_r = tid / Q_TPR;
   const bool q_active = tid < Q_TPR * Q_RPP;                  // Q tiles narrower than 256 vectors per pass
+  static_assert(!BF || (P_VECS % 2 == 0 && Q_VECS % 2 == 0 && VP >= 2 && VQ >= 2), "bf16 staging pairs the rows a thread owns");
+  // local row of a thread's p-th vector: fp32 p * RPP + slot;  bf16 2 * ((p >> 1) * RPP + slot) + (p & 1)
+  auto p_row = [&](int p) { return BF ? 2 * ((p >> 1) * P_RPP + p_r) + (p & 1) : p * P_RPP + p_r; };
+  auto q_row = [&](int p) { return BF ? 2 * ((p >> 1) * Q_RPP + q_r) + (p & 1) : p * Q_RPP + q_r; };
 
   f32x16 acc[TN][TK];
 #pragma unroll
@@ -556,17 +566,42 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
 #pragma unroll
     for (int p = 0; p < P_VECS; ++p) {
       if (part >= 0 && (p * 4) / P_VECS != part) continue;
-      const int rl = p * P_RPP + p_r;
+      const int rl = p_row(p);
       op_load<VP, PM>(P, r0, rl, n0 + p_c, pc_ok && r0 + rl < rend, praw[p]);
     }
 #pragma unroll
     for (int p = 0; p < Q_VECS; ++p) {
       if (part >= 0 && (p * 4) / Q_VECS != part) continue;
-      const int rl = p * Q_RPP + q_r;
+      const int rl = q_row(p);
       op_load<VQ, QM>(Q, r0, rl, k0 + q_c, qc_ok && rl < WG_BR && r0 + rl < rend, qraw[p]);
     }
   };
   auto commit = [&](float *Ps, float *Qs, long long r0) {
+    if constexpr (BF) {
+#pragma unroll
+      for (int u = 0; u < P_VECS / 2; ++u) {
+        const int t = u * P_RPP + p_r;
+        __attribute__((aligned(16))) float v0[VP], v1[VP], d[VP];
+        op_finish<VP, PM>(P, pcoef, praw[2 * u], r0 + 2 * t, pc_ok && r0 + 2 * t < rend, v0);
+        op_finish<VP, PM>(P, pcoef, praw[2 * u + 1], r0 + 2 * t + 1, pc_ok && r0 + 2 * t + 1 < rend, v1);
+#pragma unroll
+        for (int i = 0; i < VP; ++i) d[i] = pack_bf16(v0[i], v1[i]);
+        *reinterpret_cast<typename VecT<VP>::F *>(Ps + t * BNN + p_c) = *reinterpret_cast<typename VecT<VP>::F *>(d);
+      }
+#pragma unroll
+      for (int u = 0; u < Q_VECS / 2; ++u) {
+        const int t = u * Q_RPP + q_r;
+        if (q_active && t < WG_BR / 2) {
+          __attribute__((aligned(16))) float v0[VQ], v1[VQ], d[VQ];
+          op_finish<VQ, QM>(Q, qcoef, qraw[2 * u], r0 + 2 * t, qc_ok && r0 + 2 * t < rend, v0);
+          op_finish<VQ, QM>(Q, qcoef, qraw[2 * u + 1], r0 + 2 * t + 1, qc_ok && r0 + 2 * t + 1 < rend, v1);
+#pragma unroll
+          for (int i = 0; i < VQ; ++i) d[i] = pack_bf16(v0[i], v1[i]);
+          *reinterpret_cast<typename VecT<VQ>::F *>(Qs + t * BKK + q_c) = *reinterpret_cast<typename VecT<VQ>::F *>(d);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < P_VECS; ++p) {
       const int rl = p * P_RPP + p_r;
@@ -604,6 +639,29 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
     RS_T(2);
     if (r0 + rstep < rend) prefetch(r0 + rstep, -1);
     RS_T(3);
+    if constexpr (BF) {
+      // lane (col, g = lr), step st: dwords t = 4 (2 st + g) .. + 3 of its column; all reads first, then 2 x TN x TK MFMAs
+      float4 pa[2][TN], qb[2][TK];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const float *pp = Ps + (4 * (2 * st + lr)) * BNN + wn * TN * 32 + lcol;
+        const float *qp = Qs + (4 * (2 * st + lr)) * BKK + wk * TK * 32 + lcol;
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+          pa[st][a] = make_float4(pp[a * 32], pp[BNN + a * 32], pp[2 * BNN + a * 32], pp[3 * BNN + a * 32]);
+#pragma unroll
+        for (int b = 0; b < TK; ++b)
+          qb[st][b] = make_float4(qp[b * 32], qp[BKK + b * 32], qp[2 * BKK + b * 32], qp[3 * BKK + b * 32]);
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TK; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[st][a]),
+                                                               __builtin_bit_cast(bf16x8, qb[st][b]), acc[a][b], 0, 0, 0);
+    } else {
     // fragment reads of step s+1 are issued before the MFMAs of step s (two register sets, fully unrolled):
     // the ~100-cycle LDS latency stays under the matrix pipe instead of in front of every 4 MFMAs
     const float *pp = Ps + lr * BNN + wn * TN * 32 + lcol;
@@ -627,6 +685,7 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
 #pragma unroll
         for (int b = 0; b < TK; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s & 1][a], qb[s & 1][b], acc[a][b], 0, 0, 0);
+    }
     }
     RS_T(4);
   }
@@ -1151,11 +1210,11 @@ void launch_gemm(bool bf, int v, dim3 grid, hipStream_t st, long long rows, cons
   else if constexpr (BM == 128) launch_gemm_m<BM, BN, 1, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);   // scalar operands: tall tile only, fp32 (bf16 staging packs pairs)
 }
 
-template <int WN, int WK, int TN, int TK, int VP, int VQ>
+template <int WN, int WK, int TN, int TK, int VP, int VQ, bool BF>
 void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
                     const RowOperand &Q, float *partial) {
   const size_t lds = sizeof(float) * 2 * WG_BR * (WN * TN * 32 + WK * TK * 32);
-#define RS_WG(PM_, QM_) hipLaunchKernelGGL((wgrad_kernel<WN, WK, TN, TK, VP, VQ, PM_, QM_>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, ncols, kcols, P, Q, partial)
+#define RS_WG(PM_, QM_) hipLaunchKernelGGL((wgrad_kernel<WN, WK, TN, TK, VP, VQ, PM_, QM_, BF>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, ncols, kcols, P, Q, partial)
 #define RS_WGQ(PM_) do { if (Q.mode == OPM_ID) RS_WG(PM_, OPM_ID); else if (Q.mode == OPM_RELU1) RS_WG(PM_, OPM_RELU1); else if (Q.mode == OPM_RELU2) RS_WG(PM_, OPM_RELU2); else RS_WG(-1, -1); } while (0)
   if (VP == 1 || VQ == 1) { RS_WG(-1, -1); return; }
   if (P.mode == OPM_AFF2) RS_WGQ(OPM_AFF2);
@@ -1165,13 +1224,27 @@ void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, const int *rows_d
 #undef RS_WGQ
 #undef RS_WG
 }
+// bf16 staging pairs the rows a thread owns: needs vector operands and an even number of vectors per thread and stage
+template <int WN, int WK, int TN, int TK, int VP, int VQ>
+constexpr bool wgrad_bf16_ok() {
+  return VP >= 2 && VQ >= 2 && (WG_BR * WN * TN * 32 / VP / GM_THREADS) % 2 == 0 &&
+         ((WG_BR * WK * TK * 32 / VQ + GM_THREADS - 1) / GM_THREADS) % 2 == 0;
+}
+template <int WN, int WK, int TN, int TK, int VP, int VQ>
+void launch_wgrad_p(bool bf, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
+                    const RowOperand &Q, float *partial) {
+  if constexpr (wgrad_bf16_ok<WN, WK, TN, TK, VP, VQ>()) {
+    if (bf) { launch_wgrad_m<WN, WK, TN, TK, VP, VQ, true>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial); return; }
+  }
+  launch_wgrad_m<WN, WK, TN, TK, VP, VQ, false>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
+}
 template <int WN, int WK, int TN, int TK>
-void launch_wgrad(int vp, int vq, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
+void launch_wgrad(bool bf, int vp, int vq, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
                   const RowOperand &Q, float *partial) {
-  if (vp == 1 || vq == 1) launch_wgrad_m<WN, WK, TN, TK, 1, 1>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
-  else if (vp == 4 && vq == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 4>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
-  else if (vp == 4) launch_wgrad_m<WN, WK, TN, TK, 4, 2>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
-  else launch_wgrad_m<WN, WK, TN, TK, 2, 2>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);   // (2,4) runs as (2,2)
+  if (vp == 1 || vq == 1) launch_wgrad_p<WN, WK, TN, TK, 1, 1>(false, grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
+  else if (vp == 4 && vq == 4) launch_wgrad_p<WN, WK, TN, TK, 4, 4>(bf, grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
+  else if (vp == 4) launch_wgrad_p<WN, WK, TN, TK, 4, 2>(bf, grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
+  else launch_wgrad_p<WN, WK, TN, TK, 2, 2>(bf, grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);   // (2,4) runs as (2,2)
 }
 
 }  // namespace
@@ -1257,8 +1330,8 @@ extern "C" int rs_mlp_gemm_rows_bf16(long long rows, const int *rows_dev, int kd
   return gemm_rows_impl(true, rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
 }
 
-extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
-                            const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
+static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
+                      const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
   RS_REQUIRE(rows >= 0 && ncols >= 0 && kcols >= 0 && chunks > 0, "rs_mlp_wgrad: bad size");
   if (ncols == 0 || kcols == 0) return RS_OK;
   RS_REQUIRE(partial && dw, "rs_mlp_wgrad: null pointer");
@@ -1288,11 +1361,11 @@ extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int 
 #undef RS_WS
   } else
   if (kcols > 64) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
-    launch_wgrad<2, 2, 2, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, rows_dev, ncols, kcols, P, Q, partial);
+    launch_wgrad<2, 2, 2, 2>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   } else if (kcols > 32) {   // 128 x 64: waves 4 x 1, 1 x 2 tiles
-    launch_wgrad<4, 1, 1, 2>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, partial);
+    launch_wgrad<4, 1, 1, 2>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   } else {                   // 128 x 32: waves 4 x 1, 1 x 1 tile
-    launch_wgrad<4, 1, 1, 1>(vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, partial);
+    launch_wgrad<4, 1, 1, 1>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   }
   const long long n = (long long)ncols * kcols;
   long long rb = (n + 31) / 32;
@@ -1300,6 +1373,18 @@ extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int 
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)rb), dim3(GM_THREADS), 0, st, chunks, n, partial, dw);
   RS_CHECK_LAUNCH("rs_mlp_wgrad");
   return RS_OK;
+}
+
+extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
+                            const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
+  return wgrad_impl(false, rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
+}
+// Mixed precision: both operands rounded to bf16 after their fp32 prologue, bf16 MFMA, fp32 accumulation inside a
+// row slab; the slabs' partial products and their fixed-order sum stay fp32.  The narrow streaming kernel
+// (kcols <= 16) and the layouts that force scalar loads or one vector per thread (kcols <= 32, float4) run in fp32.
+extern "C" int rs_mlp_wgrad_bf16(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
+                                 const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
+  return wgrad_impl(true, rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
 }
 
 // ---- padded copies of up to RS_PACK_MAX conv weights (cout, cin) in one launch --------------------------------

@@ -26,8 +26,8 @@ COMPACT_GROUPS = os.environ.get("REPSURF_COMPACT", "1") != "0"
 # Arithmetic of the MFMA row GEMMs (forward and data gradient) of the HIP executor:
 #   "fp32"  v_mfma_f32_32x32x2_f32 -- the parity path (1e-5 against the reference), the default and what bench.py reports;
 #   "bf16"  BASELINE configs[4]: operands rounded to bf16 at the LDS commit, v_mfma_f32_32x32x16_bf16, fp32 accumulation
-#           and fp32 tensors in HBM (rs_mlp_gemm_rows_bf16).  Weight gradients (a reduction over 1e4-1e5 rows), BatchNorm,
-#           pooling, the constructor MLP and the classifier head stay fp32.  Tolerance: tests/test_mlp_gpu.py (bf16 section).
+#           and fp32 tensors in HBM (rs_mlp_gemm_rows_bf16, rs_mlp_wgrad_bf16; weight-gradient slabs are summed in fp32).
+#           BatchNorm, pooling, the narrow first-layer kernels, the constructor MLP and the classifier head stay fp32.  Tolerance: tests/test_mlp_gpu.py (bf16 section).
 PRECISION = os.environ.get("REPSURF_MLP_DTYPE", "fp32")
 if PRECISION not in ("fp32", "bf16"):
     raise ValueError(f"REPSURF_MLP_DTYPE={PRECISION!r}: expected fp32 or bf16")

@@ -311,7 +311,8 @@ def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None):
     chunks = wgrad_chunks(rows if rows_dev is None else max(rows // 4, 256), ncols, kcols)
     part = torch.empty((chunks, ncols * kcols), dtype=torch.float32, device=device)
     dw = torch.empty((ncols, kcols), dtype=torch.float32, device=device)
-    _lib.call("rs_mlp_wgrad", rows, rows_dev, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), chunks,
+    from . import mlp as _mlp
+    _lib.call("rs_mlp_wgrad_bf16" if _mlp.PRECISION == "bf16" else "rs_mlp_wgrad", rows, rows_dev, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), chunks,
               _ptr(dw), _stream())
     return dw
 
