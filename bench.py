@@ -139,9 +139,13 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # test hooks (tests/test_graph_gpu.py runs the world_size-2 path on a ONE-GPU box): both ranks on one device, gloo
+    # carrying the gradient all-reduce.  Never set by the driver's launch.
+    if "REPSURF_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["REPSURF_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    rdist.init(backend="nccl", device=device)                 # "nccl" is RCCL on ROCm (xGMI inside the node)
+    rdist.init(backend=os.environ.get("REPSURF_DIST_BACKEND", "nccl"), device=device)   # "nccl" is RCCL on ROCm (xGMI inside the node)
 
     import importlib
     from repsurf_amd import _lib, mlp, ops
@@ -248,6 +252,10 @@ def main():
         torch.cuda.synchronize()
         _lib.profile_enable(False)
     dt = rdist.max_over_ranks(dt, device)
+    if "REPSURF_BENCH_DUMP" in os.environ:       # test hook: every rank's parameters after the timed loop
+        torch.cuda.synchronize()
+        torch.save(torch.cat([p.detach().flatten() for p in model.parameters()]).cpu(),
+                   os.path.join(os.environ["REPSURF_BENCH_DUMP"], f"params_rank{rank}.pt"))
     prof = _lib.profile_collect()            # {abi name: [(ms, dims), ...]} from HIP events on the launch stream
 
     if rank == 0:

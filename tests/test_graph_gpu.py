@@ -168,3 +168,31 @@ def test_pipelined_sharded_step_single_rank_process_group():
         assert losses[True][2] < losses[True][0] + 0.5
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-pipeline", "--no-kernel-timing"], ["--no-graph", "--no-kernel-timing"]])
+def test_bench_world_size_two_on_one_gpu(extra, tmp_path):
+    """bench.py's N > 1 code (rank seeds, flat-gradient all-reduce between the captured graphs, Adam graph, barrier +
+    max-over-ranks timing, rank-0 JSON line) launched the way the driver launches it, with two ranks sharing the one GPU of
+    this box and gloo carrying the collective (RCCL refuses two ranks on one device).  Checks the contract fields and
+    that both ranks leave the loop with the same parameters (they started equal and applied the same averaged gradient)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    env = dict(os.environ, REPSURF_DIST_BACKEND="gloo", REPSURF_BENCH_DEVICE="0", REPSURF_BENCH_DUMP=str(tmp_path),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--no-cpu-baseline"] + extra        # extra = []: exactly the driver's flags (per-launch timing pass on rank 0)
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "dp2"
+    assert "falling back" not in res.stderr, res.stderr[-3000:]
+    a, b = (torch.load(os.path.join(str(tmp_path), f"params_rank{r}.pt")) for r in (0, 1))
+    assert torch.isfinite(a).all() and torch.equal(a, b)
