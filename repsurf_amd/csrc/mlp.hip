@@ -1303,6 +1303,9 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
   if (bn == 128 && tiles * rs_cdiv(cols, 128) < (bm == 64 ? bn_small64 : bn_small) && ep.pool_ns == 0) bn = 64;   // few rows (group_all stage): 2x the workgroups
   static const int bn32_below = env_int("RS_GEMM_BN32_BELOW", 256);
   if (bm == GM_BM && bn == 64 && cols > 64 && tiles * rs_cdiv(cols, 64) < bn32_below && ep.pool_ns == 0) bn = 32;   // still under one workgroup per CU: 4096 x 512 -> 256 runs 22 us instead of 30
+  // (32-row tiles -- 1 x 4 waves, 42 KB of LDS, 168 VGPRs for three workgroups per CU -- were measured for the compacted
+  // sa1 / sa2 launches, whose 1043 / 753 tiles of 64 rows are 3 / 2 rounds on 512 workgroups with a mostly empty last
+  // round: 1.86 ms/step against 1.83, 768 / 1024 / 512 slots alike.  The per-tile fixed costs outweigh the finer rounds.)
   const int tiles_n = rs_cdiv(cols, bn);
   int gx = persistent_blocks(tiles, tiles_n, bm);
   if (epi_mode != EPI_STORE) gx = gx < ep.partial_blocks ? gx : ep.partial_blocks;
