@@ -264,7 +264,9 @@ int rs_mlp_gemm_rows_bf16(long long rows, const int *rows_dev, int kdim, int col
                           const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream);
 
 /* Weight gradient dw[ncols][kcols] = sum_r P[r][n] * Q[r][k]; rows are split into `chunks` workgroup
- * slabs whose partial products land in partial (chunks, ncols*kcols) and are summed in a fixed order. */
+ * slabs whose partial products land in partial (chunks, ncols*kcols) and are summed in a fixed order.
+ * dw = NULL: only the partials are produced; the caller sums them (rs_reduce_partials or
+ * rs_bn_backward_finalize_reduce). */
 int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
                  const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream);
 /* Mixed precision (see rs_mlp_gemm_rows_bf16): P and Q rounded to bf16 after their fp32 prologues, bf16 MFMA with
@@ -319,6 +321,14 @@ int rs_pack_weights(const rs_pack_weights_args *args, void *stream);
 
 /* out[e] = sum_b partial[b][e], b ascending (deterministic reduction of fp32 workgroup partials). */
 int rs_reduce_partials(int nblk, long long n, const float *partial, float *out, void *stream);
+/* rs_bn_backward_finalize and rs_reduce_partials(red_chunks, red_n, red_partial, red_out) in ONE launch: in the backward
+ * chain the weight-gradient reduction of a layer (rs_mlp_wgrad called with dw = NULL leaves it to the caller) and the
+ * BatchNorm-backward finalize of the layer below follow each other, each a few microseconds of work behind a
+ * graph node's launch latency.  Same results as the two separate calls (same summation order). */
+int rs_bn_backward_finalize_reduce(int c, long long rows, int nblk, int nstat, int which, const double *partial,
+                                   const float *scale, const float *mean, const float *invstd, float *p, float *q,
+                                   float *r, float *dgamma, float *dbeta, int red_chunks, long long red_n,
+                                   const float *red_partial, float *red_out, void *stream);
 
 /* ---- classifier head on <= 64 rows (repsurf_amd/csrc/head.hip) -----------------------------------------------
  * classfier = Linear-BN1d-ReLU-Dropout-Linear-BN1d-ReLU-Dropout-Linear + log_softmax

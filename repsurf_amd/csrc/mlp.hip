@@ -888,11 +888,13 @@ wgrad_small_kernel(long long rows_arg, const int *__restrict__ rows_dev, int nco
 // out[e] = sum_c partial[c][e]   (deterministic order).  32 outputs x 8 chunk slices per workgroup:
 // consecutive lanes read consecutive outputs (coalesced), each thread sums every 8th chunk with
 // independent loads in flight, slices are combined in a fixed order through LDS.
-__global__ void __launch_bounds__(GM_THREADS)
-reduce_partials_kernel(int chunks, long long n, const float *__restrict__ partial, float *__restrict__ out) {
+// (bid, nb): the block's index and the number of blocks of the reduction -- the kernel's own grid, or a sub-range of
+// bn_bwd_finalize_reduce_kernel's
+__device__ __forceinline__ void reduce_partials_body(int bid, int nb, int chunks, long long n, const float *__restrict__ partial,
+                                                     float *__restrict__ out) {
   __shared__ float red[8][32];
   const int ex = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  for (long long e0 = (long long)blockIdx.x * 32; e0 < n; e0 += (long long)gridDim.x * 32) {
+  for (long long e0 = (long long)bid * 32; e0 < n; e0 += (long long)nb * 32) {
     const long long e = e0 + ex;
     float s = 0.f;
     if (e < n) {
@@ -921,6 +923,11 @@ reduce_partials_kernel(int chunks, long long n, const float *__restrict__ partia
     }
     __syncthreads();
   }
+}
+
+__global__ void __launch_bounds__(GM_THREADS)
+reduce_partials_kernel(int chunks, long long n, const float *__restrict__ partial, float *__restrict__ out) {
+  reduce_partials_body(blockIdx.x, gridDim.x, chunks, n, partial, out);
 }
 
 // ---- BatchNorm statistics -> affine.  Workgroup = 8 channels x 32 slices of the partial rows: consecutive
@@ -1009,6 +1016,36 @@ bn_bwd_finalize_kernel(int c, long long rows, int nblk, int nstat, int which, co
   const double db = v[0], dg = v[1];
   const double s = scale[ch], is = invstd[ch], mu = mean[ch], m = (double)rows;
   // dy = s * (dz - db/m - yhat * dg/m),  yhat = (y - mu) * is
+  const double qq = -s * is * dg / m;
+  p[ch] = (float)s;
+  q[ch] = (float)qq;
+  r[ch] = (float)(-s * db / m - qq * mu);
+  if (dgamma) dgamma[ch] = (float)dg;
+  if (dbeta) dbeta[ch] = (float)db;
+}
+
+// The weight-gradient reduction of layer l and the BatchNorm-backward finalize of layer l-1 sit next to each other in
+// the backward chain and are both a few microseconds of work behind ~5 us of graph-node latency: one launch, the first
+// `nfin` workgroups finalize, the others reduce (no barrier spans both roles).
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_reduce_kernel(int c, long long rows, int nblk, int nstat, int which, const double *__restrict__ partial,
+                              const float *__restrict__ scale, const float *__restrict__ mean,
+                              const float *__restrict__ invstd, float *__restrict__ p, float *__restrict__ q,
+                              float *__restrict__ r, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                              int nfin, int red_chunks, long long red_n, const float *__restrict__ red_partial,
+                              float *__restrict__ red_out) {
+  if ((int)blockIdx.x >= nfin) {
+    reduce_partials_body(blockIdx.x - nfin, gridDim.x - nfin, red_chunks, red_n, red_partial, red_out);
+    return;
+  }
+  const int sel[2] = {0, which};
+  double v[2];
+  bool owner;
+  reduce_stat_rows<2>(c, nblk, nstat, sel, partial, v, owner);
+  if (!owner) return;
+  const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
+  const double db = v[0], dg = v[1];
+  const double s = scale[ch], is = invstd[ch], mu = mean[ch], m = (double)rows;
   const double qq = -s * is * dg / m;
   p[ch] = (float)s;
   q[ch] = (float)qq;
@@ -1337,7 +1374,7 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
                       const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
   RS_REQUIRE(rows >= 0 && ncols >= 0 && kcols >= 0 && chunks > 0, "rs_mlp_wgrad: bad size");
   if (ncols == 0 || kcols == 0) return RS_OK;
-  RS_REQUIRE(partial && dw, "rs_mlp_wgrad: null pointer");
+  RS_REQUIRE(partial, "rs_mlp_wgrad: null pointer");
   int rc = check_operand("rs_mlp_wgrad(P)", p, rows);
   if (rc != RS_OK) return rc;
   rc = check_operand("rs_mlp_wgrad(Q)", q, rows);
@@ -1370,10 +1407,12 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
   } else {                   // 128 x 32: waves 4 x 1, 1 x 1 tile
     launch_wgrad<4, 1, 1, 1>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   }
-  const long long n = (long long)ncols * kcols;
-  long long rb = (n + 31) / 32;
-  if (rb > 2048) rb = 2048;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)rb), dim3(GM_THREADS), 0, st, chunks, n, partial, dw);
+  if (dw) {      // dw == NULL: the caller reduces `partial` itself (rs_reduce_partials / rs_bn_backward_finalize_reduce)
+    const long long n = (long long)ncols * kcols;
+    long long rb = (n + 31) / 32;
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)rb), dim3(GM_THREADS), 0, st, chunks, n, partial, dw);
+  }
   RS_CHECK_LAUNCH("rs_mlp_wgrad");
   return RS_OK;
 }
@@ -1467,6 +1506,23 @@ extern "C" int rs_bn_backward_finalize(int c, long long rows, int nblk, int nsta
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rs_cdiv(c, 8)), dim3(256), 0, (hipStream_t)stream, c, rows, nblk,
                      nstat, which, partial, scale, mean, invstd, p, q, r, dgamma, dbeta);
   RS_CHECK_LAUNCH("rs_bn_backward_finalize");
+  return RS_OK;
+}
+
+extern "C" int rs_bn_backward_finalize_reduce(int c, long long rows, int nblk, int nstat, int which, const double *partial,
+                                              const float *scale, const float *mean, const float *invstd, float *p,
+                                              float *q, float *r, float *dgamma, float *dbeta, int red_chunks,
+                                              long long red_n, const float *red_partial, float *red_out, void *stream) {
+  RS_REQUIRE(c > 0 && rows > 0 && nblk > 0 && nstat >= 2 && which >= 1 && which < nstat, "rs_bn_backward_finalize_reduce: bad size");
+  RS_REQUIRE(partial && scale && mean && invstd && p && q && r, "rs_bn_backward_finalize_reduce: null pointer");
+  RS_REQUIRE(red_chunks > 0 && red_n > 0 && red_partial && red_out, "rs_bn_backward_finalize_reduce: empty reduction");
+  const int nfin = rs_cdiv(c, 8);
+  long long rb = (red_n + 31) / 32;
+  if (rb > 2048) rb = 2048;
+  hipLaunchKernelGGL(bn_bwd_finalize_reduce_kernel, dim3(nfin + (int)rb), dim3(256), 0, (hipStream_t)stream, c, rows, nblk,
+                     nstat, which, partial, scale, mean, invstd, p, q, r, dgamma, dbeta, nfin, red_chunks, red_n, red_partial,
+                     red_out);
+  RS_CHECK_LAUNCH("rs_bn_backward_finalize_reduce");
   return RS_OK;
 }
 

@@ -305,21 +305,43 @@ def wgrad_chunks(rows, ncols, kcols):
     return max(1, min(chunks, cap))
 
 
-def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None):
+# Weight-gradient partials whose fixed-order sum rides along with the next BatchNorm-backward finalize launch of the same
+# backward call (rs_bn_backward_finalize_reduce): (partial, chunks, elements, dw).  Same stream, consumed in order;
+# `flush_reduces` sums what is left when the chain ends.
+_pending_reduce = []
+
+
+def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None, defer=False):
+    """defer=True: dw is complete only after the next bwd_coeffs() / flush_reduces() on this stream."""
     # a compacted row set fills a fraction of its capacity (the count is on the device): size the slab split
     # for a quarter of it so that slabs keep several pipeline stages and fewer partials need reducing
     chunks = wgrad_chunks(rows if rows_dev is None else max(rows // 4, 256), ncols, kcols)
     part = torch.empty((chunks, ncols * kcols), dtype=torch.float32, device=device)
     dw = torch.empty((ncols, kcols), dtype=torch.float32, device=device)
     from . import mlp as _mlp
+    defer = defer and not SIDE_WGRAD and os.environ.get("REPSURF_DEFER_REDUCE", "1") != "0"
     _lib.call("rs_mlp_wgrad_bf16" if _mlp.PRECISION == "bf16" else "rs_mlp_wgrad", rows, rows_dev, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), chunks,
-              _ptr(dw), _stream())
+              None if defer else _ptr(dw), _stream())
+    if defer:
+        _pending_reduce.append((part, chunks, ncols * kcols, dw))
     return dw
+
+
+def flush_reduces():
+    while _pending_reduce:
+        part, chunks, n, dw = _pending_reduce.pop(0)
+        _lib.call("rs_reduce_partials", chunks, n, _ptr(part), _ptr(dw), _stream())
 
 
 def bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk=None):
     """BN backward sums (`nblk` partial rows, default PARTIAL_BLOCKS) -> (p, q, r, dgamma, dbeta)."""
     buf = torch.empty((5, c), dtype=torch.float32, device=device)
+    if _pending_reduce:
+        rpart, rchunks, rn, rdw = _pending_reduce.pop(0)
+        _lib.call("rs_bn_backward_finalize_reduce", c, rows, PARTIAL_BLOCKS if nblk is None else nblk, nstat, which, part.data_ptr(),
+                  _ptr(vec.scale), _ptr(vec.mean), _ptr(vec.invstd), _ptr(buf[0]), _ptr(buf[1]), _ptr(buf[2]), _ptr(buf[3]),
+                  _ptr(buf[4]), rchunks, rn, _ptr(rpart), _ptr(rdw), _stream())
+        return buf[0], buf[1], buf[2], buf[3], buf[4]
     _lib.call("rs_bn_backward_finalize", c, rows, PARTIAL_BLOCKS if nblk is None else nblk, nstat, which, part.data_ptr(), _ptr(vec.scale),
               _ptr(vec.mean), _ptr(vec.invstd), _ptr(buf[0]), _ptr(buf[1]), _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]),
               _stream())
@@ -463,6 +485,7 @@ class _SAStack(Function):
         dout = dout.contiguous()
         grads = [None] * ctx.nparams
         nl = len(ys)
+        flush_reduces()      # (nothing, unless an earlier backward call was interrupted between a wgrad and its reduction)
         zeros = _ZeroPool(sum(w.shape[0] for w in w2ds) + (2 * s["wl2"].shape[0] if pos > 0 else 0), dev)
         first = 8 if pos > 0 else 0
         # ---- pooled layer: BN-backward sums from (groups, c) data only
@@ -498,7 +521,7 @@ class _SAStack(Function):
                                s["vf"].scale, s["vf"].shift)
             else:
                 q_op = operand(OP_ID, x, cx)
-            grads[pidx] = fork.run(lambda: wgrad(rows, cout, cin, p_op, q_op, dev, rdev))
+            grads[pidx] = fork.run(lambda: wgrad(rows, cout, cin, p_op, q_op, dev, rdev, defer=True))
             if li > 0:      # data gradient, ReLU mask and BN-backward sums of layer li-1
                 dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], ys[li - 1], vecs[li - 1], device=dev,
                                                rows_dev=rdev, wt=wts[("l", li)])
@@ -519,8 +542,8 @@ class _SAStack(Function):
                 opf = operand(OP_AFF2, dz, cin, s["yf"], cin, s1=pf, t1=rf, s2=qf, rs=rs)
                 fork.keep += [dz, pl, ql, rl, pf, qf, rf]
                 foff, fk = meta.get("feat_off", pos), meta.get("feat_k", cx - pos)
-                grads[0] = fork.run(lambda: wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev, rdev))
-                grads[4] = fork.run(lambda: wgrad(rows, cin, fk, opf, operand(OP_ID, x, cx, a_off=foff), dev, rdev))
+                grads[0] = fork.run(lambda: wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev, rdev, defer=True))
+                grads[4] = fork.run(lambda: wgrad(rows, cin, fk, opf, operand(OP_ID, x, cx, a_off=foff), dev, rdev, defer=True))
                 grads[1] = zeros.take(cin)
                 grads[5] = zeros.take(cin)
                 grads[2], grads[3], grads[6], grads[7] = dgl, dbl, dgf, dbf
@@ -534,6 +557,7 @@ class _SAStack(Function):
                 dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
                 epi = Epilogue(bias=None, out=_ptr(dx), ldo=cx, mode=EPI_STORE)
                 gemm_rows(rows, cout, cx, p_op, wts[("l", 0)], epi, rdev)
+        flush_reduces()
         fork.join()
         out_grads = [None if g is None else g.reshape(shape) for g, shape in zip(grads, meta["shapes"])]
         return (dx, None) + tuple(out_grads)

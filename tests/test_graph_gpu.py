@@ -178,13 +178,17 @@ def test_bench_world_size_two_on_one_gpu(extra, tmp_path):
     that both ranks leave the loop with the same parameters (they started equal and applied the same averaged gradient)."""
     import json
     import os
+    import socket
     import subprocess
     import sys
     from tests.util import ROOT
+    with socket.socket() as sk:      # a free rendezvous port (earlier tests of this process hold process groups of their own)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, REPSURF_DIST_BACKEND="gloo", REPSURF_BENCH_DEVICE="0", REPSURF_BENCH_DUMP=str(tmp_path),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
            "--no-cpu-baseline"] + extra        # extra = []: exactly the driver's flags (per-launch timing pass on rank 0)
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
