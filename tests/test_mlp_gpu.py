@@ -271,7 +271,7 @@ def test_bf16_row_gemm_fused_prologue_and_statistics():
 def test_bf16_sa_stack_within_restated_tolerance(groups, ns, pos, feat, widths):
     """SURVEY.md §8(d) C5 ("tolerance restated vs the fp32 reference ... to be tightened empirically").  The yardstick is
     what the reference itself would do in bf16: the torch executor (F.linear / F.batch_norm / relu / max, i.e. the
-    reference's Conv2d-BN-ReLU stack) under torch.autocast(bfloat16).  Measured (tools/_diag_bf16.py, MI355X): pooled
+    reference's Conv2d-BN-ReLU stack) under torch.autocast(bfloat16).  Measured (tools/bf16_diag.py, MI355X): pooled
     post-BN activations max-abs 3.2-3.7e-2 here against 5.3-6.1e-2 for autocast (this path keeps the conv OUTPUT in
     fp32); gradient cosine against fp32 0.987-0.996 here, 0.980-0.992 for autocast -- the max-pool argmax moves for
     near-tied rows in any bf16 forward, which re-routes whole gradient rows, so 0.999 is not reachable by either.

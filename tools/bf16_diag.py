@@ -1,3 +1,5 @@
+"""bf16 mode of the shared-MLP stacks against the fp32 path, next to the torch executor under autocast(bfloat16) (GPU box):
+the numbers tests/test_mlp_gpu.py::test_bf16_sa_stack_within_restated_tolerance asserts against."""
 import copy, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
