@@ -85,7 +85,8 @@ class PipelinedStep:
         if sharded:
             import torch.distributed as dist
             self.dist = dist
-            self.flat = attach_flat_grads(list(net.parameters()))
+            self.grads = FlatGrads(list(net.parameters()))
+            self.flat = self.grads.flat
         dev = label.device
         self.points = [points.clone(), points.clone()]
         self.label = [label.clone(), label.clone()]
@@ -144,7 +145,7 @@ class PipelinedStep:
 
     def _network(self, p):
         if self.sharded:
-            self.flat.zero_()
+            self.grads.clear()
         elif self.optimizer is not None:
             self.optimizer.zero_grad(set_to_none=True)
         else:
@@ -152,14 +153,15 @@ class PipelinedStep:
                 q.grad = None
         loss = self.criterion(self.net(self.points[p], geo=self.state[p]), self.label[p])
         loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
-        if self.optimizer is not None and not self.sharded:
+        if self.sharded:
+            self.grads.pack()
+        elif self.optimizer is not None:
             self.optimizer.step()
         return loss
 
     def _reduce(self):
-        if self.sharded and self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
-            self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(self.dist.get_world_size(self.group))
+        if self.sharded and self.dist.is_initialized():
+            self.grads.all_reduce_mean(self.dist, self.group)
 
     def _finish(self):
         """what follows the network graph in sharded mode (eagerly during warm-up, as a graph afterwards)"""
@@ -206,6 +208,50 @@ class PipelinedStep:
         return self.loss[p]
 
 
+class FlatGrads:
+    """The all-reduce buffer of the sharded steps.  Backward runs with p.grad = None, so autograd hands every gradient
+    tensor over as it is (no `grad += g` kernel per parameter: ~70 dependent graph nodes); `pack()` then copies them
+    into ONE contiguous fp32 buffer with a multi-tensor launch and points every p.grad at its slice of that buffer --
+    what the collective reduces and the optimizer reads.  Under graph capture the copy is part of the network graph and
+    the slices' addresses are what the optimizer graph bakes in."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=self.params[0].dtype, device=self.params[0].device)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def clear(self):
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def all_reduce_mean(self, dist, group=None):
+        world = dist.get_world_size(group)
+        if world <= 1:
+            return
+        if dist.get_backend(group) == "nccl":            # RCCL averages in the collective
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(world)
+
+
 def attach_flat_grads(params):
     """One contiguous fp32 buffer holding every gradient; each p.grad becomes a view into it, so autograd
     accumulates in place and ONE collective (or one memset) covers the whole model — what DDP's
@@ -236,7 +282,8 @@ class ShardedGraphedStep:
         self.dist, self.group = dist, group
         self.net, self.criterion, self.optimizer = net, criterion, optimizer
         self.points, self.label = points, label
-        self.flat = attach_flat_grads(list(net.parameters()))
+        self.grads = FlatGrads(list(net.parameters()))
+        self.flat = self.grads.flat
         self.draws = rng.StaticDraws(label.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -264,15 +311,15 @@ class ShardedGraphedStep:
         torch.cuda.synchronize()
 
     def _fwd_bwd(self):
-        self.flat.zero_()
+        self.grads.clear()
         loss = self.criterion(self.net(self.points), self.label)
         loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
+        self.grads.pack()
         return loss
 
     def _reduce(self):
-        if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
-            self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(self.dist.get_world_size(self.group))
+        if self.dist.is_initialized():
+            self.grads.all_reduce_mean(self.dist, self.group)
 
     def __call__(self):
         self.draws.refill()

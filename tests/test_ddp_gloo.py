@@ -100,3 +100,42 @@ def test_flat_gradient_buffer_allreduce():
         (f0, l0, g0), (f1, l1, g1) = out[0], out[1]
     assert torch.allclose(f0, f1) and torch.allclose(f0, (l0 + l1) / 2, atol=1e-6)
     assert torch.equal(g0, f0)                 # parameters see the averaged gradient through their views
+
+
+def _flatgrads_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from repsurf_amd import dist as rdist
+    from repsurf_amd.graph import FlatGrads
+    rdist.init(backend="gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    grads = FlatGrads(list(model.parameters()))
+    g = torch.Generator().manual_seed(rdist.rank_seed(5, rank))
+    x = torch.randn(32, 8, generator=g)
+    for _ in range(2):                         # second pass: clear() -> fresh gradient tensors -> pack() again
+        grads.clear()
+        model(x).pow(2).mean().backward()
+        assert all(p.grad.data_ptr() != v.data_ptr() for p, v in zip(grads.params, grads.views))   # handed over, not accumulated
+        local = torch.cat([p.grad.flatten() for p in model.parameters()])
+        grads.pack()
+    assert torch.equal(grads.flat, local)
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(grads.params, grads.views))
+    grads.all_reduce_mean(dist)
+    out[rank] = (grads.flat.clone(), local, torch.cat([p.grad.flatten() for p in model.parameters()]))
+    rdist.finish()
+
+
+def test_flatgrads_pack_and_allreduce():
+    """the gradient path of the sharded steps (repsurf_amd.graph.FlatGrads: backward with p.grad = None, one
+    multi-tensor pack, one all-reduce, optimizer reads the slices) on 2 gloo ranks"""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_flatgrads_worker, args=(world, port, out), nprocs=world, join=True)
+        (f0, l0, g0), (f1, l1, g1) = out[0], out[1]
+    assert torch.allclose(f0, f1) and torch.allclose(f0, (l0 + l1) / 2, atol=1e-6)
+    assert torch.equal(g0, f0)
