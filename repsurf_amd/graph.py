@@ -245,11 +245,14 @@ class FlatGrads:
         world = dist.get_world_size(group)
         if world <= 1:
             return
-        if dist.get_backend(group) == "nccl":            # RCCL averages in the collective
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
-        else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(world)
+        if dist.get_backend(group) == "nccl" and getattr(self, "_avg_ok", True):    # RCCL averages in the collective
+            try:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+                return
+            except (RuntimeError, ValueError):           # a build without ncclAvg refuses at call time: sum and scale
+                self._avg_ok = False
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        self.flat.div_(world)
 
 
 def attach_flat_grads(params):

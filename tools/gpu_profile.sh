@@ -21,4 +21,4 @@ python tools/traffic_from_pmc.py --fetch-log $D/launch_FETCH_SIZE.json --fetch-c
   --write-log $D/launch_WRITE_SIZE.json --write-csv $D/pmc_WRITE_SIZE_counter_collection.csv --out $D/traffic.json > $D/traffic.log 2>&1
 python tools/pmc_summary.py $D > $D/pmc_summary.log 2>&1
 ls -la $D | head -40
-tail -3 $D/*.log
+tail -q -n 3 $D/*.log
