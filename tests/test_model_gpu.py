@@ -128,3 +128,50 @@ def test_drop_in_with_the_reference_api_names():
     assert tri.shape == (2, 256, 8, 3, 3) and (tri[..., 0, :] == 0).all()
     sub = P.sample(64, xyz.permute(0, 2, 1))
     assert sub.shape == (2, 3, 64)
+
+
+def _bf16_fp32_step(xyz, label, seed):
+    from repsurf_amd import mlp
+    from util.utils import SmoothClsLoss
+    res = {}
+    for prec in ("fp32", "bf16"):
+        mlp.set_precision(prec)
+        try:
+            model = build_model()
+            torch.manual_seed(seed)
+            pred = model(torch.from_numpy(xyz).cuda().permute(0, 2, 1).contiguous())
+            loss = SmoothClsLoss()(pred, torch.from_numpy(label).long().cuda())
+            loss.backward()
+            torch.cuda.synchronize()
+            res[prec] = (pred.detach().cpu().numpy(), float(loss.detach()),
+                         {n: p.grad.detach().cpu().numpy().ravel().astype(np.float64) for n, p in model.named_parameters()})
+        finally:
+            mlp.set_precision("fp32")
+    return res
+
+
+def test_bf16_mode_classifier_step():
+    """BASELINE configs[4] at model level (mlp.set_precision("bf16"): bf16 MFMA operands in the shared-MLP GEMMs).
+    (a) The reference fixture's 4 clouds: geometry kernels stay fp32, so the sampled / grouped sets are the reference's;
+    log-probabilities (|.| ~ 3) stay within 0.2 of the REFERENCE's fp32 values (measured 0.09: the head's BatchNorm1d over
+    4 rows amplifies any perturbation of its input), the loss within 5e-2.
+    (b) 16 synthetic clouds: every gradient finite, all gradients together keep their direction against the fp32 path
+    (measured cosine 0.925, log-probabilities 0.078 apart; 0.84 with the fixture's 4 clouds).  Three stacks each at
+    0.99 (tests/test_mlp_gpu.py, where the same stacks under torch.autocast are the yardstick and come out slightly
+    worse), re-routed max-pool winners and a head BatchNorm over 16 rows compound; the bounds here only catch breakage."""
+    from repsurf_amd import mlp
+    mlp.set_backend("hip")
+    g = np.load(os.path.join(GOLDEN, "model_b4.npz"))
+    res = _bf16_fp32_step(g["xyz"], g["label"], int(g["rng_seed"]))
+    assert np.abs(res["fp32"][0] - g["logits"]).max() < 1e-4           # the fp32 run is the parity path
+    assert not np.array_equal(res["bf16"][0], res["fp32"][0])           # and the bf16 run really took the other kernels
+    assert np.abs(res["bf16"][0] - g["logits"]).max() < 0.2, np.abs(res["bf16"][0] - g["logits"]).max()
+    assert abs(res["bf16"][1] - res["fp32"][1]) < 5e-2
+    res = _bf16_fp32_step(cloud(21, 16, 1024), (np.arange(16) % 15).astype(np.int64), 5)
+    names = [n for n in res["fp32"][2] if not is_pre_bn_bias(n)]
+    assert all(np.isfinite(res["bf16"][2][n]).all() for n in res["bf16"][2])
+    allb, allf = (np.concatenate([res[k][2][n] for n in names]) for k in ("bf16", "fp32"))
+    cos = float(allb @ allf / (np.linalg.norm(allb) * np.linalg.norm(allf)))
+    err = np.abs(res["bf16"][0] - res["fp32"][0]).max()
+    print("bf16 vs fp32, 16 clouds: gradient cosine %.4f, log-probability max-abs %.4f" % (cos, err))
+    assert cos > 0.85 and err < 0.15, (cos, err)
