@@ -301,7 +301,8 @@ int rs_pool_max(long long groups, int nsample, int c, int relu, const int *offse
 int rs_pool_select(long long groups, int c, const float *ymax, const float *ymin, const int *amax,
                    const int *amin, const float *scale, const float *shift, float *out, int *arg, void *stream);
 /* v = dout * (out > 0) and the BatchNorm-backward sums of the pooled layer from (groups, c) data only:
- * partial (partial_blocks, 2, c) = {sum v, sum v * yhat[arg row]}. */
+ * partial (partial_blocks, 2, c) = {sum v, sum v * yhat[arg row]}.  out = NULL: the pooled layer ended without a
+ * ReLU (rs_pool_max called with relu = 0), v = dout. */
 int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout,
                          const float *out, const int *arg, const float *y, const float *mean, const float *invstd,
                          float *v, double *partial, int partial_blocks, void *stream);

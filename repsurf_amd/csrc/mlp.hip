@@ -1133,7 +1133,7 @@ pool_select_kernel(long long groups, int c, const float *__restrict__ ymax, cons
   }
 }
 
-// v[g][c] = dout * (out > 0); partial sums {sum v, sum v * yhat[arg row]} per column (BatchNorm backward
+// v[g][c] = dout * (out > 0)  (out == NULL: v = dout); partial sums {sum v, sum v * yhat[arg row]} per column (BatchNorm backward
 // of the pooled layer computed from G x C data only)
 __global__ void __launch_bounds__(GM_THREADS)
 pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ offsets, const float *__restrict__ dout,
@@ -1150,7 +1150,7 @@ pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ off
     const float mu = mean[ch], is = invstd[ch];
     for (long long g = (long long)blockIdx.x * 4 + ty; g < groups; g += (long long)gridDim.x * 4) {
       const long long e = g * c + ch;
-      const float val = out[e] > 0.f ? dout[e] : 0.f;
+      const float val = (!out || out[e] > 0.f) ? dout[e] : 0.f;      // out == NULL: the pooled layer ended without a ReLU
       v[e] = val;
       const float yy = y[((offsets ? (long long)offsets[g] : g * ns) + arg[e]) * c + ch];
       s0 += (double)val;
@@ -1564,7 +1564,7 @@ extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const 
                                     const float *invstd, float *v, double *partial, int partial_blocks, void *stream) {
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0 && partial_blocks > 0, "rs_pool_max_backward: bad size");
   if (groups == 0 || c == 0) return RS_OK;
-  RS_REQUIRE(dout && out && arg && y && mean && invstd && v && partial, "rs_pool_max_backward: null pointer");
+  RS_REQUIRE(dout && arg && y && mean && invstd && v && partial, "rs_pool_max_backward: null pointer");
   const long long want = (groups + 3) / 4;
   int gx = (int)(want < partial_blocks ? want : partial_blocks);
   hipStream_t st = (hipStream_t)stream;

@@ -106,12 +106,14 @@ def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample,
                              feat_off=feat_off, feat_k=feat_k)
 
 
-def sa_mlp_plain(x, convs, bns, nsample):
+def sa_mlp_plain(x, convs, bns, nsample, relu_last=True):
     """SurfaceAbstraction body (repsurface_utils.py:178-181)."""
     if BACKEND == "torch":
+        if not relu_last:
+            raise NotImplementedError("relu_last=False is a HIP-executor form; the torch reference of it is bn(linear(x))")
         return _torch_sa_plain(x, convs, bns, nsample)
     from . import mlp_hip
-    return mlp_hip.sa_mlp_plain(x, convs, bns, nsample)
+    return mlp_hip.sa_mlp_plain(x, convs, bns, nsample, relu_last)
 
 
 def umbrella_mlp(x, mlps, group, aggr):

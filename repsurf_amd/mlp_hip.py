@@ -445,7 +445,7 @@ class _SAStack(Function):
             w, b = params[pi], params[pi + 1]
             w2, wk = all_w2d[pi // 4], wks[pi // 4]
             last = pi + 4 >= len(params)
-            if last and training and rs.dev is None and fused_pool_ok(w2.shape[0], ns):
+            if last and training and rs.dev is None and ns > 1 and meta.get("relu_last", True) and fused_pool_ok(w2.shape[0], ns):      # (ns = 1: a plain row stack, nothing to pool)
                 y, vec, pooled = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, pool_ns=ns, wk=wk)
             else:
                 y, vec = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, rs=rs, wk=wk)
@@ -459,7 +459,7 @@ class _SAStack(Function):
             y_last, v_last = ys[-1], vecs[-1]
             out = torch.empty((groups, prev_c), dtype=torch.float32, device=dev)
             arg = torch.empty((groups, prev_c), dtype=torch.int32, device=dev)
-            _lib.call("rs_pool_max", groups, ns, prev_c, 1, _ptr(rs.offsets), _ptr(y_last), _ptr(v_last.scale),
+            _lib.call("rs_pool_max", groups, ns, prev_c, int(meta.get("relu_last", True)), _ptr(rs.offsets), _ptr(y_last), _ptr(v_last.scale),
                       _ptr(v_last.shift), _ptr(out), arg.data_ptr(), _stream())
         else:
             raise NotImplementedError("a stack needs at least one layer after the first")
@@ -492,7 +492,7 @@ class _SAStack(Function):
         c_last = ys[-1].shape[1]
         v = torch.empty_like(dout)
         part = torch.empty((PARTIAL_BLOCKS, 2, c_last), dtype=torch.float64, device=dev)
-        _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), _ptr(s["out"]),
+        _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), _ptr(s["out"]) if meta.get("relu_last", True) else None,
                   s["arg"].data_ptr(), _ptr(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
                   PARTIAL_BLOCKS, _stream())
         p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev)
@@ -585,10 +585,11 @@ def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample,
     return _SAStack.apply(x, meta, *params)
 
 
-def sa_mlp_plain(x, convs, bns, nsample):
+def sa_mlp_plain(x, convs, bns, nsample, relu_last=True):
+    """relu_last=False: the last layer ends at its BatchNorm (segmentation feature propagation, first layers)."""
     params, mods = _flat_params([], convs, bns)
     meta = {"nsample": nsample, "pos": 0, "bns": mods, "training": mods[0].training,
-            "shapes": [p.shape for p in params]}
+            "shapes": [p.shape for p in params], "relu_last": relu_last}
     return _SAStack.apply(x, meta, *params)
 
 

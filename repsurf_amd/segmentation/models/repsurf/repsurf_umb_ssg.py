@@ -4,7 +4,7 @@ state-dict keys as the reference, built on the HIP-backed modules."""
 import torch
 import torch.nn as nn
 
-from modules.repsurface_utils import UmbrellaSurfaceConstructor, SurfaceAbstractionCD, SurfaceFeaturePropagationCD
+from modules.repsurface_utils import UmbrellaSurfaceConstructor, SurfaceAbstractionCD, SurfaceFeaturePropagationCD, row_mlp
 
 
 class Model(nn.Module):
@@ -52,4 +52,5 @@ class Model(nn.Module):
         f2 = self.fp3(pfo(level2), [level3[0], f3, level3[3]])
         f1 = self.fp2(pfo(level1), [level2[0], f2, level2[3]])
         f0 = self.fp1([coord, None, offset], [level1[0], f1, level1[3]])
-        return self.classifier(f0)
+        cls = self.classifier                          # Linear-BN-ReLU on the fused kernels, then Dropout and the output Linear
+        return cls[4](cls[3](row_mlp(f0, [cls[0]], [cls[1]])))

@@ -145,6 +145,24 @@ class SurfaceAbstractionCD(nn.Module):
         return [new_center, new_normal, pooled, new_offset]
 
 
+def row_mlp(x, linears, bns, relu_last=True):
+    """[Linear, BatchNorm1d, ReLU]* on ungrouped rows (reference :281-283; the classifier's first block,
+    segmentation/models/repsurf/repsurf_umb_ssg.py:38-41).  On the GPU in training mode the chain runs on the fused
+    shared-MLP kernels as a stack of groups of ONE row (GEMM + BatchNorm sums, finalize, BN + ReLU pass; one
+    weight-gradient and one data-gradient GEMM per layer in backward) -- the framework's route costs a
+    batch-norm statistics pass of ~50 us per layer each way at 65 536 rows, and its weight gradient picks a
+    32 x 32-tile library GEMM over the 65 536-deep reduction (178 us against ~25 us here)."""
+    if len(linears) == 0:
+        return x
+    if x.is_cuda and bns[0].training and _mlp.BACKEND == "hip" and torch.is_grad_enabled():
+        return _mlp.sa_mlp_plain(x, linears, bns, 1, relu_last)
+    for i, (lin, bn) in enumerate(zip(linears, bns)):
+        x = bn(lin(x))
+        if relu_last or i + 1 < len(linears):
+            x = F.relu(x)
+    return x
+
+
 class SurfaceFeaturePropagationCD(nn.Module):
     """Feature propagation with the channel-de-differentiated first layer (reference :233-284): coarse features
     go through Linear+BatchNorm, are interpolated onto the fine points with inverse-distance weights over the
@@ -173,14 +191,12 @@ class SurfaceFeaturePropagationCD(nn.Module):
         xyz2, points2, offset2 = pos_feat_off2      # coarse: (M,3), (M,C), (B,)
         idx, d2 = ops.knnquery_offset(3, xyz2, xyz1, offset2, offset1)
         weight = ops.interp_weights(d2)
-        points2 = self.norm_f0(self.mlp_f0(points2))
+        points2 = row_mlp(points2, [self.mlp_f0], [self.norm_f0], relu_last=False)
         new_points = ops.three_interpolate(points2.unsqueeze(0), idx.unsqueeze(0), weight.unsqueeze(0)).squeeze(0)
         if self.skip:
-            new_points = new_points + self.norm_s0(self.mlp_s0(points1))
+            new_points = new_points + row_mlp(points1, [self.mlp_s0], [self.norm_s0], relu_last=False)
         new_points = F.relu(new_points)
-        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            new_points = F.relu(bn(conv(new_points)))
-        return new_points
+        return row_mlp(new_points, self.mlp_convs, self.mlp_bns)
 
 
 class UmbrellaSurfaceConstructor(nn.Module):

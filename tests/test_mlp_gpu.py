@@ -324,3 +324,44 @@ def test_bf16_weight_gradient_is_the_rounded_operand_product(rows, n, k):
     assert err < 2e-5, err
     full = p.double().T @ q.double()
     assert (dw.double() - full).abs().max().item() / full.abs().max().item() > 1e-4      # the bf16 pipe really ran
+
+
+@pytest.mark.parametrize("relu_last", [True, False])
+@pytest.mark.parametrize("rows,cin,widths", [(5000, 64, [128]), (777, 256, [256, 128]), (65536, 128, [128])])
+def test_row_stack_of_single_row_groups_matches_torch(rows, cin, widths, relu_last):
+    """[Linear, BatchNorm1d, ReLU]* on ungrouped rows through the fused kernels (groups of ONE row: segmentation feature
+    propagation and classifier, segmentation/modules/repsurface_utils.py row_mlp), with and without the last ReLU,
+    against the framework's Linear / BatchNorm1d / relu: output, input gradient, every parameter gradient."""
+    from repsurf_amd import mlp
+    mlp.set_backend("hip")
+    torch.manual_seed(rows)
+    lins = nn.ModuleList([nn.Linear(a, b) for a, b in zip([cin] + widths[:-1], widths)]).cuda()
+    bns = nn.ModuleList([nn.BatchNorm1d(b) for b in widths]).cuda().train()
+    for bn in bns:
+        nn.init.uniform_(bn.weight, 0.5, 1.5)
+        nn.init.uniform_(bn.bias, -0.3, 0.3)
+    x0 = torch.randn(rows, cin).cuda()
+    w = torch.randn(rows, widths[-1]).cuda()
+    res = {}
+    for kind in ("torch", "hip"):
+        l, b = copy.deepcopy(lins), copy.deepcopy(bns)
+        x = x0.clone().requires_grad_()
+        if kind == "hip":
+            out = mlp.sa_mlp_plain(x, l, b, 1, relu_last)
+        else:
+            out = x
+            for i, (lin, bn) in enumerate(zip(l, b)):
+                out = bn(lin(out))
+                if relu_last or i + 1 < len(l):
+                    out = torch.relu(out)
+        (out * w).sum().backward()
+        res[kind] = (out.detach(), x.grad.clone(), {n: p.grad.clone() for n, p in list(l.named_parameters()) + [("bn." + k, v) for k, v in b.named_parameters()]},
+                     [bn.running_var.clone() for bn in b])
+    assert rel(res["hip"][0], res["torch"][0]) < 2e-5
+    assert rel_l2(res["hip"][1], res["torch"][1]) < 3e-3
+    for name, gt in res["torch"][2].items():
+        if name.endswith(".bias") and not name.startswith("bn."):
+            continue                                   # Linear bias before BatchNorm: analytic zero here, fp32 noise there
+        assert rel_l2(res["hip"][2][name], gt) < 3e-3, name
+    for a, bb in zip(res["hip"][3], res["torch"][3]):
+        assert torch.allclose(a, bb, rtol=1e-4, atol=1e-6)
