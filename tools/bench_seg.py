@@ -114,7 +114,7 @@ def main():
                "sample": f"1 step (after 1 warm-up) of {nb} x {args.points}-point clouds, oracle/seg_ref.py"}
     out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, 4096-pt clouds", "value": round(args.clouds / dt, 2),
            "unit": "clouds/s", "points_per_s": round(n / dt), "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(dt * 1e3, 3), "dtype": "f32", "data": "synthetic uniform clouds + rgb, random-init weights",
+           "ms_per_step": round(dt * 1e3, 3), "dtype": "f32" if os.environ.get("REPSURF_MLP_DTYPE", "fp32") == "fp32" else "bf16 MFMA operands, f32 accumulate/storage", "data": "synthetic uniform clouds + rgb, random-init weights",
            "config": {"workload": f"configs[3]: repsurf_umb_ssg, B={args.clouds}x{args.points}x6, fwd+CE+bwd+Adam, " + mode,
                       "loss": round(float(loss.item()), 5)},
            "hip_kernel_ms_per_step": round(sum(t["ms_per_step"] for t in table), 3),
