@@ -169,8 +169,12 @@ def _pack_items(items, device):
     return outs
 
 
-# Copies made ahead of time for a whole model (prepack): (weight address, transposed) -> (weight version, copy).
+# Copies made ahead of time for a whole model (prepack): (weight address, transposed) -> (weight version, copy, source).
 # The six per-stack pack launches of a step (three forward, three backward) become one at the top of the forward.
+# An entry keeps its SOURCE tensor alive: the key is an address, and the allocator would otherwise hand a dead model's
+# block to another model's weight of the same version (two freshly initialised models), which then found the dead
+# model's transposed copy -- wrong data gradients, seen when a segmentation model followed a classifier in one process.
+# Every prepack() call starts from an empty table, so at most one model's weights are pinned.
 _prepacked = {}
 PREPACK = os.environ.get("REPSURF_PREPACK", "1") != "0"
 
@@ -183,6 +187,7 @@ def prepack(convs):
     """Pack, in one launch, what the SA stacks built on these 1x1 convolutions will ask for in this step: the padded
     forward copy of the weights whose cin is not a multiple of 4, and the transposed copy of every weight."""
     items = []
+    _prepacked.clear()
     if not PREPACK:
         return
     for conv in convs:
@@ -193,7 +198,7 @@ def prepack(convs):
     if not items:
         return
     for (w, tr), out in zip(items, _pack_items(items, items[0][0].device)):
-        _prepacked[(w.data_ptr(), bool(tr))] = (w._version, out)
+        _prepacked[(w.data_ptr(), bool(tr))] = (w._version, out, w)
 
 
 def pack_weights(w2ds, transpose, device):
@@ -203,7 +208,7 @@ def pack_weights(w2ds, transpose, device):
     outs, miss = [None] * len(w2ds), []
     for i, w in enumerate(w2ds):
         hit = _prepacked.get((w.data_ptr(), tr))
-        if hit is not None and hit[0] == w._version and hit[1].device == w.device:
+        if hit is not None and hit[0] == w._version and hit[2].shape == w.shape and hit[1].device == w.device:
             outs[i] = hit[1]
         else:
             miss.append(i)

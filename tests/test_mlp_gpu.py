@@ -365,3 +365,22 @@ def test_row_stack_of_single_row_groups_matches_torch(rows, cin, widths, relu_la
         assert rel_l2(res["hip"][2][name], gt) < 3e-3, name
     for a, bb in zip(res["hip"][3], res["torch"][3]):
         assert torch.allclose(a, bb, rtol=1e-4, atol=1e-6)
+
+
+def test_prepacked_weight_copies_do_not_outlive_their_model():
+    """The ahead-of-time weight copies are looked up by address + version: a dead model's entry must not be found by a new
+    model's weight that the allocator placed at the same address (regression: wrong data gradients in a segmentation
+    model built after a classifier had run in the same process)."""
+    from repsurf_amd import mlp_hip as H
+    torch.manual_seed(0)
+    for trial in range(4):
+        a = nn.Conv2d(8, 12, 1).cuda()
+        H.prepack([a])
+        del a
+        b = nn.Conv2d(8, 12, 1).cuda()                     # same size: the caching allocator likes to reuse the block
+        with torch.no_grad():
+            b.weight.mul_(1.0)                             # (version 1, like a parameter after its first optimizer step)
+        w2d = H._w2d(b.weight)
+        wt = H.pack_weights([w2d], True, w2d.device)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(wt[:, :12], w2d.t()), trial
