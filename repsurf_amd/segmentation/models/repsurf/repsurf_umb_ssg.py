@@ -4,6 +4,8 @@ state-dict keys as the reference, built on the HIP-backed modules."""
 import torch
 import torch.nn as nn
 
+from repsurf_amd import mlp as _mlp
+
 from modules.repsurface_utils import UmbrellaSurfaceConstructor, SurfaceAbstractionCD, SurfaceFeaturePropagationCD, row_mlp
 
 
@@ -38,8 +40,19 @@ class Model(nn.Module):
         self.surface_constructor = UmbrellaSurfaceConstructor(args.group_size + 1, repsurf_in_channel,
                                                               repsurf_out_channel)
 
+    def _packed_layers(self):
+        """every Conv1d / Linear the fused stacks of this step will ask a padded or transposed weight copy of"""
+        out = []
+        for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
+            out += [sa.mlp_l0, sa.mlp_f0] + list(sa.mlp_convs)
+        for fp in (self.fp4, self.fp3, self.fp2, self.fp1):
+            out += [fp.mlp_f0] + ([fp.mlp_s0] if fp.skip else []) + list(fp.mlp_convs)
+        return out + [self.classifier[0]]
+
     def forward(self, pos_feat_off0):
         coord, feat, offset = pos_feat_off0            # (N,3), (N,C_in-3), (B,) running row ends
+        if coord.is_cuda and self.training and torch.is_grad_enabled():
+            _mlp.prepack(self._packed_layers())        # ~23 weight-pack launches of the step in one
         level0 = [coord, self.surface_constructor(coord, offset), torch.cat([coord, feat], 1), offset]
         level1 = self.sa1(level0)
         level2 = self.sa2(level1)
