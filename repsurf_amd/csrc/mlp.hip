@@ -24,6 +24,13 @@
 #include <stdlib.h>
 #include <math.h>
 
+// The library builds this file as two translation units so that the fp32 and the bf16 instances compile in parallel
+// (Makefile): RS_MLP_TU = 0 -> every entry point except the two *_bf16 ones, 1 -> only rs_mlp_gemm_rows_bf16 and
+// rs_mlp_wgrad_bf16 (plus the fp32 instances they fall back to), 2 (default, experiment builds) -> everything.
+#ifndef RS_MLP_TU
+#define RS_MLP_TU 2
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -1240,11 +1247,16 @@ void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_de
 template <int BM, int BN>
 void launch_gemm(bool bf, int v, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                  const float *w, int ldw, const Epilogue &ep) {
-  if (bf && v == 4) launch_gemm_m<BM, BN, 4, true>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else if (bf && v == 2) launch_gemm_m<BM, BN, 2, true>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else if (v == 4) launch_gemm_m<BM, BN, 4, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else if (v == 2) launch_gemm_m<BM, BN, 2, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-  else if constexpr (BM == 128) launch_gemm_m<BM, BN, 1, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);   // scalar operands: tall tile only, fp32 (bf16 staging packs pairs)
+#if RS_MLP_TU != 0
+  if (bf && v == 4) { launch_gemm_m<BM, BN, 4, true>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep); return; }
+  if (bf && v == 2) { launch_gemm_m<BM, BN, 2, true>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep); return; }
+#endif
+#if RS_MLP_TU != 1      // (the bf16-only unit calls with bf = true: vector operands never get here)
+  if (v == 4) { launch_gemm_m<BM, BN, 4, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep); return; }
+  if (v == 2) { launch_gemm_m<BM, BN, 2, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep); return; }
+#endif
+  (void)bf;
+  if constexpr (BM == 128) launch_gemm_m<BM, BN, 1, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);   // scalar operands: tall tile only, fp32 (bf16 staging packs pairs)
 }
 
 template <int WN, int WK, int TN, int TK, int VP, int VQ, bool BF>
@@ -1270,10 +1282,13 @@ constexpr bool wgrad_bf16_ok() {
 template <int WN, int WK, int TN, int TK, int VP, int VQ>
 void launch_wgrad_p(bool bf, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
                     const RowOperand &Q, float *partial) {
-  if constexpr (wgrad_bf16_ok<WN, WK, TN, TK, VP, VQ>()) {
+  constexpr bool ok = wgrad_bf16_ok<WN, WK, TN, TK, VP, VQ>();
+  if constexpr (ok && RS_MLP_TU != 0) {
     if (bf) { launch_wgrad_m<WN, WK, TN, TK, VP, VQ, true>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial); return; }
   }
-  launch_wgrad_m<WN, WK, TN, TK, VP, VQ, false>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
+  (void)bf;
+  if constexpr (RS_MLP_TU != 1 || !ok)      // (the bf16-only unit needs the fp32 instance only where bf16 staging is impossible)
+    launch_wgrad_m<WN, WK, TN, TK, VP, VQ, false>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
 }
 template <int WN, int WK, int TN, int TK>
 void launch_wgrad(bool bf, int vp, int vq, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
@@ -1358,10 +1373,13 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
   return RS_OK;
 }
 
+#if RS_MLP_TU != 1
 extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
                                 const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
   return gemm_rows_impl(false, rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
 }
+#endif
+#if RS_MLP_TU != 0
 // Mixed precision (BASELINE configs[4]): same contract, operands rounded to bf16 at the LDS commit, bf16 MFMA with
 // fp32 accumulation.  Launches the fp32 instance where the layout forces scalar operand loads or the narrow
 // streaming kernel applies (kdim <= 16, unaligned: no matrix pipe involved).
@@ -1369,6 +1387,8 @@ extern "C" int rs_mlp_gemm_rows_bf16(long long rows, const int *rows_dev, int kd
                                      const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
   return gemm_rows_impl(true, rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
 }
+
+#endif
 
 static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
                       const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
@@ -1417,10 +1437,13 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
   return RS_OK;
 }
 
+#if RS_MLP_TU != 1
 extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
                             const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
   return wgrad_impl(false, rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
 }
+#endif
+#if RS_MLP_TU != 0
 // Mixed precision: both operands rounded to bf16 after their fp32 prologue, bf16 MFMA, fp32 accumulation inside a
 // row slab; the slabs' partial products and their fixed-order sum stay fp32.  The narrow streaming kernel
 // (kcols <= 16) and the layouts that force scalar loads or one vector per thread (kcols <= 32, float4) run in fp32.
@@ -1429,6 +1452,9 @@ extern "C" int rs_mlp_wgrad_bf16(long long rows, const int *rows_dev, int ncols,
   return wgrad_impl(true, rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
 }
 
+#endif
+
+#if RS_MLP_TU != 1      // everything below: fp32 unit only
 // ---- padded copies of up to RS_PACK_MAX conv weights (cout, cin) in one launch --------------------------------
 // transpose = 0:  dst[j*ld + k] = src[j*cin + k]  (k < cin, else 0), ld >= cin    -- forward operand of rs_mlp_gemm_rows
 //                 when cin is not a multiple of 4 (otherwise the conv weight is used in place);
@@ -1586,3 +1612,4 @@ extern "C" int rs_pool_sum(long long groups, int nsample, int c, const float *y,
   RS_CHECK_LAUNCH("rs_pool_sum");
   return RS_OK;
 }
+#endif   // RS_MLP_TU != 1

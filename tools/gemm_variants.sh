@@ -10,7 +10,7 @@ for v in NOLOAD NOMFMA TIMING; do
 done
 wait
 for v in NOLOAD NOMFMA TIMING; do
-  objs=$(ls build/*.o | grep -v "^build/mlp.hip.o")
+  objs=$(ls build/*.o | grep -v "^build/mlp")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_exp/librepsurf_$v.so $objs build_exp/mlp_$v.o
 done
 ls -la build_exp/*.so
