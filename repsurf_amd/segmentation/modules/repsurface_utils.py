@@ -168,7 +168,8 @@ class SurfaceFeaturePropagationCD(nn.Module):
     go through Linear+BatchNorm, are interpolated onto the fine points with inverse-distance weights over the
     3 nearest coarse points of the same cloud, added to Linear+BatchNorm of the skip features, ReLU, then
     [Linear, BN, ReLU]*.  3-NN search, weights and the gather-interpolation (+ its backward) are HIP kernels;
-    the plain Linear/BatchNorm1d layers on ungrouped rows are library GEMMs through PyTorch."""
+    the Linear/BatchNorm1d(/ReLU) layers on ungrouped rows run on the fused shared-MLP kernels in training mode
+    (`row_mlp`), through PyTorch in eval mode."""
 
     def __init__(self, prev_channel, skip_channel, mlp):
         super().__init__()
