@@ -32,7 +32,11 @@ oracle/_build/libgeom_oracle.so: oracle/geom_oracle.c
 	@mkdir -p oracle/_build
 	gcc -O2 -std=c11 -fPIC -shared -ffp-contract=off -fno-fast-math -o $@ $< -lm
 
+# the reference's own pointops kernels as host code (test infrastructure; needs /root/reference)
+ref:
+	$(MAKE) -f oracle/Makefile.ref
+
 clean:
 	rm -rf build $(LIBDIR)/librepsurf_hip.so oracle/_build
 
-.PHONY: all oracle clean
+.PHONY: all oracle ref clean

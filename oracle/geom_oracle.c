@@ -317,19 +317,61 @@ void oracle_three_interpolate(int b, int c, int m, int n, const float *points, c
     }
 }
 
-/* Packed-batch FPS: segmentation/modules/pointops/src/sampling/sampling_cuda_kernel.cu:14-129
- * (first pick = first row of the segment, :39; distances as in the classification kernel).
- * PARITY UNPINNED: the CUDA kernel cannot run here; ties are resolved to the lowest index. */
+/* Packed-batch FPS: segmentation/modules/pointops/src/sampling/sampling_cuda_kernel.cu:14-129, launched by
+ * pointops.py:31-49 with n = the largest cloud of the batch and tmp = 1e10.
+ * First pick = first row of the segment (:39); d = (dx*dx + dy*dy) + dz*dz on direct differences (:53), running minimum
+ * in tmp (:54-55).  Arg-max = what the kernel's strided scan + shared-memory tree computes: thread tid scans rows
+ * start+tid, start+tid+bs, ... keeping the first strict maximum (:56-57, best = -1 / besti = start), __update (:7-12)
+ * keeps the lower slot on equal values at every level of the tree (slot t against t + bs/2, then t + bs/4, ... t + 1),
+ * so among equal distances the winner is the thread whose id has the lowest BIT-REVERSED value (the last level
+ * prefers even ids, the one before ids = 0 mod 4, ...), then the lowest row of that thread; tid = (row - start) mod bs,
+ * bs = opt_n_threads(n) = min(2^floor(log2 n), 1024) (cuda_utils.h:10-13).
+ * Pinned against the kernel itself (oracle/_ref, tests/test_oracle_ref.py), ties included. */
+static int ref_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int t = 1 << pow_2;
+  if (t > 1024) t = 1024;
+  return t < 1 ? 1 : t;
+}
+
+static int bit_reverse(int v, int bs) {
+  int r = 0;
+  for (int m = 1; m < bs; m <<= 1) { r = (r << 1) | (v & 1); v >>= 1; }
+  return r;
+}
+
+int oracle_fps_block_size(int b, const int *offset) {
+  int n_max = offset[0];
+  for (int i = 1; i < b; ++i) if (offset[i] - offset[i - 1] > n_max) n_max = offset[i] - offset[i - 1];
+  return ref_opt_n_threads(n_max);
+}
+
 void oracle_fps_offset(int b, const float *xyz, const int *offset, const int *new_offset, int *idx) {
+  const int bs = oracle_fps_block_size(b, offset);
   for (int bi = 0; bi < b; ++bi) {
-    const int r0 = bi ? offset[bi - 1] : 0, n = offset[bi] - r0;
-    const int o0 = bi ? new_offset[bi - 1] : 0, m = new_offset[bi] - o0;
-    if (n <= 0 || m <= 0) continue;
-    int *loc = (int *)malloc(sizeof(int) * (size_t)m);
-    int zero = 0;
-    oracle_fps(1, n, m, xyz + (size_t)r0 * 3, &zero, loc);
-    for (int i = 0; i < m; ++i) idx[o0 + i] = loc[i] + r0;
-    free(loc);
+    const int r0 = bi ? offset[bi - 1] : 0, r1 = offset[bi];
+    const int o0 = bi ? new_offset[bi - 1] : 0, o1 = new_offset[bi];
+    if (r1 <= r0 || o1 <= o0) continue;
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)(r1 - r0));
+    for (int k = 0; k < r1 - r0; ++k) tmp[k] = 1e10f;
+    int old = r0;
+    idx[o0] = r0;
+    for (int j = o0 + 1; j < o1; ++j) {
+      const float x1 = xyz[old * 3], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+      float best = -1.0f;
+      int besti = r0, best_tid = 0;
+      for (int k = r0; k < r1; ++k) {
+        const float dx = xyz[k * 3] - x1, dy = xyz[k * 3 + 1] - y1, dz = xyz[k * 3 + 2] - z1;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        const float d2 = d < tmp[k - r0] ? d : tmp[k - r0];
+        tmp[k - r0] = d2;
+        const int tid = bit_reverse((k - r0) % bs, bs);
+        if (d2 > best || (d2 == best && tid < best_tid)) { best = d2; besti = k; best_tid = tid; }
+      }
+      old = besti;
+      idx[j] = old;
+    }
+    free(tmp);
   }
 }
 

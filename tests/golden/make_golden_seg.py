@@ -6,17 +6,20 @@ Run in the build container only (needs /root/reference):   python tests/golden/m
 The reference's segmentation path is CUDA-only: `pointops_cuda.furthestsampling_cuda` / `knnquery_cuda` are
 compiled CUDA kernels and the Python side allocates with `torch.cuda.IntTensor/FloatTensor`
 (segmentation/modules/pointops/functions/pointops.py:42-44,125-127, repsurface_utils.py:22,268).  Here
-  * `pointops_cuda` is a stub module whose two kernels are oracle/geom_oracle.c's restatements of the
-    CUDA sources (the part that stays PARITY UNPINNED), and
+  * `pointops_cuda` is oracle/_ref: the reference's OWN `*_cuda_kernel.cu` files compiled unmodified as host code
+    (oracle/Makefile.ref, oracle/ref_pointops.py) — the FPS tree reduction and the kNN heap run as written, and
   * `torch.cuda.IntTensor/FloatTensor` are replaced by CPU constructors,
-so that every line of the reference's own torch code (sample_and_group, group_by_umbrella_v2, cal_normal,
-check_nan_umb, SurfaceAbstractionCD, SurfaceFeaturePropagationCD, Model.forward) executes unmodified on CPU.
-The fixtures therefore pin everything downstream of the two kernels: feature order, rotation, NaN patching,
-numpy-RNG flips, the dual first layer, interpolation weights, the decoder wiring.
+so that every line of the reference's own code (pointops.furthestsampling / sectorized_fps / knnquery,
+sample_and_group, group_by_umbrella_v2, cal_normal, check_nan_umb, SurfaceAbstractionCD,
+SurfaceFeaturePropagationCD, Model.forward) executes unmodified on CPU.  The fixtures pin the whole path:
+sampled rows, neighbour lists, feature order, rotation, NaN patching, numpy-RNG flips, the dual first layer,
+interpolation weights, the decoder wiring.
 
 Fixtures:
   seg_geom.npz    3 packed clouds of unequal size: umbrella features (pre-MLP) through the reference
                   functions, sample_and_group outputs of one stage, interpolation weights.
+  seg_sector.npz  pointops.sectorized_fps (pointops.py:52-108) on 3 packed clouds, num_sectors 1/2/4, min_points lowered
+                  so that the sector branch runs on small clouds.
   seg_model.npz   repsurf_umb_ssg on 2 packed clouds (2048 + 1536 points): logits, loss, stage outputs
                   (subsampled), parameter-gradient norms + subsampled gradients; name-seeded weights, dropout 0.
 """
@@ -34,23 +37,12 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference/segmentation"
 
-from oracle import geom_oracle as G  # noqa: E402
+from oracle import ref_pointops  # noqa: E402
 
 
 def install_stubs():
-    pc = types.ModuleType("pointops_cuda")
-
-    def furthestsampling_cuda(b, n_max, xyz, offset, new_offset, tmp, idx):
-        idx.copy_(torch.from_numpy(G.fps_offset(xyz.numpy(), offset.numpy(), new_offset.numpy())))
-
-    def knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
-        i, d = G.knn_offset(nsample, xyz.numpy(), new_xyz.numpy(), offset.numpy(), new_offset.numpy())
-        idx.copy_(torch.from_numpy(i))
-        dist2.copy_(torch.from_numpy(d))
-
-    pc.furthestsampling_cuda = furthestsampling_cuda
-    pc.knnquery_cuda = knnquery_cuda
-    sys.modules["pointops_cuda"] = pc
+    ref_pointops.build()
+    sys.modules["pointops_cuda"] = ref_pointops.module("seg")
 
     def ctor(dtype):
         class _T:
@@ -127,7 +119,22 @@ def main():
     dr = 1.0 / (dist + 1e-8)
     out["interp_dist"] = dist.numpy()
     out["interp_weight"] = (dr / torch.sum(dr, dim=1, keepdim=True)).numpy()
+    # raw kernel outputs through the reference's own autograd Functions (pointops.py:31-49,114-130)
+    new_off = torch.tensor(np.cumsum([300 // 4, 512 // 4, 217 // 4]), dtype=torch.int32)
+    out["fps_new_offset"] = new_off.numpy()
+    out["fps_idx"] = pointops.furthestsampling(coord, offset, new_off).numpy()
+    for k in (9, 32):
+        idx, dist = pointops.knnquery(k, coord, coord, offset, offset)
+        out[f"knn{k}_idx"], out[f"knn{k}_dist"] = idx.numpy(), dist.numpy()
     np.savez_compressed(os.path.join(HERE, "seg_geom.npz"), **out)
+
+    # ---------------- sectorized FPS fixture (pointops.py:52-108), min_points lowered to reach the sector branch
+    coord, _, offset = packed(31, [600, 1500, 1000])
+    new_off = torch.tensor(np.cumsum([150, 375, 250]), dtype=torch.int32)
+    out = {"coord": coord.numpy(), "offset": offset.numpy(), "new_offset": new_off.numpy(), "min_points": np.int32(800)}
+    for ns in (1, 2, 4):
+        out[f"idx_s{ns}"] = pointops.sectorized_fps(coord, offset, new_off, ns, 800).numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "seg_sector.npz"), **out)
 
     # ---------------- model fixture
     args = argparse.Namespace(return_polar=False, in_channel=6, group_size=8, num_class=13)
