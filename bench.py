@@ -321,7 +321,7 @@ def main():
                                       f"per GPU, {args.dtype}, full encoder + head, fwd+loss+bwd"
                                       + ("" if args.no_optim else "+Adam step"),
                           "global_batch": args.batch * world, "points": args.points,
-                          "parallelism": f"dp{world}", "mlp_backend": mlp.BACKEND, "launch": mode,
+                          "parallelism": f"dp{world}", "mlp_backend": "hip", "launch": mode,
                           "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5)},
                "roofline": roofline, "cpu_baseline": cpu}
         if cpu:

@@ -129,7 +129,7 @@ class SurfaceAbstractionCD(nn.Module):
     def forward(self, center, normal, feature, geometry=None):
         center, normal = center.permute(0, 2, 1), normal.permute(0, 2, 1)
         feature = None if feature is None else feature.permute(0, 2, 1)
-        if (not self.group_all and self.return_normal and _mlp.COMPACT_GROUPS and _mlp.BACKEND == "hip"
+        if (not self.group_all and self.return_normal and _mlp.COMPACT_GROUPS
                 and self.bn_l0.training):
             return self._forward_compact(center, normal, feature, geometry)
         if self.group_all:

@@ -12,6 +12,7 @@ import os
 import torch
 
 from . import head as _head
+from . import mlp_hip
 from . import rng
 
 
@@ -54,6 +55,7 @@ class GraphedStep:
         if hasattr(self.optimizer, "sync_hyper"):
             self.optimizer.sync_hyper()    # learning-rate schedule -> device (repsurf_amd.optim.Adam)
         self.graph.replay()
+        mlp_hip.weights_changed()      # the replay updated the parameters through raw pointers
         return self.loss
 
 
@@ -85,6 +87,7 @@ class PipelinedStep:
         if sharded:
             import torch.distributed as dist
             self.dist = dist
+            sync_replicas(net, dist, group)
             self.grads = FlatGrads(list(net.parameters()))
             self.flat = self.grads.flat
         dev = label.device
@@ -205,7 +208,19 @@ class PipelinedStep:
         if sync:
             caller.wait_event(self.net_done[p])
         self.parity = 1 - p
+        mlp_hip.weights_changed()
         return self.loss[p]
+
+
+def sync_replicas(net, dist, group=None):
+    """Rank 0's parameters and buffers to every rank (what DistributedDataParallel does at construction): the sharded
+    steps only ever exchange gradients, so replicas that were not built from the same seed would diverge silently."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return
+    with torch.no_grad():
+        for t in list(net.parameters()) + list(net.buffers()):
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    mlp_hip.weights_changed()
 
 
 class FlatGrads:
@@ -285,6 +300,7 @@ class ShardedGraphedStep:
         self.dist, self.group = dist, group
         self.net, self.criterion, self.optimizer = net, criterion, optimizer
         self.points, self.label = points, label
+        sync_replicas(net, dist, group)
         self.grads = FlatGrads(list(net.parameters()))
         self.flat = self.grads.flat
         self.draws = rng.StaticDraws(label.device)
@@ -332,4 +348,5 @@ class ShardedGraphedStep:
             if hasattr(self.optimizer, "sync_hyper"):
                 self.optimizer.sync_hyper()
             self.graph_b.replay()
+        mlp_hip.weights_changed()
         return self.loss

@@ -175,7 +175,20 @@ def _pack_items(items, device):
 # block to another model's weight of the same version (two freshly initialised models), which then found the dead
 # model's transposed copy -- wrong data gradients, seen when a segmentation model followed a classifier in one process.
 # Every prepack() call starts from an empty table, so at most one model's weights are pinned.
+# Validity: an entry is a copy of the weights AS THEY WERE when prepack() ran.  torch-side updates show in
+# `tensor._version`; updates through raw pointers (repsurf_amd.optim.Adam, hipGraph replays) do not, so those call
+# `weights_changed()`, which advances `_weights_epoch` and thereby retires every entry: an eval forward after a
+# training step packs fresh copies instead of finding first-layer weights that are one optimizer step old.
 _prepacked = {}
+_weights_epoch = 0
+
+
+def weights_changed():
+    """Tell the copy cache that parameters were modified behind autograd's back (raw-pointer optimizer, graph replay)."""
+    global _weights_epoch
+    _weights_epoch += 1
+    _prepacked.clear()
+
 PREPACK = os.environ.get("REPSURF_PREPACK", "1") != "0"
 
 
@@ -198,7 +211,7 @@ def prepack(convs):
     if not items:
         return
     for (w, tr), out in zip(items, _pack_items(items, items[0][0].device)):
-        _prepacked[(w.data_ptr(), bool(tr))] = (w._version, out, w)
+        _prepacked[(w.data_ptr(), bool(tr))] = (w._version, out, w, _weights_epoch)
 
 
 def pack_weights(w2ds, transpose, device):
@@ -208,7 +221,8 @@ def pack_weights(w2ds, transpose, device):
     outs, miss = [None] * len(w2ds), []
     for i, w in enumerate(w2ds):
         hit = _prepacked.get((w.data_ptr(), tr))
-        if hit is not None and hit[0] == w._version and hit[2].shape == w.shape and hit[1].device == w.device:
+        if (hit is not None and hit[0] == w._version and hit[3] == _weights_epoch and hit[2].shape == w.shape
+                and hit[1].device == w.device):
             outs[i] = hit[1]
         else:
             miss.append(i)

@@ -66,14 +66,19 @@ _OFFSET_CACHE = {}
 
 
 def host_offsets(offset):
-    """Running ends of a packed batch as a tuple of ints (one device->host read per tensor object)."""
-    host = getattr(offset, "_rs_host", None)
-    if host is None:
-        host = tuple(int(v) for v in offset.tolist())
-        try:
-            offset._rs_host = host
-        except AttributeError:
-            pass
+    """Running ends of a packed batch as a tuple of ints (one device->host read per tensor object and content:
+    the copy is keyed on the tensor's storage address and autograd version, so an offset tensor refilled in place --
+    a reused collate buffer -- is read again; a buffer rewritten through a raw pointer or a graph replay must be a
+    fresh tensor object, its host values cannot be known without a read)."""
+    tag = (offset.data_ptr(), offset._version)
+    cached = getattr(offset, "_rs_host", None)
+    if cached is not None and cached[0] == tag:
+        return cached[1]
+    host = tuple(int(v) for v in offset.tolist())
+    try:
+        offset._rs_host = (tag, host)
+    except AttributeError:
+        pass
     return host
 
 
@@ -85,7 +90,7 @@ def offsets_tensor(host, device):
         if len(_OFFSET_CACHE) > 4096:
             _OFFSET_CACHE.clear()
         t = torch.tensor(list(host), dtype=torch.int32, device=device)
-        t._rs_host = tuple(host)
+        t._rs_host = ((t.data_ptr(), t._version), tuple(host))
         _OFFSET_CACHE[key] = t
     return t
 

@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, mlp_hip
 
 P, c_int = ctypes.c_void_p, ctypes.c_int
 MAX_TENSORS = 40
@@ -121,4 +121,5 @@ class Adam(torch.optim.Optimizer):
                 last = c0 + MAX_TENSORS >= len(ps)
                 _lib.call("rs_adam_step", ctypes.byref(tab), st["hyper"].data_ptr(), st["step"].data_ptr(),
                           st["done"].data_ptr(), 1 if last else 0, stream)
+        mlp_hip.weights_changed()       # raw-pointer update: tensor._version does not move (mlp_hip._prepacked)
         return loss

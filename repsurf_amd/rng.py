@@ -29,11 +29,18 @@ class StaticDraws:
 
     def __init__(self, device):
         self.device = device
-        self.slots = []        # (kind, b, n, device view, host view)
+        self.slots = []        # (kind, b, n, device view, (lo, words) in the arenas)
         self.cursor = None     # not None while re-running the same code path (warm-up iterations)
         self.dev = torch.zeros((self.ARENA,), dtype=torch.int32, device=device)
-        self.host = torch.zeros((self.ARENA,), dtype=torch.int32).pin_memory() if device.type == "cuda" \
-            else torch.zeros((self.ARENA,), dtype=torch.int32)
+        # TWO pinned host arenas, used alternately: the host runs ahead of the GPU under graph replay, so the H2D copy of
+        # refill s may still be pending when refill s+1 writes its numbers -- into the other arena; an arena is only
+        # rewritten after the copy that read it has finished (`copied` event).
+        cuda = device.type == "cuda"
+        self.hosts = [torch.zeros((self.ARENA,), dtype=torch.int32).pin_memory() if cuda
+                      else torch.zeros((self.ARENA,), dtype=torch.int32) for _ in range(2)]
+        self.copied = [torch.cuda.Event() if cuda else None for _ in range(2)]
+        self.pending = [False, False]
+        self.turn = 0
         self.used = 0
 
     def __enter__(self):
@@ -63,11 +70,9 @@ class StaticDraws:
         if self.used > self.ARENA:
             raise RuntimeError("StaticDraws arena exhausted")
         buf = self._typed(self.dev[lo:lo + b], kind)
-        host = self._typed(self.host[lo:lo + b], kind)
         value = _cpu_draw(kind, b, n)
-        host.copy_(value)
         buf.copy_(value)                              # first use: a real draw (never run a kernel on garbage)
-        self.slots.append((kind, b, n, buf, host))
+        self.slots.append((kind, b, n, buf, (lo, b)))
         if self.cursor is not None:
             self.cursor += 1
         return buf
@@ -75,10 +80,19 @@ class StaticDraws:
     def refill(self):
         """Fresh CPU-generator draws, in forward order, into the static buffers: one async H2D copy on the current
         stream."""
-        for kind, b, n, _, host in self.slots:
-            host.copy_(_cpu_draw(kind, b, n))
+        t = self.turn
+        self.turn = 1 - t
+        if self.pending[t]:
+            self.copied[t].synchronize()              # the copy issued two refills ago has read this arena
+            self.pending[t] = False
+        arena = self.hosts[t]
+        for kind, b, n, _, (lo, words) in self.slots:
+            self._typed(arena[lo:lo + words], kind).copy_(_cpu_draw(kind, b, n))
         if self.used:
-            self.dev[:self.used].copy_(self.host[:self.used], non_blocking=True)
+            self.dev[:self.used].copy_(arena[:self.used], non_blocking=True)
+            if self.copied[t] is not None:
+                self.copied[t].record()
+                self.pending[t] = True
 
 
 def draw(kind, b, n, device):

@@ -147,20 +147,14 @@ class SurfaceAbstractionCD(nn.Module):
 
 def row_mlp(x, linears, bns, relu_last=True):
     """[Linear, BatchNorm1d, ReLU]* on ungrouped rows (reference :281-283; the classifier's first block,
-    segmentation/models/repsurf/repsurf_umb_ssg.py:38-41).  On the GPU in training mode the chain runs on the fused
+    segmentation/models/repsurf/repsurf_umb_ssg.py:38-41).  The chain runs on the fused
     shared-MLP kernels as a stack of groups of ONE row (GEMM + BatchNorm sums, finalize, BN + ReLU pass; one
     weight-gradient and one data-gradient GEMM per layer in backward) -- the framework's route costs a
     batch-norm statistics pass of ~50 us per layer each way at 65 536 rows, and its weight gradient picks a
     32 x 32-tile library GEMM over the 65 536-deep reduction (178 us against ~25 us here)."""
     if len(linears) == 0:
         return x
-    if x.is_cuda and bns[0].training and _mlp.BACKEND == "hip" and torch.is_grad_enabled():
-        return _mlp.sa_mlp_plain(x, linears, bns, 1, relu_last)
-    for i, (lin, bn) in enumerate(zip(linears, bns)):
-        x = bn(lin(x))
-        if relu_last or i + 1 < len(linears):
-            x = F.relu(x)
-    return x
+    return _mlp.sa_mlp_plain(x, linears, bns, 1, relu_last)
 
 
 class SurfaceFeaturePropagationCD(nn.Module):
@@ -168,8 +162,8 @@ class SurfaceFeaturePropagationCD(nn.Module):
     go through Linear+BatchNorm, are interpolated onto the fine points with inverse-distance weights over the
     3 nearest coarse points of the same cloud, added to Linear+BatchNorm of the skip features, ReLU, then
     [Linear, BN, ReLU]*.  3-NN search, weights and the gather-interpolation (+ its backward) are HIP kernels;
-    the Linear/BatchNorm1d(/ReLU) layers on ungrouped rows run on the fused shared-MLP kernels in training mode
-    (`row_mlp`), through PyTorch in eval mode."""
+    the Linear/BatchNorm1d(/ReLU) layers on ungrouped rows run on the fused shared-MLP kernels (`row_mlp`), in training
+    and in eval mode (running statistics folded into the operand prologue)."""
 
     def __init__(self, prev_channel, skip_channel, mlp):
         super().__init__()

@@ -12,5 +12,5 @@ def collate_fn(batch):
         count += item.shape[0]
         offset.append(count)
     off = torch.IntTensor(offset)
-    off._rs_host = tuple(offset)
+    off._rs_host = ((off.data_ptr(), off._version), tuple(offset))      # what repsurf_amd.ops.host_offsets would read
     return torch.cat(coord), torch.cat(feat), torch.cat(label) if label[0] is not None else None, off

@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import torch_executor
+
 from tests.util import cloud, disable_dropout, name_seeded_init, ref_args
 
 pytestmark = pytest.mark.gpu
@@ -13,7 +15,7 @@ def test_graphed_step_matches_eager():
     from repsurf_amd import mlp
     from repsurf_amd.graph import GraphedStep
     from util.utils import SmoothClsLoss
-    mlp.set_backend("hip")
+    torch_executor.set_backend("hip")
     pts = torch.from_numpy(cloud(3, 8, 1024)).cuda().permute(0, 2, 1).contiguous()
     lab = torch.arange(8).cuda() % 15
     crit = SmoothClsLoss()
@@ -57,7 +59,7 @@ def test_sharded_step_single_rank_process_group():
     from repsurf_amd import mlp
     from repsurf_amd.graph import ShardedGraphedStep
     from util.utils import SmoothClsLoss
-    mlp.set_backend("hip")
+    torch_executor.set_backend("hip")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     if not dist.is_initialized():
@@ -88,7 +90,7 @@ def test_pipelined_step_matches_eager_step_for_step(monkeypatch):
     from repsurf_amd import mlp, rng
     from repsurf_amd.graph import PipelinedStep
     from util.utils import SmoothClsLoss
-    mlp.set_backend("hip")
+    torch_executor.set_backend("hip")
     calls = {"i": 0}
 
     def fake_draw(kind, b, n):
@@ -144,7 +146,7 @@ def test_pipelined_sharded_step_single_rank_process_group():
     from repsurf_amd.graph import PipelinedStep
     from repsurf_amd.optim import Adam
     from util.utils import SmoothClsLoss
-    mlp.set_backend("hip")
+    torch_executor.set_backend("hip")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29534")
     if not dist.is_initialized():

@@ -8,6 +8,8 @@ import copy
 import numpy as np
 import pytest
 import torch
+
+from tests import torch_executor
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
@@ -28,7 +30,7 @@ def make_cd(pos, feat, mlp, seed):
 
 def run_cd(mod, x, ns, pos, backend, w):
     from repsurf_amd import mlp
-    mlp.set_backend(backend)
+    torch_executor.set_backend(backend)
     mod.zero_grad()
     x = x.clone().requires_grad_()
     out = mlp.sa_mlp_cd(x, pos, mod.mlp_l0, mod.bn_l0, mod.mlp_f0, mod.bn_f0, mod.convs, mod.bns, ns)
@@ -105,7 +107,7 @@ def test_umbrella_stack_matches_torch(aggr):
     w = torch.randn(300, 10).cuda()
     res = {}
     for backend in ("torch", "hip"):
-        mlp.set_backend(backend)
+        torch_executor.set_backend(backend)
         m = copy.deepcopy(mlps)
         out = mlp.umbrella_mlp(x, m, 8, aggr)
         (out * w).sum().backward()
@@ -126,7 +128,7 @@ def test_plain_stack_matches_torch():
     w = torch.randn(50, 64).cuda()
     res = {}
     for backend in ("torch", "hip"):
-        mlp.set_backend(backend)
+        torch_executor.set_backend(backend)
         c, b = copy.deepcopy(convs), copy.deepcopy(bns)
         x = x0.clone().requires_grad_()
         out = mlp.sa_mlp_plain(x, c, b, 16)
@@ -145,7 +147,7 @@ def test_compacted_groups_match_dense(radius, ns):
     approximation.  radius 2.0 fills every ball (no padding at all), 0.25 leaves mostly padding."""
     from repsurf_amd import mlp, ops
     from tests.util import cloud
-    mlp.set_backend("hip")
+    torch_executor.set_backend("hip")
     b, n, s, cn, cf = 2, 256, 64, 10, 12
     xyz = torch.from_numpy(cloud(77, b, n)).cuda()
     fps = ops.furthestsampling(xyz, s)
@@ -290,7 +292,7 @@ def test_bf16_sa_stack_within_restated_tolerance(groups, ns, pos, feat, widths):
         mlp.set_precision("fp32")
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out_a, g_a = run_cd(copy.deepcopy(mod), x, ns, pos, "torch", w)
-    mlp.set_backend("hip")
+    torch_executor.set_backend("hip")
     err_b, err_a = (out_b - out_f).abs().max().item(), (out_a.float() - out_f).abs().max().item()
     assert err_b <= 2e-2 * max(1.0, out_f.abs().max().item()), err_b
     assert err_b <= 1.1 * err_a, (err_b, err_a)
@@ -333,7 +335,7 @@ def test_row_stack_of_single_row_groups_matches_torch(rows, cin, widths, relu_la
     propagation and classifier, segmentation/modules/repsurface_utils.py row_mlp), with and without the last ReLU,
     against the framework's Linear / BatchNorm1d / relu: output, input gradient, every parameter gradient."""
     from repsurf_amd import mlp
-    mlp.set_backend("hip")
+    torch_executor.set_backend("hip")
     torch.manual_seed(rows)
     lins = nn.ModuleList([nn.Linear(a, b) for a, b in zip([cin] + widths[:-1], widths)]).cuda()
     bns = nn.ModuleList([nn.BatchNorm1d(b) for b in widths]).cuda().train()

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import torch_executor
+
 from oracle import torch_ref
 from tests.util import GOLDEN, cloud, disable_dropout, is_pre_bn_bias, name_seeded_init, ref_args
 
@@ -42,7 +44,7 @@ def close(got, ref, rel=1e-5, floor=1e-5):
 def test_step_matches_reference_fixture(backend):
     from repsurf_amd import mlp
     from util.utils import SmoothClsLoss
-    mlp.set_backend(backend)
+    torch_executor.set_backend(backend)
     g = np.load(os.path.join(GOLDEN, "model_b4.npz"))
     model = build_model()
     grabbed = {}
@@ -82,7 +84,7 @@ def test_step_matches_reference_fixture(backend):
 def test_step_matches_oracle(backend, arch, b, seed):
     from repsurf_amd import mlp
     from util.utils import SmoothClsLoss
-    mlp.set_backend(backend)
+    torch_executor.set_backend(backend)
     model = build_model(arch)
     xyz = cloud(seed, b, 1024)
     label = np.random.RandomState(seed).randint(0, 15, (b,))
@@ -160,7 +162,7 @@ def test_bf16_mode_classifier_step():
     0.99 (tests/test_mlp_gpu.py, where the same stacks under torch.autocast are the yardstick and come out slightly
     worse), re-routed max-pool winners and a head BatchNorm over 16 rows compound; the bounds here only catch breakage."""
     from repsurf_amd import mlp
-    mlp.set_backend("hip")
+    torch_executor.set_backend("hip")
     g = np.load(os.path.join(GOLDEN, "model_b4.npz"))
     res = _bf16_fp32_step(g["xyz"], g["label"], int(g["rng_seed"]))
     assert np.abs(res["fp32"][0] - g["logits"]).max() < 1e-4           # the fp32 run is the parity path

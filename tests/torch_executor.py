@@ -1,0 +1,87 @@
+"""Plain PyTorch fp32 executor of the grouped shared-MLP stacks (F.linear / F.batch_norm / relu / max): the
+floating-point REFERENCE the MFMA kernels are tested against (tests/test_mlp_gpu.py, tests/test_model_gpu.py).
+TEST INFRASTRUCTURE ONLY: it lives here, not in repsurf_amd/, so that the product package has ONE executor.
+
+`set_backend("torch")` swaps repsurf_amd.mlp's dispatch functions for the ones below (and switches the compacted
+groups off: the reference executor works on dense groups); `set_backend("hip")` restores the product functions."""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+from repsurf_amd import mlp as _mlp
+
+_PRODUCT = {n: getattr(_mlp, n) for n in ("sa_mlp_cd", "sa_mlp_plain", "umbrella_mlp", "umbrella_mlp2", "prepack",
+                                          "deferred_counters")}
+_PRODUCT_COMPACT = _mlp.COMPACT_GROUPS
+BACKEND = "hip"
+
+
+def _w2d(conv):
+    w = conv.weight
+    return w.view(w.shape[0], w.shape[1])
+
+
+def _bn(y, bn):
+    """BatchNorm over rows (training: batch statistics + running-stat update, like nn.BatchNorm2d
+    over (B,C,nsample,npoint))."""
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    return F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                        bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
+
+
+def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample, compact=None, feat_off=None, feat_k=None):
+    assert compact is None, "the torch reference executor works on dense groups"
+    if feat_off is not None:       # aligned (padded) rows: back to the tight layout
+        x = torch.cat([x[:, :pos_channel], x[:, feat_off:feat_off + feat_k]], dim=1)
+    loc = _bn(F.linear(x[:, :pos_channel], _w2d(mlp_l0), mlp_l0.bias), bn_l0)
+    feat = _bn(F.linear(x[:, pos_channel:], _w2d(mlp_f0), mlp_f0.bias), bn_f0)
+    h = F.relu(loc + feat)
+    for conv, bn in zip(convs, bns):
+        h = F.relu(_bn(F.linear(h, _w2d(conv), conv.bias), bn))
+    return h.view(-1, nsample, h.shape[1]).max(dim=1)[0]
+
+
+def sa_mlp_plain(x, convs, bns, nsample, relu_last=True):
+    h = x
+    for i, (conv, bn) in enumerate(zip(convs, bns)):
+        h = _bn(F.linear(h, _w2d(conv), conv.bias), bn)
+        if relu_last or i + 1 < len(convs):
+            h = F.relu(h)
+    return h.view(-1, nsample, h.shape[1]).max(dim=1)[0]
+
+
+def umbrella_mlp(x, mlps, group, aggr):
+    conv0, bn0, _, conv1, bn1, _, conv2 = mlps
+    h = F.relu(_bn(F.linear(x, _w2d(conv0), conv0.bias), bn0))
+    h = F.relu(_bn(F.linear(h, _w2d(conv1), conv1.bias), bn1))
+    h = F.linear(h, _w2d(conv2), conv2.bias).view(-1, group, conv2.weight.shape[0])
+    if aggr == "max":
+        return h.max(dim=1)[0]
+    if aggr == "avg":
+        return h.mean(dim=1)
+    return h.sum(dim=1)
+
+
+def umbrella_mlp2(x, mlps, group):
+    conv0, bn0, _, conv1 = mlps
+    h = F.relu(_bn(F.linear(x, _w2d(conv0), conv0.bias), bn0))
+    return F.linear(h, _w2d(conv1), conv1.bias).view(-1, group, conv1.weight.shape[0]).sum(dim=1)
+
+
+def set_backend(name):
+    global BACKEND
+    if name not in ("hip", "torch"):
+        raise ValueError(name)
+    BACKEND = name
+    if name == "hip":
+        for n, f in _PRODUCT.items():
+            setattr(_mlp, n, f)
+        _mlp.COMPACT_GROUPS = _PRODUCT_COMPACT
+    else:
+        _mlp.sa_mlp_cd, _mlp.sa_mlp_plain = sa_mlp_cd, sa_mlp_plain
+        _mlp.umbrella_mlp, _mlp.umbrella_mlp2 = umbrella_mlp, umbrella_mlp2
+        _mlp.prepack = lambda convs: None
+        _mlp.deferred_counters = contextlib.nullcontext
+        _mlp.COMPACT_GROUPS = False

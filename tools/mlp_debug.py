@@ -13,7 +13,6 @@ g = torch.Generator().manual_seed(2)
 x = torch.randn(groups * ns, pos + feat, generator=g).cuda()
 w = torch.randn(groups, widths[-1], generator=g).cuda()
 H.DEBUG = {}
-mlp.set_backend("hip")
 xh = x.clone().requires_grad_()
 out = mlp.sa_mlp_cd(xh, pos, mod.mlp_l0, mod.bn_l0, mod.mlp_f0, mod.bn_f0, mod.convs, mod.bns, ns)
 (out * w).sum().backward()
