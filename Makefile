@@ -30,7 +30,7 @@ $(LIBDIR)/librepsurf_hip.so: $(OBJS)
 oracle: oracle/_build/libgeom_oracle.so
 oracle/_build/libgeom_oracle.so: oracle/geom_oracle.c
 	@mkdir -p oracle/_build
-	gcc -O2 -std=c11 -fPIC -shared -ffp-contract=off -fno-fast-math -o $@ $< -lm
+	gcc -O2 -std=c11 -fPIC -shared -ffp-contract=off -fno-fast-math -fopenmp -o $@ $< -lm
 
 # the reference's own pointops kernels as host code (test infrastructure; needs /root/reference)
 ref:

@@ -55,8 +55,8 @@ def parse():
     ap.add_argument("--no-optim", action="store_true", help="stop the step at backward (BASELINE.md definition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events")
-    ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--cpu-batch", type=int, default=8, help="clouds in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="clouds in the CPU-baseline sample (default: the GPU batch)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--breakdown", default="", help="write a per-kernel timing breakdown JSON here")
     ap.add_argument("--launch-log", default="", help="write the ordered (abi call, sizes) list of the timing pass "
@@ -78,12 +78,17 @@ def synthetic_batch(seed, b, n, device):
 
 
 def cpu_baseline(args, state):
-    """The CPU oracle on the same workload: B x points clouds, forward + loss + backward."""
+    """The CPU path on the same workload: B x points clouds, zero_grad -> forward -> SmoothClsLoss -> backward, 1 warm-up +
+    `--cpu-steps` timed iterations on this host.  /root/reference does not exist on the GPU box, so the
+    timed code is the oracle port (oracle/torch_ref.py: the same PyTorch CPU kernels for the dense part, the C geometry
+    threaded over clouds); profiles/cpu_port_vs_reference.json (tools/cpu_calibration.py, build container) times the port
+    and the reference's own path side by side on one host, and its ratio is quoted in `sample`."""
     from oracle import geom_oracle, torch_ref
     geom_oracle.build()
     threads = min(os.cpu_count() or 1, args.cpu_threads)
     torch.set_num_threads(threads)
-    nb = min(args.batch, args.cpu_batch)       # bounded sample: same per-cloud workload, fewer clouds
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    nb = min(args.batch, args.cpu_batch)
     g = torch.Generator().manual_seed(123)
     xyz = (torch.rand(nb, args.points, 3, generator=g) * 2 - 1).numpy()
     label = torch.randint(0, 15, (nb,), generator=g).numpy()
@@ -91,7 +96,7 @@ def cpu_baseline(args, state):
     times = []
     for i in range(1 + args.cpu_steps):
         t0 = time.perf_counter()
-        torch_ref.step(state, xyz, label, None, starts, arch=args.model)
+        torch_ref.step(state, xyz, label, None, starts, arch=args.model, timed=True)
         times.append(time.perf_counter() - t0)
     dt = float(np.mean(times[1:]))
     cpu = "?"
@@ -102,13 +107,21 @@ def cpu_baseline(args, state):
                 break
     except OSError:
         pass
+    calib = ""
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json")))
+        calib = (f"; calibration on one host ({c['host_cpu']}, {c['threads']} threads, B={c['batch']}): reference path "
+                 f"{c['reference_clouds_per_s']} clouds/s, this port {c['port_clouds_per_s']} clouds/s = "
+                 f"{c['port_over_reference_speed']}x the reference's speed (the port is the FASTER of the two, so gpu_over_cpu "
+                 f"understates the ratio to the reference)")
+    except (OSError, ValueError, KeyError):
+        pass
     return {"value": round(nb / dt, 3), "unit": "clouds/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"{args.cpu_steps} steps (after 1 warm-up) of B={nb}x{args.points} clouds through the same "
-                      f"fwd+loss+bwd workload (per-cloud work identical to the B={args.batch} GPU batch); "
-                      f"dense ops torch {torch.__version__} CPU on {threads} threads, "
-                      f"geometry single-threaded C; host CPU: {cpu}",
-            "s_per_step": round(dt, 4)}
+            "sample": f"{args.cpu_steps} timed steps (after 1 warm-up) of B={nb}x{args.points} clouds, fwd+loss+bwd; "
+                      f"dense ops torch {torch.__version__} CPU, geometry C/OpenMP, {threads} threads; "
+                      f"host CPU: {cpu}" + calib,
+            "s_per_step": round(dt, 4), "steps_s": [round(t, 4) for t in times[1:]]}
 
 
 def algorithmic_cost(name, dims):

@@ -47,8 +47,9 @@ static float sqdist_expanded(const float *q, float qq, const float *p, float pp)
  * xyz (b,n,3); start (b) first picks (the reference draws them with torch.randint, :66);
  * idx (b,m). */
 void oracle_fps(int b, int n, int m, const float *xyz, const int *start, int *idx) {
-  float *dist = (float *)malloc(sizeof(float) * (size_t)n);
+#pragma omp parallel for schedule(dynamic) if (b > 1)          /* clouds are independent: threads only change the wall time */
   for (int bi = 0; bi < b; ++bi) {
+    float *dist = (float *)malloc(sizeof(float) * (size_t)n);
     const float *pts = xyz + (size_t)bi * n * 3;
     for (int k = 0; k < n; ++k) dist[k] = 1e10f;                  /* :65 */
     int far = start ? start[bi] : 0;
@@ -65,14 +66,15 @@ void oracle_fps(int b, int n, int m, const float *xyz, const int *start, int *id
       }
       far = best;
     }
+    free(dist);
   }
-  free(dist);
 }
 
 /* query_ball_point(cuda=False)  classification/modules/pointnet2_utils.py:85-99
  * radius2 = (float)(radius**2) as the tensor/scalar comparison at :90 does. */
 void oracle_ballquery(int b, int n, int m, float radius2, int nsample, const float *new_xyz,
                       const float *xyz, int *idx) {
+#pragma omp parallel for schedule(dynamic) if (b > 1)
   for (int bi = 0; bi < b; ++bi) {
     const float *pts = xyz + (size_t)bi * n * 3;
     for (int s = 0; s < m; ++s) {
@@ -95,9 +97,10 @@ void oracle_ballquery(int b, int n, int m, float radius2, int nsample, const flo
  * ascending by (distance, index).  dist2 optional. */
 void oracle_knn(int b, int n, int m, int k, const float *xyz, const float *new_xyz, int *idx,
                 float *dist2) {
-  float *bd = (float *)malloc(sizeof(float) * (size_t)k);
-  int *bi_ = (int *)malloc(sizeof(int) * (size_t)k);
+#pragma omp parallel for schedule(dynamic) if (b > 1)
   for (int bi = 0; bi < b; ++bi) {
+    float *bd = (float *)malloc(sizeof(float) * (size_t)k);
+    int *bi_ = (int *)malloc(sizeof(int) * (size_t)k);
     const float *pts = xyz + (size_t)bi * n * 3;
     for (int s = 0; s < m; ++s) {
       const float *q = new_xyz + ((size_t)bi * m + s) * 3;
@@ -116,8 +119,8 @@ void oracle_knn(int b, int n, int m, int k, const float *xyz, const float *new_x
         if (dist2) dist2[((size_t)bi * m + s) * k + j] = j < cnt ? bd[j] : INFINITY;
       }
     }
+    free(bd); free(bi_);
   }
-  free(bd); free(bi_);
 }
 
 /* UmbrellaSurfaceConstructor up to the input of self.mlps, self-query case
@@ -214,10 +217,11 @@ static int fan_features(int g, float *ox, float *oy, float *oz, float flip, int 
 void oracle_umbrella(int b, int n, int k, const float *xyz, const float *inv_sign, int *knn_idx,
                      float *feat, unsigned char *near_tie) {
   const int g = k - 1;
-  int *nn = (int *)malloc(sizeof(int) * (size_t)k);
-  float *ox = (float *)malloc(sizeof(float) * 19 * (size_t)g);
-  float *oy = ox + g, *oz = oy + g, *work = oz + g;
+#pragma omp parallel for schedule(dynamic) if (b > 1)
   for (int bi = 0; bi < b; ++bi) {
+    int *nn = (int *)malloc(sizeof(int) * (size_t)k);
+    float *ox = (float *)malloc(sizeof(float) * 19 * (size_t)g);
+    float *oy = ox + g, *oz = oy + g, *work = oz + g;
     const float *pts = xyz + (size_t)bi * n * 3;
     for (int q = 0; q < n; ++q) {
       oracle_knn(1, n, 1, k, pts, pts + q * 3, nn, NULL);                         /* :115 */
@@ -230,8 +234,8 @@ void oracle_umbrella(int b, int n, int k, const float *xyz, const float *inv_sig
                                    feat + ((size_t)bi * n + q) * (size_t)(g * 10));
       if (near_tie) near_tie[(size_t)bi * n + q] = (unsigned char)tie;
     }
+    free(nn); free(ox);
   }
-  free(nn); free(ox);
 }
 
 /* sample_and_group feature assembly  classification/modules/repsurface_utils.py:36-57
@@ -240,6 +244,7 @@ void oracle_group_features(int b, int n, int m, int nsample, int cn, int cf, int
                            const float *center, const float *new_center, const float *normal,
                            const float *feature, const int *idx, float *out) {
   const int cpos = polar ? 6 : 3, ctot = cpos + cn + cf;
+#pragma omp parallel for schedule(static) if (b > 1)
   for (int bi = 0; bi < b; ++bi)
     for (int s = 0; s < m; ++s)
       for (int j = 0; j < nsample; ++j) {

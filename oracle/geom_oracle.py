@@ -19,7 +19,7 @@ def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
         subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-fno-fast-math", "-o", _SO, src, "-lm"])
+                               "-fno-fast-math", "-fopenmp", "-o", _SO, src, "-lm"])
     return _SO
 
 

@@ -54,11 +54,21 @@ def _gather(t, idx):
     return out.view(*idx.shape, t.shape[2])
 
 
+def _bn_train_fp32(y, w, b, eps=1e-5):
+    """What the reference itself executes (nn.BatchNorm2d -> the fp32 CPU batch_norm kernel): the TIMED leg of
+    bench.py's cpu_baseline uses it, so that the port is not slower than the thing it stands in for (the fp64
+    statistics above cost 0.9 s per 524 288 x 64 layer on 8 threads, the fp32 kernel 0.1 s)."""
+    return F.batch_norm(y, None, None, w, b, True, 0.1, eps)
+
+
 def step(state, xyz, label=None, inv_sign=None, fps_starts=None, arch="repsurf_ssg_umb", k=9,
-         want_grads=True):
+         want_grads=True, timed=False):
     """One training step on CPU.  state: {name: tensor} (reference key names); xyz (B,N,3) float32
     numpy; inv_sign (B,) +-1 or None; fps_starts: list of (B,) int arrays, one per sampling stage.
-    Returns dict with logits, loss, per-stage outputs and {name: grad}."""
+    Returns dict with logits, loss, per-stage outputs and {name: grad}.
+    timed=True: BatchNorm through torch's fp32 kernel (the reference's own arithmetic and cost) -- for timing only,
+    parity checks use the default."""
+    _bn_train = _bn_train_fp32 if timed else globals()["_bn_train"]
     p = {k_: v.detach().clone().float().requires_grad_(v.dtype.is_floating_point and want_grads)
          for k_, v in state.items() if "running" not in k_ and "num_batches" not in k_}
     xyz = np.ascontiguousarray(xyz, np.float32)

@@ -1,0 +1,94 @@
+"""The drop-in claim, EXECUTED: the reference's own model definition files
+(classification/models/repsurf/repsurf_ssg_umb.py:11-57, repsurf_ssg_umb_2x.py, segmentation/models/repsurf/
+repsurf_umb_ssg.py:13-68), loaded unmodified by path, with `modules.*` resolving to this package's mirrors.
+CPU: they construct and their parameter trees equal the mirror models' (what makes reference checkpoints load).
+GPU: their forward + backward reproduce the fixtures the reference's CPU run produced (model_b4.npz / seg_model.npz).
+The model files themselves are never part of this repository (tests/util.staged_reference_file)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import (GOLDEN, disable_dropout, is_pre_bn_bias, load_by_path, name_seeded_init, parity_report, ref_args,
+                        seg_args, seg_state, staged_reference_file, subproject)
+
+CLS = staged_reference_file("classification", "models/repsurf/repsurf_ssg_umb.py")
+CLS2X = staged_reference_file("classification", "models/repsurf/repsurf_ssg_umb_2x.py")
+SEG = staged_reference_file("segmentation", "models/repsurf/repsurf_umb_ssg.py")
+need = pytest.mark.skipif(CLS is None or SEG is None, reason="reference model files not staged (make -f oracle/Makefile.ref)")
+
+
+@need
+def test_reference_model_files_construct_over_the_mirror_modules():
+    with subproject("classification"):
+        from models.repsurf.repsurf_ssg_umb import Model as Mirror
+        from models.repsurf.repsurf_ssg_umb_2x import Model as Mirror2x
+        for path, mirror in ((CLS, Mirror), (CLS2X, Mirror2x)):
+            ref = load_by_path("ref_cls_model", path).Model(ref_args())
+            own = mirror(ref_args())
+            assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == \
+                   {k: tuple(v.shape) for k, v in own.state_dict().items()}
+        assert sum(p.numel() for p in load_by_path("ref_cls_model", CLS).Model(ref_args()).parameters()) == 1476791
+    with subproject("segmentation"):
+        from models.repsurf.repsurf_umb_ssg import Model as MirrorSeg
+        ref = load_by_path("ref_seg_model", SEG).Model(seg_args())
+        own = MirrorSeg(seg_args())
+        assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == \
+               {k: tuple(v.shape) for k, v in own.state_dict().items()}
+
+
+@need
+@pytest.mark.gpu
+def test_reference_classifier_file_forward_backward_matches_its_cpu_fixture():
+    from util.utils import SmoothClsLoss
+    g = np.load(os.path.join(GOLDEN, "model_b4.npz"))
+    model = load_by_path("ref_cls_model", CLS).Model(ref_args())
+    name_seeded_init(model)
+    disable_dropout(model)
+    model = model.cuda().train()
+    torch.manual_seed(int(g["rng_seed"]))
+    pred = model(torch.from_numpy(g["xyz"]).cuda().permute(0, 2, 1).contiguous())
+    loss = SmoothClsLoss()(pred, torch.from_numpy(g["label"]).long().cuda())
+    loss.backward()
+    err = np.abs(pred.detach().cpu().numpy() - g["logits"]).max()
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        if is_pre_bn_bias(name):
+            continue
+        got = params[name].grad.norm().item()
+        worst = max(worst, abs(got - ref) / max(ref, 1e-2))
+    parity_report("dropin_cls_reference_file", logits_max_abs=err, loss_abs=abs(loss.item() - float(g["loss"])),
+                  grad_norm_rel=worst)
+    assert err <= 5e-5 and abs(loss.item() - float(g["loss"])) < 1e-5 and worst <= 2e-3
+
+
+@need
+@pytest.mark.gpu
+def test_reference_segmentation_file_forward_backward_matches_its_cpu_fixture():
+    fx = np.load(os.path.join(GOLDEN, "seg_model.npz"))
+    with subproject("segmentation"):
+        model = load_by_path("ref_seg_model", SEG).Model(seg_args())
+        model.load_state_dict(seg_state(), strict=False)
+        disable_dropout(model)
+        model = model.cuda().train()
+        np.random.seed(9)
+        logits = model([torch.from_numpy(fx["coord"]).cuda(), torch.from_numpy(fx["rgb"]).cuda(),
+                        torch.from_numpy(fx["offset"]).cuda()])
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(fx["label"].astype(np.int64)).cuda())
+    loss.backward()
+    err = np.abs(logits.detach().cpu().numpy() - fx["logits"]).max()
+    bad, worst = [], 0.0
+    for name, p in model.named_parameters():
+        ref = fx["gsub/" + name]
+        got = p.grad.detach().cpu().numpy().reshape(-1)[::(7 if p.numel() > 4096 else 1)]
+        if float(fx["gnorm/" + name]) < 1e-5:
+            continue
+        rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-12)
+        worst = max(worst, rel)
+        if rel > 3e-2:
+            bad.append((name, rel))
+    parity_report("dropin_seg_reference_file", logits_max_abs=err, loss_abs=abs(loss.item() - float(fx["loss"])),
+                  grad_rel_l2_worst=worst)
+    assert err <= 2e-4 and abs(loss.item() - float(fx["loss"])) <= 5e-5 and not bad, (err, bad)

@@ -61,3 +61,20 @@ def test_seg_state_dict_matches_reference_names():
     ref = {k[6:]: tuple(g[k]) for k in g.files if k.startswith("shape/")}
     assert {n: tuple(p.shape) for n, p in model.named_parameters()} == ref
     assert sorted(n for n, _ in model.named_buffers()) == list(g["buffers"])
+
+
+def test_collate_fn_wire_format():
+    """util.data_util.collate_fn == segmentation/util/data_util.py:15-23: rows concatenated, running int32 ends."""
+    import torch
+    from tests.util import subproject
+    with subproject("segmentation"):
+        from util.data_util import collate_fn
+    g = torch.Generator().manual_seed(0)
+    batch = [(torch.rand(n, 3, generator=g), torch.rand(n, 3, generator=g), torch.randint(0, 13, (n,), generator=g))
+             for n in (5, 1, 7)]
+    coord, feat, label, offset = collate_fn(batch)
+    assert coord.shape == (13, 3) and feat.shape == (13, 3) and label.shape == (13,)
+    assert offset.dtype == torch.int32 and offset.tolist() == [5, 6, 13]
+    assert torch.equal(coord[5:6], batch[1][0]) and torch.equal(label[6:], batch[2][2])
+    c2, f2, l2, o2 = collate_fn([(b[0], b[1], None) for b in batch])
+    assert l2 is None and o2.tolist() == [5, 6, 13]

@@ -1,0 +1,241 @@
+"""Parity at the BENCHMARK configurations (BASELINE.json configs[1], [3], [4]) and of the call sites either side of the
+model (pre-model `sample()`, sectorized FPS, the classification L1 operator wrappers, eval after a training step).
+Every test records its measured errors through tests.util.parity_report (committed copy: profiles/r02_parity_report.jsonl)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geom_oracle as G
+from oracle import seg_ref, torch_ref
+from tests.util import (GOLDEN, cloud, disable_dropout, is_pre_bn_bias, name_seeded_init, parity_report, ref_args, seg_args,
+                        seg_state, subproject, take)
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def build_cls(arch="repsurf_ssg_umb"):
+    import importlib
+    model = importlib.import_module(f"models.repsurf.{arch}").Model(ref_args())
+    name_seeded_init(model)
+    disable_dropout(model)
+    return model.cuda().train()
+
+
+def test_classifier_step_at_the_benchmark_configuration_matches_oracle():
+    """configs[1]: B=32 x 1024 points, full repsurf_ssg_umb step (forward, SmoothClsLoss, backward) against the CPU
+    oracle on the same clouds, weights and CPU-generator draws.  Indices (FPS, ball query) bit-exact; log-probabilities
+    within 1e-5 of the tensor scale (|log p| <= ~4); gradients relative-L2."""
+    from util.utils import SmoothClsLoss
+    b, seed = 32, 11
+    model = build_cls()
+    stage_idx = {}
+    xyz = cloud(seed, b, 1024)
+    label = np.random.RandomState(seed).randint(0, 15, (b,))
+    torch.manual_seed(seed)
+    state = torch.get_rng_state()
+    flip = (torch.randint(0, 2, (b, 1, 1)).float() * 2 - 1).view(b).numpy()
+    starts = [torch.randint(0, n, (b,), dtype=torch.long).numpy().astype(np.int32) for n in (1024, 512)]
+    torch.set_rng_state(state)
+    for nm in ("sa1", "sa2", "sa3"):
+        getattr(model, nm).register_forward_hook(lambda m, i, o, nm=nm: stage_idx.__setitem__(nm, (o[0], o[2])))
+    pred = model(dev(xyz).permute(0, 2, 1).contiguous())
+    loss = SmoothClsLoss()(pred, dev(label).long())
+    loss.backward()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = torch_ref.step({k: v.cpu() for k, v in model.state_dict().items()}, xyz, label, flip, starts)
+    ties = int(ref["near_tie"].sum())
+    # sampled centres: the FPS picks of both stages are the oracle's, bit for bit
+    for nm, n_in in (("sa1", xyz), ):
+        centres = stage_idx[nm][0].permute(0, 2, 1).detach().cpu().numpy()
+        assert np.array_equal(centres, take(xyz, ref["sa1_fps"]))
+    nums = {"azimuth_near_tie_points": ties}
+    for nm in ("sa1", "sa2", "sa3"):
+        got = stage_idx[nm][1].permute(0, 2, 1).detach().cpu().numpy()
+        r = ref[nm + "_feat"].detach().numpy()
+        nums[nm + "_feat_rel"] = np.abs(got - r).max() / max(np.abs(r).max(), 1.0)
+    r = ref["logits"].detach().numpy()
+    nums["logits_rel"] = np.abs(pred.detach().cpu().numpy() - r).max() / max(np.abs(r).max(), 1.0)
+    nums["logits_scale"] = float(np.abs(r).max())
+    nums["loss_abs"] = abs(loss.item() - float(ref["loss"].detach()))
+    worst, worst_name = 0.0, ""
+    for name, p in model.named_parameters():
+        if is_pre_bn_bias(name):
+            continue
+        rg = ref["grads"][name].numpy().reshape(p.shape)
+        rel = np.linalg.norm(p.grad.cpu().numpy() - rg) / max(np.linalg.norm(rg), 1e-12)
+        if rel > worst:
+            worst, worst_name = rel, name
+    nums["grad_rel_l2_worst"], nums["grad_worst_name"] = worst, worst_name
+    parity_report("cls_b32x1024_vs_oracle", **nums)
+    for nm in ("sa1", "sa2", "sa3"):
+        assert nums[nm + "_feat_rel"] <= 1e-5, nums
+    assert nums["logits_rel"] <= 1e-5 and nums["loss_abs"] <= 2e-5, nums
+    assert worst <= 1e-2, nums
+
+
+def test_segmentation_step_at_the_benchmark_configuration_matches_oracle():
+    """configs[3]: 16 clouds x 4096 points x (xyz + rgb), 13 classes, against oracle/seg_ref.step."""
+    r = np.random.RandomState(3)
+    n = 16 * 4096
+    coord = (r.rand(n, 3) * 2 - 1).astype(np.float32)
+    rgb = r.rand(n, 3).astype(np.float32)
+    offset = (np.arange(1, 17) * 4096).astype(np.int32)
+    label = r.randint(0, 13, n).astype(np.int64)
+    with subproject("segmentation"):
+        from models.repsurf.repsurf_umb_ssg import Model
+        model = Model(seg_args())
+        model.load_state_dict(seg_state(), strict=False)
+        disable_dropout(model)
+        model = model.cuda().train()
+        np.random.seed(17)
+        flips = np.where(np.random.rand(16) < 0.5, 1.0, -1.0).astype(np.float32)
+        np.random.seed(17)
+        logits = model([dev(coord), dev(rgb), dev(offset)])
+    loss = torch.nn.functional.cross_entropy(logits, dev(label))
+    loss.backward()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = seg_ref.step(seg_state(), coord, rgb, offset, label, flips)
+    rl = ref["logits"].detach().numpy()
+    nums = {"azimuth_near_tie_points": int(ref["near_tie"].sum()),
+            "logits_max_abs": np.abs(logits.detach().cpu().numpy() - rl).max(), "logits_scale": float(np.abs(rl).max()),
+            "loss_abs": abs(loss.item() - float(ref["loss"].detach()))}
+    worst, worst_name = 0.0, ""
+    for name, p in model.named_parameters():
+        rg = ref["grads"][name].numpy().reshape(-1)
+        if np.linalg.norm(rg) < 1e-5:
+            continue
+        rel = np.linalg.norm(p.grad.detach().cpu().numpy().reshape(-1) - rg) / np.linalg.norm(rg)
+        if rel > worst:
+            worst, worst_name = rel, name
+    nums["grad_rel_l2_worst"], nums["grad_worst_name"] = worst, worst_name
+    parity_report("seg_16x4096_vs_oracle", **nums)
+    assert nums["logits_max_abs"] <= 1e-5 * max(nums["logits_scale"], 1.0) * 10, nums     # see DESIGN §4 (stated bound)
+    assert nums["loss_abs"] <= 2e-5 and worst <= 3e-2, nums
+
+
+def test_bf16_classifier_step_at_configs4_shape():
+    """configs[4]: B=64 x 2048 points, bf16 MFMA operands: finite, same geometry, close to the fp32 path."""
+    from repsurf_amd import mlp
+    from util.utils import SmoothClsLoss
+    xyz, label = cloud(31, 64, 2048), (np.arange(64) % 15).astype(np.int64)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        mlp.set_precision(prec)
+        try:
+            model = build_cls()
+            model.surface_constructor.register_forward_hook(lambda m, i, o: res.__setitem__(prec + "_normal", o.detach().clone()))
+            torch.manual_seed(5)
+            pred = model(dev(xyz).permute(0, 2, 1).contiguous())
+            loss = SmoothClsLoss()(pred, dev(label))
+            loss.backward()
+            res[prec] = (pred.detach().cpu().numpy(), float(loss.detach()),
+                         np.concatenate([p.grad.detach().cpu().numpy().ravel().astype(np.float64)
+                                         for n, p in model.named_parameters() if not is_pre_bn_bias(n)]))
+        finally:
+            mlp.set_precision("fp32")
+    assert np.isfinite(res["bf16"][0]).all() and np.isfinite(res["bf16"][2]).all()
+    assert torch.equal(res["fp32_normal"], res["bf16_normal"])        # geometry + constructor stay fp32 in both modes
+    cos = float(res["bf16"][2] @ res["fp32"][2] / (np.linalg.norm(res["bf16"][2]) * np.linalg.norm(res["fp32"][2])))
+    err = np.abs(res["bf16"][0] - res["fp32"][0]).max()
+    parity_report("cls_b64x2048_bf16_vs_fp32", grad_cosine=cos, logp_max_abs=err, loss_abs=abs(res["bf16"][1] - res["fp32"][1]))
+    assert cos > 0.9 and err < 0.15 and abs(res["bf16"][1] - res["fp32"][1]) < 5e-2
+
+
+def test_pre_model_sample_equals_oracle_fps_and_gather():
+    """modules.pointnet2_utils.sample (classification/modules/pointnet2_utils.py:114-124; the train loop's 2048 -> 1024
+    down-sampling, train_cls_scanobjectnn.py:218): the same rows as the oracle FPS from the same CPU-generator start."""
+    from modules import pointnet2_utils as P
+    b, n, m = 6, 2048, 1024
+    feat = np.concatenate([cloud(41, b, n), np.random.RandomState(1).rand(b, n, 3).astype(np.float32)], -1)   # xyz + 3
+    torch.manual_seed(123)
+    state = torch.get_rng_state()
+    start = torch.randint(0, n, (b,), dtype=torch.long).numpy().astype(np.int32)
+    torch.set_rng_state(state)
+    got = P.sample(m, dev(feat).permute(0, 2, 1).contiguous()).permute(0, 2, 1).cpu().numpy()
+    idx = G.fps(feat[:, :, :3], m, start)
+    assert np.array_equal(got, take(feat, idx))
+
+
+def test_sectorized_fps_matches_the_reference_function():
+    """pointops.sectorized_fps against the fixture produced by the reference's own function
+    (segmentation/modules/pointops/functions/pointops.py:52-108 over its own FPS kernel, make_golden_seg.py)."""
+    fx = np.load(os.path.join(GOLDEN, "seg_sector.npz"))
+    with subproject("segmentation"):
+        from modules.pointops.functions import pointops
+        for ns in (1, 2, 4):
+            got = pointops.sectorized_fps(dev(fx["coord"]), dev(fx["offset"]), dev(fx["new_offset"]), ns,
+                                          int(fx["min_points"])).cpu().numpy()
+            ref = fx[f"idx_s{ns}"]
+            same = (got == ref).mean()
+            parity_report(f"sectorized_fps_s{ns}", rows_equal_fraction=same)
+            assert np.array_equal(got, ref), (ns, same)
+
+
+def test_classification_pointops_wrappers_match_the_reference_operators():
+    """modules.pointops.functions.pointops (8 wrappers) against the reference's own autograd Functions run over its own
+    kernels (tests/golden/make_golden_pointops.py -> cls_pointops.npz).  furthestsampling / gathering / grouping /
+    nearestneighbor / interpolation: exact (the operators are copies or 3-term sums in a fixed order); ballquery / knnquery
+    follow the CPU-path distance formula (DESIGN §1 `cuda=` note): identical rows except where the two formulas round
+    across the radius / swap two neighbours."""
+    from modules.pointops.functions import pointops as P
+    fx = np.load(os.path.join(GOLDEN, "cls_pointops.npz"))
+    xyz, feats, new_xyz = dev(fx["xyz"]), dev(fx["feats"]), dev(fx["new_xyz"])
+    fps = P.furthestsampling(xyz, fx["fps"].shape[1])
+    assert np.array_equal(fps.cpu().numpy(), fx["fps"])
+    f1 = feats.clone().requires_grad_()
+    gath = P.gathering(f1, fps)
+    assert np.array_equal(gath.detach().cpu().numpy(), fx["gathering"])
+    (gath * dev(fx["gathering_w"])).sum().backward()
+    assert np.abs(f1.grad.cpu().numpy() - fx["gathering_grad"]).max() <= 1e-6
+    rows = 0
+    for r, ns in ((0.2, 16), (0.4, 32)):
+        got = P.ballquery(r, ns, xyz, new_xyz).cpu().numpy()
+        rows += int((got != fx[f"ball_{ns}"]).any(-1).sum())
+    knn = P.knnquery(9, xyz, new_xyz).cpu().numpy()
+    knn_rows = int((np.sort(knn, -1) != np.sort(fx["knn9"], -1)).any(-1).sum())
+    assert np.array_equal(np.sort(fx["knn9"], -1), np.sort(fx["knn9_heap"], -1))
+    assert np.array_equal(P.knnquery_heap(9, xyz, new_xyz).cpu().numpy(), knn)
+    parity_report("cls_pointops_wrappers", ballquery_rows_differing=rows, knn_rows_with_other_set=knn_rows)
+    assert rows <= 1 and knn_rows <= 1
+    idx = dev(fx["ball_16"])
+    f2 = feats.clone().requires_grad_()
+    grp = P.grouping(f2, idx)
+    assert np.array_equal(grp.detach().cpu().numpy(), fx["grouping"])
+    (grp * dev(fx["grouping_w"])).sum().backward()
+    assert np.abs(f2.grad.cpu().numpy() - fx["grouping_grad"]).max() <= 2e-5        # atomics on both sides
+    dist, nidx = P.nearestneighbor(xyz, new_xyz)
+    assert np.array_equal(nidx.cpu().numpy(), fx["nn_idx"])
+    assert (np.abs(dist.cpu().numpy() - fx["nn_dist"]) <= np.spacing(fx["nn_dist"])).all()   # torch.sqrt (CPU, VML) vs device
+    kf = dev(fx["interp_feats"]).requires_grad_()
+    itp = P.interpolation(kf, nidx, dev(fx["nn_weight"]))
+    assert np.abs(itp.detach().cpu().numpy() - fx["interp"]).max() <= 1e-6
+    (itp * dev(fx["interp_w"])).sum().backward()
+    assert np.abs(kf.grad.cpu().numpy() - fx["interp_grad"]).max() <= 2e-5
+
+
+def test_eval_forward_after_a_training_step_uses_the_updated_weights():
+    """the prepacked weight copies were validated by (address, tensor version) only; repsurf_amd.optim.Adam
+    updates through raw pointers, so an eval forward after a training step found first-layer copies one step old."""
+    from repsurf_amd import mlp_hip, optim
+    from util.utils import SmoothClsLoss
+    model = build_cls()
+    opt = optim.Adam(model.parameters(), lr=1e-2)
+    x = dev(cloud(3, 4, 1024)).permute(0, 2, 1).contiguous()
+    torch.manual_seed(0)
+    loss = SmoothClsLoss()(model(x), dev(np.array([1, 2, 3, 4])))
+    loss.backward()
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        torch.manual_seed(1)
+        a = model(x).clone()
+        mlp_hip.weights_changed()                 # a table that is certainly empty
+        torch.manual_seed(1)
+        b = model(x).clone()
+    assert torch.equal(a, b)

@@ -11,7 +11,7 @@ import torch
 
 from oracle import geom_oracle as G
 from oracle import seg_ref
-from tests.util import GOLDEN, seg_args, seg_state, subproject
+from tests.util import GOLDEN, parity_report, seg_args, seg_state, subproject
 
 pytestmark = pytest.mark.gpu
 
@@ -194,6 +194,8 @@ def test_seg_model_matches_oracle_and_reference_fixture():
     loss = torch.nn.functional.cross_entropy(logits, label)
     loss.backward()
     got = logits.detach().cpu().numpy()
+    parity_report("seg_fixture_2clouds", logits_max_abs=np.abs(got - fx["logits"]).max(),
+                  logits_scale=float(np.abs(fx["logits"]).max()), loss_abs=abs(loss.item() - float(fx["loss"])))
     assert np.abs(got - fx["logits"]).max() <= 2e-4               # reference's own torch code (CPU)
     assert abs(loss.item() - float(fx["loss"])) <= 5e-5
     ref = seg_ref.step(seg_state(), fx["coord"], fx["rgb"], fx["offset"], fx["label"].astype(np.int64), fx["inv_sign"])

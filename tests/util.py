@@ -166,3 +166,40 @@ def subproject(name):
         for k in now:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def parity_report(test, **numbers):
+    """Append the MEASURED errors of a parity test to gpurun_out/parity_report.jsonl (scratch; the round's copy is
+    committed under profiles/): assertions say pass/fail, this says by how much."""
+    import json
+    path = os.environ.get("REPSURF_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_report.jsonl"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps({"test": test, **{k: _num(v) for k, v in numbers.items()}}) + "\n")
+    except OSError:
+        pass
+    print("parity", test, {k: (float("%.3g" % v) if isinstance(_num(v), float) else v) for k, v in numbers.items()})
+
+
+def _num(v):
+    return v if isinstance(v, (str, list, dict, bool)) or v is None else float(v)
+
+
+def staged_reference_file(sub, rel):
+    """Path of an UNMODIFIED reference source file needed to execute the drop-in claim (the model definitions):
+    /root/reference/<sub>/<rel> in the build container, else the copy oracle/Makefile.ref stages under the git-ignored
+    oracle/_ref/dropin/ (it travels to the GPU box with the built .so files; it is never part of the history)."""
+    for base in ("/root/reference", os.path.join(ROOT, "oracle", "_ref", "dropin")):
+        p = os.path.join(base, sub, rel)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def load_by_path(name, path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
