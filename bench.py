@@ -124,6 +124,46 @@ def cpu_baseline(args, state):
             "s_per_step": round(dt, 4), "steps_s": [round(t, 4) for t in times[1:]]}
 
 
+def geometry_lines(device, points):
+    """The two geometry kernels the north-star prices separately, timed live with HIP events on the launch stream
+    (10 back-to-back launches after 3 warm-ups): ball query against the HBM roofline by its ALGORITHMIC bytes
+    4*(3BN + 3BS + BS*nsample) at the step's sa1 shape for B = 32 / 256 / 2048 clouds per launch, and FPS as
+    microseconds per pick (a dependency chain of S-1 reductions: neither HBM- nor MFMA-bound)."""
+    from repsurf_amd import ops
+
+    def timed(fn, reps=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3          # seconds per launch
+
+    g = torch.Generator().manual_seed(7)
+    ball = {}
+    n, s_, ns, r = points, 512, 32, 0.2
+    for b in (32, 256, 2048):
+        xyz = (torch.rand(b, n, 3, generator=g) * 2 - 1).to(device)
+        centres = xyz[:, :s_].contiguous()
+        t = timed(lambda: ops.ballquery(r, ns, xyz, centres))
+        nbytes = 4.0 * (3 * b * n + 3 * b * s_ + b * s_ * ns)
+        ball[str(b)] = {"us": round(t * 1e6, 2), "achieved": round(nbytes / t / 1e9, 1), "frac": round(nbytes / t / 1e9 / PEAK_HBM_GBS, 4),
+                        "algorithmic_bytes": nbytes}
+        del xyz, centres
+    fps = {}
+    for name, (b, nn, m) in {"sa1_1024_to_512": (32, points, 512), "sa2_512_to_128": (32, 512, 128),
+                             "sample_2048_to_1024": (32, 2048, 1024)}.items():
+        xyz = (torch.rand(b, nn, 3, generator=g) * 2 - 1).to(device)
+        start = torch.zeros(b, dtype=torch.int32, device=device)
+        t = timed(lambda: ops.furthestsampling(xyz, m, start))
+        fps[name] = {"us": round(t * 1e6, 1), "us_per_pick": round(t * 1e6 / (m - 1), 4), "clouds": b}
+    return ({"kernel": "rs_ballquery", "shape": f"N={n} S={s_} nsample={ns} r={r}", "bound": "hbm", "unit": "GB/s",
+             "peak": PEAK_HBM_GBS, "clouds_per_launch": ball}, fps)
+
+
 def algorithmic_cost(name, dims):
     """(unit, amount) of algorithmic work of one launch of an instrumented ABI call."""
     if name == "rs_ballquery":
@@ -326,6 +366,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, cpu_state)
+        ball_line, fps_line = geometry_lines(device, args.points) if timing else (None, None)
         out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U 1024-pt cls @ B=32 per GPU", "value": round(value, 2),
                "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -336,7 +377,7 @@ def main():
                           "global_batch": args.batch * world, "points": args.points,
                           "parallelism": f"dp{world}", "mlp_backend": "hip", "launch": mode,
                           "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5)},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "roofline_ballquery": ball_line, "fps_us_per_pick": fps_line, "cpu_baseline": cpu}
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out), flush=True)

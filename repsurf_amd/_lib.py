@@ -97,16 +97,19 @@ def load():
     return lib
 
 
-_profile = None   # None = off; else list of (name, dims, start_event, end_event)
+_profile = None   # None = off; else list of (name, dims, start_event, end_event, row-count slot | None)
+_rows_host = None  # pinned int32 arena the row counts of compacted launches are copied into (asynchronously)
+_rows_used = 0
 
 
 def profile_enable(on):
     """Per-launch timing of ABI calls with HIP events recorded on the launch stream (torch's
     current stream, the one every operator passes down).  Used by bench.py for the live
     `roofline` numbers; off by default (two event records per call)."""
-    global _profile, _frozen
+    global _profile, _frozen, _rows_used
     if on:
         _profile = []
+        _rows_used = 0
     elif _profile is not None:
         _frozen, _profile = _profile, None
 
@@ -114,36 +117,49 @@ def profile_enable(on):
 _frozen = []
 
 
+def _dims_of(entry):
+    name, dims, _, _, slot = entry
+    if slot is not None:
+        dims = dims + (f"rows={int(_rows_host[slot])}",)      # dims[0] stays the (static) capacity
+    return dims
+
+
 def profile_collect():
     """-> {abi name: [(milliseconds, (int dims...)), ...]}; call after a device synchronise."""
     out = {}
-    for name, dims, e0, e1 in _frozen:
-        out.setdefault(name, []).append((e0.elapsed_time(e1), dims))
+    for entry in _frozen:
+        out.setdefault(entry[0], []).append((entry[2].elapsed_time(entry[3]), _dims_of(entry)))
     return out
 
 
 _hip = None
 
 
-def _read_device_int(ptr):
-    """Blocking 4-byte device->host copy (profiling only; orders after the work queued so far)."""
-    global _hip
+def _copy_device_int_async(ptr):
+    """4-byte device->pinned-host copy on the launch stream, NOT waited for: a compacted launch's row count lives on the
+    device, and reading it back synchronously (as round 1 did) drained the stream in front of every such launch -- the
+    timed kernels then started on an idle, cooled-down GPU and measured 15-20 % slow.  Returns the arena slot."""
+    global _hip, _rows_host, _rows_used
+    import torch
     if _hip is None:
         _hip = ctypes.CDLL("libamdhip64.so")
-        _hip.hipMemcpy.argtypes = [c_void_p, c_void_p, ctypes.c_size_t, c_int]
-        _hip.hipMemcpy.restype = c_int
-    import torch
-    torch.cuda.current_stream().synchronize()
-    host = c_int(0)
-    rc = _hip.hipMemcpy(ctypes.byref(host), ptr, 4, 2)        # 2 = hipMemcpyDeviceToHost
+        _hip.hipMemcpyAsync.argtypes = [c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p]
+        _hip.hipMemcpyAsync.restype = c_int
+    if _rows_host is None:
+        _rows_host = torch.zeros((1 << 16,), dtype=torch.int32).pin_memory()
+    slot = _rows_used
+    if slot >= _rows_host.numel():
+        raise RepSurfHipError("profiling arena exhausted (more than 65536 compacted launches in one profiled region)")
+    _rows_used += 1
+    rc = _hip.hipMemcpyAsync(_rows_host.data_ptr() + 4 * slot, ptr, 4, 2, torch.cuda.current_stream().cuda_stream)   # 2 = DtoH
     if rc != 0:
-        raise RepSurfHipError(f"hipMemcpy of a device row count failed (hip error {rc})")
-    return int(host.value)
+        raise RepSurfHipError(f"hipMemcpyAsync of a device row count failed (hip error {rc})")
+    return slot
 
 
 def profile_sequence():
-    """-> [(abi name, dims), ...] in launch order for the last profiled region."""
-    return [(name, dims) for name, dims, _, _ in _frozen]
+    """-> [(abi name, dims), ...] in launch order for the last profiled region (after a device synchronise)."""
+    return [(entry[0], _dims_of(entry)) for entry in _frozen]
 
 
 def call(name, *args):
@@ -156,11 +172,11 @@ def call(name, *args):
         rc = getattr(lib, name)(*args)
         e1.record()
         dims = tuple(a for a, t in zip(args, SIGNATURES[name]) if t is c_int or t is c_ll)
+        slot = None
         if name in ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16", "rs_mlp_wgrad", "rs_mlp_wgrad_bf16") and args[1] is not None:
-            # compacted operand: args[0] is only the capacity, the launch's row count lives on the device.
-            # Profiling mode may synchronise: read it back so the cost model sees the rows really processed.
-            dims = dims + (f"rows={_read_device_int(args[1])}",)      # dims[0] stays the (static) capacity
-        _profile.append((name, dims, e0, e1))
+            # compacted operand: args[0] is only the capacity, the launch's row count lives on the device
+            slot = _copy_device_int_async(args[1])
+        _profile.append((name, dims, e0, e1, slot))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

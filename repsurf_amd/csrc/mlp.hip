@@ -213,6 +213,19 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
   constexpr int WR = BM / 32, WC = 4 / WR;                  // waves along rows / columns of the tile
   constexpr int CT = BN / 32 / WC;                          // 32-column MFMA tiles per wave
+#ifdef RS_EXP_LDS_EPILOGUE
+  constexpr bool DIRECT = false;
+#else
+  constexpr bool DIRECT = BM == 64;                         // short tiles: epilogue straight from the accumulators
+#endif
+#if defined(RS_EXP_NO_EARLY_PREFETCH)
+  constexpr bool EARLY_PREFETCH = false;
+#elif defined(RS_EXP_EARLY_PREFETCH_ALL)
+  constexpr bool EARLY_PREFETCH = DIRECT;
+#else
+  // forward instances only: the two-tensor backward operands + mask registers leave no room (spills at 256 VGPRs)
+  constexpr bool EARLY_PREFETCH = DIRECT && MODE >= 0 && MODE <= OPM_RELU2;
+#endif
   static_assert(CT >= 1, "tile too narrow for the wave layout");
   static_assert(!BF || V >= 2, "bf16 staging packs pairs of k");
   constexpr int PLANE_A = BF ? BM * 4 + 16 : AStage<BM>::PLANE;
@@ -300,6 +313,9 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   long long tlast = clock64();
   const long long tstart = tlast;
 #endif
+  float st0[CT], st1[CT], st2[CT];                          // DIRECT: this lane's column sums over all its tiles
+#pragma unroll
+  for (int c = 0; c < CT; ++c) { st0[c] = 0.f; st1[c] = 0.f; st2[c] = 0.f; }
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long r0 = tile * BM;
     f32x16 acc[CT];
@@ -308,7 +324,8 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
-    prefetch(r0, 0, -1);
+    // DIRECT: the first chunk of this tile was requested in front of the previous tile's epilogue (below)
+    if (!EARLY_PREFETCH || tile == (long long)blockIdx.x) prefetch(r0, 0, -1);
     RS_T(0);
     for (int ch = 0; ch < nchunks; ++ch) {
       float *As = (ch & 1) ? As1 : As0;
@@ -369,122 +386,198 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       }
       RS_T(4);
     }
-    __syncthreads();   // all fragment reads of this tile done: the staging buffers become the C tile
-    RS_T(5);
-
-    // ---- epilogue.  D[i][j]: j = lane & 31, i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)  ->  Cs[row][col]
-    float *Cs = smem;                                         // BM x BN floats (<= 64 KB)
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        Cs[(wave_r * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk) * BN + (wave_c * CT + c) * 32 + lrow] = acc[c][i];
-    __syncthreads();
-    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // this tile's column sums
-    {
+    if constexpr (DIRECT) {
+      // ---- epilogue straight from the accumulators (64-row tiles).  D[i][j]: j = lane & 31 is the output column,
+      // i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) the row: one store instruction covers two 128-byte row
+      // segments (full cache lines), a lane keeps ONE column per accumulator tile, so the BatchNorm column sums are
+      // lane-local fp32 sums that stay in registers over all tiles of this workgroup (<= 3 x CT VGPRs) and meet in
+      // LDS once, after the tile loop.  No C tile in LDS, no barrier between the K loop and the stores: the tile's
+      // write-out overlaps the other workgroup's main loop instead of a chip-wide store burst behind three barriers.
+      RS_T(5);
+      // the next tile's first operand chunk travels while this tile's results leave: the epilogue needs no LDS and few
+      // registers, and the loads have the whole write-out to land (they used to be issued behind it and waited for in full)
+      if (EARLY_PREFETCH && tile + gridDim.x < tiles) prefetch((tile + gridDim.x) * BM, 0, -1);
       const int EPI = ep.mode;
-      const int col = n0 + e_col;
-      float bias[4], ms1[4], mt1[4], mu1[4], is1[4], ms2[4], mt2[4], mu2[4], is2[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool cok = col + e < cols;
-        bias[e] = (ep.bias && cok) ? ep.bias[col + e] : 0.f;
-        ms1[e] = mt1[e] = mu1[e] = is1[e] = ms2[e] = mt2[e] = mu2[e] = is2[e] = 0.f;
-        if (EPI == EPI_MASK && cok) {
-          ms1[e] = ep.ms1[col + e]; mt1[e] = ep.mt1[col + e]; mu1[e] = ep.mean1[col + e]; is1[e] = ep.invstd1[col + e];
-          if (ep.my2) { ms2[e] = ep.ms2[col + e]; mt2[e] = ep.mt2[col + e]; mu2[e] = ep.mean2[col + e]; is2[e] = ep.invstd2[col + e]; }
-        }
-      }
-      float *out_t = ep.out + r0 * ep.ldo;                    // wave-uniform tile bases
+      int rbase = wave_r * 32 + 4 * lk;
+      asm volatile("" : "+v"(rbase));                         // opaque per tile: the 16 x 3 row offsets below are recomputed here,
+                                                              // not hoisted out of the tile loop into ~100 long-lived VGPRs
+      const int ldo = (int)ep.ldo, ldm1 = (int)ep.ldm1, ldm2 = (int)ep.ldm2;      // tile-relative offsets fit 32 bits
+      const bool full = r0 + BM <= rows;
+      float *out_t = ep.out + r0 * ep.ldo;
       const float *my1_t = ep.my1 ? ep.my1 + r0 * ep.ldm1 : nullptr;
       const float *my2_t = ep.my2 ? ep.my2 + r0 * ep.ldm2 : nullptr;
-      for (int rl = e_row; rl < BM; rl += E_RPP) {
-        if (r0 + rl >= rows || col >= cols) continue;
-        const float4 cv = *reinterpret_cast<const float4 *>(Cs + rl * BN + e_col);
-        float y[4] = {cv.x + bias[0], cv.y + bias[1], cv.z + bias[2], cv.w + bias[3]};
-        if (EPI == EPI_MASK) {
-          float y1[4], y2[4] = {0.f, 0.f, 0.f, 0.f};
-          if (ep_vec) {
-            const float4 t = *reinterpret_cast<const float4 *>(my1_t + (long long)rl * ep.ldm1 + col);
-            y1[0] = t.x; y1[1] = t.y; y1[2] = t.z; y1[3] = t.w;
-            if (my2_t) { const float4 u = *reinterpret_cast<const float4 *>(my2_t + (long long)rl * ep.ldm2 + col);
-                         y2[0] = u.x; y2[1] = u.y; y2[2] = u.z; y2[3] = u.w; }
-          } else {
+      // forward operand modes never come with the mask epilogue, backward ones never with the statistics one:
+      // the dead branch (and its registers) vanishes from the specialised instances
+      constexpr bool CAN_STATS = MODE < 0 || MODE <= OPM_RELU2, CAN_MASK = MODE < 0 || MODE >= OPM_AFF2;
+      float mw[16];
+      if (CAN_STATS && EPI == EPI_STATS) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const bool cok = col + e < cols;
-              y1[e] = cok ? my1_t[(long long)rl * ep.ldm1 + col + e] : 0.f;
-              if (my2_t) y2[e] = cok ? my2_t[(long long)rl * ep.ldm2 + col + e] : 0.f;
+        for (int i = 0; i < 16; ++i) {
+          const int rl = rbase + (i & 3) + 8 * (i >> 2);
+          mw[i] = (ep.row_mult && r0 + rl < rows) ? ep.row_mult[r0 + rl] : 1.f;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int col = n0 + (wave_c * CT + c) * 32 + lrow;
+        const bool cok = col < cols;
+        const int cc = cok ? col : cols - 1;
+        float y1v[16], y2v[16];
+        if (CAN_MASK && EPI == EPI_MASK) {                    // the 16 (32) mask loads of this column tile in flight at once
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int rl = full ? rbase + (i & 3) + 8 * (i >> 2) : (int)min((long long)(rbase + (i & 3) + 8 * (i >> 2)), rows - 1 - r0);
+            y1v[i] = my1_t[rl * ldm1 + cc];
+            y2v[i] = my2_t ? my2_t[rl * ldm2 + cc] : 0.f;
+          }
+        }
+        const float bias = ep.bias ? ep.bias[cc] : 0.f;
+        float ms1 = 0.f, mt1 = 0.f, mu1 = 0.f, is1 = 0.f, ms2 = 0.f, mt2 = 0.f, mu2 = 0.f, is2 = 0.f;
+        if (CAN_MASK && EPI == EPI_MASK) {
+          ms1 = ep.ms1[cc]; mt1 = ep.mt1[cc]; mu1 = ep.mean1[cc]; is1 = ep.invstd1[cc];
+          if (my2_t) { ms2 = ep.ms2[cc]; mt2 = ep.mt2[cc]; mu2 = ep.mean2[cc]; is2 = ep.invstd2[cc]; }
+        }
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int rl = rbase + (i & 3) + 8 * (i >> 2);
+          const bool ok = cok && (full || r0 + rl < rows);
+          float y = acc[c][i] + bias;
+          if (CAN_MASK && EPI == EPI_MASK) {
+            float z = fmaf(ms1, y1v[i], mt1);
+            if (my2_t) z += fmaf(ms2, y2v[i], mt2);
+            y = (z > 0.f && ok) ? y : 0.f;
+            t0 += y;
+            t1 = fmaf(y, (y1v[i] - mu1) * is1, t1);
+            if (my2_t) t2 = fmaf(y, (y2v[i] - mu2) * is2, t2);
+          } else if (CAN_STATS && EPI == EPI_STATS) {
+            const float yy = ok ? y : 0.f;
+            t0 = fmaf(mw[i], yy, t0);
+            t1 = fmaf(mw[i] * yy, yy, t1);
+          }
+          if (ok) out_t[rl * ldo + col] = y;
+        }
+        st0[c] += t0; st1[c] += t1; st2[c] += t2;
+      }
+      __syncthreads();   // every wave is past its fragment reads: the next tile may overwrite the staging buffers
+    } else {
+      __syncthreads();   // all fragment reads of this tile done: the staging buffers become the C tile
+      RS_T(5);
+
+      // ---- epilogue.  D[i][j]: j = lane & 31, i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)  ->  Cs[row][col]
+      float *Cs = smem;                                         // BM x BN floats (<= 64 KB)
+  #pragma unroll
+      for (int c = 0; c < CT; ++c)
+  #pragma unroll
+        for (int i = 0; i < 16; ++i)
+          Cs[(wave_r * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk) * BN + (wave_c * CT + c) * 32 + lrow] = acc[c][i];
+      __syncthreads();
+      float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // this tile's column sums
+      {
+        const int EPI = ep.mode;
+        const int col = n0 + e_col;
+        float bias[4], ms1[4], mt1[4], mu1[4], is1[4], ms2[4], mt2[4], mu2[4], is2[4];
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool cok = col + e < cols;
+          bias[e] = (ep.bias && cok) ? ep.bias[col + e] : 0.f;
+          ms1[e] = mt1[e] = mu1[e] = is1[e] = ms2[e] = mt2[e] = mu2[e] = is2[e] = 0.f;
+          if (EPI == EPI_MASK && cok) {
+            ms1[e] = ep.ms1[col + e]; mt1[e] = ep.mt1[col + e]; mu1[e] = ep.mean1[col + e]; is1[e] = ep.invstd1[col + e];
+            if (ep.my2) { ms2[e] = ep.ms2[col + e]; mt2[e] = ep.mt2[col + e]; mu2[e] = ep.mean2[col + e]; is2[e] = ep.invstd2[col + e]; }
+          }
+        }
+        float *out_t = ep.out + r0 * ep.ldo;                    // wave-uniform tile bases
+        const float *my1_t = ep.my1 ? ep.my1 + r0 * ep.ldm1 : nullptr;
+        const float *my2_t = ep.my2 ? ep.my2 + r0 * ep.ldm2 : nullptr;
+        for (int rl = e_row; rl < BM; rl += E_RPP) {
+          if (r0 + rl >= rows || col >= cols) continue;
+          const float4 cv = *reinterpret_cast<const float4 *>(Cs + rl * BN + e_col);
+          float y[4] = {cv.x + bias[0], cv.y + bias[1], cv.z + bias[2], cv.w + bias[3]};
+          if (EPI == EPI_MASK) {
+            float y1[4], y2[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ep_vec) {
+              const float4 t = *reinterpret_cast<const float4 *>(my1_t + (long long)rl * ep.ldm1 + col);
+              y1[0] = t.x; y1[1] = t.y; y1[2] = t.z; y1[3] = t.w;
+              if (my2_t) { const float4 u = *reinterpret_cast<const float4 *>(my2_t + (long long)rl * ep.ldm2 + col);
+                           y2[0] = u.x; y2[1] = u.y; y2[2] = u.z; y2[3] = u.w; }
+            } else {
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const bool cok = col + e < cols;
+                y1[e] = cok ? my1_t[(long long)rl * ep.ldm1 + col + e] : 0.f;
+                if (my2_t) y2[e] = cok ? my2_t[(long long)rl * ep.ldm2 + col + e] : 0.f;
+              }
             }
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float z = fmaf(ms1[e], y1[e], mt1[e]);
+              if (my2_t) z += fmaf(ms2[e], y2[e], mt2[e]);
+              y[e] = z > 0.f ? y[e] : 0.f;
+              s0[e] += y[e];
+              s1[e] = fmaf(y[e], (y1[e] - mu1[e]) * is1[e], s1[e]);
+              if (my2_t) s2[e] = fmaf(y[e], (y2[e] - mu2[e]) * is2[e], s2[e]);
+            }
+          } else if (EPI == EPI_STATS) {
+            const float mw = ep.row_mult ? ep.row_mult[r0 + rl] : 1.f;      // copies this compacted row stands for
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) { s0[e] = fmaf(mw, y[e], s0[e]); s1[e] = fmaf(mw * y[e], y[e], s1[e]); }
           }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float z = fmaf(ms1[e], y1[e], mt1[e]);
-            if (my2_t) z += fmaf(ms2[e], y2[e], mt2[e]);
-            y[e] = z > 0.f ? y[e] : 0.f;
-            s0[e] += y[e];
-            s1[e] = fmaf(y[e], (y1[e] - mu1[e]) * is1[e], s1[e]);
-            if (my2_t) s2[e] = fmaf(y[e], (y2[e] - mu2[e]) * is2[e], s2[e]);
+          if (ep_vec) {
+            *reinterpret_cast<float4 *>(out_t + (long long)rl * ep.ldo + col) = make_float4(y[0], y[1], y[2], y[3]);
+          } else {
+  #pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < cols) out_t[(long long)rl * ep.ldo + col + e] = y[e];
           }
-        } else if (EPI == EPI_STATS) {
-          const float mw = ep.row_mult ? ep.row_mult[r0 + rl] : 1.f;      // copies this compacted row stands for
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { s0[e] = fmaf(mw, y[e], s0[e]); s1[e] = fmaf(mw * y[e], y[e], s1[e]); }
-        }
-        if (ep_vec) {
-          *reinterpret_cast<float4 *>(out_t + (long long)rl * ep.ldo + col) = make_float4(y[0], y[1], y[2], y[3]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (col + e < cols) out_t[(long long)rl * ep.ldo + col + e] = y[e];
         }
       }
-    }
-    if (ep.pool_ns > 0) {
-      // Max-pool over nsample folded into the producing GEMM: BatchNorm's scale is not known yet (its
-      // statistics are still being summed), so keep the raw extremes of y per (group, column) — the
-      // pooled activation is relu(scale * (scale >= 0 ? max : min) + shift), resolved by rs_pool_select.
-      constexpr int TPC = GM_THREADS / BN, RPT = BM / TPC;        // threads per column, rows per thread
-      const int c = tid % BN, part = tid / BN, col = n0 + c;
-      if (col < cols) {
-        const float bb = ep.bias ? ep.bias[col] : 0.f;
-        for (int g0 = part * RPT; g0 < (part + 1) * RPT && r0 + g0 < rows; g0 += ep.pool_ns) {
-          float mx = -INFINITY, mn = INFINITY;
-          int ax = 0, an = 0;
-          for (int k = 0; k < ep.pool_ns; ++k) {
-            const float v = Cs[(g0 + k) * BN + c] + bb;
-            if (v > mx) { mx = v; ax = k; }
-            if (v < mn) { mn = v; an = k; }
+      if (ep.pool_ns > 0) {
+        // Max-pool over nsample folded into the producing GEMM: BatchNorm's scale is not known yet (its
+        // statistics are still being summed), so keep the raw extremes of y per (group, column) — the
+        // pooled activation is relu(scale * (scale >= 0 ? max : min) + shift), resolved by rs_pool_select.
+        constexpr int TPC = GM_THREADS / BN, RPT = BM / TPC;        // threads per column, rows per thread
+        const int c = tid % BN, part = tid / BN, col = n0 + c;
+        if (col < cols) {
+          const float bb = ep.bias ? ep.bias[col] : 0.f;
+          for (int g0 = part * RPT; g0 < (part + 1) * RPT && r0 + g0 < rows; g0 += ep.pool_ns) {
+            float mx = -INFINITY, mn = INFINITY;
+            int ax = 0, an = 0;
+            for (int k = 0; k < ep.pool_ns; ++k) {
+              const float v = Cs[(g0 + k) * BN + c] + bb;
+              if (v > mx) { mx = v; ax = k; }
+              if (v < mn) { mn = v; an = k; }
+            }
+            const long long o = ((r0 + g0) / ep.pool_ns) * cols + col;
+            ep.pool_max[o] = mx; ep.pool_min[o] = mn; ep.pool_amax[o] = ax; ep.pool_amin[o] = an;
           }
-          const long long o = ((r0 + g0) / ep.pool_ns) * cols + col;
-          ep.pool_max[o] = mx; ep.pool_min[o] = mn; ep.pool_amax[o] = ax; ep.pool_amin[o] = an;
         }
       }
-    }
-    __syncthreads();   // C tile consumed before the statistics / the next tile's staging overwrite it
-    if (ep.mode != EPI_STORE) {
-      // Column sums of this tile -> fp64 partial row of this workgroup.  The sums leave the registers here, per tile,
-      // instead of riding along in 24 VGPRs of fp64 accumulators: with those live across the K loop the dual-operand
-      // instances spilled operand pointers to scratch, and a scratch reload in front of a prefetch waits for every older
-      // global load (in-order vmcnt) -- the prefetch latency was exposed once per chunk.
-      double *red = reinterpret_cast<double *>(smem);         // 3 x E_RPP x BN doubles = 24 KB
-      const int nstat = (ep.mode == EPI_MASK && ep.my2) ? 3 : 2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {                           // columns beyond `cols` accumulated zeros only
-        red[(0 * E_RPP + e_row) * BN + e_col + e] = (double)s0[e];
-        red[(1 * E_RPP + e_row) * BN + e_col + e] = (double)s1[e];
-        if (nstat == 3) red[(2 * E_RPP + e_row) * BN + e_col + e] = (double)s2[e];
-      }
-      __syncthreads();
-      if (tid < BN && n0 + tid < cols) {
-        for (int sidx = 0; sidx < nstat; ++sidx) {
-          double t = 0.0;
-          for (int p = 0; p < E_RPP; ++p) t += red[(sidx * E_RPP + p) * BN + tid];
-          double *dst = ep.partial + ((long long)blockIdx.x * nstat + sidx) * cols + n0 + tid;
-          *dst = (tile == (long long)blockIdx.x) ? t : *dst + t;    // first tile of this workgroup stores, later ones add
+      __syncthreads();   // C tile consumed before the statistics / the next tile's staging overwrite it
+      if (ep.mode != EPI_STORE) {
+        // Column sums of this tile -> fp64 partial row of this workgroup.  The sums leave the registers here, per tile,
+        // instead of riding along in 24 VGPRs of fp64 accumulators: with those live across the K loop the dual-operand
+        // instances spilled operand pointers to scratch, and a scratch reload in front of a prefetch waits for every older
+        // global load (in-order vmcnt) -- the prefetch latency was exposed once per chunk.
+        double *red = reinterpret_cast<double *>(smem);         // 3 x E_RPP x BN doubles = 24 KB
+        const int nstat = (ep.mode == EPI_MASK && ep.my2) ? 3 : 2;
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {                           // columns beyond `cols` accumulated zeros only
+          red[(0 * E_RPP + e_row) * BN + e_col + e] = (double)s0[e];
+          red[(1 * E_RPP + e_row) * BN + e_col + e] = (double)s1[e];
+          if (nstat == 3) red[(2 * E_RPP + e_row) * BN + e_col + e] = (double)s2[e];
         }
+        __syncthreads();
+        if (tid < BN && n0 + tid < cols) {
+          for (int sidx = 0; sidx < nstat; ++sidx) {
+            double t = 0.0;
+            for (int p = 0; p < E_RPP; ++p) t += red[(sidx * E_RPP + p) * BN + tid];
+            double *dst = ep.partial + ((long long)blockIdx.x * nstat + sidx) * cols + n0 + tid;
+            *dst = (tile == (long long)blockIdx.x) ? t : *dst + t;    // first tile of this workgroup stores, later ones add
+          }
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     RS_T(6);
   }
@@ -498,6 +591,28 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   }
 #endif
 
+  if constexpr (DIRECT) {
+    if (ep.mode != EPI_STORE && (long long)blockIdx.x < tiles) {
+      // lane-local column sums -> this workgroup's fp64 partial row: 4 contributions per column (2 row waves x 2 lane halves)
+      double *red = reinterpret_cast<double *>(smem);         // [stat][4][BN] doubles <= 12 KB (staging is idle: barrier below)
+      const int nstat = (ep.mode == EPI_MASK && ep.my2) ? 3 : 2;
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int cl = (wave_c * CT + c) * 32 + lrow, slot = wave_r * 2 + lk;
+        red[(0 * 4 + slot) * BN + cl] = (double)st0[c];
+        red[(1 * 4 + slot) * BN + cl] = (double)st1[c];
+        if (nstat == 3) red[(2 * 4 + slot) * BN + cl] = (double)st2[c];
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < cols)
+        for (int sidx = 0; sidx < nstat; ++sidx) {
+          const double t = (red[(sidx * 4 + 0) * BN + tid] + red[(sidx * 4 + 1) * BN + tid]) +
+                           (red[(sidx * 4 + 2) * BN + tid] + red[(sidx * 4 + 3) * BN + tid]);
+          ep.partial[((long long)blockIdx.x * nstat + sidx) * cols + n0 + tid] = t;
+        }
+    }
+  }
   if (ep.mode != EPI_STORE && tid < BN && n0 + tid < cols) {
     // the finalize kernel sums `partial_blocks` rows: rows no workgroup owns read as zero (no memset launch);
     // a workgroup without a tile zeroes its own row too
