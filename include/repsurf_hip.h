@@ -57,6 +57,9 @@ int rs_furthestsampling(int b, int n, int m, const float *xyz, const int *start,
  * (segmentation/modules/pointops/src/sampling/sampling_cuda_kernel.cu:14-171):
  * cloud i owns rows [offset[i-1], offset[i]); picks new_offset[i]-new_offset[i-1]
  * samples starting from its first row; idx holds global row numbers. */
+/* Exactly equal distances: the winner is the row the reference kernel's strided scan + shared-memory tree keeps --
+ * reference thread t = (row - first row) mod bs, bs = opt_n_threads(n_max) (cuda_utils.h:10-13); lowest BIT-REVERSED t,
+ * then the lowest row of that thread (sampling_cuda_kernel.cu:44-58, __update :7-12). */
 int rs_furthestsampling_offset(int b, int n_max, const float *xyz, const int *offset,
                                const int *new_offset, float *temp, int *idx, void *stream);
 
@@ -411,6 +414,22 @@ typedef struct rs_umbrella_mlp {
 } rs_umbrella_mlp;
 int rs_umbrella_mlp_pass(int pass, const rs_umbrella_mlp *m, float out_scale, float *out,
                          double *stat_partial, float *dw_partial, int nblk, void *stream);
+
+/* ---- sectorized FPS on the device: pointops.sectorized_fps
+ * (segmentation/modules/pointops/functions/pointops.py:52-108) without its host loop and read-backs.
+ * rs_sectorize: per cloud, angle = atan2(x, y), S + 1 linspace boundaries over [min, max + 1e-4], stable partition of the
+ * rows into S angular sectors (S = sec_base[i+1] - sec_base[i] = 1 for clouds below min_points, num_sectors otherwise;
+ * sec_base (b + 1) is the running sector count, the host knows the cloud sizes).  Outputs: indices (n_tot) = original row
+ * of every sector row, sector_xyz (n_tot, 3), sector_offset / new_sector_offset (sec_base[b]) running ends (picks per
+ * sector = new_size / S, remainder in the last, :82-84), *n_max_dev = largest sector (zero it before the call).
+ * rs_furthestsampling_sectors: rs_furthestsampling_offset over those sectors; the tie rule's block size comes from
+ * *n_max_dev, n_bound >= every sector (the largest cloud).  rs_take_int: out[i] = table[idx[i]] (:105). */
+int rs_sectorize(int b, const float *xyz, const int *offset, const int *new_offset, const int *sec_base, int num_sectors,
+                 int min_points, int *indices, float *sector_xyz, int *sector_offset, int *new_sector_offset,
+                 int *n_max_dev, void *stream);
+int rs_furthestsampling_sectors(int b, int n_bound, const int *n_max_dev, const float *xyz, const int *offset,
+                                const int *new_offset, float *temp, int *idx, void *stream);
+int rs_take_int(int n, const int *table, const int *idx, int *out, void *stream);
 
 #ifdef __cplusplus
 }

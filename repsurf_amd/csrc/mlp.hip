@@ -1305,9 +1305,10 @@ int env_int(const char *name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-int persistent_blocks(long long tiles, int tiles_n, int bm) {
+int persistent_blocks(long long tiles, int tiles_n, int bm, bool fwd) {
   static const int slots128 = env_int("RS_GEMM_SLOTS", 512), slots64 = env_int("RS_GEMM_SLOTS64", 512);
-  const int slots = bm == 64 ? slots64 : slots128;
+  static const int slots64f = env_int("RS_GEMM_SLOTS64_FWD", 0);   // forward instances (<= 168 VGPRs) can run 3 per CU
+  const int slots = bm == 64 ? ((fwd && slots64f > 0) ? slots64f : slots64) : slots128;
   long long want = slots / (tiles_n > 0 ? tiles_n : 1);   // ~2 (tall tiles) / 3-4 (short tiles) workgroups per CU over the whole grid
   if (want < 64) want = 64;
   return (int)(tiles < want ? tiles : want);
@@ -1474,7 +1475,7 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
   // sa1 / sa2 launches, whose 1043 / 753 tiles of 64 rows are 3 / 2 rounds on 512 workgroups with a mostly empty last
   // round: 1.86 ms/step against 1.83, 768 / 1024 / 512 slots alike.  The per-tile fixed costs outweigh the finer rounds.)
   const int tiles_n = rs_cdiv(cols, bn);
-  int gx = persistent_blocks(tiles, tiles_n, bm);
+  int gx = persistent_blocks(tiles, tiles_n, bm, E.mode <= OPM_RELU2);
   if (epi_mode != EPI_STORE) gx = gx < ep.partial_blocks ? gx : ep.partial_blocks;
   const dim3 grid(gx, tiles_n);
   hipStream_t st = (hipStream_t)stream;

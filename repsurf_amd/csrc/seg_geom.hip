@@ -217,6 +217,113 @@ interp_weights_kernel(long long n, const float *__restrict__ dist2, float *__res
   weight[r * 3 + 0] = r0 / s; weight[r * 3 + 1] = r1 / s; weight[r * 3 + 2] = r2 / s;
 }
 
+
+// ---- sectorized FPS, device side (pointops.sectorized_fps, segmentation/modules/pointops/functions/pointops.py:52-108) ----
+// One workgroup per cloud does what the reference's host loop does with ~10 torch calls and several host read-backs
+// per cloud: angle = atan2(x, y) (:71, x FIRST), its min / max, the S + 1 boundaries of
+// torch.linspace(min, max + 1e-4, S + 1) (:72; the kernel's two-sided formula: start + i*step below the middle,
+// end - (S - i)*step above), S = 1 for clouds below min_points (:66-69), the STABLE partition of the cloud's rows into
+// the sectors [r_s, r_s+1) (:73-76, torch.where keeps row order), the sectors' running ends, and the picks per sector
+// new_size // S with the remainder in the last one (:82-84).  Every row of a cloud lands in exactly one sector, so the
+// sectors of cloud i occupy rows [offset[i-1], offset[i]) of the sector arrays and its picks
+// [new_offset[i-1], new_offset[i]): no cross-cloud dependency, nothing read back by the host.
+constexpr int SEC_MAX = 64;
+
+__global__ void __launch_bounds__(SG_THREADS)
+sectorize_kernel(const float *__restrict__ xyz, const int *__restrict__ offset, const int *__restrict__ new_offset,
+                 const int *__restrict__ sec_base, int num_sectors, int min_points, int *__restrict__ indices,
+                 float *__restrict__ sector_xyz, int *__restrict__ sector_offset, int *__restrict__ new_sector_offset,
+                 int *__restrict__ n_max_dev) {
+  __shared__ float red_lo[SG_THREADS / 64], red_hi[SG_THREADS / 64];
+  __shared__ float edge[SEC_MAX + 1];
+  __shared__ int cnt[SEC_MAX], first[SEC_MAX];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = c ? offset[c - 1] : 0, r1 = offset[c], n = r1 - r0;
+  const int m0 = c ? new_offset[c - 1] : 0, m = new_offset[c] - m0;
+  const int S = sec_base[c + 1] - sec_base[c];           // 1 or num_sectors, decided on the host from the cloud sizes
+  (void)num_sectors; (void)min_points;
+  if (n <= 0) {
+    if (tid < S) { sector_offset[sec_base[c] + tid] = r0; new_sector_offset[sec_base[c] + tid] = m0; }
+    return;
+  }
+  float lo = INFINITY, hi = -INFINITY;
+  for (int r = r0 + tid; r < r1; r += SG_THREADS) {
+    const float a = atan2f(xyz[(size_t)r * 3 + 0], xyz[(size_t)r * 3 + 1]);
+    lo = fminf(lo, a);
+    hi = fmaxf(hi, a);
+  }
+  // floats order like their sign-magnitude bit patterns: reduce through the monotone unsigned key
+  auto key = [](float v) { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+  auto unkey = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); };
+  const float wlo = unkey(rs_wave_min_u32(key(lo))), whi = unkey(rs_wave_max_u32(key(hi)));
+  if (lane == 0) { red_lo[wave] = wlo; red_hi[wave] = whi; }
+  if (tid < SEC_MAX) cnt[tid] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    float a0 = red_lo[0], a1 = red_hi[0];
+    for (int w = 1; w < SG_THREADS / 64; ++w) { a0 = fminf(a0, red_lo[w]); a1 = fmaxf(a1, red_hi[w]); }
+    const float start = a0, end = a1 + 1e-4f;
+    const int steps = S + 1;
+    const float step = (end - start) / (float)(steps - 1);
+    for (int i = 0; i < steps; ++i)
+      edge[i] = i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - i - 1);
+  }
+  __syncthreads();
+  auto sector_of = [&](float a) {
+    int s = -1;
+    for (int i = 0; i < S; ++i) s = (a >= edge[i] && a < edge[i + 1]) ? i : s;
+    return s;
+  };
+  for (int r = r0 + tid; r < r1; r += SG_THREADS) {
+    const int s = sector_of(atan2f(xyz[(size_t)r * 3 + 0], xyz[(size_t)r * 3 + 1]));
+    if (s >= 0) atomicAdd(&cnt[s], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0, biggest = 0;
+    const int quota = m / S;
+    for (int i = 0; i < S; ++i) {
+      first[i] = acc;
+      acc += cnt[i];
+      biggest = max(biggest, cnt[i]);
+      sector_offset[sec_base[c] + i] = r0 + acc;
+      new_sector_offset[sec_base[c] + i] = m0 + (i + 1 < S ? (i + 1) * quota : m);
+    }
+    atomicMax(n_max_dev, biggest);
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // stable partition by the first wave: 64 rows at a time, one ballot per sector, rank inside the chunk by mbcnt;
+  // lane i carries the running fill of sector i (S <= 64), read with v_readlane, so the loop touches no LDS
+  int run = lane < S ? first[lane] : 0;
+  for (int c0 = r0; c0 < r1; c0 += 64) {
+    const int r = c0 + lane;
+    const bool in = r < r1;
+    float x = 0.f, y = 0.f, z = 0.f;
+    int s = -1;
+    if (in) {
+      x = xyz[(size_t)r * 3 + 0]; y = xyz[(size_t)r * 3 + 1]; z = xyz[(size_t)r * 3 + 2];
+      s = sector_of(atan2f(x, y));
+    }
+    for (int i = 0; i < S; ++i) {
+      const unsigned long long mask = __ballot(s == i);
+      const int base = __builtin_amdgcn_readlane(run, i);
+      if (s == i) {
+        const int pos = r0 + base + rs_mbcnt(mask);
+        indices[pos] = r;
+        sector_xyz[(size_t)pos * 3 + 0] = x; sector_xyz[(size_t)pos * 3 + 1] = y; sector_xyz[(size_t)pos * 3 + 2] = z;
+      }
+      if (lane == i) run += __popcll(mask);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(SG_THREADS)
+take_int_kernel(int n, const int *__restrict__ table, const int *__restrict__ idx, int *__restrict__ out) {
+  const int i = blockIdx.x * SG_THREADS + threadIdx.x;
+  if (i < n) out[i] = table[idx[i]];
+}
+
 }  // namespace
 
 extern "C" int rs_knnquery_offset(int m, int nsample, const float *xyz, const float *new_xyz,
@@ -276,5 +383,34 @@ extern "C" int rs_interp_weights(long long n, const float *dist2, float *weight,
   hipLaunchKernelGGL(interp_weights_kernel, dim3(rs_cdiv(n, SG_THREADS)), dim3(SG_THREADS), 0,
                      (hipStream_t)stream, n, dist2, weight);
   RS_CHECK_LAUNCH("rs_interp_weights");
+  return RS_OK;
+}
+
+
+// Device half of pointops.sectorized_fps (segmentation/modules/pointops/functions/pointops.py:52-108), see
+// sectorize_kernel.  sec_base (b + 1): running number of sectors before each cloud (1 or num_sectors per cloud, the
+// host knows the cloud sizes).  n_max_dev must be zero on entry; it returns the largest sector (the `n` the reference
+// hands to its FPS kernel, which fixes that kernel's block size and tie rule).
+extern "C" int rs_sectorize(int b, const float *xyz, const int *offset, const int *new_offset, const int *sec_base,
+                            int num_sectors, int min_points, int *indices, float *sector_xyz, int *sector_offset,
+                            int *new_sector_offset, int *n_max_dev, void *stream) {
+  RS_REQUIRE(b >= 0, "rs_sectorize: negative size");
+  if (b == 0) return RS_OK;
+  RS_REQUIRE(num_sectors >= 1 && num_sectors <= SEC_MAX, "rs_sectorize: num_sectors=%d outside 1..%d", num_sectors, SEC_MAX);
+  RS_REQUIRE(xyz && offset && new_offset && sec_base && indices && sector_xyz && sector_offset && new_sector_offset && n_max_dev,
+             "rs_sectorize: null pointer");
+  hipLaunchKernelGGL(sectorize_kernel, dim3(b), dim3(SG_THREADS), 0, (hipStream_t)stream, xyz, offset, new_offset, sec_base,
+                     num_sectors, min_points, indices, sector_xyz, sector_offset, new_sector_offset, n_max_dev);
+  RS_CHECK_LAUNCH("rs_sectorize");
+  return RS_OK;
+}
+
+/* out[i] = table[idx[i]]  (idx = indices[idx.long()], pointops.py:105) */
+extern "C" int rs_take_int(int n, const int *table, const int *idx, int *out, void *stream) {
+  RS_REQUIRE(n >= 0, "rs_take_int: negative size");
+  if (n == 0) return RS_OK;
+  RS_REQUIRE(table && idx && out, "rs_take_int: null pointer");
+  hipLaunchKernelGGL(take_int_kernel, dim3(rs_cdiv(n, SG_THREADS)), dim3(SG_THREADS), 0, (hipStream_t)stream, n, table, idx, out);
+  RS_CHECK_LAUNCH("rs_take_int");
   return RS_OK;
 }

@@ -122,6 +122,43 @@ def furthestsampling_offset(xyz, offset, new_offset):
     return idx
 
 
+def sectorized_fps(xyz, offset, new_offset, num_sectors, min_points=10000):
+    """pointops.sectorized_fps (segmentation/modules/pointops/functions/pointops.py:52-108) on the device: clouds of at
+    least `min_points` rows are cut into `num_sectors` sectors of atan2(x, y), each sector gets new_size // num_sectors
+    picks (the last also the remainder) from an independent FPS.  Three launches (sectorize, FPS over the sectors,
+    index remap) and NO host read-back: sector sizes stay on the device, output sizes follow from the offsets' host
+    copies.  -> idx (Mtot,) int32 global rows."""
+    _need_gpu(xyz, offset, new_offset)
+    xyz, offset, new_offset = _f32c(xyz), _i32c(offset), _i32c(new_offset)
+    host, new_host = host_offsets(offset), host_offsets(new_offset)
+    sizes = [e - s for s, e in zip((0,) + host[:-1], host)]
+    per = [1 if n < min_points else int(num_sectors) for n in sizes]
+    if num_sectors <= 1 or all(p == 1 for p in per):
+        # every cloud keeps a single sector, whose row list is the cloud itself in order: plain FPS
+        return furthestsampling_offset(xyz, offset, new_offset)
+    base, acc = [0], 0
+    for p in per:
+        acc += p
+        base.append(acc)
+    dev = xyz.device
+    sec_base = offsets_tensor(base, dev)
+    n_tot, s_tot, m_tot = xyz.shape[0], acc, (new_host[-1] if new_host else 0)
+    indices = torch.empty((n_tot,), dtype=torch.int32, device=dev)
+    sector_xyz = torch.empty((n_tot, 3), dtype=torch.float32, device=dev)
+    ends = torch.empty((2, s_tot), dtype=torch.int32, device=dev)
+    n_max_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _lib.call("rs_sectorize", len(host), _p(xyz), _p(offset), _p(new_offset), _p(sec_base), int(num_sectors), int(min_points),
+              _p(indices), _p(sector_xyz), _p(ends[0]), _p(ends[1]), _p(n_max_dev), _stream())
+    n_bound = max(sizes)
+    picks = torch.empty((m_tot,), dtype=torch.int32, device=dev)
+    temp = torch.empty((n_tot,), dtype=torch.float32, device=dev) if n_bound > 14000 else None
+    _lib.call("rs_furthestsampling_sectors", s_tot, n_bound, _p(n_max_dev), _p(sector_xyz), _p(ends[0]), _p(ends[1]), _p(temp),
+              _p(picks), _stream())
+    out = torch.empty_like(picks)
+    _lib.call("rs_take_int", m_tot, _p(indices), _p(picks), _p(out), _stream())
+    return out
+
+
 def umbrella_fan_offset(xyz, new_xyz, knn_idx, new_offset, inv_sign=None, rotate=True):
     """Segmentation umbrella fan: knn_idx (M,k) global rows of the k nearest neighbours (query included) ->
     (M, k, 10) = [polar, normal, const, centroid] per fan triangle

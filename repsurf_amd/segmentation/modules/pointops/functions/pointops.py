@@ -16,43 +16,12 @@ def furthestsampling(xyz, offset, new_offset):
 
 
 def sectorized_fps(xyz, offset, new_offset, num_sectors, min_points=10000):
-    """Farthest point sampling inside angular sectors (reference :52-111): clouds of at least `min_points`
-    points are cut into `num_sectors` sectors of atan2(x, y), each sector gets new_size // num_sectors picks
-    (the last one also the remainder) from an independent FPS -- num_sectors times more workgroups, each with a
-    num_sectors times shorter dependency chain.  Sector sizes depend on the data, so this op reads them back
-    to the host (one read per call; the reference does several per cloud)."""
-    host, new_host = ops.host_offsets(offset), ops.host_offsets(new_offset)
-    if num_sectors <= 1 or all(e - s < min_points for s, e in zip((0,) + host[:-1], host)):
-        # every cloud keeps a single sector, whose point list is the cloud itself in order: plain FPS, no read-back
-        return ops.furthestsampling_offset(xyz, offset, new_offset)
-    pieces, new_sizes = [], []
-    last, new_last = 0, 0
-    for end, new_end in zip(host, new_host):
-        size, new_size = end - last, new_end - new_last
-        sectors = 1 if size < min_points else num_sectors
-        pts = xyz[last:end]
-        angle = torch.atan2(pts[:, 0], pts[:, 1])
-        edges = torch.linspace(float(angle.min()), float(angle.max()) + 1e-4, sectors + 1, device=xyz.device)
-        for s in range(sectors):
-            pieces.append(torch.where((angle >= edges[s]) & (angle < edges[s + 1]))[0] + last)
-        quota = [new_size // sectors] * sectors
-        quota[-1] += new_size % sectors
-        new_sizes += quota
-        last, new_last = end, new_end
-    sizes = [int(p.shape[0]) for p in pieces]
-    indices = torch.cat(pieces)
-    run, acc = [], 0
-    for s in sizes:
-        acc += s
-        run.append(acc)
-    new_run, acc = [], 0
-    for s in new_sizes:
-        acc += s
-        new_run.append(acc)
-    sector_xyz = xyz[indices].contiguous()
-    idx = ops.furthestsampling_offset(sector_xyz, ops.offsets_tensor(run, xyz.device),
-                                      ops.offsets_tensor(new_run, xyz.device))
-    return indices[idx.long()].to(torch.int32)
+    """Farthest point sampling inside angular sectors (reference :52-111): clouds of at least `min_points` points are cut
+    into `num_sectors` sectors of atan2(x, y), each sector gets new_size // num_sectors picks (the last one also the
+    remainder) from an independent FPS -- num_sectors times more workgroups, each with a num_sectors times shorter
+    dependency chain.  Runs entirely on the device (repsurf_amd.ops.sectorized_fps: sectorize kernel, FPS over the
+    sectors, index remap); the reference's per-cloud host loop and its read-backs are gone."""
+    return ops.sectorized_fps(xyz, offset, new_offset, num_sectors, min_points)
 
 
 def knnquery(nsample, xyz, new_xyz, offset, new_offset):
