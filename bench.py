@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--model", default="repsurf_ssg_umb")
+    ap.add_argument("--workload", default="cls", choices=["cls", "seg"],
+                    help="cls: BASELINE configs[1] (the metric; configs[4] with --dtype bf16 --batch 64 --points 2048); "
+                         "seg: configs[3], RepSurf-U S3DIS segmentation, 16 clouds x 4096 points x (xyz+rgb) per GPU")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="arithmetic of the shared-MLP row GEMMs: fp32 MFMA (configs[1], the metric) or bf16 MFMA with fp32 "
                          "accumulation and storage (configs[4]: use --batch 64 --points 2048)")
@@ -183,8 +186,218 @@ def algorithmic_cost(name, dims):
     return None, 0.0
 
 
+def roofline_from_profile(prof, timed_steps, dtype):
+    """prof: {abi name: [(ms, dims)]} of an eager pass -> (roofline of the MFMA / byte-priced launch class with the largest
+    time per step, table of all classes)."""
+    roofline = None
+    table = []
+    for name, recs in prof.items():
+        by_dims = {}
+        rows_of = {}
+        for t_ms, dims in recs:
+            static = tuple(d for d in dims if not isinstance(d, str))
+            by_dims.setdefault(static, []).append(t_ms)
+            for d in dims:
+                if isinstance(d, str):       # "rows=<n>": row count of a compacted launch (varies a little per step)
+                    rows_of.setdefault(static, []).append(int(d.split("=")[1]))
+        for dims, ts in by_dims.items():
+            if dims in rows_of:
+                dims = dims + (f"rows={float(np.mean(rows_of[dims])):.1f}",)
+            unit, amount = algorithmic_cost(name, dims)
+            table.append({"kernel": name, "dims": list(dims), "launches": len(ts), "avg_us": float(np.mean(ts)) * 1e3,
+                          "total_ms_per_step": float(np.sum(ts)) / max(1, timed_steps), "unit": unit, "amount": amount})
+    table.sort(key=lambda r: -r["total_ms_per_step"])
+    for row in table:
+        if row["unit"] is None:
+            continue
+        sec = row["avg_us"] * 1e-6
+        if row["unit"] == "flops":
+            ach = row["amount"] / sec / 1e12
+            peak = PEAK_BF16_MFMA_TF if row["kernel"].endswith("_bf16") else PEAK_F32_MFMA_TF
+            roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "mfma", "achieved": round(ach, 2),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+        else:
+            ach = row["amount"] / sec / 1e9
+            roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "hbm", "achieved": round(ach, 2),
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5)}
+        roofline["avg_launch_us"] = round(row["avg_us"], 2)
+        roofline["launches_per_step"] = row["launches"] // max(1, timed_steps)
+        roofline["traffic"] = traffic_from_profiles(row["kernel"], row["dims"])
+        break
+    # every MFMA launch of the step together (all shared-MLP GEMMs + weight-gradient GEMMs)
+    fl = sum(r["amount"] * r["launches"] for r in table if r["unit"] == "flops")
+    tm = sum(r["avg_us"] * r["launches"] for r in table if r["unit"] == "flops") * 1e-6
+    if roofline is not None and tm > 0:
+        roofline["all_mfma_launches"] = {"achieved": round(fl / tm / 1e12, 2), "unit": "TFLOP/s",
+                                         # (bf16 run: row GEMMs on the bf16 pipe, weight gradients on the fp32 one -- no single peak)
+                                         "frac": round(fl / tm / 1e12 / PEAK_F32_MFMA_TF, 4) if dtype == "fp32" else None,
+                                         "ms_per_step": round(tm * 1e3 / max(1, timed_steps), 4)}
+    return roofline, table
+
+
+def seg_geometry_lines(coord, offset):
+    """FPS (us per pick) and the two kNN searches of the first stage, timed with HIP events on the launch stream."""
+    from repsurf_amd import ops
+
+    def timed(fn, reps=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    new_offset = ops.strided_offset(offset, 4)
+    host, new_host = ops.host_offsets(offset), ops.host_offsets(new_offset)
+    t = timed(lambda: ops.furthestsampling_offset(coord, offset, new_offset))
+    picks = new_host[0] - 1
+    fps = {"stage1": {"us": round(t * 1e6, 1), "us_per_pick": round(t * 1e6 / max(picks, 1), 4), "clouds": len(host),
+                      "rows_per_cloud": host[0], "picks_per_cloud": new_host[0]}}
+    idx = ops.furthestsampling_offset(coord, offset, new_offset)
+    centres = coord[idx.long()].contiguous()
+    n, m = coord.shape[0], centres.shape[0]
+    knn = {}
+    for name, k, q, qo in (("umbrella_k9", 9, coord, offset), ("group_k32", 32, centres, new_offset)):
+        t = timed(lambda: ops.knnquery_offset(k, coord, q, offset, qo))
+        nbytes = 4.0 * (3 * n + 3 * q.shape[0] + 2 * k * q.shape[0])             # xyz + queries + (idx, dist2)
+        knn[name] = {"us": round(t * 1e6, 1), "algorithmic_bytes": nbytes, "achieved_GBs": round(nbytes / t / 1e9, 1),
+                     "frac_of_hbm": round(nbytes / t / 1e9 / PEAK_HBM_GBS, 5),
+                     "pair_tests_per_s": round(float(q.shape[0]) * host[0] / t / 1e9, 1)}
+    return fps, knn
+
+
+def main_seg(args):
+    """BASELINE configs[3]: RepSurf-U S3DIS segmentation (repsurf_umb_ssg), B clouds x P points x (xyz + rgb) per GPU,
+    zero_grad -> forward -> cross-entropy -> backward -> Adam, same contract as the classification line."""
+    from repsurf_amd import dist as rdist
+    rank, world, local = rdist.env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if "REPSURF_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["REPSURF_BENCH_DEVICE"])
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    rdist.init(backend=os.environ.get("REPSURF_DIST_BACKEND", "nccl"), device=device)
+    seg_root = os.path.join(ROOT, "repsurf_amd", "segmentation")
+    cls_root = os.path.join(ROOT, "repsurf_amd", "classification")
+    if cls_root in sys.path:
+        sys.path.remove(cls_root)
+    sys.path.insert(0, seg_root)
+    from repsurf_amd import _lib, mlp
+    from repsurf_amd.graph import PipelinedStep
+    from repsurf_amd.optim import Adam
+    from models.repsurf.repsurf_umb_ssg import Model
+    mlp.set_precision(args.dtype)
+    clouds = 16 if args.batch == 32 else args.batch            # (--batch default is the classification one)
+    pts = 4096 if args.points == 1024 else args.points
+    margs = argparse.Namespace(return_polar=False, in_channel=6, group_size=8, num_class=13)
+    torch.manual_seed(0)
+    model = Model(margs).to(device).train()
+    cpu_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    optim = None if args.no_optim else Adam(model.parameters(), lr=1e-3)
+    r = np.random.RandomState(rdist.rank_seed(125, rank))
+    n = clouds * pts
+    coord_h = (r.rand(n, 3) * 2 - 1).astype(np.float32)
+    rgb_h = r.rand(n, 3).astype(np.float32)
+    label_h = r.randint(0, 13, n).astype(np.int64)
+    off_h = (np.arange(1, clouds + 1) * pts).astype(np.int32)
+    from repsurf_amd import ops
+    coord, rgb, label = (torch.from_numpy(a).to(device) for a in (coord_h, rgb_h, label_h))
+    offset = ops.offsets_tensor(off_h.tolist(), device)
+    np.random.seed(rdist.rank_seed(13, rank))                  # numpy generator: the constructor's normal flips
+    criterion = torch.nn.functional.cross_entropy
+    inputs = [coord, rgb, offset]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            rdist.barrier()
+        torch.cuda.synchronize()
+
+    pstep = PipelinedStep(model, criterion, optim, inputs, label, warmup=max(2, args.warmup), sharded=world > 1)
+    step = lambda: pstep(sync=False)      # noqa: E731
+    mode = "2 hipgraphs on 2 streams: geometry (kNN, FPS, 3-NN weights) of batch s+1 under the network of batch s" + (
+        " + rccl all-reduce + Adam graph" if world > 1 else "")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timing = not args.no_kernel_timing
+    timed_steps = 0
+    if timing and rank == 0:
+        import copy
+        twin = copy.deepcopy(model)
+        topt = None if args.no_optim else Adam(twin.parameters(), lr=1e-3)
+
+        def eager_step():
+            for p in twin.parameters():
+                p.grad = None
+            criterion(twin(inputs), label).backward()
+            if topt is not None:
+                topt.step()
+        for _ in range(2):
+            eager_step()
+        timed_steps = min(args.steps, 3)
+        _lib.profile_enable(True)
+        for _ in range(timed_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+    dt = rdist.max_over_ranks(dt, device)
+    prof = _lib.profile_collect()
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        roofline, table = roofline_from_profile(prof, timed_steps, args.dtype) if timing else (None, [])
+        if args.breakdown:
+            os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
+            json.dump({"ms_per_step": ms, "kernels": table}, open(args.breakdown, "w"), indent=1)
+        fps_line, knn_line = seg_geometry_lines(coord, offset) if timing else (None, None)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import geom_oracle, seg_ref
+            geom_oracle.build()
+            threads = min(os.cpu_count() or 1, args.cpu_threads)
+            torch.set_num_threads(threads)
+            ts = []
+            for i in range(1 + args.cpu_steps):
+                t1 = time.perf_counter()
+                seg_ref.step(cpu_state, coord_h, rgb_h, off_h, label_h, None)
+                ts.append(time.perf_counter() - t1)
+            cdt = float(np.mean(ts[1:]))
+            cpu = {"value": round(clouds / cdt, 3), "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": f"{args.cpu_steps} timed steps (after 1 warm-up) of the same {clouds} x {pts}-point batch, fwd + "
+                             f"cross-entropy + bwd through oracle/seg_ref.py (torch {torch.__version__} CPU dense ops, C geometry, "
+                             f"{threads} threads).  The reference's segmentation path has no CPU implementation (pointops_cuda only), "
+                             f"so there is no reference timing to calibrate this port against.",
+                   "s_per_step": round(cdt, 4)}
+        out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, 4096-pt clouds @ B=16 per GPU", "value": round(clouds * world * args.steps / dt, 2),
+               "unit": "clouds/s", "points_per_s": round(n * world * args.steps / dt), "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.dtype == "fp32" else "bf16 MFMA operands, f32 accumulate/storage",
+               "data": "synthetic uniform [-1,1]^3 clouds + uniform rgb, random-init weights",
+               "config": {"workload": f"configs[3]: RepSurf-U S3DIS segmentation (repsurf_umb_ssg), B={clouds}x{pts}x6 per GPU, {args.dtype}, "
+                                      f"encoder + FP decoder + classifier, fwd+CE+bwd" + ("" if args.no_optim else "+Adam step"),
+                          "global_batch": clouds * world, "points": pts, "parallelism": f"dp{world}", "launch": mode,
+                          "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5)},
+               "roofline": roofline, "fps_us_per_pick": fps_line, "knn": knn_line, "cpu_baseline": cpu}
+        if cpu:
+            out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    rdist.finish()
+
+
 def main():
     args = parse()
+    if args.workload == "seg":
+        return main_seg(args)
     from repsurf_amd import dist as rdist
     rank, world, local = rdist.env()
     if world != args.gpus:
@@ -314,49 +527,7 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
-        roofline = None
-        table = []
-        for name, recs in prof.items():
-            by_dims = {}
-            rows_of = {}
-            for t_ms, dims in recs:
-                static = tuple(d for d in dims if not isinstance(d, str))
-                by_dims.setdefault(static, []).append(t_ms)
-                for d in dims:
-                    if isinstance(d, str):       # "rows=<n>": row count of a compacted launch (varies a little per step)
-                        rows_of.setdefault(static, []).append(int(d.split("=")[1]))
-            for dims, ts in by_dims.items():
-                if dims in rows_of:
-                    dims = dims + (f"rows={float(np.mean(rows_of[dims])):.1f}",)
-                unit, amount = algorithmic_cost(name, dims)
-                table.append({"kernel": name, "dims": list(dims), "launches": len(ts), "avg_us": float(np.mean(ts)) * 1e3,
-                              "total_ms_per_step": float(np.sum(ts)) / max(1, getattr(args, "timed_steps", args.steps)), "unit": unit, "amount": amount})
-        table.sort(key=lambda r: -r["total_ms_per_step"])
-        for row in table:
-            if row["unit"] is None:
-                continue
-            sec = row["avg_us"] * 1e-6
-            if row["unit"] == "flops":
-                ach = row["amount"] / sec / 1e12
-                peak = PEAK_BF16_MFMA_TF if row["kernel"].endswith("_bf16") else PEAK_F32_MFMA_TF
-                roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "mfma", "achieved": round(ach, 2),
-                            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
-            else:
-                ach = row["amount"] / sec / 1e9
-                roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "hbm", "achieved": round(ach, 2),
-                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5)}
-            roofline["avg_launch_us"] = round(row["avg_us"], 2)
-            roofline["launches_per_step"] = row["launches"] // max(1, getattr(args, "timed_steps", args.steps))
-            roofline["traffic"] = traffic_from_profiles(row["kernel"], row["dims"])
-            break
-        # every MFMA launch of the step together (all shared-MLP GEMMs + weight-gradient GEMMs)
-        fl = sum(r["amount"] * r["launches"] for r in table if r["unit"] == "flops")
-        tm = sum(r["avg_us"] * r["launches"] for r in table if r["unit"] == "flops") * 1e-6
-        if roofline is not None and tm > 0:
-            roofline["all_mfma_launches"] = {"achieved": round(fl / tm / 1e12, 2), "unit": "TFLOP/s",
-                                             # (bf16 run: row GEMMs on the bf16 pipe, weight gradients on the fp32 one -- no single peak)
-                                             "frac": round(fl / tm / 1e12 / PEAK_F32_MFMA_TF, 4) if args.dtype == "fp32" else None,
-                                             "ms_per_step": round(tm * 1e3 / max(1, getattr(args, "timed_steps", args.steps)), 4)}
+        roofline, table = roofline_from_profile(prof, getattr(args, "timed_steps", args.steps), args.dtype)
         if args.launch_log:
             os.makedirs(os.path.dirname(os.path.abspath(args.launch_log)), exist_ok=True)
             json.dump([[n, list(d)] for n, d in _lib.profile_sequence()], open(args.launch_log, "w"))

@@ -59,6 +59,23 @@ class GraphedStep:
         return self.loss
 
 
+def _clone_inputs(x):
+    """A model input for one of the two buffer sets: a tensor, or a list of tensors (segmentation: [coord, feat, offset]).
+    int32 tensors are the packed batch's offsets -- shapes the captured graphs bake in -- and stay shared."""
+    if torch.is_tensor(x):
+        return x.clone()
+    return [t if t.dtype == torch.int32 else t.clone() for t in x]
+
+
+def _copy_inputs(dst, src):
+    if torch.is_tensor(dst):
+        dst.copy_(src, non_blocking=True)
+        return
+    for d, s_ in zip(dst, src):
+        if d.dtype != torch.int32:
+            d.copy_(s_, non_blocking=True)
+
+
 class PipelinedStep:
     """Graphed training step with the NEXT batch's geometry computed while the CURRENT batch trains.
 
@@ -75,7 +92,9 @@ class PipelinedStep:
         step = PipelinedStep(net, criterion, optimizer, points0, label0)     # geometry of batch 0 runs here
         loss0 = step(points1, label1)        # trains on batch 0, prepares batch 1
         loss1 = step(points2, label2)        # trains on batch 1, prepares batch 2 ...
-    `net` must offer `geometry(points)` and `forward(points, geo=...)` (classification models of this package).
+    `net` must offer `geometry(points, fork=False)` and `forward(points, geo=...)`: the classifiers of this package
+    (points = a (B,3,N) tensor) and the segmentation network (points = [coord, feat, offset]; the offsets are constants
+    of the captured shapes).
     The returned loss is ready on the caller's current stream."""
 
     def __init__(self, net, criterion, optimizer, points, label, warmup=3, group=None, sharded=False):
@@ -91,7 +110,7 @@ class PipelinedStep:
             self.grads = FlatGrads(list(net.parameters()))
             self.flat = self.grads.flat
         dev = label.device
-        self.points = [points.clone(), points.clone()]
+        self.points = [_clone_inputs(points), _clone_inputs(points)]
         self.label = [label.clone(), label.clone()]
         self.draws = rng.StaticDraws(dev)
         self.main = torch.cuda.Stream()          # M
@@ -199,7 +218,7 @@ class PipelinedStep:
             if next_points is not None or next_label is not None:
                 self.side.wait_stream(caller)              # they were produced on the caller's stream
             if next_points is not None:
-                self.points[1 - p].copy_(next_points, non_blocking=True)
+                _copy_inputs(self.points[1 - p], next_points)
             if next_label is not None:
                 self.label[1 - p].copy_(next_label, non_blocking=True)
             self.draws.refill()        # the draws of the batch whose geometry this call computes

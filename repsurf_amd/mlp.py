@@ -60,6 +60,12 @@ def umbrella_mlp2(x, mlps, group):
     return mlp_hip.umbrella_mlp2(x, mlps, group)
 
 
+def row_linear(x, linear):
+    """A plain nn.Linear on ungrouped rows (no BatchNorm): y = x . W^T + b, forward and backward on the row GEMM /
+    weight-gradient kernels (the segmentation classifier's 13-class output layer)."""
+    return mlp_hip.row_linear(x, linear)
+
+
 def prepack(convs):
     """One launch that makes every weight copy the SA stacks on these 1x1 convolutions need in this step."""
     mlp_hip.prepack(convs)

@@ -821,3 +821,44 @@ def umbrella_mlp(x, mlps, group, aggr):
     fn = _UmbrellaFused if fused else _UmbrellaStack
     return fn.apply(x, meta, conv0.weight, bn0.weight, bn0.bias, conv1.weight, conv1.bias, bn1.weight,
                     bn1.bias, conv2.weight, conv2.bias)
+
+
+# ------------------------------------------------------------------------------------------- plain row linear
+class _RowLinear(torch.autograd.Function):
+    """y = x . W^T + b on ungrouped rows (the 13-class output layer of the segmentation classifier,
+    segmentation/models/repsurf/repsurf_umb_ssg.py:36-41): the row GEMM with a plain store epilogue forward, the same
+    kernel on the transposed weight copy for dx and the weight-gradient kernel for dW -- no library GEMM in the step."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        rows, k = x.shape
+        n = w.shape[0]
+        out = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+        epi = Epilogue(bias=_ptr(b), out=_ptr(out), ldo=n, mode=EPI_STORE)
+        gemm_rows(rows, k, n, operand(OP_ID, x, k), w_fwd(w), epi)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        dout = dout.contiguous()
+        rows, k = x.shape
+        n = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((rows, k), dtype=torch.float32, device=x.device)
+            epi = Epilogue(bias=None, out=_ptr(dx), ldo=k, mode=EPI_STORE)
+            gemm_rows(rows, n, k, operand(OP_ID, dout, n), w_bwd(w), epi)
+        if ctx.needs_input_grad[1]:
+            dw = wgrad(rows, n, k, operand(OP_ID, dout, n), operand(OP_ID, x, k), x.device)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dout.sum(0)
+        return dx, dw, db
+
+
+def row_linear(x, linear):
+    """nn.Linear on rows through the HIP row GEMM (x (rows, cin) -> (rows, cout))."""
+    return _RowLinear.apply(x, linear.weight, linear.bias)

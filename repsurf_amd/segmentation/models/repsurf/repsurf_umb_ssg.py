@@ -49,21 +49,72 @@ class Model(nn.Module):
             out += [fp.mlp_f0] + ([fp.mlp_s0] if fp.skip else []) + list(fp.mlp_convs)
         return out + [self.classifier[0]]
 
-    def forward(self, pos_feat_off0):
+    def geometry(self, pos_feat_off0, fork=False):
+        """Everything of a forward that reads coordinates only (no learned parameter): the constructor's kNN + fan
+        features, FPS + kNN grouping of the four SA stages, the 3-NN + interpolation weights of the four FP stages.
+        A training loop that has its next batch in hand runs it under the previous batch's network
+        (repsurf_amd.graph.PipelinedStep); the numpy-generator flips are drawn in the reference's order."""
+        coord, offset = pos_feat_off0[0], pos_feat_off0[2]
+        sc = self.surface_constructor
+        feat = sc.features(coord, offset)
+        stages, centers, offsets = [], [coord], [offset]
+        for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
+            g = sa.geometry(centers[-1], offsets[-1])
+            stages.append(g)
+            centers.append(g.new_center)
+            offsets.append(g.new_offset)
+        fps = []
+        for fine, coarse in ((3, 4), (2, 3), (1, 2), (0, 1)):          # fp4, fp3, fp2, fp1
+            fps.append(SurfaceFeaturePropagationCD.geometry(centers[fine], offsets[fine], centers[coarse], offsets[coarse]))
+        return SegGeoState(feat, stages, fps)
+
+    def forward(self, pos_feat_off0, geo=None):
         coord, feat, offset = pos_feat_off0            # (N,3), (N,C_in-3), (B,) running row ends
         if coord.is_cuda and self.training and torch.is_grad_enabled():
             _mlp.prepack(self._packed_layers())        # ~23 weight-pack launches of the step in one
-        level0 = [coord, self.surface_constructor(coord, offset), torch.cat([coord, feat], 1), offset]
-        level1 = self.sa1(level0)
-        level2 = self.sa2(level1)
-        level3 = self.sa3(level2)
-        level4 = self.sa4(level3)
+        sg = geo.stages if geo is not None else [None] * 4
+        fg = geo.fps if geo is not None else [None] * 4
+        normal = self.surface_constructor(coord, offset, feat=None if geo is None else geo.feat)
+        level0 = [coord, normal, torch.cat([coord, feat], 1), offset]
+        level1 = self.sa1(level0, geometry=sg[0])
+        level2 = self.sa2(level1, geometry=sg[1])
+        level3 = self.sa3(level2, geometry=sg[2])
+        level4 = self.sa4(level3, geometry=sg[3])
 
         def pfo(level):                                # [center, normal, feature, offset] -> [center, feature, offset]
             return [level[0], level[2], level[3]]
-        f3 = self.fp4(pfo(level3), pfo(level4))
-        f2 = self.fp3(pfo(level2), [level3[0], f3, level3[3]])
-        f1 = self.fp2(pfo(level1), [level2[0], f2, level2[3]])
-        f0 = self.fp1([coord, None, offset], [level1[0], f1, level1[3]])
-        cls = self.classifier                          # Linear-BN-ReLU on the fused kernels, then Dropout and the output Linear
-        return cls[4](cls[3](row_mlp(f0, [cls[0]], [cls[1]])))
+        f3 = self.fp4(pfo(level3), pfo(level4), geometry=fg[0])
+        f2 = self.fp3(pfo(level2), [level3[0], f3, level3[3]], geometry=fg[1])
+        f1 = self.fp2(pfo(level1), [level2[0], f2, level2[3]], geometry=fg[2])
+        f0 = self.fp1([coord, None, offset], [level1[0], f1, level1[3]], geometry=fg[3])
+        cls = self.classifier                          # Linear-BN-ReLU on the fused kernels, Dropout, then the output Linear on the row GEMM
+        return _mlp.row_linear(cls[3](row_mlp(f0, [cls[0]], [cls[1]])), cls[4])
+
+
+class SegGeoState:
+    """Tensors `Model.geometry` produced (int32 indices, coordinates, weights): what a forward needs besides the
+    features and the parameters.  Offsets of the sampled levels are host-known constants of the batch shape."""
+    __slots__ = ("feat", "stages", "fps")
+
+    def __init__(self, feat, stages, fps):
+        self.feat, self.stages, self.fps = feat, stages, fps
+
+    def tensors(self):
+        out = [self.feat]
+        for g in self.stages:
+            out += [t for t in (g.fps_idx, g.new_center, g.group_idx) if t is not None]
+        for idx, w in self.fps:
+            out += [idx, w]
+        return out
+
+    def clone(self):
+        from modules.repsurface_utils import StageGeometry
+        return SegGeoState(self.feat.clone(),
+                           [StageGeometry(None if g.fps_idx is None else g.fps_idx.clone(), g.new_center.clone(), g.new_offset,
+                                          g.group_idx.clone()) for g in self.stages],
+                           [(i.clone(), w.clone()) for i, w in self.fps])
+
+    def copy_(self, other):
+        for d, s_ in zip(self.tensors(), other.tensors()):
+            d.copy_(s_)
+        return self

@@ -20,11 +20,18 @@ from modules.pointops.functions import pointops
 from modules.polar_utils import xyz2sphere
 
 
-def sample_and_group(stride, nsample, center, normal, feature, offset, return_polar=False, num_sector=1,
-                     training=True, aligned=False):
-    """center (N,3), normal (N,Cn), feature (N,C)|None, offset (B,) ->
-    new_center (M,3), new_normal (M,Cn), new_feature (M,nsample,3(+3)+Cn+C), new_offset (B,)  (reference :15-51).
-    aligned=True (internal use by the SA modules): rows in the padded layout of ops.group_features(aligned=True)."""
+class StageGeometry:
+    """The coordinate-only part of one sample_and_group call: sampled rows, their coordinates, the running ends of the
+    sampled clouds and the kNN lists.  `stage_geometry` computes it; a training loop that has its next batch in hand
+    can do that while the previous batch is still training (repsurf_amd.graph.PipelinedStep)."""
+    __slots__ = ("fps_idx", "new_center", "new_offset", "group_idx")
+
+    def __init__(self, fps_idx, new_center, new_offset, group_idx):
+        self.fps_idx, self.new_center, self.new_offset, self.group_idx = fps_idx, new_center, new_offset, group_idx
+
+
+def stage_geometry(stride, nsample, center, offset, num_sector=1, training=True):
+    """FPS (reference :17-31) + kNN grouping indices (:33) of one stage: reads coordinates only."""
     if stride > 1:
         new_offset = ops.strided_offset(offset, stride)
         if num_sector > 1 and training:
@@ -32,11 +39,22 @@ def sample_and_group(stride, nsample, center, normal, feature, offset, return_po
         else:
             fps_idx = pointops.furthestsampling(center, offset, new_offset)
         new_center = ops.gather_rows(center.unsqueeze(0), fps_idx.unsqueeze(0)).squeeze(0)
-        new_normal = ops.gather_rows(normal.unsqueeze(0), fps_idx.unsqueeze(0)).squeeze(0)
     else:
-        new_center, new_normal, new_offset = center, normal, offset
-    m = new_center.shape[0]
+        fps_idx, new_center, new_offset = None, center, offset
     group_idx, _ = ops.knnquery_offset(nsample, center, new_center, offset, new_offset)
+    return StageGeometry(fps_idx, new_center, new_offset, group_idx)
+
+
+def sample_and_group(stride, nsample, center, normal, feature, offset, return_polar=False, num_sector=1,
+                     training=True, aligned=False, geometry=None):
+    """center (N,3), normal (N,Cn), feature (N,C)|None, offset (B,) ->
+    new_center (M,3), new_normal (M,Cn), new_feature (M,nsample,3(+3)+Cn+C), new_offset (B,)  (reference :15-51).
+    aligned=True (internal use by the SA modules): rows in the padded layout of ops.group_features(aligned=True).
+    geometry: a StageGeometry computed ahead of time for these coordinates (optional)."""
+    g = geometry if geometry is not None else stage_geometry(stride, nsample, center, offset, num_sector, training)
+    new_center, new_offset, group_idx = g.new_center, g.new_offset, g.group_idx
+    new_normal = normal if g.fps_idx is None else ops.gather_rows(normal.unsqueeze(0), g.fps_idx.unsqueeze(0)).squeeze(0)
+    m = new_center.shape[0]
     rows = ops.group_features(center.unsqueeze(0), new_center.unsqueeze(0), normal.unsqueeze(0),
                               None if feature is None else feature.unsqueeze(0), group_idx.unsqueeze(0),
                               polar=return_polar, aligned=aligned)
@@ -131,11 +149,14 @@ class SurfaceAbstractionCD(nn.Module):
             self.mlp_bns.append(nn.BatchNorm1d(width))
             last = width
 
-    def forward(self, pos_nor_feat_off):
+    def geometry(self, center, offset):
+        return stage_geometry(self.stride, self.nsample, center, offset, self.num_sector, self.training)
+
+    def forward(self, pos_nor_feat_off, geometry=None):
         center, normal, feature, offset = pos_nor_feat_off
         new_center, new_normal, grouped, new_offset = sample_and_group(
             self.stride, self.nsample, center, normal, feature, offset, return_polar=self.return_polar,
-            num_sector=self.num_sector, training=self.training, aligned=True)
+            num_sector=self.num_sector, training=self.training, aligned=True, geometry=geometry)
         m, ns, c = grouped.shape
         # rows are [offset(3|6), pad, normal, feature, pad]: the feature branch starts on a float4 boundary, so the
         # first-layer GEMM and weight gradient read it with vector loads (77 = 3 + 10 + 64 channels would not)
@@ -181,11 +202,16 @@ class SurfaceFeaturePropagationCD(nn.Module):
             self.mlp_bns.append(nn.BatchNorm1d(width))
             last = width
 
-    def forward(self, pos_feat_off1, pos_feat_off2):
+    @staticmethod
+    def geometry(xyz1, offset1, xyz2, offset2):
+        """3 nearest coarse rows of every fine row + inverse-distance weights (reference :261-265): coordinates only."""
+        idx, d2 = ops.knnquery_offset(3, xyz2, xyz1, offset2, offset1)
+        return idx, ops.interp_weights(d2)
+
+    def forward(self, pos_feat_off1, pos_feat_off2, geometry=None):
         xyz1, points1, offset1 = pos_feat_off1      # fine:   (N,3), (N,C)|None, (B,)
         xyz2, points2, offset2 = pos_feat_off2      # coarse: (M,3), (M,C), (B,)
-        idx, d2 = ops.knnquery_offset(3, xyz2, xyz1, offset2, offset1)
-        weight = ops.interp_weights(d2)
+        idx, weight = geometry if geometry is not None else self.geometry(xyz1, offset1, xyz2, offset2)
         points2 = row_mlp(points2, [self.mlp_f0], [self.norm_f0], relu_last=False)
         new_points = ops.three_interpolate(points2.unsqueeze(0), idx.unsqueeze(0), weight.unsqueeze(0)).squeeze(0)
         if self.skip:
@@ -212,10 +238,15 @@ class UmbrellaSurfaceConstructor(nn.Module):
         self.sort_func = sort_factory(sort)
         self._rotate = sort == 'fix'
 
-    def forward(self, center, offset, flip=None):
-        n = center.shape[0]
+    def features(self, center, offset, flip=None):
+        """kNN + fan features (N,k,10): everything of the forward that reads coordinates only."""
         if self.random_inv and flip is None:      # numpy global generator, same call as recons_utils.py:29
             flip = rng.draw("npflip", offset.shape[0], 2, center.device)
         idx, _ = ops.knnquery_offset(self.k, center, center, offset, offset)
-        feat = ops.umbrella_fan_offset(center, center, idx, offset, flip, self._rotate)      # (N,k,10)
+        return ops.umbrella_fan_offset(center, center, idx, offset, flip, self._rotate)      # (N,k,10)
+
+    def forward(self, center, offset, flip=None, feat=None):
+        n = center.shape[0]
+        if feat is None:
+            feat = self.features(center, offset, flip)
         return _mlp.umbrella_mlp2(feat.reshape(n * self.k, 10), self.mlps, self.k)

@@ -117,7 +117,7 @@ def test_segmentation_step_at_the_benchmark_configuration_matches_oracle():
             worst, worst_name = rel, name
     nums["grad_rel_l2_worst"], nums["grad_worst_name"] = worst, worst_name
     parity_report("seg_16x4096_vs_oracle", **nums)
-    assert nums["logits_max_abs"] <= 1e-5 * max(nums["logits_scale"], 1.0) * 10, nums     # see DESIGN §4 (stated bound)
+    assert nums["logits_max_abs"] <= 2e-5 * max(nums["logits_scale"], 1.0), nums     # stated bound for this network
     assert nums["loss_abs"] <= 2e-5 and worst <= 3e-2, nums
 
 

@@ -210,10 +210,12 @@ def test_seg_model_matches_oracle_and_reference_fixture():
     got = logits.detach().cpu().numpy()
     parity_report("seg_fixture_2clouds", logits_max_abs=np.abs(got - fx["logits"]).max(),
                   logits_scale=float(np.abs(fx["logits"]).max()), loss_abs=abs(loss.item() - float(fx["loss"])))
-    assert np.abs(got - fx["logits"]).max() <= 2e-4               # reference's own torch code (CPU)
+    # reference's own torch code (CPU).  Stated bound for this 13-BatchNorm-deep network: 2e-5 of the logit scale
+    # (measured 1.2e-5, profiles/r02_parity_report.jsonl); the north-star's 1e-5 holds for every classification tensor
+    assert np.abs(got - fx["logits"]).max() <= 2e-5 * max(1.0, float(np.abs(fx["logits"]).max()))
     assert abs(loss.item() - float(fx["loss"])) <= 5e-5
     ref = seg_ref.step(seg_state(), fx["coord"], fx["rgb"], fx["offset"], fx["label"].astype(np.int64), fx["inv_sign"])
-    assert np.abs(got - ref["logits"].detach().numpy()).max() <= 2e-4
+    assert np.abs(got - ref["logits"].detach().numpy()).max() <= 2e-5 * max(1.0, float(np.abs(fx["logits"]).max()))
     bad = []
     for name, p in model.named_parameters():
         r = ref["grads"][name].numpy().reshape(-1)
@@ -256,3 +258,62 @@ def test_pc_median_filter_matches_oracle_knn():
     idx, _ = G.knn_offset(16, coord, coord, off, off)
     ref = torch.median(torch.from_numpy(label[idx]), 1)[0].numpy()      # lower median of 16, like the reference
     assert np.array_equal(got, ref)
+
+
+def test_row_linear_matches_torch():
+    """mlp.row_linear (the 13-class output layer on the row GEMM / weight-gradient kernels) against nn.Linear."""
+    from repsurf_amd import mlp
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(128, 13).cuda()
+    x = torch.randn(5000, 128, device="cuda", requires_grad=True)
+    w = torch.randn(5000, 13, device="cuda")
+    out = mlp.row_linear(x, lin)
+    (out * w).sum().backward()
+    got = (out.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None
+    lin.zero_grad()
+    ref = lin(x)
+    (ref * w).sum().backward()
+    for a, b in zip(got, (ref.detach(), x.grad, lin.weight.grad, lin.bias.grad)):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+
+
+def test_seg_pipelined_step_matches_eager(monkeypatch):
+    """PipelinedStep over the segmentation network: the geometry of batch s+1 (constructor kNN + fan features, FPS + kNN
+    of four SA stages, 3-NN weights of four FP stages) runs under the network of batch s; every replay's loss must be the
+    eager loss of the same batch with the same normal flips."""
+    from repsurf_amd import rng
+    from repsurf_amd.graph import PipelinedStep
+    calls = {"i": 0}
+
+    def fake_draw(kind, b, n):
+        i = calls["i"]
+        calls["i"] += 1
+        return (((torch.arange(b) * 5 + i * 3) % 2).float() * 2. - 1.)
+
+    monkeypatch.setattr(rng, "_cpu_draw", fake_draw)
+    sizes = [1024, 768]
+    batches, labels = [], []
+    from repsurf_amd import ops as _ops
+    off = _ops.offsets_tensor(np.cumsum(sizes).tolist(), torch.device("cuda"))
+    for seed in (3, 4):
+        xyz, _ = packed_cloud(seed, sizes)
+        r = np.random.RandomState(seed)
+        batches.append([dev(xyz), dev(r.rand(sum(sizes), 3).astype(np.float32)), off])
+        labels.append(dev(r.randint(0, 13, sum(sizes)).astype(np.int64)))
+    crit = torch.nn.functional.cross_entropy
+    with subproject("segmentation"):
+        piped = _seg_model()
+        step = PipelinedStep(piped, crit, None, batches[0], labels[0], warmup=1)
+        first = calls["i"] - 1                       # the draw behind the geometry the first replay consumes
+        got = [step(batches[(s + 1) % 2], labels[(s + 1) % 2]).item() for s in range(4)]
+        eager = _seg_model()
+        want = []
+        for s in range(4):
+            calls["i"] = first + s
+            for p in eager.parameters():
+                p.grad = None
+            loss = crit(eager(batches[s % 2]), labels[s % 2])
+            loss.backward()
+            want.append(loss.item())
+    assert np.allclose(got, want, atol=3e-5), (got, want)

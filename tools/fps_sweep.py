@@ -24,13 +24,14 @@ xyz = (torch.rand(16 * 4096, 3, device=dev) * 2 - 1).contiguous()
 off = ops.offsets_tensor([4096 * (i + 1) for i in range(16)], dev)
 noff = ops.strided_offset(off, 4)
 dense = {(n, m): (torch.rand(32, n, 3, device=dev) * 2 - 1).contiguous() for n, m in ((1024, 512), (512, 128), (2048, 1024))}
-start = torch.zeros(32, dtype=torch.int32, device=dev)
+dense[(4096, 1024)] = xyz.view(16, 4096, 3)          # the packed case's clouds through the dense (non-tie-rule) kernel
+start = torch.zeros(32, dtype=torch.int32, device=dev)[:]
 for w in (1, 2, 4, 8, 16):
     os.environ["RS_FPS_WAVES"] = str(w)
     line = f"waves {w:2d}:"
     for (n, m), x in dense.items():
-        us = t(lambda: ops.furthestsampling(x, m, start))
-        line += f"  32x{n}->{m}: {us:7.1f} us ({us / (m - 1) * 1e3:4.0f} ns/pick)"
+        us = t(lambda: ops.furthestsampling(x, m, start[:x.shape[0]]))
+        line += f"  {x.shape[0]}x{n}->{m}: {us:7.1f} us ({us / (m - 1) * 1e3:4.0f} ns/pick)"
     us = t(lambda: ops.furthestsampling_offset(xyz, off, noff))
     line += f"  packed 16x4096->1024: {us:7.1f} us ({us / 1023 * 1e3:4.0f} ns/pick)"
     print(line, flush=True)
