@@ -173,10 +173,10 @@ def algorithmic_cost(name, dims):
         b, n, m, ns = dims
         return "bytes", 4.0 * (3 * b * n + 3 * b * m + b * m * ns)
     # compacted launches: dims[0] is the capacity, the rows really processed come as a trailing "rows=<mean>" note
-    notes = [d for d in dims if isinstance(d, str)]
+    notes = dict(d.split("=", 1) for d in dims if isinstance(d, str))
     dims = [d for d in dims if not isinstance(d, str)]
-    if notes:
-        dims[0] = float(notes[0].split("=")[1])
+    if "rows" in notes:
+        dims[0] = float(notes["rows"])
     if name in ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16"):
         rows, kdim, cols = dims[:3]
         return "flops", 2.0 * rows * kdim * cols
@@ -184,6 +184,25 @@ def algorithmic_cost(name, dims):
         rows, ncols, kcols = dims[:3]
         return "flops", 2.0 * rows * ncols * kcols
     return None, 0.0
+
+
+def algorithmic_bytes(name, dims):
+    """HBM bytes one launch must move (each operand / mask tensor read once, the output written once):
+    row GEMM: 4 * rows * (K * operand tensors + N * (1 + mask tensors)); weight gradient: 4 * rows * (N * P tensors +
+    K * Q tensors).  Operand tensors: ID / RELU1 / BCAST 1, RELU2 / AFF2 / POOLED 2 (POOLED's pooled gradient is small)."""
+    notes = dict(d.split("=", 1) for d in dims if isinstance(d, str))
+    ints = [d for d in dims if not isinstance(d, str)]
+    rows = float(notes["rows"]) if "rows" in notes else float(ints[0])
+    ntens = {0: 1, 1: 1, 2: 2, 3: 2, 4: 1, 5: 0}          # per operand mode (POOLED: y only; BCAST: broadcast source is tiny)
+    if name.startswith("rs_mlp_gemm_rows") and "op" in notes:
+        k, n = ints[1], ints[2]
+        epi = notes.get("epi", "0")
+        masks = 0 if not epi.startswith("2") else (2 if epi.endswith("+2") else 1)
+        return 4.0 * rows * (k * ntens[int(notes["op"])] + n * (1 + masks))
+    if name.startswith("rs_mlp_wgrad") and "p" in notes:
+        n, k = ints[1], ints[2]
+        return 4.0 * rows * (n * ntens[int(notes["p"])] + k * ntens[int(notes["q"])])
+    return None
 
 
 def roofline_from_profile(prof, timed_steps, dtype):
@@ -195,10 +214,11 @@ def roofline_from_profile(prof, timed_steps, dtype):
         by_dims = {}
         rows_of = {}
         for t_ms, dims in recs:
-            static = tuple(d for d in dims if not isinstance(d, str))
+            # the class key: sizes + operand / epilogue modes; "rows=<n>" (row count of a compacted launch) varies a little per step
+            static = tuple(d for d in dims if not (isinstance(d, str) and d.startswith("rows=")))
             by_dims.setdefault(static, []).append(t_ms)
             for d in dims:
-                if isinstance(d, str):       # "rows=<n>": row count of a compacted launch (varies a little per step)
+                if isinstance(d, str) and d.startswith("rows="):
                     rows_of.setdefault(static, []).append(int(d.split("=")[1]))
         for dims, ts in by_dims.items():
             if dims in rows_of:
@@ -223,6 +243,7 @@ def roofline_from_profile(prof, timed_steps, dtype):
         roofline["avg_launch_us"] = round(row["avg_us"], 2)
         roofline["launches_per_step"] = row["launches"] // max(1, timed_steps)
         roofline["traffic"] = traffic_from_profiles(row["kernel"], row["dims"])
+        roofline["algorithmic_bytes"] = algorithmic_bytes(row["kernel"], row["dims"])
         break
     # every MFMA launch of the step together (all shared-MLP GEMMs + weight-gradient GEMMs)
     fl = sum(r["amount"] * r["launches"] for r in table if r["unit"] == "flops")
@@ -518,6 +539,7 @@ def main():
         torch.cuda.synchronize()
         _lib.profile_enable(False)
     dt = rdist.max_over_ranks(dt, device)
+    allreduce_us = rdist.time_allreduce(sum(p.numel() for p in model.parameters()), device) if world > 1 else None
     if "REPSURF_BENCH_DUMP" in os.environ:       # test hook: every rank's parameters after the timed loop
         torch.cuda.synchronize()
         torch.save(torch.cat([p.detach().flatten() for p in model.parameters()]).cpu(),
@@ -537,7 +559,8 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, cpu_state)
-        ball_line, fps_line = geometry_lines(device, args.points) if timing else (None, None)
+        # (skipped under --launch-log: a PMC pass matches dispatches to the logged calls, extra launches would shift them)
+        ball_line, fps_line = geometry_lines(device, args.points) if (timing and not args.launch_log) else (None, None)
         out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U 1024-pt cls @ B=32 per GPU", "value": round(value, 2),
                "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -547,7 +570,9 @@ def main():
                                       + ("" if args.no_optim else "+Adam step"),
                           "global_batch": args.batch * world, "points": args.points,
                           "parallelism": f"dp{world}", "mlp_backend": "hip", "launch": mode,
-                          "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5)},
+                          "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5),
+                          "allreduce_us": None if allreduce_us is None else round(allreduce_us, 1),
+                          "allreduce_bytes": 4 * sum(p.numel() for p in model.parameters()) if world > 1 else None},
                "roofline": roofline, "roofline_ballquery": ball_line, "fps_us_per_pick": fps_line, "cpu_baseline": cpu}
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
@@ -556,7 +581,7 @@ def main():
 
 
 def traffic_key(kernel, dims):
-    return kernel + "|" + ",".join(str(d) for d in dims if not isinstance(d, str))
+    return kernel + "|" + ",".join(str(d) for d in dims if not (isinstance(d, str) and d.startswith("rows=")))
 
 
 def traffic_from_profiles(kernel, dims):

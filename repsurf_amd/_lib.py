@@ -176,6 +176,13 @@ def call(name, *args):
         e1.record()
         dims = tuple(a for a, t in zip(args, SIGNATURES[name]) if t is c_int or t is c_ll)
         slot = None
+        # operand / epilogue modes: a forward GEMM and the data-gradient GEMM of the same sizes read different numbers of
+        # tensors (1-2 against 3-4) -- separate launch classes with their own algorithmic bytes
+        if name in ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16"):
+            op, ep = args[4]._obj, args[7]._obj
+            dims = dims + (f"op={op.mode}", f"epi={ep.mode}{'+2' if ep.my2 else ''}")
+        elif name in ("rs_mlp_wgrad", "rs_mlp_wgrad_bf16"):
+            dims = dims + (f"p={args[4]._obj.mode}", f"q={args[5]._obj.mode}")
         if name in ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16", "rs_mlp_wgrad", "rs_mlp_wgrad_bf16") and args[1] is not None:
             # compacted operand: args[0] is only the capacity, the launch's row count lives on the device
             slot = _copy_device_int_async(args[1])

@@ -218,13 +218,15 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
 #else
   constexpr bool DIRECT = BM == 64;                         // short tiles: epilogue straight from the accumulators
 #endif
-#if defined(RS_EXP_NO_EARLY_PREFETCH)
-  constexpr bool EARLY_PREFETCH = false;
-#elif defined(RS_EXP_EARLY_PREFETCH_ALL)
+#if defined(RS_EXP_EARLY_PREFETCH_ALL)
   constexpr bool EARLY_PREFETCH = DIRECT;
-#else
-  // forward instances only: the two-tensor backward operands + mask registers leave no room (spills at 256 VGPRs)
+#elif defined(RS_EXP_EARLY_PREFETCH_FWD)
   constexpr bool EARLY_PREFETCH = DIRECT && MODE >= 0 && MODE <= OPM_RELU2;
+#else
+  // Requesting the next tile's first chunk in front of the write-out was measured on one box (60-step replays, two runs
+  // each): off 1.7201 / 1.7225 ms per step, forward instances only 1.7338 / 1.7279, all instances 1.7459 / 1.7512 -- the
+  // ~20 extra live VGPRs cost more than the hidden latency brings.  Kept for experiments only.
+  constexpr bool EARLY_PREFETCH = false;
 #endif
   static_assert(CT >= 1, "tile too narrow for the wave layout");
   static_assert(!BF || V >= 2, "bf16 staging packs pairs of k");

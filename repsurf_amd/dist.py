@@ -57,6 +57,28 @@ def max_over_ranks(seconds, device=None):
     return float(t.item())
 
 
+def time_allreduce(numel, device, reps=10):
+    """Microseconds of ONE all-reduce (AVG) of a flat fp32 buffer of `numel` elements -- the step's only data-path
+    collective -- averaged over `reps` back-to-back calls after a barrier; max over ranks.  None when world_size is 1."""
+    _, world, _ = env()
+    if world == 1 or not dist.is_initialized():
+        return None
+    buf = torch.zeros(numel, dtype=torch.float32, device=device)
+    for _ in range(2):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    cuda = torch.device(device).type == "cuda"
+    if cuda:
+        torch.cuda.synchronize()
+    dist.barrier()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    if cuda:
+        torch.cuda.synchronize()
+    return max_over_ranks((time.perf_counter() - t0) / reps, device) * 1e6
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

@@ -19,21 +19,27 @@ import collections
 import csv
 import json
 
+import re
+
+# ABI call -> the kernels it can launch (exactly ONE dispatch of this set per call).  Round 1 matched "wgrad_kernel" /
+# "gemm_rows_kernel" only: calls that took the narrow streaming kernels (wgrad_small_kernel, gemm_small_kernel) had no
+# dispatch of their own, the 1:1 alignment slipped and several size classes showed the same bytes.
 FAMILY = {
-    "rs_mlp_gemm_rows": "gemm_rows_kernel",
-    "rs_mlp_wgrad": "wgrad_kernel",
-    "rs_ballquery": "ballquery_kernel",
-    "rs_furthestsampling": "fps_",
-    "rs_umbrella_features": "umbrella_kernel",
-    "rs_pool_max": "pool_max_kernel",
-    "rs_pool_max_backward": "pool_max_bwd_kernel",
-    "rs_group_features_compact": "compact_features_kernel",
-    "rs_group_features_compact_backward": "compact_scatter_kernel",
+    "rs_mlp_gemm_rows": r"gemm_rows_kernel|gemm_small_kernel",
+    "rs_mlp_wgrad": r"wgrad_kernel|wgrad_small_kernel",
+    "rs_ballquery": r"ballquery_kernel|ballquery_grid_kernel",
+    "rs_furthestsampling": r"fps_reg_kernel|fps_global_kernel",
+    "rs_umbrella_features": r"umbrella_kernel",
+    "rs_pool_max": r"pool_max_kernel|pool_max_long_kernel",
+    "rs_pool_max_backward": r"pool_max_bwd_kernel",
+    "rs_group_features_compact": r"compact_features_kernel",
+    "rs_group_features_compact_backward": r"compact_scatter_kernel",
 }
 
 
 def key(name, dims):
-    return name + "|" + ",".join(str(d) for d in dims if not isinstance(d, str))
+    """sizes + operand / epilogue modes (same key as bench.traffic_key); the per-launch "rows=<n>" note is dropped"""
+    return name + "|" + ",".join(str(d) for d in dims if not (isinstance(d, str) and d.startswith("rows=")))
 
 
 def per_family(csv_path, counter):
@@ -43,22 +49,33 @@ def per_family(csv_path, counter):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     for r in rows:
         for abi, sub in FAMILY.items():
-            if sub in r["Kernel_Name"]:
+            if re.search(r"(?<![a-z_])(" + sub + r")", r["Kernel_Name"]):
                 name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
                 fam[abi].append((float(r["Counter_Value"]), name.split("(")[0]))
     return fam
 
 
-def collect(log_path, csv_path, counter):
+def collect(log_path, csv_path, counter, warm_steps, logged_steps):
+    """The run did `warm_steps` unlogged steps, then `logged_steps` logged ones (bench.py --warmup W --steps K --no-graph);
+    anything the process launched afterwards (bench.py's geometry micro-timings) comes later in dispatch order.  The
+    logged calls of a family are therefore its dispatches [per_step * W, per_step * (W + K))."""
     log = json.load(open(log_path))
     fam = per_family(csv_path, counter)
     out = collections.defaultdict(list)
     for abi in FAMILY:
         calls = [(n, d) for n, d in log if n == abi]
         disp = fam.get(abi, [])
-        if not calls or len(disp) < len(calls):
+        if not calls:
             continue
-        for (n, d), (v, kname) in zip(calls, disp[-len(calls):]):
+        if len(calls) % logged_steps:
+            print(f"warning: {abi}: {len(calls)} logged calls are not a multiple of {logged_steps} steps, skipped")
+            continue
+        per_step = len(calls) // logged_steps
+        lo = per_step * warm_steps
+        if len(disp) < lo + len(calls):
+            print(f"warning: {abi}: {len(disp)} dispatches < {lo} + {len(calls)}, skipped")
+            continue
+        for (n, d), (v, kname) in zip(calls, disp[lo:lo + len(calls)]):
             out[key(n, d)].append((v, kname))
     return out
 
@@ -70,9 +87,11 @@ def main():
     ap.add_argument("--write-log", required=True)
     ap.add_argument("--write-csv", required=True)
     ap.add_argument("--out", default="profiles/traffic.json")
+    ap.add_argument("--warm-steps", type=int, default=1)
+    ap.add_argument("--logged-steps", type=int, default=2)
     a = ap.parse_args()
-    rd = collect(a.fetch_log, a.fetch_csv, "FETCH_SIZE")
-    wr = collect(a.write_log, a.write_csv, "WRITE_SIZE")
+    rd = collect(a.fetch_log, a.fetch_csv, "FETCH_SIZE", a.warm_steps, a.logged_steps)
+    wr = collect(a.write_log, a.write_csv, "WRITE_SIZE", a.warm_steps, a.logged_steps)
     res = {}
     for k in sorted(set(rd) | set(wr)):
         r = [v for v, _ in rd.get(k, [])]
