@@ -293,6 +293,268 @@ ballquery_grid_kernel(int b, int n, int m, float radius2, int nsample, int wpc, 
   }
 }
 
+
+// ---- cell list, second design (round 2) --------------------------------------------------------------------------
+// ballquery_grid_kernel above spends its time in latency, not work: a thread walks 9 rows of cells one after the other,
+// every candidate costs a dependent LDS chain (order[j] -> x/y/z/|p|^2), a wave pays the LONGEST row of its 64 lanes nine
+// times over, hits are insertion-sorted in LDS (a dependent read-compare-write chain as long as the busiest lane's
+// count squared) and 72 KB of LDS per 256 threads leave 2 waves per SIMD to hide any of it.  Here:
+//   * the cloud is counting-sorted BY CELL into an array of float4 (x, y, z, |p|^2) + an index array, so a candidate is
+//     one 16-byte LDS read at address j and the three x-neighbour cells of a row are one contiguous range;
+//   * a thread walks ONE flattened candidate stream (row changes folded into the loop), so a wave pays the longest lane's
+//     TOTAL (~40 candidates) instead of nine per-row maxima (~72);
+//   * points stay in registers between the bounding-box, histogram and scatter passes (no second read), the prefix sum of
+//     the cell counts is a wave scan + one LDS hop (2 barriers instead of 16);
+//   * a thread keeps up to BC_HCAP hits in its LDS row and sorts them in REGISTERS with a Batcher network (19 / 63
+//     compare-exchanges for <= 8 / <= 16 hits: straight-line v_min/v_max, no LDS round trips);
+//   * rows with more hits (dense clusters) are redone by their thread into a small per-workgroup arena (one more walk),
+//     rows beyond the arena by the repeated-minimum walk; both write their row to global memory themselves;
+//   * the other rows leave through one coalesced sweep over the (centres x nsample) block, padding expanded on the fly.
+// Same distance arithmetic and threshold as the scan kernel: bit-identical neighbour lists (tests/test_geometry_gpu.py).
+// Phase costs at B = 2048 x 1024 points x 512 centres, r = 0.2 (RS_BALLQUERY_DBG builds, profiles/r02/): see DESIGN.md §5.
+constexpr int BC_THREADS = 512;
+constexpr int BC_HCAP = 16;
+constexpr int BC_PP = BG_MAXN / BC_THREADS;              // points a thread carries in registers (8)
+constexpr int BC_OVF_ROWS = 16, BC_OVF_CAP = 64;         // arena for rows with BC_HCAP < hits <= BC_OVF_CAP
+
+__device__ __forceinline__ void bc_cx(int &a, int &b) { const int lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
+template <int N> __device__ __forceinline__ void bc_sort(int (&v)[16]) {
+  constexpr unsigned char P8[19][2] = {{0,1},{2,3},{0,2},{1,3},{1,2},{4,5},{6,7},{4,6},{5,7},{5,6},{0,4},{2,6},{2,4},{1,5},{3,7},{3,5},{1,2},{3,4},{5,6}};
+  constexpr unsigned char P16[63][2] = {{0,1},{2,3},{0,2},{1,3},{1,2},{4,5},{6,7},{4,6},{5,7},{5,6},{0,4},{2,6},{2,4},{1,5},{3,7},{3,5},{1,2},{3,4},{5,6},
+    {8,9},{10,11},{8,10},{9,11},{9,10},{12,13},{14,15},{12,14},{13,15},{13,14},{8,12},{10,14},{10,12},{9,13},{11,15},{11,13},{9,10},{11,12},{13,14},
+    {0,8},{4,12},{4,8},{2,10},{6,14},{6,10},{2,4},{6,8},{10,12},{1,9},{5,13},{5,9},{3,11},{7,15},{7,11},{3,5},{7,9},{11,13},{1,2},{3,4},{5,6},{7,8},{9,10},{11,12},{13,14}};
+  if constexpr (N == 8) {
+#pragma unroll
+    for (int i = 0; i < 19; ++i) bc_cx(v[P8[i][0]], v[P8[i][1]]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 63; ++i) bc_cx(v[P16[i][0]], v[P16[i][1]]);
+  }
+}
+
+__global__ void __launch_bounds__(BC_THREADS)
+ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
+                       const float *__restrict__ xyz, int *__restrict__ idx, int *__restrict__ cnt_out, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float4 *sp4 = reinterpret_cast<float4 *>(lds);               // (x, y, z, |p|^2) sorted by cell
+  int *sid = reinterpret_cast<int *>(lds + 4 * n);
+  int *cstart = sid + n;                                        // ncell + 1 running starts
+  int *cursor = cstart + BG_MAXCELLS + 1;                       // scatter cursors; later the per-centre hit counts
+  int *hits = cursor + BG_MAXCELLS;                             // BC_THREADS rows of BC_HCAP + 1
+  int *ovf = hits + BC_THREADS * (BC_HCAP + 1);                 // BC_OVF_ROWS rows of BC_OVF_CAP
+  __shared__ float red[6][BC_THREADS / 64];
+  __shared__ int wsum[BC_THREADS / 64];
+  __shared__ int ovf_used;
+
+  const int cloud = blockIdx.x;
+  const float *pts = xyz + (size_t)cloud * n * 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // A. this thread's points (registers), bounding box
+  float px[BC_PP], py[BC_PP], pz[BC_PP];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int k = 0; k < BC_PP; ++k) {
+    const int p = tid + k * BC_THREADS;
+    if (p < n) {
+      px[k] = pts[p * 3 + 0]; py[k] = pts[p * 3 + 1]; pz[k] = pts[p * 3 + 2];
+      lo[0] = fminf(lo[0], px[k]); lo[1] = fminf(lo[1], py[k]); lo[2] = fminf(lo[2], pz[k]);
+      hi[0] = fmaxf(hi[0], px[k]); hi[1] = fmaxf(hi[1], py[k]); hi[2] = fmaxf(hi[2], pz[k]);
+    } else { px[k] = py[k] = pz[k] = 0.f; }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float l = lo[a], h = hi[a];
+    for (int off = 32; off > 0; off >>= 1) { l = fminf(l, __shfl_xor(l, off, 64)); h = fmaxf(h, __shfl_xor(h, off, 64)); }
+    if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+  }
+  __syncthreads();
+  float ext = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float l = red[a][0], h = red[3 + a][0];
+#pragma unroll
+    for (int w = 1; w < BC_THREADS / 64; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+    lo[a] = l; hi[a] = h;
+    ext = fmaxf(ext, h - l);
+  }
+  // B. grid geometry: the same formulas as ballquery_grid_kernel (cell edge >= 1.001 r)
+  const float cell = fmaxf(sqrtf(radius2) * 1.001f, ext * (1.0001f / BG_MAXG));
+  const float inv = 1.0f / cell;
+  int g[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) g[a] = min(BG_MAXG, (int)((hi[a] - lo[a]) * inv) + 1);
+  const int ncell = g[0] * g[1] * g[2];
+  auto cell_of = [&](float x, float y, float z) {
+    const int cx = min(g[0] - 1, (int)((x - lo[0]) * inv));
+    const int cy = min(g[1] - 1, (int)((y - lo[1]) * inv));
+    const int cz = min(g[2] - 1, (int)((z - lo[2]) * inv));
+    return (cz * g[1] + cy) * g[0] + cx;
+  };
+
+  // C. histogram
+  for (int c = tid; c < ncell; c += BC_THREADS) cstart[c] = 0;
+  __syncthreads();
+  int pc[BC_PP];
+#pragma unroll
+  for (int k = 0; k < BC_PP; ++k)
+    if (tid + k * BC_THREADS < n) { pc[k] = cell_of(px[k], py[k], pz[k]); atomicAdd(&cstart[pc[k]], 1); }
+  __syncthreads();
+  // D. exclusive scan of the counts: a run of consecutive cells per thread, wave scan, one LDS hop
+  const int per = (ncell + BC_THREADS - 1) / BC_THREADS;
+  int run = 0;
+  for (int k = 0; k < per; ++k) { const int c = tid * per + k; if (c < ncell) run += cstart[c]; }
+  int incl = run;
+  for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - run;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  for (int k = 0; k < per; ++k) {
+    const int c = tid * per + k;
+    if (c < ncell) { const int v = cstart[c]; cstart[c] = base; cursor[c] = base; base += v; }
+  }
+  if (tid == 0) cstart[ncell] = n;
+  __syncthreads();
+  // E. scatter the points into their cells (order inside a cell is arbitrary: hits are sorted by index afterwards)
+#pragma unroll
+  for (int k = 0; k < BC_PP; ++k) {
+    const int p = tid + k * BC_THREADS;
+    if (p < n) {
+      const int pos = atomicAdd(&cursor[pc[k]], 1);
+      sp4[pos] = make_float4(px[k], py[k], pz[k], rs_sqnorm(px[k], py[k], pz[k]));
+      sid[pos] = p;
+    }
+  }
+  __syncthreads();
+  if (dbg == 1) return;                                         // (experiment: cost of the build alone)
+
+  // F. centres, BC_THREADS at a time
+  int *hcount = cursor;                                         // the cursors are spent: one count per thread / centre
+  int *row = hits + tid * (BC_HCAP + 1);
+  for (int qb = 0; qb < m; qb += BC_THREADS) {
+    const int q = qb + tid;
+    int count = 0;
+    float qx = 0.f, qy = 0.f, qz = 0.f, qq = 0.f;
+    int x0 = 1, x1 = 0, y0 = 0, z0 = 0, ny = 0, nrows = 0;
+    if (tid == 0) ovf_used = 0;
+    if (q < m) {
+      const float *c = new_xyz + ((size_t)cloud * m + q) * 3;
+      qx = c[0]; qy = c[1]; qz = c[2]; qq = rs_sqnorm(qx, qy, qz);
+      const float fx = fminf(fmaxf((qx - lo[0]) * inv, -2.f), (float)BG_MAXG + 2.f);
+      const float fy = fminf(fmaxf((qy - lo[1]) * inv, -2.f), (float)BG_MAXG + 2.f);
+      const float fz = fminf(fmaxf((qz - lo[2]) * inv, -2.f), (float)BG_MAXG + 2.f);
+      const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+      x0 = max(cx - 1, 0); x1 = min(cx + 1, g[0] - 1);
+      y0 = max(cy - 1, 0); const int y1 = min(cy + 1, g[1] - 1);
+      z0 = max(cz - 1, 0); const int z1 = min(cz + 1, g[2] - 1);
+      ny = y1 - y0 + 1;
+      nrows = (x0 <= x1 && ny > 0 && z1 >= z0) ? ny * (z1 - z0 + 1) : 0;
+    }
+    // one flattened candidate stream: (row r, position j); a lane leaves when its rows are exhausted.
+    // visit(j) is called once per candidate of the centre's <= 27 cells.
+    auto walk = [&](auto &&visit) {
+      int r = 0, ry = 0, rz = 0, j = 0, jend = 0;
+      while (true) {
+        while (j >= jend && r < nrows) {
+          const int cb = ((z0 + rz) * g[1] + (y0 + ry)) * g[0];
+          j = cstart[cb + x0]; jend = cstart[cb + x1 + 1];
+          ++r; if (++ry == ny) { ry = 0; ++rz; }
+        }
+        if (j >= jend) break;
+        visit(j);
+        ++j;
+      }
+    };
+    walk([&](int j) {
+      const float4 c4 = sp4[j];
+      const float d = rs_sqdist_expanded(qx, qy, qz, qq, c4.x, c4.y, c4.z, c4.w);
+      if (!(d > radius2)) {
+        if (count < BC_HCAP) row[count] = sid[j];
+        ++count;
+      }
+    });
+    if (dbg == 2) { if (count == 12345) idx[0] = count; continue; }      // (experiment: build + walk)
+    if (q < m && cnt_out) cnt_out[(size_t)cloud * m + q] = count > 0 ? min(count, nsample) : 1;
+    // sort the hits by index in registers (wave-uniform choice of the network: 8 or 16 wide)
+    {
+      const int kept = min(count, BC_HCAP);
+      const int wmax = __builtin_amdgcn_readfirstlane((int)rs_wave_max_u32((unsigned)kept));
+      if (wmax > 1) {
+        int v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (i < 8 || wmax > 8) ? ((i < kept) ? row[i] : 0x7fffffff) : 0x7fffffff;
+        if (wmax > 8) bc_sort<16>(v); else bc_sort<8>(v);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if ((i < 8 || wmax > 8) && i < kept) row[i] = v[i];
+      }
+    }
+    hcount[tid] = q < m ? count : 0;
+    __syncthreads();
+    if (dbg == 3) continue;                                       // (experiment: build + walk + sort)
+    // coalesced write-out of the rows with <= BC_HCAP hits; padding = the lowest hit (an empty ball yields zeros)
+    const int nq = min(BC_THREADS, m - qb);
+    int *dst = idx + ((size_t)cloud * m + qb) * nsample;
+    if (dbg != 5) {
+      int ql = tid / nsample, sl = tid - ql * nsample;
+      const int dq = BC_THREADS / nsample, ds = BC_THREADS - dq * nsample;
+      for (int e = tid; e < nq * nsample; e += BC_THREADS) {
+        const int c = hcount[ql];
+        if (c <= BC_HCAP) {
+          const int *h = hits + ql * (BC_HCAP + 1);
+          const int take = min(c, nsample);
+          dst[e] = c > 0 ? h[sl < take ? sl : 0] : 0;
+        }
+        ql += dq; sl += ds;
+        if (sl >= nsample) { sl -= nsample; ++ql; }
+      }
+    }
+    // rows with more than BC_HCAP hits (dense clusters): straight to global memory by their own thread
+    if (dbg != 4 && q < m && count > BC_HCAP) {
+      int *out = idx + ((size_t)cloud * m + q) * nsample;
+      const int want = min(count, nsample);
+      const int slot = count <= BC_OVF_CAP ? atomicAdd(&ovf_used, 1) : BC_OVF_ROWS;
+      if (slot < BC_OVF_ROWS) {
+        // one more walk collects every hit into the arena, an insertion sort orders them (<= 64, rare)
+        int *o = ovf + slot * BC_OVF_CAP;
+        int c2 = 0;
+        walk([&](int j) {
+          const float4 c4 = sp4[j];
+          const float d = rs_sqdist_expanded(qx, qy, qz, qq, c4.x, c4.y, c4.z, c4.w);
+          if (!(d > radius2)) o[c2++] = sid[j];
+        });
+        for (int i = 1; i < c2; ++i) {
+          const int v = o[i];
+          int t = i - 1;
+          while (t >= 0 && o[t] > v) { o[t + 1] = o[t]; --t; }
+          o[t + 1] = v;
+        }
+        for (int s2 = 0; s2 < nsample; ++s2) out[s2] = o[s2 < want ? s2 : 0];
+      } else {
+        // arena exhausted / more than BC_OVF_CAP hits: the nsample lowest indices by repeated minimum over the candidates
+        int last = -1, first = 0;
+        for (int s2 = 0; s2 < want; ++s2) {
+          int best = 0x7fffffff;
+          walk([&](int j) {
+            const int p = sid[j];
+            if (p > last && p < best) {
+              const float4 c4 = sp4[j];
+              const float d = rs_sqdist_expanded(qx, qy, qz, qq, c4.x, c4.y, c4.z, c4.w);
+              if (!(d > radius2)) best = p;
+            }
+          });
+          out[s2] = best;
+          if (s2 == 0) first = best;
+          last = best;
+        }
+        for (int s2 = want; s2 < nsample; ++s2) out[s2] = first;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int rs_ballquery(int b, int n, int m, float radius2, int nsample, const float *new_xyz,
@@ -308,6 +570,15 @@ extern "C" int rs_ballquery(int b, int n, int m, float radius2, int nsample, con
   static const int grid_mode = getenv("RS_BALLQUERY_GRID") ? atoi(getenv("RS_BALLQUERY_GRID")) : -1;
   const bool grid_ok = n <= BG_MAXN && n >= 64 && nsample <= 64;
   const bool use_grid = grid_mode > 0 || (grid_mode < 0 && (long long)b * m >= 65536 && n >= 1024 && nsample <= 32);
+  // 2 (default where the grid applies): the register-carried, cell-sorted variant; 1: the first cell-list kernel
+  static const int cells_on = getenv("RS_BALLQUERY_CELLS") ? atoi(getenv("RS_BALLQUERY_CELLS")) : 1;
+  if (use_grid && grid_ok && cells_on && nsample >= 1 && nsample <= BC_THREADS) {
+    const size_t lds = (size_t)n * 20 + sizeof(int) * (2 * BG_MAXCELLS + 1 + (size_t)BC_THREADS * (BC_HCAP + 1) + BC_OVF_ROWS * BC_OVF_CAP);
+    static const int dbg = getenv("RS_BALLQUERY_DBG") ? atoi(getenv("RS_BALLQUERY_DBG")) : 0;
+    hipLaunchKernelGGL(ballquery_cells_kernel, dim3(b), dim3(BC_THREADS), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
+    RS_CHECK_LAUNCH("rs_ballquery");
+    return RS_OK;
+  }
   if (use_grid && grid_ok) {
     // workgroups per cloud: one when the batch alone fills the chip, more (each rebuilds the small grid) otherwise
     int wpc = 1;

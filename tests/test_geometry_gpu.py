@@ -237,9 +237,12 @@ def test_full_size_properties(ops):
     assert torch.equal(ops.furthestsampling(xyz, 512, start), f1)
 
 
-def test_ballquery_grid_variant_bit_exact():
-    """The cell-list variant of rs_ballquery (forced with RS_BALLQUERY_GRID=1; the selection is read once per process,
-    hence the subprocess) returns the brute-force rows bit for bit: uniform, clustered (rows overflow nsample),
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells", ["1", "0"])
+def test_ballquery_grid_variant_bit_exact(cells):
+    """The cell-list variants of rs_ballquery (forced with RS_BALLQUERY_GRID=1; RS_BALLQUERY_CELLS=1: the cell-sorted,
+    register-carried kernel, 0: the first cell-list kernel; the selection is read once per process,
+    hence the subprocess) return the brute-force rows bit for bit: uniform, clustered (rows overflow nsample),
     lattice (exact distance ties at the radius) and duplicated points, both radii of the shipped model."""
     import subprocess
     import sys
@@ -264,7 +267,7 @@ xyz = cloud(1, 1, 256, "uniform")
 assert (ops.ballquery(0.1, 8, torch.from_numpy(xyz).cuda(), torch.from_numpy(far).cuda()).cpu().numpy() == 0).all()
 print("grid variant ok")
 ''' % ROOT
-    env = dict(os.environ, RS_BALLQUERY_GRID="1")
+    env = dict(os.environ, RS_BALLQUERY_GRID="1", RS_BALLQUERY_CELLS=cells)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "grid variant ok" in out.stdout, out.stderr[-2000:]
 

@@ -317,3 +317,26 @@ def test_seg_pipelined_step_matches_eager(monkeypatch):
             loss.backward()
             want.append(loss.item())
     assert np.allclose(got, want, atol=3e-5), (got, want)
+
+
+def test_scene_scale_knn_and_median_filter():
+    """SURVEY §8(f)4 at scene scale: one cloud of 60 000 points through the packed kNN kernel (the whole-scene median
+    filter's search, segmentation/util/utils.py:235-245).  Bit-exact neighbour lists and distances against the oracle for
+    a 300-query subset (the oracle's O(N) scan per query is the reference kernel's algorithm); the filter's output is the
+    median of the labels over those lists."""
+    r = np.random.RandomState(5)
+    n = 60000
+    coord = (r.rand(n, 3) * np.array([8.0, 6.0, 3.0])).astype(np.float32)        # a room-sized box in metres
+    label = r.randint(0, 13, n).astype(np.int64)
+    off = np.array([n], np.int32)
+    with subproject("segmentation"):
+        from modules.pointops.functions import pointops
+        from util.utils import pc_median_filter_gpu
+        idx, dist = pointops.knnquery(16, dev(coord), dev(coord), dev(off), dev(off))
+        got = pc_median_filter_gpu(dev(coord), dev(label), group_size=16)
+    q = r.choice(n, 300, replace=False)
+    oi, od = G.knn_offset(16, coord, coord[q], off, np.array([len(q)], np.int32))
+    assert np.array_equal(idx.cpu().numpy()[q], oi)
+    assert np.abs(dist.cpu().numpy()[q] - np.sqrt(od)).max() <= 1e-6
+    ref = torch.median(torch.from_numpy(label[idx.cpu().numpy().astype(np.int64)]), 1)[0].numpy()
+    assert np.array_equal(got, ref)
