@@ -243,7 +243,15 @@ def roofline_from_profile(prof, timed_steps, dtype):
         roofline["avg_launch_us"] = round(row["avg_us"], 2)
         roofline["launches_per_step"] = row["launches"] // max(1, timed_steps)
         roofline["traffic"] = traffic_from_profiles(row["kernel"], row["dims"])
-        roofline["algorithmic_bytes"] = algorithmic_bytes(row["kernel"], row["dims"])
+        ab = algorithmic_bytes(row["kernel"], row["dims"])
+        roofline["algorithmic_bytes"] = ab
+        if ab and row["unit"] == "flops":
+            # a GEMM-shaped launch is priced against the roof that binds it: narrow layers (K, N <= 64) move more bytes per
+            # flop than the chip's balance (157 TF / 8 TB/s = 20 flop/B) and are HBM-bound, the wide ones are MFMA-bound
+            t_hbm, t_mfma = ab / (PEAK_HBM_GBS * 1e9), row["amount"] / (roofline["peak"] * 1e12)
+            roofline["frac_mfma"], roofline["frac_hbm"] = roofline["frac"], round(t_hbm / sec, 4)
+            if t_hbm > t_mfma:
+                roofline.update(bound="hbm", achieved=round(ab / sec / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(t_hbm / sec, 4))
         break
     # every MFMA launch of the step together (all shared-MLP GEMMs + weight-gradient GEMMs)
     fl = sum(r["amount"] * r["launches"] for r in table if r["unit"] == "flops")
