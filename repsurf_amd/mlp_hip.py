@@ -352,8 +352,18 @@ def flush_reduces():
         _lib.call("rs_reduce_partials", chunks, n, _ptr(part), _ptr(dw), _stream())
 
 
-def bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk=None):
-    """BN backward sums (`nblk` partial rows, default PARTIAL_BLOCKS) -> (p, q, r, dgamma, dbeta)."""
+def bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk=None, frozen=False):
+    """BN backward sums (`nblk` partial rows, default PARTIAL_BLOCKS) -> (p, q, r, dgamma, dbeta).
+    frozen=True (eval mode: the layer normalised with its running statistics, which are constants): dy = scale * dz, i.e.
+    p = scale, q = r = 0; dgamma / dbeta are the same sums (vec.mean / vec.invstd hold the running statistics)."""
+    if frozen:
+        out = _bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk)
+        zero = torch.zeros((2, c), dtype=torch.float32, device=device)
+        return vec.scale, zero[0], zero[1], out[3], out[4]
+    return _bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk)
+
+
+def _bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk=None):
     buf = torch.empty((5, c), dtype=torch.float32, device=device)
     if _pending_reduce:
         rpart, rchunks, rn, rdw = _pending_reduce.pop(0)
@@ -492,8 +502,7 @@ class _SAStack(Function):
     @staticmethod
     def backward(ctx, dout):
         s, meta = ctx.saved, ctx.meta
-        if not meta["training"]:
-            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented in the HIP executor")
+        frozen = not meta["training"]          # eval mode: BatchNorm is a constant affine (running statistics)
         x = s["x"]
         dev = x.device
         rows, cx = x.shape
@@ -514,7 +523,7 @@ class _SAStack(Function):
         _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), _ptr(s["out"]) if meta.get("relu_last", True) else None,
                   s["arg"].data_ptr(), _ptr(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
                   PARTIAL_BLOCKS, _stream())
-        p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev)
+        p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev, frozen=frozen)
         p_op = operand(OP_POOLED, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, arg=s["arg"], ns=ns, rs=rs)
         dx = None
         fork = _Fork(dev)
@@ -531,7 +540,8 @@ class _SAStack(Function):
             pidx = first + 4 * li
             cout, cin = w2ds[li].shape
             grads[pidx + 2], grads[pidx + 3] = dg, db
-            grads[pidx + 1] = zeros.take(cout)      # bias before BN: exactly 0
+            # bias before BN: exactly 0 with batch statistics; through frozen statistics it is scale * sum(dz)
+            grads[pidx + 1] = vecs[li].scale * db if frozen else zeros.take(cout)
             # the activation that fed this layer, rebuilt on the fly from the stored conv outputs
             if li > 0:
                 q_op = operand(OP_RELU1, ys[li - 1], cin, s1=vecs[li - 1].scale, t1=vecs[li - 1].shift)
@@ -544,7 +554,7 @@ class _SAStack(Function):
             if li > 0:      # data gradient, ReLU mask and BN-backward sums of layer li-1
                 dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], ys[li - 1], vecs[li - 1], device=dev,
                                                rows_dev=rdev, wt=wts[("l", li)])
-                p, q, r, dg, db = bwd_coeffs(cin, full, part, nstat, 1, vecs[li - 1], dev)
+                p, q, r, dg, db = bwd_coeffs(cin, full, part, nstat, 1, vecs[li - 1], dev, frozen=frozen)
                 if DEBUG is not None:
                     DEBUG["layer%d" % li] = dict(dz=dz, part=part, p=p, q=q, r=r, dg=dg, db=db, y=ys[li - 1], vec=vecs[li - 1])
                 p_op = operand(OP_AFF2, dz, cin, ys[li - 1], cin, s1=p, t1=r, s2=q, rs=rs)
@@ -552,8 +562,8 @@ class _SAStack(Function):
             elif pos > 0:   # two-branch first layer: one masked gradient, two BatchNorms
                 dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], s["yl"], s["vl"], s["yf"], s["vf"],
                                                device=dev, rows_dev=rdev, wt=wts[("l", 0)])
-                pl, ql, rl, dgl, dbl = bwd_coeffs(cin, full, part, 3, 1, s["vl"], dev)
-                pf, qf, rf, dgf, dbf = bwd_coeffs(cin, full, part, 3, 2, s["vf"], dev)
+                pl, ql, rl, dgl, dbl = bwd_coeffs(cin, full, part, 3, 1, s["vl"], dev, frozen=frozen)
+                pf, qf, rf, dgf, dbf = bwd_coeffs(cin, full, part, 3, 2, s["vf"], dev, frozen=frozen)
                 if DEBUG is not None:
                     DEBUG.update(dz0=dz, part0=part, pl=pl, ql=ql, rl=rl, pf=pf, qf=qf, rf=rf, dgl=dgl, dbl=dbl,
                                  dgf=dgf, dbf=dbf, yl=s["yl"], yf=s["yf"], vl=s["vl"], vf=s["vf"])
@@ -563,8 +573,8 @@ class _SAStack(Function):
                 foff, fk = meta.get("feat_off", pos), meta.get("feat_k", cx - pos)
                 grads[0] = fork.run(lambda: wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev, rdev, defer=True))
                 grads[4] = fork.run(lambda: wgrad(rows, cin, fk, opf, operand(OP_ID, x, cx, a_off=foff), dev, rdev, defer=True))
-                grads[1] = zeros.take(cin)
-                grads[5] = zeros.take(cin)
+                grads[1] = s["vl"].scale * dbl if frozen else zeros.take(cin)
+                grads[5] = s["vf"].scale * dbf if frozen else zeros.take(cin)
                 grads[2], grads[3], grads[6], grads[7] = dgl, dbl, dgf, dbf
                 if ctx.needs_input_grad[0]:
                     # Only the feature channels [pos:] carry a gradient (coordinates are inputs); the grouping
@@ -650,8 +660,7 @@ class _UmbrellaStack(Function):
     @staticmethod
     def backward(ctx, dout):
         s, meta = ctx.saved, ctx.meta
-        if not meta["training"]:
-            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented in the HIP executor")
+        frozen = not meta["training"]          # eval mode: BatchNorm is a constant affine (running statistics)
         x, y0, v0, y1, v1 = s["x"], s["y0"], s["v0"], s["y1"], s["v1"]
         dev = x.device
         rows, cx = x.shape
@@ -670,15 +679,16 @@ class _UmbrellaStack(Function):
             g_c2 = dout.sum(0) * group
         g_w2 = wgrad(rows, c2n, c1n, p2, operand(OP_RELU1, y1, c1n, s1=v1.scale, t1=v1.shift), dev)
         dz1, part, nstat = dgrad_masked(rows, c2n, c1n, p2, s["w2"], y1, v1, device=dev)
-        pa, qa, ra, g_g1, g_b1 = bwd_coeffs(c1n, rows, part, nstat, 1, v1, dev)
+        pa, qa, ra, g_g1, g_b1 = bwd_coeffs(c1n, rows, part, nstat, 1, v1, dev, frozen=frozen)
         p1 = operand(OP_AFF2, dz1, c1n, y1, c1n, s1=pa, t1=ra, s2=qa)
         g_w1 = wgrad(rows, c1n, c0n, p1, operand(OP_RELU1, y0, c0n, s1=v0.scale, t1=v0.shift), dev)
         dz0, part0, nstat0 = dgrad_masked(rows, c1n, c0n, p1, s["w1"], y0, v0, device=dev)
-        pb, qb, rb, g_g0, g_b0 = bwd_coeffs(c0n, rows, part0, nstat0, 1, v0, dev)
+        pb, qb, rb, g_g0, g_b0 = bwd_coeffs(c0n, rows, part0, nstat0, 1, v0, dev, frozen=frozen)
         p0 = operand(OP_AFF2, dz0, c0n, y0, c0n, s1=pb, t1=rb, s2=qb)
         g_w0 = wgrad(rows, c0n, cx, p0, operand(OP_ID, x, cx), dev)
         shp = meta["shapes"]
-        g_c1 = torch.zeros(c1n, dtype=torch.float32, device=dev)          # bias before BN: exactly 0
+        # bias before BN: exactly 0 with batch statistics; scale * sum(dz) through frozen ones
+        g_c1 = v1.scale * g_b1 if frozen else torch.zeros(c1n, dtype=torch.float32, device=dev)
         return (None, None, g_w0.reshape(shp[0]), g_g0, g_b0, g_w1.reshape(shp[1]), g_c1, g_g1, g_b1,
                 g_w2.reshape(shp[2]), g_c2)
 
@@ -786,8 +796,7 @@ class _UmbrellaStack2(Function):
     @staticmethod
     def backward(ctx, dout):
         s, meta = ctx.saved, ctx.meta
-        if not meta["training"]:
-            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented in the HIP executor")
+        frozen = not meta["training"]
         x, y0, v0 = s["x"], s["y0"], s["v0"]
         dev = x.device
         rows, cx = x.shape
@@ -798,11 +807,11 @@ class _UmbrellaStack2(Function):
         g_c1 = dout.sum(0) * group
         g_w1 = wgrad(rows, c1n, c0n, p1, operand(OP_RELU1, y0, c0n, s1=v0.scale, t1=v0.shift), dev)
         dz0, part0, nstat0 = dgrad_masked(rows, c1n, c0n, p1, s["w1"], y0, v0, device=dev)
-        pb, qb, rb, g_g0, g_b0 = bwd_coeffs(c0n, rows, part0, nstat0, 1, v0, dev)
+        pb, qb, rb, g_g0, g_b0 = bwd_coeffs(c0n, rows, part0, nstat0, 1, v0, dev, frozen=frozen)
         p0 = operand(OP_AFF2, dz0, c0n, y0, c0n, s1=pb, t1=rb, s2=qb)
         g_w0 = wgrad(rows, c0n, cx, p0, operand(OP_ID, x, cx), dev)
         shp = meta["shapes"]
-        g_c0 = torch.zeros(c0n, dtype=torch.float32, device=dev)          # bias before BN: exactly 0
+        g_c0 = v0.scale * g_b0 if frozen else torch.zeros(c0n, dtype=torch.float32, device=dev)   # bias before BN
         return None, None, g_w0.reshape(shp[0]), g_c0, g_g0, g_b0, g_w1.reshape(shp[1]), g_c1
 
 

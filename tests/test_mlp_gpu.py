@@ -386,3 +386,58 @@ def test_prepacked_weight_copies_do_not_outlive_their_model():
         wt = H.pack_weights([w2d], True, w2d.device)[0]
         torch.cuda.synchronize()
         assert torch.equal(wt[:, :12], w2d.t()), trial
+
+
+@pytest.mark.parametrize("groups,ns,pos,feat,widths", [CASES[0], CASES[4]])
+def test_sa_cd_stack_eval_mode_forward_and_backward(groups, ns, pos, feat, widths):
+    """model.eval(): BatchNorm normalises with its running statistics (constants).  Forward and every gradient of the HIP
+    stack against the PyTorch executor in eval mode (round 1 raised NotImplementedError in this backward)."""
+    mod = make_cd(pos, feat, widths, 3)
+    g = torch.Generator().manual_seed(5)
+    for bn in [mod.bn_l0, mod.bn_f0] + list(mod.bns):
+        bn.running_mean.copy_(torch.randn(bn.num_features, generator=g).cuda() * 0.2)
+        bn.running_var.copy_(torch.rand(bn.num_features, generator=g).cuda() + 0.5)
+    mod.eval()
+    x = torch.randn(groups * ns, pos + feat, generator=g).cuda()
+    w = torch.randn(groups, widths[-1], generator=g).cuda()
+    ref_mod = copy.deepcopy(mod)
+    out_t, g_t = run_cd(ref_mod, x, ns, pos, "torch", w)
+    out_h, g_h = run_cd(mod, x, ns, pos, "hip", w)
+    assert rel(out_h, out_t) < 2e-5, rel(out_h, out_t)
+    for name in g_t:
+        assert rel_l2(g_h[name], g_t[name]) < 3e-3, (name, rel_l2(g_h[name], g_t[name]))
+    assert torch.equal(mod.bn_l0.running_mean, ref_mod.bn_l0.running_mean)          # eval: statistics untouched
+
+
+@pytest.mark.parametrize("kind", ["cls3", "seg2"])
+def test_constructor_stacks_eval_mode_forward_and_backward(kind):
+    """The umbrella constructors' MLPs in eval mode (running statistics): forward and every gradient, bias gradients of the
+    convolutions in front of a BatchNorm included (non-zero through frozen statistics), against the PyTorch executor."""
+    from repsurf_amd import mlp
+    torch.manual_seed(7)
+    if kind == "cls3":
+        mlps = nn.Sequential(nn.Conv2d(10, 10, 1, bias=False), nn.BatchNorm2d(10), nn.ReLU(True), nn.Conv2d(10, 10, 1),
+                             nn.BatchNorm2d(10), nn.ReLU(True), nn.Conv2d(10, 10, 1)).cuda()
+    else:
+        mlps = nn.Sequential(nn.Conv1d(10, 10, 1), nn.BatchNorm1d(10), nn.ReLU(True), nn.Conv1d(10, 10, 1)).cuda()
+    for m in mlps:
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 1.5)
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+            nn.init.uniform_(m.bias, -0.3, 0.3)
+    mlps.eval()
+    group = 8 if kind == "cls3" else 9
+    x = torch.randn(200 * group, 10).cuda()
+    w = torch.randn(200, 10).cuda()
+    res = {}
+    for backend in ("torch", "hip"):
+        torch_executor.set_backend(backend)
+        m = copy.deepcopy(mlps)
+        out = mlp.umbrella_mlp(x, m, group, "sum") if kind == "cls3" else mlp.umbrella_mlp2(x, m, group)
+        (out * w).sum().backward()
+        res[backend] = (out.detach(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    torch_executor.set_backend("hip")
+    assert rel(res["hip"][0], res["torch"][0]) < 2e-5
+    for name, gt in res["torch"][1].items():
+        assert rel_l2(res["hip"][1][name], gt) < 3e-3, name
