@@ -431,6 +431,21 @@ int rs_furthestsampling_sectors(int b, int n_bound, const int *n_max_dev, const 
                                 const int *new_offset, float *temp, int *idx, void *stream);
 int rs_take_int(int n, const int *table, const int *idx, int *out, void *stream);
 
+/* ---- whole-scene kNN through a uniform grid (repsurf_amd/csrc/scene_knn.hip): pointops.knnquery for ONE large cloud, the
+ * search of segmentation/util/utils.py:235-245 (pc_median_filter_gpu) / tool/test_s3dis.py:203-232 at N ~ 1e5..1e6.
+ * lo / hi (3 HOST floats each): the rows' bounding box, cell: cell edge, g (3 HOST ints): cells per axis (<= 2^26 cells).
+ * rs_scene_cells: cell index per row + histogram (counts: g0*g1*g2 + 1 ints, zeroed by the caller); the caller turns the
+ * histogram into first positions (rs_exclusive_scan).  rs_scene_scatter: rows into cell-sorted float4 (x, y, z, row bits);
+ * `cursor` = a copy of the first positions, advanced in place.  rs_scene_knn: per query the nsample (<= 32) nearest rows of
+ * its 27 cells, ascending by (squared distance, row) -- same arithmetic and tie rule as rs_knnquery_offset; flag[q] = 0: the
+ * list is complete (nsample-th distance below the cell edge) and idx / dist2 row q is written; 1: run rs_knnquery_offset for
+ * this query. */
+int rs_scene_cells(int n, const float *xyz, const float *lo, const float *hi, float cell, const int *g, int *cell_of,
+                   int *counts, void *stream);
+int rs_scene_scatter(int n, const float *xyz, const int *cell_of, int *cursor, float *sorted, void *stream);
+int rs_scene_knn(int m, int nsample, const float *queries, const float *lo, const float *hi, float cell, const int *g,
+                 const int *starts, const float *sorted, int *idx, float *dist2, int *flag, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -58,6 +58,9 @@ SIGNATURES = {
     "rs_head_input_backward": [c_int, c_int, c_int, P, P, P, P],
     "rs_smooth_cls_loss": [c_int, c_int, c_float, P, P, P, P, P],
     "rs_adam_step": [P, P, P, P, c_int, P],
+    "rs_scene_cells": [c_int, P, P, P, ctypes.c_float, P, P, P, P],
+    "rs_scene_scatter": [c_int, P, P, P, P, P],
+    "rs_scene_knn": [c_int, c_int, P, P, P, ctypes.c_float, P, P, P, P, P, P, P],
     "rs_sectorize": [c_int, P, P, P, P, c_int, c_int, P, P, P, P, P, P],
     "rs_furthestsampling_sectors": [c_int, c_int, P, P, P, P, P, P, P],
     "rs_take_int": [c_int, P, P, P, P],

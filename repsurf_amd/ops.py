@@ -159,6 +159,60 @@ def sectorized_fps(xyz, offset, new_offset, num_sectors, min_points=10000):
     return out
 
 
+SCENE_GRID_MIN_ROWS = 32768      # below this the tiled scan (rs_knnquery_offset) is as fast and needs no set-up
+
+
+def knn_scene(nsample, xyz, new_xyz=None, return_stats=False):
+    """k nearest rows inside ONE large cloud (whole-scene inference: segmentation/util/utils.py:235-245,
+    tool/test_s3dis.py:203-232; pointops.knnquery with a single-entry offset): xyz (N,3), new_xyz (M,3) | None = xyz ->
+    idx (M,nsample) int32, dist2 (M,nsample) -- the same lists, bit for bit, as `knnquery_offset`, through a uniform grid:
+    rows are counting-sorted into cells of edge ~ (nsample / density)^(1/3), a query scans its 27 cells and its list is
+    accepted when the nsample-th distance is below the cell edge (then no row outside the block can be closer); the other
+    queries (and those outside the rows' bounding box) go through the exact tiled scan.  Reads the bounding box and the
+    flagged queries back to the host (a scene-level helper, not a training-step operator)."""
+    import ctypes
+    _need_gpu(xyz, new_xyz)
+    xyz = _f32c(xyz)
+    q = xyz if new_xyz is None else _f32c(new_xyz)
+    n, m, dev = xyz.shape[0], q.shape[0], xyz.device
+    one = offsets_tensor([n], dev)
+    if n < SCENE_GRID_MIN_ROWS or nsample > 32:
+        idx, d2 = knnquery_offset(nsample, xyz, q, one, offsets_tensor([m], dev))
+        return (idx, d2, {"grid": False}) if return_stats else (idx, d2)
+    lo_t, hi_t = xyz.min(0).values, xyz.max(0).values
+    lo, hi = [float(v) for v in lo_t.tolist()], [float(v) for v in hi_t.tolist()]
+    ext = [max(h - l, 1e-6) for l, h in zip(lo, hi)]
+    vol = ext[0] * ext[1] * ext[2]
+    cell = (nsample * vol / n) ** (1.0 / 3.0)                   # ~nsample rows per cell at the mean density
+    g = [int(e / cell) + 1 for e in ext]
+    while g[0] * g[1] * g[2] > (1 << 24):                        # keep the cell table <= 64 MB
+        cell *= 1.26
+        g = [int(e / cell) + 1 for e in ext]
+    ncell = g[0] * g[1] * g[2]
+    f3, i3 = ctypes.c_float * 3, ctypes.c_int * 3
+    clo, chi, cg = f3(*lo), f3(*hi), i3(*g)
+    counts = torch.zeros((ncell + 1,), dtype=torch.int32, device=dev)
+    cell_of = torch.empty((n,), dtype=torch.int32, device=dev)
+    _lib.call("rs_scene_cells", n, _p(xyz), clo, chi, cell, cg, _p(cell_of), _p(counts), _stream())
+    starts = torch.empty((ncell + 2,), dtype=torch.int32, device=dev)
+    _lib.call("rs_exclusive_scan", ncell + 1, _p(counts), _p(starts), _stream())
+    cursor = starts[:ncell + 1].clone()
+    cells = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    _lib.call("rs_scene_scatter", n, _p(xyz), _p(cell_of), _p(cursor), _p(cells), _stream())
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=dev)
+    d2 = torch.empty((m, nsample), dtype=torch.float32, device=dev)
+    flag = torch.empty((m,), dtype=torch.int32, device=dev)
+    _lib.call("rs_scene_knn", m, nsample, _p(q), clo, chi, cell, cg, _p(starts), _p(cells), _p(idx), _p(d2), _p(flag), _stream())
+    bad = torch.nonzero(flag).squeeze(1)
+    if bad.numel():
+        bi, bd = knnquery_offset(nsample, xyz, q[bad].contiguous(), one, offsets_tensor([int(bad.numel())], dev))
+        idx[bad] = bi
+        d2[bad] = bd
+    if return_stats:
+        return idx, d2, {"grid": True, "cells": ncell, "cell_edge": cell, "rescanned": int(bad.numel())}
+    return idx, d2
+
+
 def umbrella_fan_offset(xyz, new_xyz, knn_idx, new_offset, inv_sign=None, rotate=True):
     """Segmentation umbrella fan: knn_idx (M,k) global rows of the k nearest neighbours (query included) ->
     (M, k, 10) = [polar, normal, const, centroid] per fan triangle

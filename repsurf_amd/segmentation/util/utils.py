@@ -3,7 +3,6 @@ the loss factory and the whole-scene kNN median filter used at test time (refere
 import torch
 import torch.nn as nn
 
-from modules.pointops.functions import pointops
 from repsurf_amd import ops
 
 
@@ -13,9 +12,9 @@ def get_loss(weight=None, ignore_label=None):
 
 def pc_median_filter_gpu(coord, label, group_size=16):
     """Median of the predicted labels over each point's `group_size` nearest neighbours (itself included) of one
-    whole scene: coord (N,3), label (N,) -> numpy (N,)  (reference :233-245).  The kNN runs on the packed-batch
-    HIP kernel with a single cloud; the scene size is known on the host, so nothing is read back for the search."""
-    offset = ops.offsets_tensor([coord.shape[0]], coord.device)
-    group_idx, _ = pointops.knnquery(group_size, coord, coord, offset, offset)
+    whole scene: coord (N,3), label (N,) -> numpy (N,)  (reference :233-245).  The kNN runs through
+    repsurf_amd.ops.knn_scene: a uniform-grid search at scene scale (exactly the lists of the tiled scan), the scan itself
+    for small clouds."""
+    group_idx, _ = ops.knn_scene(group_size, coord)        # grid search for scenes, the tiled scan below 32 768 rows
     group_label = label[group_idx.view(-1).long()].view(coord.shape[0], group_size)
     return torch.median(group_label, 1)[0].cpu().numpy()

@@ -340,3 +340,32 @@ def test_scene_scale_knn_and_median_filter():
     assert np.abs(dist.cpu().numpy()[q] - np.sqrt(od)).max() <= 1e-6
     ref = torch.median(torch.from_numpy(label[idx.cpu().numpy().astype(np.int64)]), 1)[0].numpy()
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("kind,n,k", [("room", 120000, 16), ("uniform", 60000, 8), ("room", 70000, 3), ("room", 40000, 32)])
+def test_scene_grid_knn_equals_scan(ops, kind, n, k):
+    """ops.knn_scene (uniform grid + exact re-scan of the queries whose list cannot be proven complete) returns the tiled
+    scan's lists and distances bit for bit: scene-like surfaces (points on walls / floor / furniture planes: density far from
+    uniform, many empty cells), a uniform box, queries = the rows and queries elsewhere (some outside the bounding box)."""
+    r = np.random.RandomState(n + k)
+    if kind == "room":
+        parts = []
+        for axis, val in ((2, 0.0), (2, 3.0), (0, 0.0), (0, 8.0), (1, 0.0), (1, 6.0), (2, 0.8), (2, 0.45)):
+            p = r.rand(n // 8, 3) * np.array([8.0, 6.0, 3.0])
+            p[:, axis] = val + 0.01 * r.randn(n // 8)
+            parts.append(p)
+        xyz = np.concatenate(parts).astype(np.float32)
+    else:
+        xyz = (r.rand(n, 3) * np.array([4.0, 4.0, 3.0])).astype(np.float32)
+    x = dev(xyz)
+    off = ops.offsets_tensor([xyz.shape[0]], x.device)
+    idx, d2, stats = ops.knn_scene(k, x, return_stats=True)
+    ref_i, ref_d = ops.knnquery_offset(k, x, x, off, off)
+    assert stats["grid"] and stats["rescanned"] < 0.05 * xyz.shape[0], stats
+    assert torch.equal(idx, ref_i) and torch.equal(d2, ref_d), stats
+    qn = 5000
+    qs = (r.rand(qn, 3) * np.array([9.0, 7.0, 3.5]) - 0.5).astype(np.float32)          # ~25 % outside the bounding box
+    qi, qd, qstats = ops.knn_scene(k, x, dev(qs), return_stats=True)
+    ri, rd = ops.knnquery_offset(k, x, dev(qs), off, ops.offsets_tensor([qn], x.device))
+    assert torch.equal(qi, ri) and torch.equal(qd, rd), qstats
+    print("scene kNN", kind, n, k, stats, "queries elsewhere:", qstats)
