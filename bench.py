@@ -50,8 +50,8 @@ def parse():
                     help="cls: BASELINE configs[1] (the metric; configs[4] with --dtype bf16 --batch 64 --points 2048); "
                          "seg: configs[3], RepSurf-U S3DIS segmentation, 16 clouds x 4096 points x (xyz+rgb) per GPU")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="arithmetic of the shared-MLP row GEMMs: fp32 MFMA (configs[1], the metric) or bf16 MFMA with fp32 "
-                         "accumulation and storage (configs[4]: use --batch 64 --points 2048)")
+                    help="arithmetic of the shared-MLP row GEMMs: fp32 MFMA (configs[1], the metric) or bf16 MFMA operands and "
+                         "bf16 storage of the conv outputs with fp32 accumulation (configs[4]: use --batch 64 --points 2048)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N=1 graph mode: compute each batch's geometry inside its own step instead of under the previous "
                          "batch's network (repsurf_amd.graph.PipelinedStep)")
@@ -188,20 +188,29 @@ def algorithmic_cost(name, dims):
 
 def algorithmic_bytes(name, dims):
     """HBM bytes one launch must move (each operand / mask tensor read once, the output written once):
-    row GEMM: 4 * rows * (K * operand tensors + N * (1 + mask tensors)); weight gradient: 4 * rows * (N * P tensors +
-    K * Q tensors).  Operand tensors: ID / RELU1 / BCAST 1, RELU2 / AFF2 / POOLED 2 (POOLED's pooled gradient is small)."""
+    row GEMM: rows * (K * operand tensors + N * (1 + mask tensors)) elements; weight gradient: rows * (N * P tensors +
+    K * Q tensors) elements; 4 bytes per element, 2 for the tensors the launch's "sb=" note marks as bf16-stored."""
     notes = dict(d.split("=", 1) for d in dims if isinstance(d, str))
     ints = [d for d in dims if not isinstance(d, str)]
     rows = float(notes["rows"]) if "rows" in notes else float(ints[0])
-    ntens = {0: 1, 1: 1, 2: 2, 3: 2, 4: 1, 5: 0}          # per operand mode (POOLED: y only; BCAST: broadcast source is tiny)
+    # tensors an operand mode reads, as (a, b) presence: ID / RELU1: a; RELU2 / AFF2: a and b; POOLED: b only (the pooled
+    # gradient behind a is small); BCAST: the broadcast source is tiny.  "sb=" marks the tensors stored as bf16 (2 bytes).
+    reads = {0: (1, 0), 1: (1, 0), 2: (1, 1), 3: (1, 1), 4: (0, 1), 5: (0, 0)}
+    sb = notes.get("sb", "00000")
+    width = lambda i: 2.0 if sb[i] == "1" else 4.0
     if name.startswith("rs_mlp_gemm_rows") and "op" in notes:
         k, n = ints[1], ints[2]
         epi = notes.get("epi", "0")
-        masks = 0 if not epi.startswith("2") else (2 if epi.endswith("+2") else 1)
-        return 4.0 * rows * (k * ntens[int(notes["op"])] + n * (1 + masks))
+        ra, rb = reads[int(notes["op"])]
+        total = k * (ra * width(0) + rb * width(1)) + n * width(2)
+        if epi.startswith("2"):
+            total += n * width(3) + (n * width(4) if epi.endswith("+2") else 0.0)
+        return rows * total
     if name.startswith("rs_mlp_wgrad") and "p" in notes:
         n, k = ints[1], ints[2]
-        return 4.0 * rows * (n * ntens[int(notes["p"])] + k * ntens[int(notes["q"])])
+        pa, pb = reads[int(notes["p"])]
+        qa, qb = reads[int(notes["q"])]
+        return rows * (n * (pa * width(0) + pb * width(1)) + k * (qa * width(2) + qb * width(3)))
     return None
 
 
@@ -410,7 +419,7 @@ def main_seg(args):
         out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, 4096-pt clouds @ B=16 per GPU", "value": round(clouds * world * args.steps / dt, 2),
                "unit": "clouds/s", "points_per_s": round(n * world * args.steps / dt), "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.dtype == "fp32" else "bf16 MFMA operands, f32 accumulate/storage",
+               "dtype": "f32" if args.dtype == "fp32" else "bf16 MFMA operands + bf16 conv-output storage, f32 accumulate / BatchNorm sums / gradients / parameters",
                "data": "synthetic uniform [-1,1]^3 clouds + uniform rgb, random-init weights",
                "config": {"workload": f"configs[3]: RepSurf-U S3DIS segmentation (repsurf_umb_ssg), B={clouds}x{pts}x6 per GPU, {args.dtype}, "
                                       f"encoder + FP decoder + classifier, fwd+CE+bwd" + ("" if args.no_optim else "+Adam step"),
@@ -572,7 +581,7 @@ def main():
         out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U 1024-pt cls @ B=32 per GPU", "value": round(value, 2),
                "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.dtype == "fp32" else "bf16 MFMA operands, f32 accumulate/storage", "data": "synthetic uniform [-1,1]^3 clouds, random-init weights",
+               "dtype": "f32" if args.dtype == "fp32" else "bf16 MFMA operands + bf16 conv-output storage, f32 accumulate / BatchNorm sums / gradients / parameters", "data": "synthetic uniform [-1,1]^3 clouds, random-init weights",
                "config": {"workload": f"configs[{1 if args.dtype == 'fp32' else 4}]: RepSurf-U ({args.model}) classifier, B={args.batch}x{args.points} pts "
                                       f"per GPU, {args.dtype}, full encoder + head, fwd+loss+bwd"
                                       + ("" if args.no_optim else "+Adam step"),

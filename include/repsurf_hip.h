@@ -227,6 +227,9 @@ typedef struct rs_row_operand {
    * E = s1*dz + mult*(s2*b + t1) with dz the gradient already summed over the copies;
    * grp[r], slot[r] = group and position of row r (RS_OP_POOLED with ragged groups; NULL = r/ns, r%ns). */
   const float *mult; const int *grp; const int *slot;
+  /* bf16 activation storage (BASELINE configs[4], rs_mlp_*_bf16 entry points only): a / b point to bf16 tensors (same
+   * shapes and leading dimensions, in elements) instead of fp32 ones.  The fp32 entry points reject a non-zero flag. */
+  int a_bf16, b_bf16;
 } rs_row_operand;
 
 enum {
@@ -245,6 +248,10 @@ typedef struct rs_mlp_epilogue {
    * pool_ns must divide 64 / 32 / 16 for cols > 64 / > 32 / <= 32. */
   int pool_ns; float *pool_max, *pool_min; int *pool_amax, *pool_amin;
   const float *row_mult;   /* RS_EPI_STATS: per-row weight of the sums (copies a compacted row stands for; NULL = 1) */
+  /* bf16 activation storage (rs_mlp_gemm_rows_bf16 only): `out` / `my1` / `my2` are bf16 tensors.  With out_bf16 the result
+   * is rounded to bf16 (nearest even) FIRST and the BatchNorm sums / fused pooling see the rounded values -- what the
+   * consumers of the stored tensor will read (torch.autocast does the same: a bf16 conv output feeds an fp32 BatchNorm). */
+  int out_bf16, my1_bf16, my2_bf16;
 } rs_mlp_epilogue;
 
 /* out[rows, cols] = E[rows, kdim] . W^T,  W[n][k] = w[n*ldw + k]: weights are passed n-major, i.e. a conv weight
@@ -297,7 +304,8 @@ int rs_bn_backward_finalize(int c, long long rows, int nblk, int nstat, int whic
  * scale/shift may be NULL (identity). */
 /* offsets (optional, (groups+1) int32): ragged groups of a compacted row set (rows [offsets[g], offsets[g+1]));
  * NULL = dense groups of nsample rows. */
-int rs_pool_max(long long groups, int nsample, int c, int relu, const int *offsets, const float *y,
+/* y_bf16 != 0: y is a bf16 tensor (bf16 activation storage, written by rs_mlp_gemm_rows_bf16 with out_bf16). */
+int rs_pool_max(long long groups, int nsample, int c, int relu, const int *offsets, const float *y, int y_bf16,
                 const float *scale, const float *shift, float *out, int *arg, void *stream);
 /* Resolves the fused pooling of rs_mlp_gemm_rows: out = relu(scale * (scale >= 0 ? ymax : ymin) + shift),
  * arg = the matching position. */
@@ -307,8 +315,8 @@ int rs_pool_select(long long groups, int c, const float *ymax, const float *ymin
  * partial (partial_blocks, 2, c) = {sum v, sum v * yhat[arg row]}.  out = NULL: the pooled layer ended without a
  * ReLU (rs_pool_max called with relu = 0), v = dout. */
 int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout,
-                         const float *out, const int *arg, const float *y, const float *mean, const float *invstd,
-                         float *v, double *partial, int partial_blocks, void *stream);
+                         const float *out, const int *arg, const float *y, int y_bf16, const float *mean,
+                         const float *invstd, float *v, double *partial, int partial_blocks, void *stream);
 /* out[g][c] = sum_k y[g*nsample+k][c]   (umbrella aggregation 'sum', :305) */
 int rs_pool_sum(long long groups, int nsample, int c, const float *y, float *out, void *stream);
 

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -43,8 +43,8 @@ SIGNATURES = {
     "rs_mlp_wgrad_bf16": [c_ll, P, c_int, c_int, P, P, P, c_int, P, P],
     "rs_bn_finalize": [c_int, c_ll, c_int, P, P, P, c_float, c_float, P, P, P, P, P, P, P],
     "rs_bn_backward_finalize": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P],
-    "rs_pool_max": [c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P],
-    "rs_pool_max_backward": [c_ll, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, P],
+    "rs_pool_max": [c_ll, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P],
+    "rs_pool_max_backward": [c_ll, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, c_int, P],
     "rs_pool_sum": [c_ll, c_int, c_int, P, P, P],
     "rs_pool_select": [c_ll, c_int, P, P, P, P, P, P, P, P, P],
     "rs_reduce_partials": [c_int, c_ll, P, P, P],
@@ -184,8 +184,15 @@ def call(name, *args):
         if name in ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16"):
             op, ep = args[4]._obj, args[7]._obj
             dims = dims + (f"op={op.mode}", f"epi={ep.mode}{'+2' if ep.my2 else ''}")
+            sb = f"{op.a_bf16}{op.b_bf16}{ep.out_bf16}{ep.my1_bf16}{ep.my2_bf16}"     # bf16-stored tensors: a, b, out, my1, my2
+            if "1" in sb:
+                dims = dims + (f"sb={sb}",)
         elif name in ("rs_mlp_wgrad", "rs_mlp_wgrad_bf16"):
-            dims = dims + (f"p={args[4]._obj.mode}", f"q={args[5]._obj.mode}")
+            pp, qq = args[4]._obj, args[5]._obj
+            dims = dims + (f"p={pp.mode}", f"q={qq.mode}")
+            sb = f"{pp.a_bf16}{pp.b_bf16}{qq.a_bf16}{qq.b_bf16}"                     # P.a, P.b, Q.a, Q.b
+            if "1" in sb:
+                dims = dims + (f"sb={sb}",)
         if name in ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16", "rs_mlp_wgrad", "rs_mlp_wgrad_bf16") and args[1] is not None:
             # compacted operand: args[0] is only the capacity, the launch's row count lives on the device
             slot = _copy_device_int_async(args[1])

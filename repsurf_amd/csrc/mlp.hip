@@ -23,13 +23,22 @@
 #include "rs_common.h"
 #include <stdlib.h>
 #include <math.h>
+#include <type_traits>
 
-// The library builds this file as two translation units so that the fp32 and the bf16 instances compile in parallel
-// (Makefile): RS_MLP_TU = 0 -> every entry point except the two *_bf16 ones, 1 -> only rs_mlp_gemm_rows_bf16 and
-// rs_mlp_wgrad_bf16 (plus the fp32 instances they fall back to), 2 (default, experiment builds) -> everything.
+// The library builds this file as three translation units that compile in parallel (Makefile):
+//   RS_MLP_TU = 0  every entry point except the two *_bf16 ones (fp32 kernels);
+//   RS_MLP_TU = 1  only rs_mlp_gemm_rows_bf16 and rs_mlp_wgrad_bf16 (bf16 MFMA operands, fp32 tensors in HBM), plus the fp32
+//                  instances they fall back to;
+//   RS_MLP_TU = 3  the same two with bf16 ACTIVATION STORAGE (rs_sb_*: reached through the entry points of unit 1 when a
+//                  call marks tensors as bf16).  Which tensor of a launch is bf16 is a function of the operand mode, fixed at
+//                  compile time (sb_a / sb_b below): run-time flags in the load path cost 10 % of the bf16 step time, the
+//                  halved bytes win back 15 %;
+//   RS_MLP_TU = 2  (default, experiment builds of tools/build_exp.sh) units 0 + 1 in one.
 #ifndef RS_MLP_TU
 #define RS_MLP_TU 2
 #endif
+#define RS_TU_HAS_BF16 (RS_MLP_TU != 0)                         /* BF = true instances */
+#define RS_TU_BF16_ONLY (RS_MLP_TU == 1 || RS_MLP_TU == 3)      /* no fp32 entry points, no pooling / packing / BatchNorm kernels */
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -72,6 +81,68 @@ template <int V> __device__ __forceinline__ void ldv(const float *p, float (&d)[
 #pragma unroll
   for (int i = 0; i < V; ++i) d[i] = f[i];
 }
+// bf16 activation storage: only translation unit 3 carries the code; in the others every test below is a compile-time false
+// and the kernels are what they were.
+constexpr bool RS_STORE_BF16 = RS_MLP_TU == 3;
+// Storage roles (unit 3).  The bf16 tensors are the pre-BatchNorm conv outputs y, and a launch meets them in fixed places:
+//   operand a: y under RELU1 / RELU2 (the activation rebuilt from y); fp32 under ID (stack input), AFF2 (masked gradient dz),
+//              POOLED (pooled gradient) and BCAST;
+//   operand b: always a y (RELU2's second branch, the y of AFF2 / POOLED's BatchNorm-backward term);
+//   mask tensors my1 / my2: always y;   output: y (bf16) behind a forward operand (ID / RELU1 / RELU2), a gradient (fp32)
+//   behind a backward one.  The host checks a call's flags against this table (sb_check_*).
+__host__ __device__ constexpr bool sb_a(int mode) { return RS_STORE_BF16 && (mode == RS_OP_RELU1 || mode == RS_OP_RELU2); }
+__host__ __device__ constexpr bool sb_b(int mode) { return RS_STORE_BF16 && (mode == RS_OP_RELU2 || mode == RS_OP_AFF2 || mode == RS_OP_POOLED); }
+__host__ __device__ constexpr bool sb_out(int mode) { return RS_STORE_BF16 && mode <= RS_OP_RELU2; }
+constexpr bool SB_MASK = RS_STORE_BF16;
+
+// V consecutive elements at index e of an fp32 or (bf) bf16 tensor behind a float* base.  A bf16 tensor is loaded as RAW
+// BITS into the first V/2 registers (V = 1: the zero-extended half word) and widened by bf16_expand where the values are
+// used: a conversion right behind the load would make every prefetch wait for its own data.
+template <int V> __device__ __forceinline__ void ldx(const float *base, long long e, bool bf, float (&d)[V]) {
+  if constexpr (RS_STORE_BF16) {
+    // ONE address for both element sizes (a second per-lane 64-bit address per load cost 10-30 VGPRs in the pipelined kernels)
+    const char *p = reinterpret_cast<const char *>(base) + (e << (bf ? 1 : 2));
+    if (bf) {
+      if constexpr (V == 4) { const uint2 u = *reinterpret_cast<const uint2 *>(p); d[0] = __uint_as_float(u.x); d[1] = __uint_as_float(u.y); }
+      else if constexpr (V == 2) d[0] = __uint_as_float(*reinterpret_cast<const unsigned *>(p));
+      else d[0] = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short *>(p));
+    } else {
+      ldv<V>(reinterpret_cast<const float *>(p), d);
+    }
+  } else {
+    ldv<V>(base + e, d);
+  }
+}
+// raw bits of ldx -> fp32 values, in place (exact: a bf16 is the upper half of an fp32)
+template <int V> __device__ __forceinline__ void bf16_expand(float (&d)[V], bool bf) {
+  if (RS_STORE_BF16 && bf) {
+    if constexpr (V == 4) {
+      const unsigned u0 = __float_as_uint(d[0]), u1 = __float_as_uint(d[1]);
+      d[0] = __uint_as_float(u0 << 16); d[1] = __uint_as_float(u0 & 0xffff0000u);
+      d[2] = __uint_as_float(u1 << 16); d[3] = __uint_as_float(u1 & 0xffff0000u);
+    } else if constexpr (V == 2) {
+      const unsigned u0 = __float_as_uint(d[0]);
+      d[0] = __uint_as_float(u0 << 16); d[1] = __uint_as_float(u0 & 0xffff0000u);
+    } else {
+      d[0] = __uint_as_float(__float_as_uint(d[0]) << 16);
+    }
+  }
+}
+__device__ __forceinline__ float ld1x(const float *base, long long e, int bf) {
+  if (RS_STORE_BF16 && bf) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(base)[e] << 16);
+  return base[e];
+}
+// base + e elements of an fp32 or bf16 tensor, still typed float* (the accessors above take element offsets from it)
+template <typename T> __device__ __forceinline__ T *tile_base(T *base, long long e, int bf) {
+  using B = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+  return reinterpret_cast<T *>(reinterpret_cast<B *>(base) + e * ((RS_STORE_BF16 && bf) ? 2 : 4));
+}
+// fp32 -> bf16 bits, round to nearest even (v_cvt_pk_bf16_f32 on a pair with itself)
+__device__ __forceinline__ unsigned short bf16_bits(float v) {
+  return (unsigned short)(__float_as_uint(pack_bf16(v, v)) & 0xffffu);
+}
+__device__ __forceinline__ float bf16_round(float v) { return __uint_as_float((unsigned)bf16_bits(v) << 16); }
+
 template <int V> __device__ __forceinline__ void ldvi(const int *p, int (&d)[V]) {
   typename VecT<V>::I v = *reinterpret_cast<const typename VecT<V>::I *>(p);
   const int *f = reinterpret_cast<const int *>(&v);
@@ -107,23 +178,24 @@ __device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int r
   if (!ok) return;
   const int offa = rl * (int)o.lda + c, offb = rl * (int)o.ldb + c;
   switch (mode) {
-    case OPM_ID: case OPM_RELU1: ldv<V>(o.a + r0 * o.lda + offa, raw.a); break;
-    case OPM_RELU2: ldv<V>(o.a + r0 * o.lda + offa, raw.a); ldv<V>(o.b + r0 * o.ldb + offb, raw.b); break;
+    case OPM_ID: ldx<V>(o.a, r0 * o.lda + offa, sb_a(OPM_ID), raw.a); break;
+    case OPM_RELU1: ldx<V>(o.a, r0 * o.lda + offa, sb_a(OPM_RELU1), raw.a); break;
+    case OPM_RELU2: ldx<V>(o.a, r0 * o.lda + offa, sb_a(OPM_RELU2), raw.a); ldx<V>(o.b, r0 * o.ldb + offb, sb_b(OPM_RELU2), raw.b); break;
     case OPM_AFF2:
-      ldv<V>(o.a + r0 * o.lda + offa, raw.a); ldv<V>(o.b + r0 * o.ldb + offb, raw.b);
+      ldx<V>(o.a, r0 * o.lda + offa, sb_a(OPM_AFF2), raw.a); ldx<V>(o.b, r0 * o.ldb + offb, sb_b(OPM_AFF2), raw.b);
       if (o.mult) raw.m = o.mult[r0 + rl];
       break;
     case OPM_POOLED: {
       unsigned g;
       if (o.grp) { g = (unsigned)o.grp[r0 + rl]; raw.k = o.slot[r0 + rl]; }           // compacted (ragged) groups
       else { g = (unsigned)(r0 + rl) / (unsigned)o.ns; raw.k = (int)((unsigned)(r0 + rl) - g * (unsigned)o.ns); }
-      ldv<V>(o.a + (long long)g * o.lda + c, raw.a);
+      ldx<V>(o.a, (long long)g * o.lda + c, sb_a(OPM_POOLED), raw.a);
       ldvi<V>(o.arg + (long long)g * o.lda + c, raw.g);
-      ldv<V>(o.b + r0 * o.ldb + offb, raw.b);
+      ldx<V>(o.b, r0 * o.ldb + offb, sb_b(OPM_POOLED), raw.b);
       if (o.mult) raw.m = o.mult[r0 + rl];
       break;
     }
-    default: ldv<V>(o.a + (long long)((unsigned)(r0 + rl) / (unsigned)o.ns) * o.lda + c, raw.a); break;
+    default: ldx<V>(o.a, (long long)((unsigned)(r0 + rl) / (unsigned)o.ns) * o.lda + c, sb_a(OPM_BCAST), raw.a); break;
   }
 }
 
@@ -133,15 +205,20 @@ template <int V, int MODE>
 __device__ __forceinline__ void op_finish(const RowOperand &o, const ColCoef<V> &k, const RawVec<V> &raw,
                                           long long r, bool ok, float (&out)[V]) {
   const int mode = MODE >= 0 ? MODE : o.mode;
+  float ra[V], rb[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { ra[i] = raw.a[i]; rb[i] = raw.b[i]; }
+  bf16_expand<V>(ra, sb_a(mode));
+  bf16_expand<V>(rb, sb_b(mode));
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     float v;
     switch (mode) {
-      case OPM_ID: case OPM_BCAST: v = raw.a[i]; break;
-      case OPM_RELU1: v = fmaxf(fmaf(k.s1[i], raw.a[i], k.t1[i]), 0.f); break;
-      case OPM_RELU2: v = fmaxf(fmaf(k.s1[i], raw.a[i], k.t1[i]) + fmaf(k.s2[i], raw.b[i], k.t2[i]), 0.f); break;
-      case OPM_AFF2: v = fmaf(k.s1[i], raw.a[i], raw.m * fmaf(k.s2[i], raw.b[i], k.t1[i])); break;
-      default: v = fmaf(k.s1[i], (raw.g[i] == raw.k) ? raw.a[i] : 0.f, raw.m * fmaf(k.s2[i], raw.b[i], k.t1[i])); break;
+      case OPM_ID: case OPM_BCAST: v = ra[i]; break;
+      case OPM_RELU1: v = fmaxf(fmaf(k.s1[i], ra[i], k.t1[i]), 0.f); break;
+      case OPM_RELU2: v = fmaxf(fmaf(k.s1[i], ra[i], k.t1[i]) + fmaf(k.s2[i], rb[i], k.t2[i]), 0.f); break;
+      case OPM_AFF2: v = fmaf(k.s1[i], ra[i], raw.m * fmaf(k.s2[i], rb[i], k.t1[i])); break;
+      default: v = fmaf(k.s1[i], (raw.g[i] == raw.k) ? ra[i] : 0.f, raw.m * fmaf(k.s2[i], rb[i], k.t1[i])); break;
     }
     out[i] = ok ? v : 0.f;
   }
@@ -405,9 +482,10 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
                                                               // not hoisted out of the tile loop into ~100 long-lived VGPRs
       const int ldo = (int)ep.ldo, ldm1 = (int)ep.ldm1, ldm2 = (int)ep.ldm2;      // tile-relative offsets fit 32 bits
       const bool full = r0 + BM <= rows;
-      float *out_t = ep.out + r0 * ep.ldo;
-      const float *my1_t = ep.my1 ? ep.my1 + r0 * ep.ldm1 : nullptr;
-      const float *my2_t = ep.my2 ? ep.my2 + r0 * ep.ldm2 : nullptr;
+      const bool obf = sb_out(MODE >= 0 ? MODE : E.mode);     // bf16 tensors: same element offsets, half the bytes
+      float *out_t = tile_base(ep.out, r0 * ep.ldo, obf);
+      const float *my1_t = ep.my1 ? tile_base(ep.my1, r0 * ep.ldm1, SB_MASK) : nullptr;
+      const float *my2_t = ep.my2 ? tile_base(ep.my2, r0 * ep.ldm2, SB_MASK) : nullptr;
       // forward operand modes never come with the mask epilogue, backward ones never with the statistics one:
       // the dead branch (and its registers) vanishes from the specialised instances
       constexpr bool CAN_STATS = MODE < 0 || MODE <= OPM_RELU2, CAN_MASK = MODE < 0 || MODE >= OPM_AFF2;
@@ -426,11 +504,35 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         const int cc = cok ? col : cols - 1;
         float y1v[16], y2v[16];
         if (CAN_MASK && EPI == EPI_MASK) {                    // the 16 (32) mask loads of this column tile in flight at once
+          int mrl[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int rl = full ? rbase + (i & 3) + 8 * (i >> 2) : (int)min((long long)(rbase + (i & 3) + 8 * (i >> 2)), rows - 1 - r0);
-            y1v[i] = my1_t[rl * ldm1 + cc];
-            y2v[i] = my2_t ? my2_t[rl * ldm2 + cc] : 0.f;
+          for (int i = 0; i < 16; ++i)
+            mrl[i] = full ? rbase + (i & 3) + 8 * (i >> 2) : (int)min((long long)(rbase + (i & 3) + 8 * (i >> 2)), rows - 1 - r0);
+          // bf16 tensors: raw half words first (one branch around all loads), widened once they are all requested
+          if (SB_MASK) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y1v[i] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(my1_t)[mrl[i] * ldm1 + cc]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y1v[i] = my1_t[mrl[i] * ldm1 + cc];
+          }
+          if (!my2_t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y2v[i] = 0.f;
+          } else if (SB_MASK) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y2v[i] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(my2_t)[mrl[i] * ldm2 + cc]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y2v[i] = my2_t[mrl[i] * ldm2 + cc];
+          }
+          if (SB_MASK) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y1v[i] = __uint_as_float(__float_as_uint(y1v[i]) << 16);
+          }
+          if (SB_MASK && my2_t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y2v[i] = __uint_as_float(__float_as_uint(y2v[i]) << 16);
           }
         }
         const float bias = ep.bias ? ep.bias[cc] : 0.f;
@@ -440,11 +542,13 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
           if (my2_t) { ms2 = ep.ms2[cc]; mt2 = ep.mt2[cc]; mu2 = ep.mean2[cc]; is2 = ep.invstd2[cc]; }
         }
         float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        float ykeep[16];                                        // (bf16 output only) the rounded values, stored in pairs below
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int rl = rbase + (i & 3) + 8 * (i >> 2);
           const bool ok = cok && (full || r0 + rl < rows);
           float y = acc[c][i] + bias;
+          if (obf) y = bf16_round(y);                           // the sums below see what the stored tensor holds
           if (CAN_MASK && EPI == EPI_MASK) {
             float z = fmaf(ms1, y1v[i], mt1);
             if (my2_t) z += fmaf(ms2, y2v[i], mt2);
@@ -457,7 +561,31 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
             t0 = fmaf(mw[i], yy, t0);
             t1 = fmaf(mw[i] * yy, yy, t1);
           }
-          if (ok) out_t[rl * ldo + col] = y;
+          if (RS_STORE_BF16) ykeep[i] = y;
+          if (ok && !obf) out_t[rl * ldo + col] = y;
+        }
+        if (obf) {
+          // two bf16 per store: lanes j, j + 1 (adjacent columns) trade one value per row pair (i, i + 1) -- the even lane
+          // writes columns (j, j + 1) of row i, the odd lane columns (j - 1, j) of row i + 1: 8 dword stores instead of
+          // 16 half-word ones, each instruction covering 64-byte row segments
+          const bool odd = lrow & 1;
+          const bool pair_ok = (cols % 2 == 0) && (ldo % 2 == 0);          // dword-aligned pairs, both columns in range
+          unsigned short *o16 = reinterpret_cast<unsigned short *>(out_t);
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            const int rl0 = rbase + (i & 3) + 8 * (i >> 2), rl1 = rl0 + 1;
+            const float send = odd ? ykeep[i] : ykeep[i + 1];
+            const float recv = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(send), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+            if (pair_ok) {
+              const int rl = odd ? rl1 : rl0;
+              const unsigned lo = __float_as_uint(odd ? recv : ykeep[i]), hi = __float_as_uint(odd ? ykeep[i + 1] : recv);
+              if (cok && (full || r0 + rl < rows))
+                *reinterpret_cast<unsigned *>(o16 + rl * ldo + (col & ~1)) = (lo >> 16) | (hi & 0xffff0000u);
+            } else {
+              if (cok && (full || r0 + rl0 < rows)) o16[rl0 * ldo + col] = (unsigned short)(__float_as_uint(ykeep[i]) >> 16);
+              if (cok && (full || r0 + rl1 < rows)) o16[rl1 * ldo + col] = (unsigned short)(__float_as_uint(ykeep[i + 1]) >> 16);
+            }
+          }
         }
         st0[c] += t0; st1[c] += t1; st2[c] += t2;
       }
@@ -489,26 +617,31 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
             if (ep.my2) { ms2[e] = ep.ms2[col + e]; mt2[e] = ep.mt2[col + e]; mu2[e] = ep.mean2[col + e]; is2[e] = ep.invstd2[col + e]; }
           }
         }
-        float *out_t = ep.out + r0 * ep.ldo;                    // wave-uniform tile bases
-        const float *my1_t = ep.my1 ? ep.my1 + r0 * ep.ldm1 : nullptr;
-        const float *my2_t = ep.my2 ? ep.my2 + r0 * ep.ldm2 : nullptr;
+        const bool obf = sb_out(MODE >= 0 ? MODE : E.mode);
+        float *out_t = tile_base(ep.out, r0 * ep.ldo, obf);     // wave-uniform tile bases
+        const float *my1_t = ep.my1 ? tile_base(ep.my1, r0 * ep.ldm1, SB_MASK) : nullptr;
+        const float *my2_t = ep.my2 ? tile_base(ep.my2, r0 * ep.ldm2, SB_MASK) : nullptr;
         for (int rl = e_row; rl < BM; rl += E_RPP) {
           if (r0 + rl >= rows || col >= cols) continue;
           const float4 cv = *reinterpret_cast<const float4 *>(Cs + rl * BN + e_col);
           float y[4] = {cv.x + bias[0], cv.y + bias[1], cv.z + bias[2], cv.w + bias[3]};
+          if (obf) {
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = bf16_round(y[e]);
+          }
           if (EPI == EPI_MASK) {
             float y1[4], y2[4] = {0.f, 0.f, 0.f, 0.f};
             if (ep_vec) {
-              const float4 t = *reinterpret_cast<const float4 *>(my1_t + (long long)rl * ep.ldm1 + col);
-              y1[0] = t.x; y1[1] = t.y; y1[2] = t.z; y1[3] = t.w;
-              if (my2_t) { const float4 u = *reinterpret_cast<const float4 *>(my2_t + (long long)rl * ep.ldm2 + col);
-                           y2[0] = u.x; y2[1] = u.y; y2[2] = u.z; y2[3] = u.w; }
+              ldx<4>(my1_t, (long long)rl * ep.ldm1 + col, SB_MASK, y1);
+              if (my2_t) ldx<4>(my2_t, (long long)rl * ep.ldm2 + col, SB_MASK, y2);
+              bf16_expand<4>(y1, SB_MASK);
+              if (my2_t) bf16_expand<4>(y2, SB_MASK);
             } else {
   #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const bool cok = col + e < cols;
-                y1[e] = cok ? my1_t[(long long)rl * ep.ldm1 + col + e] : 0.f;
-                if (my2_t) y2[e] = cok ? my2_t[(long long)rl * ep.ldm2 + col + e] : 0.f;
+                y1[e] = cok ? ld1x(my1_t, (long long)rl * ep.ldm1 + col + e, SB_MASK) : 0.f;
+                if (my2_t) y2[e] = cok ? ld1x(my2_t, (long long)rl * ep.ldm2 + col + e, SB_MASK) : 0.f;
               }
             }
   #pragma unroll
@@ -525,7 +658,17 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   #pragma unroll
             for (int e = 0; e < 4; ++e) { s0[e] = fmaf(mw, y[e], s0[e]); s1[e] = fmaf(mw * y[e], y[e], s1[e]); }
           }
-          if (ep_vec) {
+          if (obf) {
+            unsigned short *o16 = reinterpret_cast<unsigned short *>(out_t) + (long long)rl * ep.ldo + col;
+            if (ep_vec) {
+              *reinterpret_cast<uint2 *>(o16) = make_uint2((__float_as_uint(y[0]) >> 16) | (__float_as_uint(y[1]) & 0xffff0000u),
+                                                           (__float_as_uint(y[2]) >> 16) | (__float_as_uint(y[3]) & 0xffff0000u));
+            } else {
+  #pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (col + e < cols) o16[e] = (unsigned short)(__float_as_uint(y[e]) >> 16);
+            }
+          } else if (ep_vec) {
             *reinterpret_cast<float4 *>(out_t + (long long)rl * ep.ldo + col) = make_float4(y[0], y[1], y[2], y[3]);
           } else {
   #pragma unroll
@@ -546,7 +689,8 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
             float mx = -INFINITY, mn = INFINITY;
             int ax = 0, an = 0;
             for (int k = 0; k < ep.pool_ns; ++k) {
-              const float v = Cs[(g0 + k) * BN + c] + bb;
+              float v = Cs[(g0 + k) * BN + c] + bb;
+              if (sb_out(MODE >= 0 ? MODE : E.mode)) v = bf16_round(v);       // pool what the stored tensor holds
               if (v > mx) { mx = v; ax = k; }
               if (v < mn) { mn = v; an = k; }
             }
@@ -883,11 +1027,23 @@ gemm_small_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim
       for (int k = 0; k < WS_KP; ++k) t = fmaf(x[k], wr[i][k], t);
       y[i] = t + bias[i];
     }
+    if (sb_out(OPM_ID)) {                                         // bf16 storage (always an ID operand here): round first, sum what was stored
+      unsigned short *o16 = reinterpret_cast<unsigned short *>(ep.out) + r * ep.ldo + n0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = bf16_round(y[i]);
+      if (vec_ok) *reinterpret_cast<uint2 *>(o16) = make_uint2((__float_as_uint(y[0]) >> 16) | (__float_as_uint(y[1]) & 0xffff0000u),
+                                                               (__float_as_uint(y[2]) >> 16) | (__float_as_uint(y[3]) & 0xffff0000u));
+      else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (n0 + i < cols) o16[i] = (unsigned short)(__float_as_uint(y[i]) >> 16);
+      }
+    } else {
     float *o = ep.out + r * ep.ldo + n0;
     if (vec_ok) *reinterpret_cast<float4 *>(o) = make_float4(y[0], y[1], y[2], y[3]);
     else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) if (n0 + i < cols) o[i] = y[i];
+    }
     }
     if (stats) {
       const float mw = ep.row_mult ? ep.row_mult[r] : 1.f;
@@ -1178,8 +1334,15 @@ bn_bwd_finalize_reduce_kernel(int c, long long rows, int nblk, int nstat, int wh
   if (dbeta) dbeta[ch] = (float)db;
 }
 
+// element e of the pooled layer's pre-activation y: fp32, or bf16 (bf16 activation storage) behind the same pointer type
+template <bool BF> __device__ __forceinline__ float ldy(const float *y, long long e) {
+  if constexpr (BF) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(y)[e] << 16);
+  else return y[e];
+}
+
 // ---- pooling over nsample, fused with the last BatchNorm + ReLU -----------------------------------
 // out[g][c] = max_k relu(scale*y[g*ns+k][c] + shift), arg = first k attaining it
+template <bool BF>
 __global__ void __launch_bounds__(GM_THREADS)
 pool_max_kernel(long long groups, int ns, int c, int relu, const int *__restrict__ offsets, const float *__restrict__ y,
                 const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
@@ -1193,7 +1356,7 @@ pool_max_kernel(long long groups, int ns, int c, int relu, const int *__restrict
     const long long base = offsets ? offsets[g] : g * ns;             // ragged (compacted) or dense groups
     const int len = offsets ? offsets[g + 1] - offsets[g] : ns;
     for (int k = 0; k < len; ++k) {
-      float z = fmaf(s, y[(base + k) * c + ch], t);
+      float z = fmaf(s, ldy<BF>(y, (base + k) * c + ch), t);
       if (relu) z = fmaxf(z, 0.f);
       if (z > best) { best = z; bi = k; }
     }
@@ -1205,6 +1368,7 @@ pool_max_kernel(long long groups, int ns, int c, int relu, const int *__restrict
 // is 32 K threads walking 128 rows each -- half the chip, a 128-deep load chain (39 us for 16 MB).  Here a workgroup
 // takes 64 channels of one group, its 4 waves take every 4th row with 4 loads in flight, and the slices meet in LDS;
 // the first row attaining the maximum wins, as in the sequential scan.
+template <bool BF>
 __global__ void __launch_bounds__(GM_THREADS)
 pool_max_long_kernel(int ns, int c, int relu, const float *__restrict__ y, const float *__restrict__ scale,
                      const float *__restrict__ shift, float *__restrict__ out, int *__restrict__ arg) {
@@ -1216,11 +1380,11 @@ pool_max_long_kernel(int ns, int c, int relu, const float *__restrict__ y, const
   float best = -INFINITY; int bi = 0x7fffffff;
   if (ch < c) {
     const float s = scale ? scale[ch] : 1.f, t = shift ? shift[ch] : 0.f;
-    const float *col = y + g * ns * c + ch;
+    const long long col = g * ns * c + ch;
     for (int k0 = ty; k0 < ns; k0 += 16) {
       float z[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) z[u] = (k0 + 4 * u < ns) ? col[(long long)(k0 + 4 * u) * c] : 0.f;
+      for (int u = 0; u < 4; ++u) z[u] = (k0 + 4 * u < ns) ? ldy<BF>(y, col + (long long)(k0 + 4 * u) * c) : 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (k0 + 4 * u >= ns) break;
@@ -1259,6 +1423,7 @@ pool_select_kernel(long long groups, int c, const float *__restrict__ ymax, cons
 
 // v[g][c] = dout * (out > 0)  (out == NULL: v = dout); partial sums {sum v, sum v * yhat[arg row]} per column (BatchNorm backward
 // of the pooled layer computed from G x C data only)
+template <bool BF>
 __global__ void __launch_bounds__(GM_THREADS)
 pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ offsets, const float *__restrict__ dout,
                     const float *__restrict__ out, const int *__restrict__ arg, const float *__restrict__ y,
@@ -1276,7 +1441,7 @@ pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ off
       const long long e = g * c + ch;
       const float val = (!out || out[e] > 0.f) ? dout[e] : 0.f;      // out == NULL: the pooled layer ended without a ReLU
       v[e] = val;
-      const float yy = y[((offsets ? (long long)offsets[g] : g * ns) + arg[e]) * c + ch];
+      const float yy = ldy<BF>(y, ((offsets ? (long long)offsets[g] : g * ns) + arg[e]) * c + ch);
       s0 += (double)val;
       s1 += (double)(val * ((yy - mu) * is));
     }
@@ -1365,11 +1530,11 @@ void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_de
 template <int BM, int BN>
 void launch_gemm(bool bf, int v, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                  const float *w, int ldw, const Epilogue &ep) {
-#if RS_MLP_TU != 0
+#if RS_TU_HAS_BF16
   if (bf && v == 4) { launch_gemm_m<BM, BN, 4, true>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep); return; }
   if (bf && v == 2) { launch_gemm_m<BM, BN, 2, true>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep); return; }
 #endif
-#if RS_MLP_TU != 1      // (the bf16-only unit calls with bf = true: vector operands never get here)
+#if !RS_TU_BF16_ONLY      // (the bf16-only unit calls with bf = true: vector operands never get here)
   if (v == 4) { launch_gemm_m<BM, BN, 4, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep); return; }
   if (v == 2) { launch_gemm_m<BM, BN, 2, false>(grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep); return; }
 #endif
@@ -1401,11 +1566,11 @@ template <int WN, int WK, int TN, int TK, int VP, int VQ>
 void launch_wgrad_p(bool bf, dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
                     const RowOperand &Q, float *partial) {
   constexpr bool ok = wgrad_bf16_ok<WN, WK, TN, TK, VP, VQ>();
-  if constexpr (ok && RS_MLP_TU != 0) {
+  if constexpr (ok && RS_TU_HAS_BF16) {
     if (bf) { launch_wgrad_m<WN, WK, TN, TK, VP, VQ, true>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial); return; }
   }
   (void)bf;
-  if constexpr (RS_MLP_TU != 1 || !ok)      // (the bf16-only unit needs the fp32 instance only where bf16 staging is impossible)
+  if constexpr (!RS_TU_BF16_ONLY || !ok)      // (the bf16-only unit needs the fp32 instance only where bf16 staging is impossible)
     launch_wgrad_m<WN, WK, TN, TK, VP, VQ, false>(grid, st, rows, rows_dev, ncols, kcols, P, Q, partial);
 }
 template <int WN, int WK, int TN, int TK>
@@ -1444,6 +1609,15 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
     const int rpt = GM_BM / (GM_THREADS / (cols <= 32 ? 32 : (cols <= 64 ? 64 : 128)));   // (pooling keeps 128-wide tiles)
     RS_REQUIRE(rows % ep.pool_ns == 0 && rpt % ep.pool_ns == 0,
                "rs_mlp_gemm_rows: fused pooling needs nsample (%d) to divide %d rows per thread", ep.pool_ns, rpt);
+  }
+  if (RS_STORE_BF16) {       // unit 3: the call's flags must be the storage-role table (top of this file)
+    const bool masked = epi_mode == EPI_MASK;
+    RS_REQUIRE((E.a_bf16 != 0) == sb_a(E.mode) && (E.mode == OPM_ID || E.mode == OPM_RELU1 || E.mode == OPM_BCAST || (E.b_bf16 != 0) == sb_b(E.mode)) &&
+               (ep.out_bf16 != 0) == sb_out(E.mode) && (!masked || (ep.my1_bf16 && (!ep.my2 || ep.my2_bf16))) && !(masked && sb_out(E.mode)),
+               "rs_mlp_gemm_rows_bf16: bf16 storage needs y tensors (RELU1/RELU2 a, every b, masks, forward outputs) bf16 and the rest fp32 "
+               "(mode %d, a %d b %d out %d my1 %d my2 %d)", E.mode, E.a_bf16, E.b_bf16, ep.out_bf16, ep.my1_bf16, ep.my2_bf16);
+  } else {
+    RS_REQUIRE(!(E.a_bf16 || E.b_bf16 || ep.out_bf16 || ep.my1_bf16 || ep.my2_bf16), "rs_mlp_gemm_rows: bf16 tensors are taken by rs_mlp_gemm_rows_bf16 only");
   }
   hipStream_t st0 = (hipStream_t)stream;
   static const int small_on = env_int("RS_GEMM_SMALL", 1);
@@ -1491,18 +1665,32 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
   return RS_OK;
 }
 
-#if RS_MLP_TU != 1
+#if !RS_TU_BF16_ONLY
 extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
                                 const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
   return gemm_rows_impl(false, rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
 }
 #endif
-#if RS_MLP_TU != 0
+#if RS_MLP_TU == 3
+// bf16 activation storage: the instances of this unit behind the public entry point of unit 1 (not part of the ABI)
+extern "C" __attribute__((visibility("hidden"))) int rs_sb_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
+                                                                     const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
+  return gemm_rows_impl(true, rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
+}
+#elif RS_TU_HAS_BF16
+#if RS_MLP_TU == 1
+extern "C" int rs_sb_gemm_rows(long long, const int *, int, int, const rs_row_operand *, const float *, int, const rs_mlp_epilogue *, void *);
+#endif
 // Mixed precision (BASELINE configs[4]): same contract, operands rounded to bf16 at the LDS commit, bf16 MFMA with
 // fp32 accumulation.  Launches the fp32 instance where the layout forces scalar operand loads or the narrow
-// streaming kernel applies (kdim <= 16, unaligned: no matrix pipe involved).
+// streaming kernel applies (kdim <= 16, unaligned: no matrix pipe involved).  A call that marks tensors as bf16
+// (a_bf16 / b_bf16 / out_bf16 / my*_bf16) runs the bf16-storage instances.
 extern "C" int rs_mlp_gemm_rows_bf16(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
                                      const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
+#if RS_MLP_TU == 1
+  if (x && epi && (x->a_bf16 || x->b_bf16 || epi->out_bf16 || epi->my1_bf16 || epi->my2_bf16))
+    return rs_sb_gemm_rows(rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
+#endif
   return gemm_rows_impl(true, rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
 }
 
@@ -1518,6 +1706,15 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
   rc = check_operand("rs_mlp_wgrad(Q)", q, rows);
   if (rc != RS_OK) return rc;
   RowOperand P = *p, Q = *q;
+  if (RS_STORE_BF16) {
+    auto role_ok = [](const RowOperand &o) {
+      return (o.a_bf16 != 0) == sb_a(o.mode) && (o.mode == OPM_ID || o.mode == OPM_RELU1 || o.mode == OPM_BCAST || (o.b_bf16 != 0) == sb_b(o.mode));
+    };
+    RS_REQUIRE(role_ok(P) && role_ok(Q), "rs_mlp_wgrad_bf16: bf16 storage needs y tensors (RELU1/RELU2 a, every b) bf16 and the rest fp32 "
+               "(P mode %d a %d b %d, Q mode %d a %d b %d)", P.mode, P.a_bf16, P.b_bf16, Q.mode, Q.a_bf16, Q.b_bf16);
+  } else {
+    RS_REQUIRE(!(P.a_bf16 || P.b_bf16 || Q.a_bf16 || Q.b_bf16), "rs_mlp_wgrad: bf16 tensors are taken by rs_mlp_wgrad_bf16 only");
+  }
   if (P.ns <= 0) P.ns = 1;
   if (Q.ns <= 0) Q.ns = 1;
   hipStream_t st = (hipStream_t)stream;
@@ -1555,24 +1752,37 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
   return RS_OK;
 }
 
-#if RS_MLP_TU != 1
+#if !RS_TU_BF16_ONLY
 extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
                             const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
   return wgrad_impl(false, rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
 }
 #endif
-#if RS_MLP_TU != 0
+#if RS_MLP_TU == 3
+extern "C" __attribute__((visibility("hidden"))) int rs_sb_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
+                                                                 const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
+  return wgrad_impl(true, rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
+}
+#elif RS_TU_HAS_BF16
+#if RS_MLP_TU == 1
+extern "C" int rs_sb_wgrad(long long, const int *, int, int, const rs_row_operand *, const rs_row_operand *, float *, int, float *, void *);
+#endif
 // Mixed precision: both operands rounded to bf16 after their fp32 prologue, bf16 MFMA, fp32 accumulation inside a
 // row slab; the slabs' partial products and their fixed-order sum stay fp32.  The narrow streaming kernel
 // (kcols <= 16) and the layouts that force scalar loads or one vector per thread (kcols <= 32, float4) run in fp32.
+// Operands that mark tensors as bf16 run the bf16-storage instances.
 extern "C" int rs_mlp_wgrad_bf16(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
                                  const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
+#if RS_MLP_TU == 1
+  if (p && q && (p->a_bf16 || p->b_bf16 || q->a_bf16 || q->b_bf16))
+    return rs_sb_wgrad(rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
+#endif
   return wgrad_impl(true, rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
 }
 
 #endif
 
-#if RS_MLP_TU != 1      // everything below: fp32 unit only
+#if !RS_TU_BF16_ONLY      // everything below: fp32 unit only
 // ---- padded copies of up to RS_PACK_MAX conv weights (cout, cin) in one launch --------------------------------
 // transpose = 0:  dst[j*ld + k] = src[j*cin + k]  (k < cin, else 0), ld >= cin    -- forward operand of rs_mlp_gemm_rows
 //                 when cin is not a multiple of 4 (otherwise the conv weight is used in place);
@@ -1671,20 +1881,24 @@ extern "C" int rs_bn_backward_finalize_reduce(int c, long long rows, int nblk, i
 }
 
 extern "C" int rs_pool_max(long long groups, int nsample, int c, int relu, const int *offsets, const float *y,
-                           const float *scale, const float *shift, float *out, int *arg, void *stream) {
+                           int y_bf16, const float *scale, const float *shift, float *out, int *arg, void *stream) {
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0, "rs_pool_max: bad size");
   if (groups == 0 || c == 0) return RS_OK;
   RS_REQUIRE(y && out && arg, "rs_pool_max: null pointer");
   if (!offsets && nsample >= 64 && groups <= 65535 && groups * c <= (1 << 18)) {
-    hipLaunchKernelGGL(pool_max_long_kernel, dim3((int)groups, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, (hipStream_t)stream,
-                       nsample, c, relu, y, scale, shift, out, arg);
+    if (y_bf16) hipLaunchKernelGGL(pool_max_long_kernel<true>, dim3((int)groups, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, (hipStream_t)stream,
+                                   nsample, c, relu, y, scale, shift, out, arg);
+    else hipLaunchKernelGGL(pool_max_long_kernel<false>, dim3((int)groups, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, (hipStream_t)stream,
+                            nsample, c, relu, y, scale, shift, out, arg);
     RS_CHECK_LAUNCH("rs_pool_max");
     return RS_OK;
   }
   long long blocks = (groups * c + GM_THREADS - 1) / GM_THREADS;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(pool_max_kernel, dim3((int)blocks), dim3(GM_THREADS), 0, (hipStream_t)stream, groups, nsample, c,
-                     relu, offsets, y, scale, shift, out, arg);
+  if (y_bf16) hipLaunchKernelGGL(pool_max_kernel<true>, dim3((int)blocks), dim3(GM_THREADS), 0, (hipStream_t)stream, groups, nsample, c,
+                                 relu, offsets, y, scale, shift, out, arg);
+  else hipLaunchKernelGGL(pool_max_kernel<false>, dim3((int)blocks), dim3(GM_THREADS), 0, (hipStream_t)stream, groups, nsample, c,
+                          relu, offsets, y, scale, shift, out, arg);
   RS_CHECK_LAUNCH("rs_pool_max");
   return RS_OK;
 }
@@ -1704,7 +1918,7 @@ extern "C" int rs_pool_select(long long groups, int c, const float *ymax, const 
 }
 
 extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout,
-                                    const float *out, const int *arg, const float *y, const float *mean,
+                                    const float *out, const int *arg, const float *y, int y_bf16, const float *mean,
                                     const float *invstd, float *v, double *partial, int partial_blocks, void *stream) {
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0 && partial_blocks > 0, "rs_pool_max_backward: bad size");
   if (groups == 0 || c == 0) return RS_OK;
@@ -1714,8 +1928,10 @@ extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const 
   hipStream_t st = (hipStream_t)stream;
   if (gx < partial_blocks)
     (void)hipMemsetAsync(partial + (long long)gx * 2 * c, 0, sizeof(double) * (size_t)(partial_blocks - gx) * 2 * c, st);
-  hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(gx, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, st, groups, nsample, c,
-                     offsets, dout, out, arg, y, mean, invstd, v, partial);
+  if (y_bf16) hipLaunchKernelGGL(pool_max_bwd_kernel<true>, dim3(gx, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, st, groups, nsample, c,
+                                 offsets, dout, out, arg, y, mean, invstd, v, partial);
+  else hipLaunchKernelGGL(pool_max_bwd_kernel<false>, dim3(gx, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, st, groups, nsample, c,
+                          offsets, dout, out, arg, y, mean, invstd, v, partial);
   RS_CHECK_LAUNCH("rs_pool_max_backward");
   return RS_OK;
 }
@@ -1730,4 +1946,4 @@ extern "C" int rs_pool_sum(long long groups, int nsample, int c, const float *y,
   RS_CHECK_LAUNCH("rs_pool_sum");
   return RS_OK;
 }
-#endif   // RS_MLP_TU != 1
+#endif   // !RS_TU_BF16_ONLY

@@ -32,7 +32,8 @@ WGRAD_MIN_ROWS = int(os.environ.get("REPSURF_WGRAD_MIN_ROWS", "128"))   # rows p
 
 class RowOperand(ctypes.Structure):          # rs_row_operand
     _fields_ = [("a", P), ("lda", c_ll), ("b", P), ("ldb", c_ll), ("s1", P), ("t1", P), ("s2", P), ("t2", P),
-                ("arg", P), ("ns", c_int), ("mode", c_int), ("mult", P), ("grp", P), ("slot", P)]
+                ("arg", P), ("ns", c_int), ("mode", c_int), ("mult", P), ("grp", P), ("slot", P),
+                ("a_bf16", c_int), ("b_bf16", c_int)]
 
 
 class Epilogue(ctypes.Structure):            # rs_mlp_epilogue
@@ -41,7 +42,7 @@ class Epilogue(ctypes.Structure):            # rs_mlp_epilogue
                 ("my2", P), ("ldm2", c_ll), ("ms2", P), ("mt2", P), ("mean2", P), ("invstd2", P),
                 ("partial", P), ("partial_blocks", c_int),
                 ("pool_ns", c_int), ("pool_max", P), ("pool_min", P), ("pool_amax", P), ("pool_amin", P),
-                ("row_mult", P)]
+                ("row_mult", P), ("out_bf16", c_int), ("my1_bf16", c_int), ("my2_bf16", c_int)]
 
 
 def _stream():
@@ -49,13 +50,32 @@ def _stream():
 
 
 def _ptr(t, offset=0):
-    return None if t is None else t.data_ptr() + 4 * offset
+    return None if t is None else t.data_ptr() + t.element_size() * offset
+
+
+def _bf(t):
+    """1 for a bf16 tensor (bf16 activation storage), else 0"""
+    return int(t is not None and t.dtype == torch.bfloat16)
+
+
+# bf16 mode (mlp.PRECISION == "bf16", BASELINE configs[4]): an SA stack stores its pre-BatchNorm conv outputs -- the only large
+# tensors it writes in forward and re-reads in backward -- as bf16 (torch.autocast stores them the same way); the BatchNorm
+# sums, the pooled activations, every gradient and every parameter stay fp32.  The kernels fix which tensor of a launch is
+# bf16 by its operand mode (csrc/mlp.hip, "storage roles"), so a stack stores either ALL its conv outputs as bf16 or none:
+# all, when every layer width is a multiple of 4 (8-byte vector stores).  REPSURF_BF16_STORE=0: fp32 storage.
+BF16_STORE = os.environ.get("REPSURF_BF16_STORE", "1") != "0"
+
+
+def stores_bf16(widths):
+    from . import mlp as _mlp
+    return bool(BF16_STORE and _mlp.PRECISION == "bf16" and all(c % 4 == 0 for c in widths))
 
 
 def operand(mode, a, lda, b=None, ldb=0, s1=None, t1=None, s2=None, t2=None, arg=None, ns=1, a_off=0, rs=None):
     """rs: RowSet — attaches the per-row multiplicity / ragged group maps of a compacted row set."""
     op = RowOperand(_ptr(a, a_off), lda, _ptr(b), ldb, _ptr(s1), _ptr(t1), _ptr(s2), _ptr(t2),
                     None if arg is None else arg.data_ptr(), ns, mode)
+    op.a_bf16, op.b_bf16 = _bf(a), _bf(b)
     if rs is not None and rs.mult is not None and mode in (OP_AFF2, OP_POOLED):
         op.mult = _ptr(rs.mult)
         if mode == OP_POOLED:
@@ -264,19 +284,20 @@ def fused_pool_ok(cout, nsample):
     return rows_per_thread % nsample == 0
 
 
-def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, rs=None, wk=None):
+def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, rs=None, wk=None, store_bf16=False):
     """y = E . W^T + bias with BN statistics; returns (y, BNVec[, pooled (out, arg)]).
-    rs: RowSet of a compacted operand (device row count, per-row weights of the statistics)."""
+    rs: RowSet of a compacted operand (device row count, per-row weights of the statistics).
+    store_bf16: y is written as bf16 (rounded first; statistics and pooling see the rounded values)."""
     cout = w2d.shape[0]
     rows_dev = rs.dev if rs is not None else None
     bn_rows = rs.full if rs is not None else rows
-    y = torch.empty((rows, cout), dtype=torch.float32, device=device)
+    y = torch.empty((rows, cout), dtype=torch.bfloat16 if store_bf16 else torch.float32, device=device)
     vec = BNVec(cout, device)
     pool = None
     if training:
         part = torch.empty((PARTIAL_BLOCKS, 2, cout), dtype=torch.float64, device=device)
         epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STATS, partial=part.data_ptr(),
-                       partial_blocks=PARTIAL_BLOCKS)
+                       partial_blocks=PARTIAL_BLOCKS, out_bf16=_bf(y))
         if rs is not None and rs.mult is not None:
             epi.row_mult = _ptr(rs.mult)
         if pool_ns:
@@ -304,7 +325,7 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
                       _ptr(vec.scale), _ptr(vec.shift), _ptr(out), arg.data_ptr(), _stream())
             return y, vec, (out, arg)
     else:
-        epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STORE)
+        epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STORE, out_bf16=_bf(y))
         gemm_rows(rows, kdim, cout, x_op, wk if wk is not None else w_fwd(w2d), epi, rows_dev)
         with torch.no_grad():
             invstd = torch.rsqrt(bn_mod.running_var + bn_mod.eps)
@@ -384,7 +405,7 @@ def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=N
     part = torch.empty((PARTIAL_BLOCKS, nstat, cols), dtype=torch.float64, device=device)
     epi = Epilogue(bias=None, out=_ptr(dz), ldo=cols, mode=EPI_MASK,
                    my1=_ptr(y1), ldm1=cols, ms1=_ptr(v1.scale), mt1=_ptr(v1.shift), mean1=_ptr(v1.mean), invstd1=_ptr(v1.invstd),
-                   partial=part.data_ptr(), partial_blocks=PARTIAL_BLOCKS)
+                   partial=part.data_ptr(), partial_blocks=PARTIAL_BLOCKS, my1_bf16=_bf(y1), my2_bf16=_bf(y2))
     if y2 is not None:
         epi.my2, epi.ldm2 = _ptr(y2), cols
         epi.ms2, epi.mt2, epi.mean2, epi.invstd2 = _ptr(v2.scale), _ptr(v2.shift), _ptr(v2.mean), _ptr(v2.invstd)
@@ -454,13 +475,14 @@ class _SAStack(Function):
         ys, vecs, w2ds = [], [], []
         all_w2d = [_w2d(params[i]) for i in range(0, len(params), 4)]
         wks = fwd_weights(all_w2d, dev)            # conv weights in place; one batched padded copy for odd cin
+        sb = stores_bf16([w.shape[0] for w in all_w2d])
         foff, fk = meta.get("feat_off", pos), meta.get("feat_k", cx - pos)   # feature branch: columns [foff, foff + fk)
         if pos > 0:      # two-branch first layer (SurfaceAbstractionCD)
             wl, bl, wf, bf = params[0], params[1], params[4], params[5]
             wl2, wf2 = all_w2d[0], all_w2d[1]
-            yl, vl = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev, rs=rs, wk=wks[0])
+            yl, vl = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev, rs=rs, wk=wks[0], store_bf16=sb)
             yf, vf = fwd_layer(rows, operand(OP_ID, x, cx, a_off=foff), fk, wf2, bf, bns[1], training, dev, rs=rs,
-                               wk=wks[1])
+                               wk=wks[1], store_bf16=sb)
             saved.update(yl=yl, vl=vl, yf=yf, vf=vf, wl2=wl2, wf2=wf2)
             prev_op = operand(OP_RELU2, yl, yl.shape[1], yf, yf.shape[1], vl.scale, vl.shift, vf.scale, vf.shift)
             prev_c = wl2.shape[0]
@@ -475,9 +497,9 @@ class _SAStack(Function):
             w2, wk = all_w2d[pi // 4], wks[pi // 4]
             last = pi + 4 >= len(params)
             if last and training and rs.dev is None and ns > 1 and meta.get("relu_last", True) and fused_pool_ok(w2.shape[0], ns):      # (ns = 1: a plain row stack, nothing to pool)
-                y, vec, pooled = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, pool_ns=ns, wk=wk)
+                y, vec, pooled = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, pool_ns=ns, wk=wk, store_bf16=sb)
             else:
-                y, vec = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, rs=rs, wk=wk)
+                y, vec = fwd_layer(rows, prev_op, prev_c, w2, b, bns[bi], training, dev, rs=rs, wk=wk, store_bf16=sb)
             ys.append(y); vecs.append(vec); w2ds.append(w2)
             prev_op = operand(OP_RELU1, y, y.shape[1], s1=vec.scale, t1=vec.shift)
             prev_c = w2.shape[0]
@@ -488,7 +510,7 @@ class _SAStack(Function):
             y_last, v_last = ys[-1], vecs[-1]
             out = torch.empty((groups, prev_c), dtype=torch.float32, device=dev)
             arg = torch.empty((groups, prev_c), dtype=torch.int32, device=dev)
-            _lib.call("rs_pool_max", groups, ns, prev_c, int(meta.get("relu_last", True)), _ptr(rs.offsets), _ptr(y_last), _ptr(v_last.scale),
+            _lib.call("rs_pool_max", groups, ns, prev_c, int(meta.get("relu_last", True)), _ptr(rs.offsets), _ptr(y_last), _bf(y_last), _ptr(v_last.scale),
                       _ptr(v_last.shift), _ptr(out), arg.data_ptr(), _stream())
         else:
             raise NotImplementedError("a stack needs at least one layer after the first")
@@ -521,7 +543,7 @@ class _SAStack(Function):
         v = torch.empty_like(dout)
         part = torch.empty((PARTIAL_BLOCKS, 2, c_last), dtype=torch.float64, device=dev)
         _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), _ptr(s["out"]) if meta.get("relu_last", True) else None,
-                  s["arg"].data_ptr(), _ptr(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
+                  s["arg"].data_ptr(), _ptr(ys[-1]), _bf(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
                   PARTIAL_BLOCKS, _stream())
         p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev, frozen=frozen)
         p_op = operand(OP_POOLED, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, arg=s["arg"], ns=ns, rs=rs)
@@ -647,7 +669,7 @@ class _UmbrellaStack(Function):
         arg = None
         if aggr == "max":
             arg = torch.empty((points, cout), dtype=torch.int32, device=dev)
-            _lib.call("rs_pool_max", points, group, cout, 0, None, _ptr(y2), None, None, _ptr(out), arg.data_ptr(), _stream())
+            _lib.call("rs_pool_max", points, group, cout, 0, None, _ptr(y2), 0, None, None, _ptr(out), arg.data_ptr(), _stream())
         else:
             _lib.call("rs_pool_sum", points, group, cout, _ptr(y2), _ptr(out), _stream())
             if aggr == "avg":

@@ -197,7 +197,7 @@ def test_pool_max_first_maximum(groups, ns, c):
     shift = (torch.randint(-8, 8, (c,), generator=g).float() / 64).cuda()
     out = torch.empty((groups, c), dtype=torch.float32, device="cuda")
     arg = torch.empty((groups, c), dtype=torch.int32, device="cuda")
-    _lib.call("rs_pool_max", groups, ns, c, 1, None, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+    _lib.call("rs_pool_max", groups, ns, c, 1, None, y.data_ptr(), 0, scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
               arg.data_ptr(), torch.cuda.current_stream().cuda_stream)
     z = torch.relu(torch.addcmul(shift, y, scale)).view(groups, ns, c)      # fma(scale, y, shift) like the kernel
     ref = z.max(dim=1)
@@ -208,7 +208,7 @@ def test_pool_max_first_maximum(groups, ns, c):
 
 # ---------------------------------------------------------------------------------------------------------------
 # bf16 mixed precision (BASELINE configs[4]): rs_mlp_gemm_rows_bf16 = operands rounded to bf16 at the LDS commit,
-# v_mfma_f32_32x32x16_bf16, fp32 accumulation and storage.
+# v_mfma_f32_32x32x16_bf16, fp32 accumulation; fp32 or (activation storage, below) bf16 output.
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float64)
 
@@ -273,12 +273,12 @@ def test_bf16_row_gemm_fused_prologue_and_statistics():
 def test_bf16_sa_stack_within_restated_tolerance(groups, ns, pos, feat, widths):
     """SURVEY.md §8(d) C5 ("tolerance restated vs the fp32 reference ... to be tightened empirically").  The yardstick is
     what the reference itself would do in bf16: the torch executor (F.linear / F.batch_norm / relu / max, i.e. the
-    reference's Conv2d-BN-ReLU stack) under torch.autocast(bfloat16).  Measured (tools/bf16_diag.py, MI355X): pooled
-    post-BN activations max-abs 3.2-3.7e-2 here against 5.3-6.1e-2 for autocast (this path keeps the conv OUTPUT in
-    fp32); gradient cosine against fp32 0.987-0.996 here, 0.980-0.992 for autocast -- the max-pool argmax moves for
+    reference's Conv2d-BN-ReLU stack) under torch.autocast(bfloat16).  Like autocast, this path rounds the operands AND
+    stores the conv outputs as bf16 (fp32 accumulation, fp32 BatchNorm statistics of the stored values).  Measured
+    (MI355X): gradient cosine against fp32 0.987-0.996 here, 0.980-0.992 for autocast -- the max-pool argmax moves for
     near-tied rows in any bf16 forward, which re-routes whole gradient rows, so 0.999 is not reachable by either.
-    Asserted: activations <= 2e-2 of the output scale and no worse than autocast; every gradient's cosine >= 0.98
-    and >= autocast's - 2e-3."""
+    Asserted: activations <= 2e-2 of the output scale and no worse than 1.1 x autocast; every gradient's cosine >= 0.98
+    and >= autocast's - 5e-3."""
     from repsurf_amd import mlp
     mod = make_cd(pos, feat, widths, 1)
     g = torch.Generator().manual_seed(2)
@@ -304,7 +304,7 @@ def test_bf16_sa_stack_within_restated_tolerance(groups, ns, pos, feat, widths):
         if g_f[name].abs().max() == 0:
             continue
         cb, ca = cos(g_b[name], g_f[name]), cos(g_a[name].float(), g_f[name])
-        assert cb >= 0.98 and cb >= min(0.999, ca - 2e-3), (name, cb, ca)
+        assert cb >= 0.98 and cb >= min(0.999, ca - 5e-3), (name, cb, ca)
 
 
 @pytest.mark.parametrize("rows,n,k", [(5000, 128, 128), (4096, 1024, 512), (1000, 128, 64), (777, 200, 40), (33, 64, 66),
@@ -326,6 +326,151 @@ def test_bf16_weight_gradient_is_the_rounded_operand_product(rows, n, k):
     assert err < 2e-5, err
     full = p.double().T @ q.double()
     assert (dw.double() - full).abs().max().item() / full.abs().max().item() > 1e-4      # the bf16 pipe really ran
+
+
+# bf16 activation storage (configs[4]): the conv outputs y a stack saves for backward are written as bf16 by the producing
+# GEMM and read back as bf16 by every consumer (the kernels fix WHICH tensors of a launch are bf16 by its operand mode:
+# csrc/mlp.hip "storage roles").  Reading a bf16 tensor is exact, so a consumer must give BIT-IDENTICAL results on bf16
+# tensors and on fp32 tensors holding the same (bf16-representable) values through the fp32-storage kernels; a producer must
+# store exactly the nearest-even rounding of what the fp32-storage launch stores, and sum the statistics of the rounded values.
+def _bf16_vals(shape, g, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("rows,k,n", [(5000, 128, 256), (333, 64, 64), (4096, 138, 128), (70, 32, 32)])
+@pytest.mark.parametrize("mode", ["relu1", "relu2", "aff2", "pooled"])
+def test_bf16_stored_operands_read_exactly(rows, k, n, mode):
+    from repsurf_amd import mlp_hip as H, mlp
+    ns = 5 if rows % 5 == 0 else 1
+    g = torch.Generator().manual_seed(rows + k + len(mode))
+    y_a, y_b = _bf16_vals((rows, k), g).cuda(), _bf16_vals((rows, k), g).cuda()
+    dz = torch.randn(rows, k, generator=g).cuda()                          # masked gradient (fp32 in both storage modes)
+    s1, t1, s2, t2 = (torch.randn(k, generator=g).cuda() for _ in range(4))
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda()
+    grad = torch.randn(rows // ns, k, generator=g).cuda()                 # pooled gradient (fp32, small)
+    arg = torch.randint(0, ns, (rows // ns, k), generator=g, dtype=torch.int32).cuda()
+    other = torch.randn(rows, n, generator=g).cuda()
+
+    y_a32, y_b32 = y_a.float(), y_b.float()            # (kept alive here: an operand descriptor holds raw pointers only)
+
+    def op(store):
+        ya, yb = (y_a, y_b) if store else (y_a32, y_b32)
+        if mode == "relu1":
+            return H.operand(H.OP_RELU1, ya, k, s1=s1, t1=t1)
+        if mode == "relu2":
+            return H.operand(H.OP_RELU2, ya, k, yb, k, s1, t1, s2, t2)
+        if mode == "aff2":
+            return H.operand(H.OP_AFF2, dz, k, yb, k, s1=s1, t1=t1, s2=s2)
+        return H.operand(H.OP_POOLED, grad, k, yb, k, s1=s1, t1=t1, s2=s2, arg=arg, ns=ns)
+    res = []
+    mlp.set_precision("bf16")
+    try:
+        for store in (True, False):
+            fwd = mode in ("relu1", "relu2")                               # a forward operand's output is a y: bf16 when stored
+            out = torch.zeros((rows, n), dtype=torch.bfloat16 if (store and fwd) else torch.float32, device="cuda")
+            H.gemm_rows(rows, k, n, op(store), H.w_fwd(w), H.Epilogue(bias=None, out=H._ptr(out), ldo=n, mode=H.EPI_STORE, out_bf16=H._bf(out)))
+            as_p = H.wgrad(rows, k, n, op(store), H.operand(H.OP_ID, other, n), dz.device)
+            as_q = H.wgrad(rows, n, k, H.operand(H.OP_ID, other, n), op(store), dz.device) if fwd else as_p
+            res.append((out, as_p, as_q))
+    finally:
+        mlp.set_precision("fp32")
+    assert all(torch.isfinite(t.float()).all() for t in res[0])
+    assert torch.equal(res[0][0], res[1][0].to(res[0][0].dtype))          # (forward: the rounded fp32-storage output)
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("rows,k,n", [(5000, 128, 256), (333, 64, 64), (4096, 10, 64), (4099, 3, 64), (70, 256, 32), (1024, 128, 128)])
+@pytest.mark.parametrize("epi", ["store", "stats", "stats_pool"])
+def test_bf16_stored_output_is_the_rounded_fp32_output(rows, k, n, epi):
+    from repsurf_amd import mlp_hip as H, mlp
+    if epi == "stats_pool" and (rows % 8 or not H.fused_pool_ok(n, 8)):
+        pytest.skip("fused pooling needs whole groups per thread")
+    g = torch.Generator().manual_seed(rows + n + len(epi))
+    x = torch.randn(rows, k + 1, generator=g).cuda()[:, 1:] if k == 3 else torch.randn(rows, k, generator=g).cuda()   # k = 3: odd base -> scalar loads
+    ldx = x.stride(0)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    res = {}
+    mlp.set_precision("bf16")
+    try:
+        for store in ("fp32", "bf16"):
+            out = torch.zeros((rows, n), dtype=torch.float32 if store == "fp32" else torch.bfloat16, device="cuda")
+            part = torch.zeros((H.PARTIAL_BLOCKS, 2, n), dtype=torch.float64, device="cuda")
+            e = H.Epilogue(bias=H._ptr(bias), out=H._ptr(out), ldo=n, out_bf16=H._bf(out), mode=H.EPI_STORE if epi == "store" else H.EPI_STATS,
+                           partial=part.data_ptr(), partial_blocks=H.PARTIAL_BLOCKS)
+            pool = None
+            if epi == "stats_pool":
+                ext = torch.zeros((2, rows // 8, n), device="cuda")
+                pos = torch.zeros((2, rows // 8, n), dtype=torch.int32, device="cuda")
+                e.pool_ns, e.pool_max, e.pool_min, e.pool_amax, e.pool_amin = 8, H._ptr(ext[0]), H._ptr(ext[1]), pos[0].data_ptr(), pos[1].data_ptr()
+                pool = (ext, pos)
+            H.gemm_rows(rows, k, n, H.operand(H.OP_ID, x, ldx), H.w_fwd(w), e)
+            res[store] = (out, part.sum(0), pool)
+    finally:
+        mlp.set_precision("fp32")
+    assert torch.equal(res["bf16"][0], res["fp32"][0].to(torch.bfloat16))            # round to nearest even, nothing else
+    o = res["bf16"][0].double()
+    if epi != "store":      # sums of the STORED values
+        assert torch.allclose(res["bf16"][1][0], o.sum(0), rtol=1e-5, atol=2e-3)
+        assert torch.allclose(res["bf16"][1][1], (o * o).sum(0), rtol=1e-5, atol=2e-3)
+    if epi == "stats_pool":  # extremes of the STORED values, first position attaining them
+        ext, pos = res["bf16"][2]
+        grp = res["bf16"][0].float().view(rows // 8, 8, n)
+        assert torch.equal(ext[0], grp.max(1).values) and torch.equal(ext[1], grp.min(1).values)
+
+
+@pytest.mark.parametrize("rows,k,n", [(5000, 128, 256), (333, 64, 64), (70, 256, 32), (1024, 128, 128)])
+@pytest.mark.parametrize("two", [False, True])
+def test_bf16_stored_mask_tensors_read_exactly(rows, k, n, two):
+    """Data-gradient GEMM: the ReLU masks and the BatchNorm-backward sums rebuilt from bf16-stored y tensors equal the ones
+    from fp32 tensors holding the same values, bit for bit (output dz and the fp64 partial sums)."""
+    from repsurf_amd import mlp_hip as H, mlp
+    g = torch.Generator().manual_seed(rows + n + two)
+    dz_in, y_in = torch.randn(rows, k, generator=g).cuda(), _bf16_vals((rows, k), g).cuda()
+    p, q, r = (torch.randn(k, generator=g).cuda() for _ in range(3))
+    w = (torch.randn(k, n, generator=g) / k ** 0.5).cuda()
+    y1, y2 = _bf16_vals((rows, n), g).cuda(), _bf16_vals((rows, n), g).cuda()
+    v1, v2 = H.BNVec(n, dz_in.device), H.BNVec(n, dz_in.device)
+    for v in (v1, v2):
+        for t in (v.scale, v.shift, v.mean, v.invstd):
+            t.copy_(torch.randn(n, generator=g))
+    res = []
+    f32 = {id(t): t.float() for t in (y_in, y1, y2)}     # (kept alive here: the descriptors hold raw pointers only)
+    mlp.set_precision("bf16")
+    try:
+        for store in (True, False):
+            cv = (lambda t: t) if store else (lambda t: f32[id(t)])
+            p_op = H.operand(H.OP_AFF2, dz_in, k, cv(y_in), k, s1=p, t1=r, s2=q)
+            dz, part, nstat = H.dgrad_masked(rows, k, n, p_op, w, cv(y1), v1, cv(y2) if two else None, v2 if two else None, device=dz_in.device)
+            res.append((dz, part.sum(0)))
+    finally:
+        mlp.set_precision("fp32")
+    assert torch.isfinite(res[0][0]).all() and res[0][0].abs().max() > 0
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("groups,ns,c,relu", [(2048, 32, 128, 1), (32, 128, 1024, 1), (700, 24, 64, 0)])
+def test_bf16_stored_activation_pools_exactly(groups, ns, c, relu):
+    from repsurf_amd import mlp_hip as H, _lib
+    g = torch.Generator().manual_seed(groups + c)
+    y16 = _bf16_vals((groups * ns, c), g).cuda()
+    scale, shift, mean, invstd = (torch.randn(c, generator=g).cuda() for _ in range(4))
+    dout = torch.randn(groups, c, generator=g).cuda()
+    res = []
+    for y in (y16, y16.float()):
+        out = torch.empty((groups, c), device="cuda")
+        arg = torch.empty((groups, c), dtype=torch.int32, device="cuda")
+        _lib.call("rs_pool_max", groups, ns, c, relu, None, H._ptr(y), H._bf(y), H._ptr(scale), H._ptr(shift), H._ptr(out), arg.data_ptr(), H._stream())
+        v = torch.empty_like(dout)
+        part = torch.empty((H.PARTIAL_BLOCKS, 2, c), dtype=torch.float64, device="cuda")
+        _lib.call("rs_pool_max_backward", groups, ns, c, None, H._ptr(dout), H._ptr(out) if relu else None, arg.data_ptr(), H._ptr(y), H._bf(y),
+                  H._ptr(mean), H._ptr(invstd), H._ptr(v), part.data_ptr(), H.PARTIAL_BLOCKS, H._stream())
+        res.append((out, arg, v, part.sum(0)))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    z = y16.float().view(groups, ns, c) * scale + shift
+    ref = (torch.relu(z) if relu else z).max(1).values
+    assert torch.allclose(res[0][0], ref, rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("relu_last", [True, False])
@@ -407,6 +552,44 @@ def test_sa_cd_stack_eval_mode_forward_and_backward(groups, ns, pos, feat, width
     for name in g_t:
         assert rel_l2(g_h[name], g_t[name]) < 3e-3, (name, rel_l2(g_h[name], g_t[name]))
     assert torch.equal(mod.bn_l0.running_mean, ref_mod.bn_l0.running_mean)          # eval: statistics untouched
+
+
+@pytest.mark.parametrize("groups,ns,pos,feat,widths", [CASES[0], CASES[1], (5, 7, 3, 5, [18, 42])])
+@pytest.mark.parametrize("training", [True, False])
+def test_bf16_storage_against_fp32_storage_of_the_same_stack(groups, ns, pos, feat, widths, training):
+    """bf16 mode with and without bf16 activation storage (train and eval mode; the last case has widths that are no multiple of
+    4: such a stack keeps fp32 storage and both runs must be IDENTICAL).  Storage rounds each conv output once more (to the
+    format its consumer would have rounded it to anyway after BN+ReLU): the two runs stay within the bf16 tolerance of
+    each other, and the stored run is really a different one."""
+    from repsurf_amd import mlp, mlp_hip as H
+    mod = make_cd(pos, feat, widths, 3)
+    g = torch.Generator().manual_seed(9)
+    for bn in [mod.bn_l0, mod.bn_f0] + list(mod.bns):
+        bn.running_mean.copy_(torch.randn(bn.num_features, generator=g).cuda() * 0.2)
+        bn.running_var.copy_(torch.rand(bn.num_features, generator=g).cuda() + 0.5)
+    mod.train(training)
+    x = torch.randn(groups * ns, pos + feat, generator=g).cuda()
+    w = torch.randn(groups, widths[-1], generator=g).cuda()
+    res = {}
+    mlp.set_precision("bf16")
+    try:
+        for store in (True, False):
+            H.BF16_STORE = store
+            res[store] = run_cd(copy.deepcopy(mod), x, ns, pos, "hip", w)
+    finally:
+        H.BF16_STORE = True
+        mlp.set_precision("fp32")
+    (out_s, g_s), (out_f, g_f) = res[True], res[False]
+    if any(c % 4 for c in widths):
+        assert torch.equal(out_s, out_f) and all(torch.equal(g_s[n], g_f[n]) for n in g_f)
+        return
+    assert not torch.equal(out_s, out_f)
+    assert torch.isfinite(out_s).all() and (out_s - out_f).abs().max().item() <= 2e-2 * max(1.0, out_f.abs().max().item())
+    for name in g_f:
+        if g_f[name].abs().max() == 0:
+            continue
+        cos = torch.nn.functional.cosine_similarity(g_s[name].flatten().double(), g_f[name].flatten().double(), dim=0).item()
+        assert cos >= 0.98, (name, cos)
 
 
 @pytest.mark.parametrize("kind", ["cls3", "seg2"])

@@ -122,31 +122,56 @@ def test_segmentation_step_at_the_benchmark_configuration_matches_oracle():
 
 
 def test_bf16_classifier_step_at_configs4_shape():
-    """configs[4]: B=64 x 2048 points, bf16 MFMA operands: finite, same geometry, close to the fp32 path."""
+    """configs[4]: B=64 x 2048 points, bf16 MFMA operands AND bf16 storage of the conv outputs: finite, same geometry, and as
+    close to the fp32 path as the reference's own layers are under torch.autocast(bfloat16) (the yardstick of DESIGN §5a,
+    here at model level: the torch executor of the SA stacks under autocast, everything else as in the fp32 run).  A bf16
+    forward moves the max-pool argmax of near-tied rows, which re-routes whole gradient rows: the gradient cosine against
+    fp32 is ~0.9 for either implementation, so it is asserted relative to autocast's."""
     from repsurf_amd import mlp
+    from tests import torch_executor
     from util.utils import SmoothClsLoss
     xyz, label = cloud(31, 64, 2048), (np.arange(64) % 15).astype(np.int64)
     res = {}
+
+    def run(tag):
+        model = build_cls()
+        model.surface_constructor.register_forward_hook(lambda m, i, o: res.__setitem__(tag + "_normal", o.detach().clone()))
+        torch.manual_seed(5)
+        pred = model(dev(xyz).permute(0, 2, 1).contiguous())
+        loss = SmoothClsLoss()(pred, dev(label))
+        loss.backward()
+        res[tag] = (pred.detach().cpu().numpy(), float(loss.detach()),
+                    np.concatenate([p.grad.detach().cpu().numpy().ravel().astype(np.float64)
+                                    for n, p in model.named_parameters() if not is_pre_bn_bias(n)]))
     for prec in ("fp32", "bf16"):
         mlp.set_precision(prec)
         try:
-            model = build_cls()
-            model.surface_constructor.register_forward_hook(lambda m, i, o: res.__setitem__(prec + "_normal", o.detach().clone()))
-            torch.manual_seed(5)
-            pred = model(dev(xyz).permute(0, 2, 1).contiguous())
-            loss = SmoothClsLoss()(pred, dev(label))
-            loss.backward()
-            res[prec] = (pred.detach().cpu().numpy(), float(loss.detach()),
-                         np.concatenate([p.grad.detach().cpu().numpy().ravel().astype(np.float64)
-                                         for n, p in model.named_parameters() if not is_pre_bn_bias(n)]))
+            run(prec)
         finally:
             mlp.set_precision("fp32")
+    torch_executor.set_backend("torch")
+    try:
+        def under_autocast(fn):
+            def wrapped(*a, **k):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    return fn(*a, **k).float()
+            return wrapped
+        mlp.sa_mlp_cd, mlp.sa_mlp_plain = under_autocast(torch_executor.sa_mlp_cd), under_autocast(torch_executor.sa_mlp_plain)
+        run("autocast")
+    finally:
+        torch_executor.set_backend("hip")
     assert np.isfinite(res["bf16"][0]).all() and np.isfinite(res["bf16"][2]).all()
     assert torch.equal(res["fp32_normal"], res["bf16_normal"])        # geometry + constructor stay fp32 in both modes
-    cos = float(res["bf16"][2] @ res["fp32"][2] / (np.linalg.norm(res["bf16"][2]) * np.linalg.norm(res["fp32"][2])))
-    err = np.abs(res["bf16"][0] - res["fp32"][0]).max()
-    parity_report("cls_b64x2048_bf16_vs_fp32", grad_cosine=cos, logp_max_abs=err, loss_abs=abs(res["bf16"][1] - res["fp32"][1]))
-    assert cos > 0.9 and err < 0.15 and abs(res["bf16"][1] - res["fp32"][1]) < 5e-2
+
+    def against_fp32(tag):
+        g, f = res[tag][2], res["fp32"][2]
+        return float(g @ f / (np.linalg.norm(g) * np.linalg.norm(f))), float(np.abs(res[tag][0] - res["fp32"][0]).max())
+    (cos, err), (cos_a, err_a) = against_fp32("bf16"), against_fp32("autocast")
+    parity_report("cls_b64x2048_bf16_vs_fp32", grad_cosine=cos, logp_max_abs=err, loss_abs=abs(res["bf16"][1] - res["fp32"][1]),
+                  autocast_grad_cosine=cos_a, autocast_logp_max_abs=err_a)
+    assert cos > 0.85 and cos >= cos_a - 0.02, (cos, cos_a)
+    assert err < 0.15 and err <= 1.25 * err_a + 1e-2, (err, err_a)
+    assert abs(res["bf16"][1] - res["fp32"][1]) < 5e-2
 
 
 def test_pre_model_sample_equals_oracle_fps_and_gather():
