@@ -164,15 +164,27 @@ int rs_group_features_backward(int b, int n, int m, int nsample, int cn, int cf,
  * Outputs (capacity b*m*nsample rows): out (rows, ctot), mult[row] = copies the row stands for
  * (nsample-cnt+1 for slot 0, else 1), grp[row], slot[row], src[row] = cloud*n + idx (gather/scatter address). */
 int rs_exclusive_scan(int n, const int *in, int *out, void *stream);
+/* The bookkeeping alone (offsets by rs_exclusive_scan of cnt, then mult / grp / slot / src): it needs the ball query's
+ * (idx, cnt) only, so a pipelined step builds it in its geometry stage, off the critical path. */
+int rs_compact_index(int b, int n, int m, int nsample, const int *idx, const int *cnt, int *offsets, int *grp, int *slot,
+                     int *src, float *mult, void *stream);
+/* have_index != 0: offsets / mult / grp / slot / src come from rs_compact_index (read, not written); 0: `offsets` is given
+ * and the other four are built here.  fps_idx (b*m) + new_normal (b*m, cn), both or neither: the same launch also writes
+ * the centres' own normal rows, new_normal[g, :] = normal[cloud(g)*n + fps_idx[g], :] (index_points(normal, fps_idx),
+ * classification/modules/repsurface_utils.py:31). */
 int rs_group_features_compact(int b, int n, int m, int nsample, int cn, int cf, int polar,
                               const float *center, const float *new_center, const float *normal,
                               const float *feature, const int *idx, const int *cnt, const int *offsets,
-                              float *out, float *mult, int *grp, int *slot, int *src, void *stream);
+                              float *out, float *mult, int *grp, int *slot, int *src, int have_index,
+                              const int *fps_idx, float *new_normal, void *stream);
 /* grad_normal / grad_feature [src[row], :] += grad_out[row, gathered channels] for row < *rows_dev
- * (gradients of the copies are already summed per row: one atomic per distinct neighbour). */
+ * (gradients of the copies are already summed per row: one atomic per distinct neighbour), both tensors in one launch.
+ * fps_idx (b*m) + grad_new_normal (b*m rows, ldg floats apart), both or neither: the backward of the centre rows,
+ * grad_normal[cloud(g)*n + fps_idx[g], :] += grad_new_normal[g*ldg + :], in the same launch. */
 int rs_group_features_compact_backward(long long capacity, const int *rows_dev, int cn, int cf, int polar,
                                        const float *grad_out, const int *src, float *grad_normal,
-                                       float *grad_feature, void *stream);
+                                       float *grad_feature, int b, int n, int m, const int *fps_idx,
+                                       const float *grad_new_normal, long long ldg, void *stream);
 /* group_all variant (sample_and_group_all, repsurface_utils.py:62-88):
  * row (b, j) = [center (3), polar of center (3, if polar), normal (cn), feature (cf)]. */
 int rs_group_all_features(int b, int n, int cn, int cf, int polar, const float *center,
@@ -313,8 +325,9 @@ int rs_pool_select(long long groups, int c, const float *ymax, const float *ymin
                    const int *amin, const float *scale, const float *shift, float *out, int *arg, void *stream);
 /* v = dout * (out > 0) and the BatchNorm-backward sums of the pooled layer from (groups, c) data only:
  * partial (partial_blocks, 2, c) = {sum v, sum v * yhat[arg row]}.  out = NULL: the pooled layer ended without a
- * ReLU (rs_pool_max called with relu = 0), v = dout. */
-int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout,
+ * ReLU (rs_pool_max called with relu = 0), v = dout.  dout: (groups, c) rows `ldd` floats apart (0 = c): the pooled
+ * activations' gradient is often a column slice of a wider tensor. */
+int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout, long long ldd,
                          const float *out, const int *arg, const float *y, int y_bf16, const float *mean,
                          const float *invstd, float *v, double *partial, int partial_blocks, void *stream);
 /* out[g][c] = sum_k y[g*nsample+k][c]   (umbrella aggregation 'sum', :305) */

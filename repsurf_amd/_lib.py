@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -30,8 +30,9 @@ SIGNATURES = {
     "rs_group_features_backward": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P],
     "rs_group_all_features": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_exclusive_scan": [c_int, P, P, P],
-    "rs_group_features_compact": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P],
-    "rs_group_features_compact_backward": [c_ll, P, c_int, c_int, c_int, P, P, P, P, P],
+    "rs_compact_index": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P],
+    "rs_group_features_compact": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P],
+    "rs_group_features_compact_backward": [c_ll, P, c_int, c_int, c_int, P, P, P, P, c_int, c_int, c_int, P, P, c_ll, P],
     "rs_group_rows": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "rs_group_rows_backward": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "rs_three_nn": [c_int, c_int, c_int, P, P, P, P, P],
@@ -44,7 +45,7 @@ SIGNATURES = {
     "rs_bn_finalize": [c_int, c_ll, c_int, P, P, P, c_float, c_float, P, P, P, P, P, P, P],
     "rs_bn_backward_finalize": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P],
     "rs_pool_max": [c_ll, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P],
-    "rs_pool_max_backward": [c_ll, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, c_int, P],
+    "rs_pool_max_backward": [c_ll, c_int, c_int, P, P, c_ll, P, P, P, c_int, P, P, P, P, c_int, P],
     "rs_pool_sum": [c_ll, c_int, c_int, P, P, P],
     "rs_pool_select": [c_ll, c_int, P, P, P, P, P, P, P, P, P],
     "rs_reduce_partials": [c_int, c_ll, P, P, P],

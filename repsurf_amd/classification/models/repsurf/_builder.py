@@ -6,6 +6,7 @@ Both shipped variants are: UmbrellaSurfaceConstructor -> a ladder of SurfaceAbst
 are the reference's, so its checkpoints load
 (classification/models/repsurf/repsurf_ssg_umb.py:11-57, repsurf_ssg_umb_2x.py:11-61).
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -31,17 +32,14 @@ class GeoState:
     def tensors(self):
         out = [self.feat]
         for g in self.stages:
-            out += [g.fps_idx, g.new_center, g.idx, g.cnt]
+            out += g.tensors()
         return out
 
     def clone(self):
-        from repsurf_amd.geometry import StageGeometry
-        return GeoState(self.feat.clone(), [StageGeometry(g.fps_idx.clone(), g.new_center.clone(), g.idx.clone(),
-                                                          g.cnt.clone()) for g in self.stages])
+        return GeoState(self.feat.clone(), [g.clone() for g in self.stages])
 
     def copy_(self, other):
-        for d, s_ in zip(self.tensors(), other.tensors()):
-            d.copy_(s_)
+        torch._foreach_copy_(self.tensors(), other.tensors())       # one launch per dtype instead of one per tensor
         return self
 
 
@@ -89,12 +87,16 @@ class UmbrellaClassifier(nn.Module):
         flip = rng.draw("flip", center.shape[0], 2, center.device) if sc.random_inv else None
         xyz = center.permute(0, 2, 1).contiguous()
         if fork:        # in-step form: the FPS chain goes to the side stream first, the kNN hides it
-            plan = GeometryPlan(xyz, self._sampling, fork=True)
+            plan = GeometryPlan(xyz, self._sampling, fork=True, compact=self._compact())
             feat = sc.features(center, flip)
         else:           # one serial branch next to another batch's network: full-chip kNN first (under the light
             feat = sc.features(center, flip)    # head of that forward), the 32-workgroup FPS chains afterwards (1.98 vs 2.00 ms)
-            plan = GeometryPlan(xyz, self._sampling, fork=False)
+            plan = GeometryPlan(xyz, self._sampling, fork=False, compact=self._compact())
         return GeoState(feat, [plan.stage(i) for i in range(len(self._sampling))])
+
+    def _compact(self):
+        """the SA stages take the compacted-groups path (training mode): their bookkeeping belongs to the geometry"""
+        return bool(_mlp.COMPACT_GROUPS and self.training)
 
     def _sa_convs(self):
         out = []
@@ -114,7 +116,7 @@ class UmbrellaClassifier(nn.Module):
             # same CPU-generator order as the reference: the constructor's flip first, then one FPS start per stage
             sc = self.surface_constructor
             flip = rng.draw("flip", center.shape[0], 2, center.device) if sc.random_inv else None
-            plan = GeometryPlan(center.permute(0, 2, 1).contiguous(), self._sampling)
+            plan = GeometryPlan(center.permute(0, 2, 1).contiguous(), self._sampling, compact=self._compact())
             normal = sc(center, flip=flip)
         else:
             normal = self.surface_constructor(center)

@@ -41,10 +41,23 @@ def sample_and_group(npoint, radius, nsample, center, normal, feature, return_no
     return new_center, new_normal, rows.view(b, s, nsample, -1)
 
 
+_zero_centers = {}
+
+
+def _zero_center(b, device):
+    """the (B,1,3) zeros sample_and_group_all returns as new_center / new_normal: a constant, filled once per (B, device)"""
+    key = (b, str(device))
+    if key not in _zero_centers:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():      # (a capture's allocations belong to its graph)
+            return torch.zeros((b, 1, 3), dtype=torch.float32, device=device)
+        _zero_centers[key] = torch.zeros((b, 1, 3), dtype=torch.float32, device=device)
+    return _zero_centers[key]
+
+
 def sample_and_group_all(center, normal, feature, return_normal=True, return_polar=False):
     """-> new_center zeros (B,1,3), new_normal = new_center, new_feature (B,1,N,C') (reference :62-88)."""
     b, n, _ = center.shape
-    new_center = center.new_zeros((b, 1, 3))
+    new_center = _zero_center(b, center.device)
     src_normal = normal if return_normal else normal.new_zeros((b, n, 0))
     rows = ops.group_all_features(center, src_normal, feature, polar=return_polar)
     return new_center, new_center, rows.view(b, 1, n, -1)
@@ -153,8 +166,9 @@ def _sa_forward_compact(self, center, normal, feature, geometry):
         idx, cnt = ops.ballquery(self.radius, self.nsample, center, new_center, return_count=True)
     else:
         fps_idx, new_center, idx, cnt = geometry.fps_idx, geometry.new_center, geometry.idx, geometry.cnt
-    new_normal = index_points(normal, fps_idx)
-    groups = ops.group_features_compact(center, new_center, normal, feature, idx, cnt, polar=self.return_polar)
+    # the centres' own normal rows (index_points(normal, fps_idx), reference :31) come out of the grouping launches
+    groups, new_normal = ops.group_features_compact(center, new_center, normal, feature, idx, cnt, polar=self.return_polar,
+                                                    index=getattr(geometry, "index", None), fps_idx=fps_idx)
     pooled = _mlp.sa_mlp_cd(groups.x, self.pos_channel, self.mlp_l0, self.bn_l0, self.mlp_f0, self.bn_f0,
                             self.mlp_convs, self.mlp_bns, self.nsample, compact=groups)
     b, s = fps_idx.shape

@@ -191,52 +191,58 @@ exclusive_scan_kernel(int n, const int *__restrict__ in, int *__restrict__ out) 
   if (t == 1023) out[n] = part[1023];
 }
 
-// n <= 16384: every thread owns 16 consecutive counts (four 16-byte loads issued together), scans them in registers,
-// the wave scans its 64 totals with shuffles and the 16 wave totals go through LDS -- two barriers instead of the
-// twenty of the generic kernel, one memory latency instead of sixteen (22 us -> ~3 us at 16384 counts; the scan sits
-// between ball query and the first grouped GEMM on the critical path).
+// Every thread owns 16 consecutive counts of a 16384-count block (four 16-byte loads issued together), scans them in
+// registers, the wave scans its 64 totals with shuffles and the 16 wave totals go through LDS -- one barrier and one memory
+// latency per block instead of the twenty barriers / sixteen latencies of the generic kernel (22 us -> ~3 us at 16384
+// counts; the scan sits between ball query and the first grouped GEMM on the critical path).  Longer inputs (configs[4]:
+// 32768 groups; the cell histogram of a whole scene) walk the blocks with a running carry.
 __global__ void __launch_bounds__(1024)
 exclusive_scan16_kernel(int n, const int *__restrict__ in, int *__restrict__ out) {
-  __shared__ int wsum[16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, base = t * 16;
-  int v[16];
+  __shared__ int wsum[2][16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int carry = 0;
+  for (int b0 = 0, it = 0; b0 < n; b0 += 16384, ++it) {
+    const int base = b0 + t * 16;
+    int v[16];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = base + 4 * q;
-    if (i + 4 <= n) {
-      const int4 x = *reinterpret_cast<const int4 *>(in + i);
-      v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
-    } else {
+    for (int q = 0; q < 4; ++q) {
+      const int i = base + 4 * q;
+      if (i + 4 <= n) {
+        const int4 x = *reinterpret_cast<const int4 *>(in + i);
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[4 * q + e] = (i + e < n) ? in[i + e] : 0;
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = (i + e < n) ? in[i + e] : 0;
+      }
     }
-  }
-  int tot = 0;
+    int tot = 0;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { const int x = v[e]; v[e] = tot; tot += x; }     // exclusive inside the thread
-  int inc = tot;                                                                  // inclusive scan over the wave
+    for (int e = 0; e < 16; ++e) { const int x = v[e]; v[e] = tot; tot += x; }     // exclusive inside the thread
+    int inc = tot;                                                                  // inclusive scan over the wave
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += o;
-  }
-  if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
-  int wbase = 0, total = 0;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) { const int x = wsum[w]; if (w < wave) wbase += x; total += x; }
-  const int pre = wbase + inc - tot;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = base + 4 * q;
-    if (i + 4 <= n) {
-      *reinterpret_cast<int4 *>(out + i) = make_int4(pre + v[4 * q], pre + v[4 * q + 1], pre + v[4 * q + 2], pre + v[4 * q + 3]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (i + e < n) out[i + e] = pre + v[4 * q + e];
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
     }
+    if (lane == 63) wsum[it & 1][wave] = inc;       // two buffers: the next block's totals cannot overtake this block's readers
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int x = wsum[it & 1][w]; if (w < wave) wbase += x; total += x; }
+    const int pre = carry + wbase + inc - tot;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = base + 4 * q;
+      if (i + 4 <= n) {
+        *reinterpret_cast<int4 *>(out + i) = make_int4(pre + v[4 * q], pre + v[4 * q + 1], pre + v[4 * q + 2], pre + v[4 * q + 3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (i + e < n) out[i + e] = pre + v[4 * q + e];
+      }
+    }
+    carry += total;
   }
-  if (t == 0) out[n] = total;
+  if (t == 0) out[n] = carry;
 }
 
 __global__ void __launch_bounds__(GR_THREADS)
@@ -258,12 +264,23 @@ compact_index_kernel(long long groups, int nsample, int groups_per_cloud, int n,
 }
 
 // X[u, :] = [center[src]-new_center[g] (3), polar (3)?, normal[src] (cn), feature[src] (cf)] for u < *rows_dev
+// fps_idx != NULL: the same launch also gathers the centres' own normal rows, new_normal[g, :] = normal[cloud(g) * n + fps_idx[g], :]
+// (index_points(normal, fps_idx), repsurface_utils.py:31) -- one launch less on the critical path per stage
 __global__ void __launch_bounds__(GR_THREADS)
 compact_features_kernel(const int *__restrict__ rows_dev, int cn, int cf, int cpos, int ctot,
                         const float *__restrict__ center, const float *__restrict__ new_center,
                         const float *__restrict__ normal, const float *__restrict__ feature,
-                        const int *__restrict__ grp, const int *__restrict__ src, float *__restrict__ out) {
+                        const int *__restrict__ grp, const int *__restrict__ src, float *__restrict__ out,
+                        long long groups, int m, int n, const int *__restrict__ fps_idx, float *__restrict__ new_normal) {
   const long long total = (long long)(*rows_dev) * ctot;
+  if (fps_idx) {
+    const long long extra = groups * cn;
+    for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < extra; e += (long long)gridDim.x * GR_THREADS) {
+      const long long g = e / cn;
+      const int ch = (int)(e - g * cn);
+      new_normal[e] = normal[((g / m) * n + fps_idx[g]) * cn + ch];
+    }
+  }
   for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GR_THREADS) {
     const long long u = e / ctot;
     const int ch = (int)(e - u * ctot);
@@ -290,15 +307,30 @@ compact_features_kernel(const int *__restrict__ rows_dev, int cn, int cf, int cp
   }
 }
 
-// grad_src[src[u], :] += grad_out[u, c0 : c0+cw]   — one atomic per distinct neighbour
+// grad_normal[src[u], :] += grad_out[u, cpos : cpos+cn], grad_feature[src[u], :] += grad_out[u, cpos+cn : ctot] -- one atomic per
+// distinct neighbour and channel, both tensors in ONE launch; fps_idx != NULL: also the backward of the centre-row gather
+// of compact_features_kernel, grad_normal[cloud(g) * n + fps_idx[g], :] += grad_new_normal[g * ldg + :]
 __global__ void __launch_bounds__(GR_THREADS)
-compact_scatter_kernel(const int *__restrict__ rows_dev, int cw, int c0, int ctot, const float *__restrict__ grad_out,
-                       const int *__restrict__ src, float *__restrict__ grad_src) {
+compact_scatter_kernel(const int *__restrict__ rows_dev, int cn, int cf, int cpos, int ctot, const float *__restrict__ grad_out,
+                       const int *__restrict__ src, float *__restrict__ grad_normal, float *__restrict__ grad_feature,
+                       long long groups, int m, int n, const int *__restrict__ fps_idx, const float *__restrict__ grad_new_normal,
+                       long long ldg) {
+  const int c0 = grad_normal ? 0 : cn, cw = (grad_normal ? cn : 0) + (grad_feature ? cf : 0);     // channels [c0, c0 + cw) behind cpos
   const long long total = (long long)(*rows_dev) * cw;
   for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GR_THREADS) {
     const long long u = e / cw;
-    const int ch = (int)(e - u * cw);
-    atomicAdd(grad_src + (long long)src[u] * cw + ch, grad_out[u * ctot + c0 + ch]);
+    const int ch = c0 + (int)(e - u * cw);
+    const float v = grad_out[u * ctot + cpos + ch];
+    if (ch < cn) atomicAdd(grad_normal + (long long)src[u] * cn + ch, v);
+    else atomicAdd(grad_feature + (long long)src[u] * cf + (ch - cn), v);
+  }
+  if (fps_idx) {
+    const long long extra = groups * cn;
+    for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < extra; e += (long long)gridDim.x * GR_THREADS) {
+      const long long g = e / cn;
+      const int ch = (int)(e - g * cn);
+      atomicAdd(grad_normal + ((g / m) * n + fps_idx[g]) * cn + ch, grad_new_normal[g * ldg + ch]);
+    }
   }
 }
 
@@ -413,7 +445,7 @@ extern "C" int rs_group_all_features(int b, int n, int cn, int cf, int polar, co
 extern "C" int rs_exclusive_scan(int n, const int *in, int *out, void *stream) {
   RS_REQUIRE(n >= 0, "rs_exclusive_scan: negative size");
   RS_REQUIRE(in && out, "rs_exclusive_scan: null pointer");
-  if (n <= 16384 && (((size_t)in | (size_t)out) & 15) == 0)
+  if ((((size_t)in | (size_t)out) & 15) == 0)
     hipLaunchKernelGGL(exclusive_scan16_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, in, out);
   else
     hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, in, out);
@@ -421,40 +453,65 @@ extern "C" int rs_exclusive_scan(int n, const int *in, int *out, void *stream) {
   return RS_OK;
 }
 
+// offsets (groups + 1), grp / slot / src / mult (capacity = groups * nsample): the bookkeeping of the compacted groups from the
+// ball query's (idx, cnt) alone -- no features involved, so a pipelined step builds it in the geometry stage
+extern "C" int rs_compact_index(int b, int n, int m, int nsample, const int *idx, const int *cnt, int *offsets, int *grp, int *slot,
+                                int *src, float *mult, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "rs_compact_index: negative size");
+  const long long groups = (long long)b * m;
+  RS_REQUIRE(offsets, "rs_compact_index: null pointer");
+  int rc = rs_exclusive_scan((int)groups, cnt ? cnt : offsets, offsets, stream);
+  if (rc != RS_OK || groups == 0 || nsample == 0) return rc;
+  RS_REQUIRE(idx && cnt && grp && slot && src && mult, "rs_compact_index: null pointer");
+  hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(groups * nsample)), dim3(GR_THREADS), 0, (hipStream_t)stream, groups, nsample, m, n,
+                     idx, cnt, offsets, grp, slot, src, mult);
+  RS_CHECK_LAUNCH("rs_compact_index");
+  return RS_OK;
+}
+
+// have_index != 0: offsets / grp / slot / src / mult were built by rs_compact_index (only the feature rows are written here).
+// fps_idx, new_normal (optional, both or neither): new_normal (b*m, cn) = normal rows of the centres themselves, same launch.
 extern "C" int rs_group_features_compact(int b, int n, int m, int nsample, int cn, int cf, int polar,
                                          const float *center, const float *new_center, const float *normal,
                                          const float *feature, const int *idx, const int *cnt, const int *offsets,
-                                         float *out, float *mult, int *grp, int *slot, int *src, void *stream) {
+                                         float *out, float *mult, int *grp, int *slot, int *src, int have_index,
+                                         const int *fps_idx, float *new_normal, void *stream) {
   RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0 && cn >= 0 && cf >= 0, "rs_group_features_compact: negative size");
   const long long groups = (long long)b * m;
   if (groups == 0 || nsample == 0) return RS_OK;
   RS_REQUIRE(center && new_center && idx && cnt && offsets && out && mult && grp && slot && src, "rs_group_features_compact: null pointer");
   RS_REQUIRE(cn == 0 || normal, "rs_group_features_compact: normal is NULL but cn=%d", cn);
   RS_REQUIRE(cf == 0 || feature, "rs_group_features_compact: feature is NULL but cf=%d", cf);
+  RS_REQUIRE((fps_idx == nullptr) == (new_normal == nullptr), "rs_group_features_compact: fps_idx and new_normal come together");
   const int cpos = polar ? 6 : 3, ctot = cpos + cn + cf;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(groups * nsample)), dim3(GR_THREADS), 0, st, groups, nsample, m, n,
-                     idx, cnt, offsets, grp, slot, src, mult);
+  if (!have_index)
+    hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(groups * nsample)), dim3(GR_THREADS), 0, st, groups, nsample, m, n,
+                       idx, cnt, offsets, grp, slot, src, mult);
   hipLaunchKernelGGL(compact_features_kernel, dim3(grid_for(groups * nsample * ctot / 4 + 1)), dim3(GR_THREADS), 0, st,
-                     offsets + groups, cn, cf, cpos, ctot, center, new_center, normal, feature, grp, src, out);
+                     offsets + groups, cn, cf, cpos, ctot, center, new_center, normal, feature, grp, src, out,
+                     groups, m, n, cn > 0 ? fps_idx : nullptr, new_normal);
   RS_CHECK_LAUNCH("rs_group_features_compact");
   return RS_OK;
 }
 
+// fps_idx / grad_new_normal (optional, both or neither; rows ldg floats apart): backward of the centre-row gather, same launch.
 extern "C" int rs_group_features_compact_backward(long long capacity, const int *rows_dev, int cn, int cf, int polar,
                                                   const float *grad_out, const int *src, float *grad_normal,
-                                                  float *grad_feature, void *stream) {
+                                                  float *grad_feature, int b, int n, int m, const int *fps_idx,
+                                                  const float *grad_new_normal, long long ldg, void *stream) {
   RS_REQUIRE(capacity >= 0 && cn >= 0 && cf >= 0, "rs_group_features_compact_backward: negative size");
   if (capacity == 0) return RS_OK;
   RS_REQUIRE(rows_dev && grad_out && src, "rs_group_features_compact_backward: null pointer");
+  RS_REQUIRE((fps_idx == nullptr) == (grad_new_normal == nullptr), "rs_group_features_compact_backward: fps_idx and grad_new_normal come together");
+  RS_REQUIRE(!fps_idx || (grad_normal && ldg >= cn && b >= 0 && m >= 0), "rs_group_features_compact_backward: the centre rows add into grad_normal");
   const int cpos = polar ? 6 : 3, ctot = cpos + cn + cf;
-  hipStream_t st = (hipStream_t)stream;
-  if (grad_normal && cn > 0)
-    hipLaunchKernelGGL(compact_scatter_kernel, dim3(grid_for(capacity * cn / 4 + 1)), dim3(GR_THREADS), 0, st, rows_dev, cn, cpos,
-                       ctot, grad_out, src, grad_normal);
-  if (grad_feature && cf > 0)
-    hipLaunchKernelGGL(compact_scatter_kernel, dim3(grid_for(capacity * cf / 4 + 1)), dim3(GR_THREADS), 0, st, rows_dev, cf,
-                       cpos + cn, ctot, grad_out, src, grad_feature);
+  if (cn == 0) grad_normal = nullptr;
+  if (cf == 0) grad_feature = nullptr;
+  if (!grad_normal && !grad_feature) return RS_OK;
+  const int cw = (grad_normal ? cn : 0) + (grad_feature ? cf : 0);
+  hipLaunchKernelGGL(compact_scatter_kernel, dim3(grid_for(capacity * cw / 4 + 1)), dim3(GR_THREADS), 0, (hipStream_t)stream, rows_dev, cn, cf,
+                     cpos, ctot, grad_out, src, grad_normal, grad_feature, (long long)b * m, m, n, fps_idx, grad_new_normal, ldg);
   RS_CHECK_LAUNCH("rs_group_features_compact_backward");
   return RS_OK;
 }

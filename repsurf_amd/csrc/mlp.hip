@@ -1425,10 +1425,10 @@ pool_select_kernel(long long groups, int c, const float *__restrict__ ymax, cons
 // of the pooled layer computed from G x C data only)
 template <bool BF>
 __global__ void __launch_bounds__(GM_THREADS)
-pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ offsets, const float *__restrict__ dout,
+pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ offsets, const float *__restrict__ dout, long long ldd,
                     const float *__restrict__ out, const int *__restrict__ arg, const float *__restrict__ y,
                     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ v,
-                    double *__restrict__ partial) {
+                    double *__restrict__ partial, int partial_blocks) {
   // workgroup = 64 columns x 4 group lanes; column sums stay in registers over the group loop and are
   // combined across the 4 lanes through LDS (fixed order)
   __shared__ double red[4][64][2];
@@ -1439,7 +1439,7 @@ pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ off
     const float mu = mean[ch], is = invstd[ch];
     for (long long g = (long long)blockIdx.x * 4 + ty; g < groups; g += (long long)gridDim.x * 4) {
       const long long e = g * c + ch;
-      const float val = (!out || out[e] > 0.f) ? dout[e] : 0.f;      // out == NULL: the pooled layer ended without a ReLU
+      const float val = (!out || out[e] > 0.f) ? dout[g * ldd + ch] : 0.f;      // out == NULL: the pooled layer ended without a ReLU
       v[e] = val;
       const float yy = ldy<BF>(y, ((offsets ? (long long)offsets[g] : g * ns) + arg[e]) * c + ch);
       s0 += (double)val;
@@ -1451,6 +1451,11 @@ pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ off
   if (ty == 0 && ch < c) {
     partial[((long long)blockIdx.x * 2 + 0) * c + ch] = (red[0][tx][0] + red[1][tx][0]) + (red[2][tx][0] + red[3][tx][0]);
     partial[((long long)blockIdx.x * 2 + 1) * c + ch] = (red[0][tx][1] + red[1][tx][1]) + (red[2][tx][1] + red[3][tx][1]);
+    // the finalize kernel sums `partial_blocks` rows: the ones no workgroup owns read as zero (no memset launch)
+    for (int pb = blockIdx.x + gridDim.x; pb < partial_blocks; pb += gridDim.x) {
+      partial[((long long)pb * 2 + 0) * c + ch] = 0.0;
+      partial[((long long)pb * 2 + 1) * c + ch] = 0.0;
+    }
   }
 }
 
@@ -1917,21 +1922,21 @@ extern "C" int rs_pool_select(long long groups, int c, const float *ymax, const 
   return RS_OK;
 }
 
-extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout,
+extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout, long long ldd,
                                     const float *out, const int *arg, const float *y, int y_bf16, const float *mean,
                                     const float *invstd, float *v, double *partial, int partial_blocks, void *stream) {
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0 && partial_blocks > 0, "rs_pool_max_backward: bad size");
   if (groups == 0 || c == 0) return RS_OK;
   RS_REQUIRE(dout && arg && y && mean && invstd && v && partial, "rs_pool_max_backward: null pointer");
+  if (ldd <= 0) ldd = c;
+  RS_REQUIRE(ldd >= c, "rs_pool_max_backward: row stride of dout %lld < %d channels", ldd, c);
   const long long want = (groups + 3) / 4;
   int gx = (int)(want < partial_blocks ? want : partial_blocks);
   hipStream_t st = (hipStream_t)stream;
-  if (gx < partial_blocks)
-    (void)hipMemsetAsync(partial + (long long)gx * 2 * c, 0, sizeof(double) * (size_t)(partial_blocks - gx) * 2 * c, st);
   if (y_bf16) hipLaunchKernelGGL(pool_max_bwd_kernel<true>, dim3(gx, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, st, groups, nsample, c,
-                                 offsets, dout, out, arg, y, mean, invstd, v, partial);
+                                 offsets, dout, ldd, out, arg, y, mean, invstd, v, partial, partial_blocks);
   else hipLaunchKernelGGL(pool_max_bwd_kernel<false>, dim3(gx, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, st, groups, nsample, c,
-                          offsets, dout, out, arg, y, mean, invstd, v, partial);
+                          offsets, dout, ldd, out, arg, y, mean, invstd, v, partial, partial_blocks);
   RS_CHECK_LAUNCH("rs_pool_max_backward");
   return RS_OK;
 }

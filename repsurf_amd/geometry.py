@@ -22,18 +22,43 @@ def _side_stream(device):
 
 
 class StageGeometry:
-    __slots__ = ("fps_idx", "new_center", "idx", "cnt")
+    """index: the compacted groups' bookkeeping (ops.CompactIndex) when the plan was asked for it -- like everything here it
+    depends on coordinates only, and the grouped MLP of the stage would otherwise build it on the critical path."""
+    __slots__ = ("fps_idx", "new_center", "idx", "cnt", "index")
 
-    def __init__(self, fps_idx, new_center, idx, cnt=None):
-        self.fps_idx, self.new_center, self.idx, self.cnt = fps_idx, new_center, idx, cnt
+    def __init__(self, fps_idx, new_center, idx, cnt=None, index=None):
+        self.fps_idx, self.new_center, self.idx, self.cnt, self.index = fps_idx, new_center, idx, cnt, index
+
+    def tensors(self):
+        out = [self.fps_idx, self.new_center, self.idx, self.cnt]
+        if self.index is not None:
+            # (grp, slot, src are rows of one (3, capacity) allocation: copied as that one tensor)
+            out += [self.index.offsets, self.index.mult, self.index.grp._base if self.index.grp._base is not None else self.index.grp]
+            if self.index.grp._base is None:
+                out += [self.index.slot, self.index.src]
+        return out
+
+    def clone(self):
+        from .ops import CompactIndex
+        index = None
+        if self.index is not None:
+            i = self.index
+            if i.grp._base is not None:
+                meta = i.grp._base.clone()
+                index = CompactIndex(i.offsets.clone(), i.mult.clone(), meta[0], meta[1], meta[2])
+            else:
+                index = CompactIndex(i.offsets.clone(), i.mult.clone(), i.grp.clone(), i.slot.clone(), i.src.clone())
+        return StageGeometry(self.fps_idx.clone(), self.new_center.clone(), self.idx.clone(), self.cnt.clone(), index)
 
 
 class GeometryPlan:
     """plan = GeometryPlan(xyz (B,N,3), [(npoint, radius, nsample), ...]); plan.stage(i) joins the side stream
     on first use and returns that stage's (fps_idx, new_center, ball idx)."""
 
-    def __init__(self, xyz, stages, fork=True):
-        """fork=False: everything on the current stream (the caller already runs this off the critical path)."""
+    def __init__(self, xyz, stages, fork=True, compact=False):
+        """fork=False: everything on the current stream (the caller already runs this off the critical path).
+        compact=True: also build every stage's ops.CompactIndex (scan of the ball-query counts + row bookkeeping)."""
+        from .ops import CompactIndex
         self.stages = []
         self.events = []
         self.main = torch.cuda.current_stream()
@@ -49,7 +74,8 @@ class GeometryPlan:
             self.stages.append(StageGeometry(torch.empty((b, npoint), dtype=torch.int32, device=dev),
                                              torch.empty((b, npoint, 3), dtype=torch.float32, device=dev),
                                              torch.empty((b, npoint, nsample), dtype=torch.int32, device=dev),
-                                             torch.empty((b, npoint), dtype=torch.int32, device=dev)))
+                                             torch.empty((b, npoint), dtype=torch.int32, device=dev),
+                                             CompactIndex.empty(b * npoint, nsample, dev) if compact else None))
         if fork:
             side.wait_stream(self.main)
         with torch.cuda.stream(side):
@@ -63,6 +89,10 @@ class GeometryPlan:
                           g.new_center.data_ptr(), st_ptr)
                 _lib.call("rs_ballquery", b, n, npoint, r2, nsample, g.new_center.data_ptr(), center.data_ptr(),
                           g.idx.data_ptr(), g.cnt.data_ptr(), st_ptr)
+                if g.index is not None:
+                    ci = g.index
+                    _lib.call("rs_compact_index", b, n, npoint, nsample, g.idx.data_ptr(), g.cnt.data_ptr(), ci.offsets.data_ptr(),
+                              ci.grp.data_ptr(), ci.slot.data_ptr(), ci.src.data_ptr(), ci.mult.data_ptr(), st_ptr)
                 center, n = g.new_center, npoint
                 if fork:
                     self.events.append(side.record_event())      # stage i is usable as soon as ITS kernels are done

@@ -17,6 +17,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
+from . import zeros as _zeros
 
 P, c_int, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 MAX_ROWS = 64
@@ -153,7 +154,7 @@ class _Head(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _lib.call("rs_head_input_backward", r, n1, k0, dz1.data_ptr(), w1.data_ptr(), dx.data_ptr(), _stream())
-        zeros = torch.zeros((n1 + n2,), dtype=torch.float32, device=dev)     # Linear biases in front of a BatchNorm: exactly 0
+        zeros = _zeros.take(n1 + n2, dev)     # Linear biases in front of a BatchNorm: exactly 0
         return dx, None, dw1, zeros[:n1], dg1, dbe1, dw2, zeros[n1:], dg2, dbe2, dw3, db3
 
 

@@ -19,6 +19,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
+from . import zeros as _zeros
 
 c_int, c_ll, P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
 OP_ID, OP_RELU1, OP_RELU2, OP_AFF2, OP_POOLED, OP_BCAST = range(6)
@@ -94,20 +95,6 @@ class RowSet:
         else:
             self.dev, self.full = compact["rows_dev"], compact["rows_full"]
             self.mult, self.grp, self.slot, self.offsets = compact["mult"], compact["grp"], compact["slot"], compact["offsets"]
-
-
-class _ZeroPool:
-    """Exact-zero gradients of the biases that feed a BatchNorm: one fill kernel per backward, sliced
-    (distinct memory per parameter, so an in-place gradient op downstream cannot alias)."""
-
-    def __init__(self, total, device):
-        self.buf = torch.zeros(total, dtype=torch.float32, device=device)
-        self.used = 0
-
-    def take(self, n):
-        out = self.buf[self.used:self.used + n]
-        self.used += n
-        return out
 
 
 _pending_counters = []
@@ -532,17 +519,17 @@ class _SAStack(Function):
         rs = s["rs"]
         groups, full, rdev = rs.full // ns, rs.full, rs.dev
         ys, vecs, w2ds = s["ys"], s["vecs"], s["w2ds"]
-        dout = dout.contiguous()
+        if dout.dim() != 2 or dout.stride(1) != 1 or dout.stride(0) < dout.shape[1]:      # (a column slice of a wider tensor is read in place)
+            dout = dout.contiguous()
         grads = [None] * ctx.nparams
         nl = len(ys)
         flush_reduces()      # (nothing, unless an earlier backward call was interrupted between a wgrad and its reduction)
-        zeros = _ZeroPool(sum(w.shape[0] for w in w2ds) + (2 * s["wl2"].shape[0] if pos > 0 else 0), dev)
         first = 8 if pos > 0 else 0
         # ---- pooled layer: BN-backward sums from (groups, c) data only
         c_last = ys[-1].shape[1]
-        v = torch.empty_like(dout)
+        v = torch.empty(dout.shape, dtype=torch.float32, device=dev)
         part = torch.empty((PARTIAL_BLOCKS, 2, c_last), dtype=torch.float64, device=dev)
-        _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), _ptr(s["out"]) if meta.get("relu_last", True) else None,
+        _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), dout.stride(0), _ptr(s["out"]) if meta.get("relu_last", True) else None,
                   s["arg"].data_ptr(), _ptr(ys[-1]), _bf(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
                   PARTIAL_BLOCKS, _stream())
         p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev, frozen=frozen)
@@ -563,7 +550,7 @@ class _SAStack(Function):
             cout, cin = w2ds[li].shape
             grads[pidx + 2], grads[pidx + 3] = dg, db
             # bias before BN: exactly 0 with batch statistics; through frozen statistics it is scale * sum(dz)
-            grads[pidx + 1] = vecs[li].scale * db if frozen else zeros.take(cout)
+            grads[pidx + 1] = vecs[li].scale * db if frozen else _zeros.take(cout, dev)
             # the activation that fed this layer, rebuilt on the fly from the stored conv outputs
             if li > 0:
                 q_op = operand(OP_RELU1, ys[li - 1], cin, s1=vecs[li - 1].scale, t1=vecs[li - 1].shift)
@@ -595,8 +582,8 @@ class _SAStack(Function):
                 foff, fk = meta.get("feat_off", pos), meta.get("feat_k", cx - pos)
                 grads[0] = fork.run(lambda: wgrad(rows, cin, pos, opl, operand(OP_ID, x, cx), dev, rdev, defer=True))
                 grads[4] = fork.run(lambda: wgrad(rows, cin, fk, opf, operand(OP_ID, x, cx, a_off=foff), dev, rdev, defer=True))
-                grads[1] = s["vl"].scale * dbl if frozen else zeros.take(cin)
-                grads[5] = s["vf"].scale * dbf if frozen else zeros.take(cin)
+                grads[1] = s["vl"].scale * dbl if frozen else _zeros.take(cin, dev)
+                grads[5] = s["vf"].scale * dbf if frozen else _zeros.take(cin, dev)
                 grads[2], grads[3], grads[6], grads[7] = dgl, dbl, dgf, dbf
                 if ctx.needs_input_grad[0]:
                     # Only the feature channels [pos:] carry a gradient (coordinates are inputs); the grouping
@@ -710,7 +697,7 @@ class _UmbrellaStack(Function):
         g_w0 = wgrad(rows, c0n, cx, p0, operand(OP_ID, x, cx), dev)
         shp = meta["shapes"]
         # bias before BN: exactly 0 with batch statistics; scale * sum(dz) through frozen ones
-        g_c1 = v1.scale * g_b1 if frozen else torch.zeros(c1n, dtype=torch.float32, device=dev)
+        g_c1 = v1.scale * g_b1 if frozen else _zeros.take(c1n, dev)
         return (None, None, g_w0.reshape(shp[0]), g_g0, g_b0, g_w1.reshape(shp[1]), g_c1, g_g1, g_b1,
                 g_w2.reshape(shp[2]), g_c2)
 
@@ -785,7 +772,7 @@ class _UmbrellaFused(Function):
         desc.c0 = _ptr(p0)
         run(5, 0)
         shp = meta["shapes"]
-        g_c1 = torch.zeros(10, dtype=torch.float32, device=dev)             # bias before BN: exactly 0
+        g_c1 = _zeros.take(10, dev)             # bias before BN: exactly 0
         return (None, None, res[0, :100].reshape(shp[0]), g_g0, g_b0, res[1, :100].reshape(shp[1]), g_c1, g_g1, g_b1,
                 res[2, :100].reshape(shp[2]), res[2, 100:])
 
@@ -833,7 +820,7 @@ class _UmbrellaStack2(Function):
         p0 = operand(OP_AFF2, dz0, c0n, y0, c0n, s1=pb, t1=rb, s2=qb)
         g_w0 = wgrad(rows, c0n, cx, p0, operand(OP_ID, x, cx), dev)
         shp = meta["shapes"]
-        g_c0 = v0.scale * g_b0 if frozen else torch.zeros(c0n, dtype=torch.float32, device=dev)   # bias before BN
+        g_c0 = v0.scale * g_b0 if frozen else _zeros.take(c0n, dev)   # bias before BN
         return None, None, g_w0.reshape(shp[0]), g_c0, g_g0, g_b0, g_w1.reshape(shp[1]), g_c1
 
 

@@ -397,9 +397,51 @@ class CompactGroups:
         return self.offsets.data_ptr() + 4 * self.groups
 
 
+class CompactIndex:
+    """The bookkeeping of compacted groups (rs_compact_index): offsets (groups + 1), mult / grp / slot / src (capacity).  It
+    depends on the ball query's (idx, cnt) only, so the geometry stage of a pipelined step builds it ahead of time."""
+    __slots__ = ("offsets", "mult", "grp", "slot", "src")
+
+    def __init__(self, offsets, mult, grp, slot, src):
+        self.offsets, self.mult, self.grp, self.slot, self.src = offsets, mult, grp, slot, src
+
+    @staticmethod
+    def empty(groups, nsample, dev):
+        cap = groups * nsample
+        meta = torch.empty((3, cap), dtype=torch.int32, device=dev)
+        return CompactIndex(torch.empty((groups + 1,), dtype=torch.int32, device=dev), torch.empty((cap,), dtype=torch.float32, device=dev),
+                            meta[0], meta[1], meta[2])
+
+
+def compact_index(idx, cnt, n, out=None, stream=None):
+    """idx (B, M, ns), cnt (B, M) of a ball query over clouds of n points -> CompactIndex."""
+    _need_gpu(idx, cnt)
+    idx, cnt = _i32c(idx), _i32c(cnt)
+    b, m, ns = idx.shape
+    ci = out if out is not None else CompactIndex.empty(b * m, ns, idx.device)
+    _lib.call("rs_compact_index", b, n, m, ns, _p(idx), _p(cnt), _p(ci.offsets), _p(ci.grp), _p(ci.slot), _p(ci.src), _p(ci.mult),
+              _stream() if stream is None else stream)
+    return ci
+
+
+def _row_stride(t, rows, c):
+    """t viewed as (rows, c) with unit inner stride: its row stride, or None when it is not that regular"""
+    if t.numel() != rows * c or t.stride(-1) != 1:
+        return None
+    ld = t.stride(-2)
+    if ld < c:
+        return None
+    lead, step = t.shape[:-2], ld * t.shape[-2]
+    for d in range(len(lead) - 1, -1, -1):          # leading dimensions must continue the same row pitch
+        if lead[d] != 1 and t.stride(d) != step:
+            return None
+        step *= lead[d]
+    return ld
+
+
 class _GroupFeaturesCompact(Function):
     @staticmethod
-    def forward(ctx, center, new_center, normal, feature, idx, cnt, polar):
+    def forward(ctx, center, new_center, normal, feature, idx, cnt, polar, index, fps_idx):
         _need_gpu(center, new_center, normal, feature, idx, cnt)
         center, new_center, normal = _f32c(center), _f32c(new_center), _f32c(normal)
         idx, cnt = _i32c(idx), _i32c(cnt)
@@ -411,56 +453,94 @@ class _GroupFeaturesCompact(Function):
         ctot = (6 if polar else 3) + cn + cf
         dev = center.device
         groups, cap = b * m, b * m * ns
-        offsets = torch.empty((groups + 1,), dtype=torch.int32, device=dev)
-        _lib.call("rs_exclusive_scan", groups, _p(cnt), _p(offsets), _stream())
+        have = index is not None
+        if not have:
+            index = CompactIndex.empty(groups, ns, dev)
+            _lib.call("rs_exclusive_scan", groups, _p(cnt), _p(index.offsets), _stream())
+        offsets, mult, grp, slot, src = index.offsets, index.mult, index.grp, index.slot, index.src
         out = torch.empty((cap, ctot), dtype=torch.float32, device=dev)
-        mult = torch.empty((cap,), dtype=torch.float32, device=dev)
-        meta = torch.empty((3, cap), dtype=torch.int32, device=dev)
-        grp, slot, src = meta[0], meta[1], meta[2]
+        fps_idx = None if (fps_idx is None or cn == 0) else _i32c(fps_idx)
+        new_normal = None if fps_idx is None else torch.empty((b, m, cn), dtype=torch.float32, device=dev)
         _lib.call("rs_group_features_compact", b, n, m, ns, cn, cf, int(polar), _p(center), _p(new_center),
                   _p(normal), _p(feature), _p(idx), _p(cnt), _p(offsets), _p(out), _p(mult), _p(grp), _p(slot),
-                  _p(src), _stream())
-        ctx.save_for_backward(src, offsets)
-        ctx.dims = (b, n, cn, cf, int(polar), cap, groups)
+                  _p(src), int(have), _p(fps_idx), _p(new_normal), _stream())
+        ctx.save_for_backward(src, offsets, fps_idx)
+        ctx.dims = (b, n, m, cn, cf, int(polar), cap, groups)
         ctx.need = (ctx.needs_input_grad[2], feature is not None and ctx.needs_input_grad[3])
         ctx.mark_non_differentiable(mult, grp, slot, src, offsets)
-        ctx.set_materialize_grads(False)      # no zero-filled "gradients" for the five index/bookkeeping outputs
-        return out, mult, grp, slot, src, offsets
+        ctx.set_materialize_grads(False)      # no zero-filled "gradients" for the index/bookkeeping outputs or an unused new_normal
+        if new_normal is None:
+            new_normal = torch.empty((0,), dtype=torch.float32, device=dev)
+            ctx.mark_non_differentiable(new_normal)
+        return out, new_normal, mult, grp, slot, src, offsets
 
     @staticmethod
-    def backward(ctx, grad_out, *unused):
-        src, offsets = ctx.saved_tensors
-        b, n, cn, cf, polar, cap, groups = ctx.dims
-        if grad_out is None:
-            return (None,) * 7
+    def backward(ctx, grad_out, grad_new_normal, *unused):
+        src, offsets, fps_idx = ctx.saved_tensors
+        b, n, m, cn, cf, polar, cap, groups = ctx.dims
+        if grad_out is None and grad_new_normal is None:
+            return (None,) * 9
+        dev = src.device
+        centre = fps_idx is not None and grad_new_normal is not None and ctx.need[0]
+        gn, gf = _zero_pair(b * n, cn if ctx.need[0] else 0, cf if (ctx.need[1] and grad_out is not None) else 0, (b, n), dev)
+        if grad_out is None:       # only the centres' own rows were used downstream
+            if centre:
+                g = _f32c(grad_new_normal)
+                _lib.call("rs_gather_rows_backward", b, n, m, cn, _p(g), _p(fps_idx), _p(gn), _stream())
+            return None, None, gn, gf, None, None, None, None, None
         grad_out = _f32c(grad_out)
-        dev = grad_out.device
-        gn, gf = _zero_pair(b * n, cn if ctx.need[0] else 0, cf if ctx.need[1] else 0, (b, n), dev)
+        ldg = 0
+        if centre:
+            ldg = _row_stride(grad_new_normal, groups, cn)
+            if ldg is None:
+                grad_new_normal, ldg = _f32c(grad_new_normal), cn
         if gn is not None or gf is not None:
             _lib.call("rs_group_features_compact_backward", cap, offsets.data_ptr() + 4 * groups, cn, cf, polar,
-                      _p(grad_out), _p(src), _p(gn), _p(gf), _stream())
-        return None, None, gn, gf, None, None, None
+                      _p(grad_out), _p(src), _p(gn), _p(gf), b, n, m, _p(fps_idx) if centre else None,
+                      _p(grad_new_normal) if centre else None, ldg, _stream())
+        return None, None, gn, gf, None, None, None, None, None
 
 
-def group_features_compact(center, new_center, normal, feature, idx, cnt, polar=True):
-    """Compacted grouped operand (see CompactGroups); differentiable w.r.t. normal and feature."""
-    out, mult, grp, slot, src, offsets = _GroupFeaturesCompact.apply(center, new_center, normal, feature, idx, cnt, polar)
-    return CompactGroups(out, mult, grp, slot, src, offsets, idx.shape[0] * idx.shape[1], idx.shape[2])
+def group_features_compact(center, new_center, normal, feature, idx, cnt, polar=True, index=None, fps_idx=None):
+    """Compacted grouped operand (see CompactGroups); differentiable w.r.t. normal and feature.
+    index: a CompactIndex built ahead of time from the same (idx, cnt) (else built here).
+    fps_idx (B, M): also return index_points(normal, fps_idx) -- the centres' own normal rows -- from the same launches
+    (forward: inside the gather kernel; backward: inside the scatter kernel, into the same gradient buffer, instead of a
+    fill + scatter + add of their own): -> (CompactGroups, new_normal (B, M, cn))."""
+    out, new_normal, mult, grp, slot, src, offsets = _GroupFeaturesCompact.apply(center, new_center, normal, feature, idx, cnt, polar,
+                                                                                 index, fps_idx)
+    groups = CompactGroups(out, mult, grp, slot, src, offsets, idx.shape[0] * idx.shape[1], idx.shape[2])
+    return groups if fps_idx is None else (groups, new_normal)
+
+
+class _GroupAllFeatures(Function):
+    @staticmethod
+    def forward(ctx, center, normal, feature, polar):
+        _need_gpu(center, normal, feature)
+        center, normal = _f32c(center), _f32c(normal)
+        feature = None if feature is None else _f32c(feature)
+        b, n, _ = center.shape
+        cn, cf = normal.shape[2], 0 if feature is None else feature.shape[2]
+        cpos = 6 if polar else 3
+        out = torch.empty((b * n, cpos + cn + cf), dtype=torch.float32, device=center.device)
+        _lib.call("rs_group_all_features", b, n, cn, cf, int(polar), _p(center), _p(normal), _p(feature), _p(out), _stream())
+        ctx.dims = (b, n, cpos, cn, cf)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        b, n, cpos, cn, cf = ctx.dims
+        # column slices of the incoming gradient, as views: the consumers (rs_pool_max_backward's `ldd`, the compacted
+        # grouping's `ldg`) read rows at a pitch, so nothing is copied
+        gn = grad[:, cpos:cpos + cn].view(b, n, cn) if ctx.needs_input_grad[1] else None
+        gf = grad[:, cpos + cn:].view(b, n, cf) if (cf and ctx.needs_input_grad[2]) else None
+        return None, gn, gf, None
 
 
 def group_all_features(center, normal, feature, polar=True):
-    """sample_and_group_all (repsurface_utils.py:62-88) -> (B*N, 3+3*polar+Cn+Cf).
-    A pure per-row concat: differentiable pieces (normal, feature) are concatenated with torch.cat
-    so autograd needs no custom backward; the coordinate block comes from the HIP kernel."""
-    _need_gpu(center, normal, feature)
-    center = _f32c(center)
-    b, n, _ = center.shape
-    pos = torch.empty((b * n, 6 if polar else 3), dtype=torch.float32, device=center.device)
-    _lib.call("rs_group_all_features", b, n, 0, 0, int(polar), _p(center), None, None, _p(pos), _stream())
-    parts = [pos, normal.reshape(b * n, -1)]
-    if feature is not None:
-        parts.append(feature.reshape(b * n, -1))
-    return torch.cat(parts, dim=1)
+    """sample_and_group_all (repsurface_utils.py:62-88) -> (B*N, 3+3*polar+Cn+Cf), one launch; differentiable w.r.t. normal
+    and feature (their gradients are column slices of the row gradient, returned as views)."""
+    return _GroupAllFeatures.apply(center, normal, feature, polar)
 
 
 # ----------------------------------------------------------------------------- three-NN interpolation

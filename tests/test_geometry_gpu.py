@@ -273,14 +273,116 @@ print("grid variant ok")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 5, 63, 4096, 16383, 16384, 20000])
+@pytest.mark.parametrize("n", [0, 1, 5, 63, 4096, 16383, 16384, 16385, 20000, 32768, 49153, 1000003])
 def test_exclusive_scan_matches_cumsum(n):
     """offsets of the compacted groups (rs_exclusive_scan): out[i] = sum_{j<i} in[j], out[n] = total; bit-exact."""
     from repsurf_amd import _lib
     g = torch.Generator().manual_seed(n)
     cnt = torch.randint(0, 65, (n,), generator=g, dtype=torch.int32).cuda()
     out = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
-    _lib.call("rs_exclusive_scan", n, cnt.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.call("rs_exclusive_scan", n, cnt.data_ptr() if n else out.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     ref = torch.zeros(n + 1, dtype=torch.int64)
     ref[1:] = torch.cumsum(cnt.cpu().to(torch.int64), 0)
     assert torch.equal(out.cpu().to(torch.int64), ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launches taken off the critical path of a stage (round 2): the compacted groups' bookkeeping built ahead of time, the
+# centres' own normal rows gathered / scattered inside the grouping launches, gradients read at a row pitch
+@pytest.mark.gpu
+@pytest.mark.parametrize("radius,ns,cf", [(0.25, 16, 12), (0.5, 32, 0), (2.0, 8, 5)])
+def test_compact_grouping_with_prebuilt_index_and_fused_centre_rows(radius, ns, cf):
+    """ops.group_features_compact(index=..., fps_idx=...) against the separate launches it replaces: the operand, the
+    bookkeeping and new_normal bit for bit; the gradients of normal / feature equal to scatter(grouped) + scatter(centre
+    rows) (atomic fp32 sums: order-dependent rounding only), also with the centre-row gradient given as a column slice."""
+    from repsurf_amd import ops
+    from tests.util import cloud
+    b, n, s, cn = 3, 256, 64, 10
+    xyz = torch.from_numpy(cloud(78, b, n)).cuda()
+    fps = ops.furthestsampling(xyz, s)
+    centres = ops.gather_rows(xyz, fps)
+    idx, cnt = ops.ballquery(radius, ns, xyz, centres, return_count=True)
+    g = torch.Generator().manual_seed(4)
+    normal0 = torch.randn(b, n, cn, generator=g).cuda()
+    feature0 = torch.randn(b, n, cf, generator=g).cuda() if cf else None
+    ctot = 6 + cn + cf
+    w_rows = torch.randn(b * s * ns, ctot, generator=g).cuda()
+    wide = torch.randn(b * s, cn + 7, generator=g).cuda()                      # the centre rows' gradient: columns [3, 3 + cn) of this
+    res = {}
+    for kind in ("separate", "fused", "fused_strided"):
+        normal = normal0.clone().requires_grad_()
+        feature = None if feature0 is None else feature0.clone().requires_grad_()
+        if kind == "separate":
+            cg = ops.group_features_compact(xyz, centres, normal, feature, idx, cnt, polar=True)
+            new_normal = ops.gather_rows(normal, fps)
+        else:
+            index = ops.compact_index(idx, cnt, n)
+            cg, new_normal = ops.group_features_compact(xyz, centres, normal, feature, idx, cnt, polar=True, index=index, fps_idx=fps)
+        rows = int(cg.offsets[-1])
+        loss = (cg.x[:rows] * w_rows[:rows]).sum()
+        if kind == "fused_strided":        # autograd hands the Function a (b, s, cn) view with row pitch cn + 7
+            new_normal.backward(wide[:, 3:3 + cn].view(b, s, cn), retain_graph=True)
+            loss.backward()
+        else:
+            (loss + (new_normal.reshape(b * s, cn) * wide[:, 3:3 + cn]).sum()).backward()
+        res[kind] = (cg, new_normal.detach(), rows, normal.grad.clone(), None if feature is None else feature.grad.clone())
+    sep = res["separate"]
+    for kind in ("fused", "fused_strided"):
+        got = res[kind]
+        assert got[2] == sep[2] == int(cnt.sum())
+        r = got[2]
+        assert torch.equal(got[0].x[:r], sep[0].x[:r]) and torch.equal(got[1], sep[1])
+        for name in ("offsets",):
+            assert torch.equal(getattr(got[0], name), getattr(sep[0], name))
+        for name in ("mult", "grp", "slot", "src"):
+            assert torch.equal(getattr(got[0], name)[:r], getattr(sep[0], name)[:r]), name
+        if kind == "fused":
+            assert torch.allclose(got[3], sep[3], rtol=1e-5, atol=1e-5)
+            if cf:
+                assert torch.allclose(got[4], sep[4], rtol=1e-5, atol=1e-5)
+    # the strided run accumulates the two contributions in two backward calls: compare with the sum
+    assert torch.allclose(res["fused_strided"][3], sep[3], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_group_all_gradients_are_column_slices():
+    from repsurf_amd import ops
+    from tests.util import cloud
+    b, n, cn, cf = 4, 128, 10, 24
+    xyz = torch.from_numpy(cloud(5, b, n)).cuda()
+    g = torch.Generator().manual_seed(8)
+    normal, feature = torch.randn(b, n, cn, generator=g).cuda().requires_grad_(), torch.randn(b, n, cf, generator=g).cuda().requires_grad_()
+    w = torch.randn(b * n, 6 + cn + cf, generator=g).cuda()
+    rows = ops.group_all_features(xyz, normal, feature, polar=True)
+    assert torch.equal(rows[:, 6:6 + cn], normal.detach().view(b * n, cn)) and torch.equal(rows[:, 6 + cn:], feature.detach().view(b * n, cf))
+    (rows * w).sum().backward()
+    assert torch.equal(normal.grad, w[:, 6:6 + cn].reshape(b, n, cn)) and torch.equal(feature.grad, w[:, 6 + cn:].reshape(b, n, cf))
+
+
+@pytest.mark.gpu
+def test_zero_pool_is_fresh_per_backward_pass_and_never_aliases():
+    from repsurf_amd import zeros
+
+    class Z(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            a, b2 = zeros.take(100, g.device), zeros.take(5000, g.device)
+            c = zeros.take(zeros.CAPACITY, g.device)          # does not fit the rest of the chunk: a new one
+            assert a.data_ptr() != b2.data_ptr() and a.untyped_storage().data_ptr() == b2.untyped_storage().data_ptr()
+            assert c.untyped_storage().data_ptr() != a.untyped_storage().data_ptr()
+            Z.seen.append((a, b2, c))
+            return g
+    Z.seen = []
+    x = torch.ones(4, device="cuda", requires_grad=True)
+    for _ in range(2):
+        Z.apply(x).sum().backward()
+        a, b2, c = Z.seen[-1]
+        assert float(a.abs().sum() + b2.abs().sum() + c.abs().sum()) == 0.0
+        a.fill_(3.0)                                          # an in-place op on a handed-out gradient ...
+    assert not zeros._pool and not zeros._armed                # ... cannot reach the next pass: the pool died with its pass
+    assert float(Z.seen[1][0].sum()) == 300.0 and float(Z.seen[1][1].abs().sum()) == 0.0
+    assert float(zeros.take(7, x.device).abs().sum()) == 0.0   # outside a backward pass: plain zeros
