@@ -311,6 +311,26 @@ int rs_bn_backward_finalize(int c, long long rows, int nblk, int nstat, int whic
                             const float *scale, const float *mean, const float *invstd, float *p,
                             float *q, float *r, float *dgamma, float *dbeta, void *stream);
 
+/* Several of the small jobs above in one launch (each is microseconds of work behind a graph node's ~5 us latency, and a
+ * stack issues them in pairs): rs_bn_finalize for up to RS_BN_BATCH_MAX layers (the two BatchNorms of a two-branch first
+ * layer: classification/modules/repsurface_utils.py:236-241); rs_bn_backward_finalize for up to RS_TAIL_FIN_MAX layers
+ * together with rs_reduce_partials for up to RS_TAIL_RED_MAX weight gradients. */
+#define RS_BN_BATCH_MAX 4
+#define RS_TAIL_FIN_MAX 2
+#define RS_TAIL_RED_MAX 4
+typedef struct {
+  int c, nblk; long long rows; const double *partial; const float *gamma, *beta; float eps, momentum;
+  float *scale, *shift, *save_mean, *save_invstd, *running_mean, *running_var;
+} rs_bn_item;                                         /* the arguments of rs_bn_finalize */
+typedef struct {
+  int c, nblk, nstat, which; long long rows; const double *partial; const float *scale, *mean, *invstd;
+  float *p, *q, *r, *dgamma, *dbeta;
+} rs_bn_bwd_item;                                     /* the arguments of rs_bn_backward_finalize */
+typedef struct { int chunks; long long n; const float *partial; float *out; } rs_reduce_item;   /* ... of rs_reduce_partials */
+typedef struct { int nfin, nred; rs_bn_bwd_item fin[RS_TAIL_FIN_MAX]; rs_reduce_item red[RS_TAIL_RED_MAX]; } rs_backward_tail_work;
+int rs_bn_finalize_batch(const rs_bn_item *items, int n, void *stream);
+int rs_backward_tail(const rs_backward_tail_work *work, void *stream);
+
 /* out[g][c] = max_k f(scale*y[g*nsample+k][c] + shift), f = relu when `relu` != 0, arg = first k
  * attaining it (torch.max(new_feature, 2)[0] fused with the last BatchNorm + ReLU, :243-244);
  * scale/shift may be NULL (identity). */

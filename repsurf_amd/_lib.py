@@ -49,6 +49,8 @@ SIGNATURES = {
     "rs_pool_sum": [c_ll, c_int, c_int, P, P, P],
     "rs_pool_select": [c_ll, c_int, P, P, P, P, P, P, P, P, P],
     "rs_reduce_partials": [c_int, c_ll, P, P, P],
+    "rs_backward_tail": [P, P],
+    "rs_bn_finalize_batch": [P, c_int, P],
     "rs_bn_backward_finalize_reduce": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, c_ll, P, P, P],
     "rs_pack_weights": [P, P],
     "rs_umbrella_mlp_pass": [c_int, P, c_float, P, P, P, c_int, P],

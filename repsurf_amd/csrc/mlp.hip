@@ -1214,11 +1214,11 @@ reduce_partials_kernel(int chunks, long long n, const float *__restrict__ partia
 // lanes read consecutive channels (64-byte rows of doubles), slices are combined through LDS in a
 // fixed order (deterministic).
 template <int NS>   // number of statistics reduced together
-__device__ __forceinline__ void reduce_stat_rows(int c, int nblk, int nstat, const int (&which)[NS],
+__device__ __forceinline__ void reduce_stat_rows(int cb, int c, int nblk, int nstat, const int (&which)[NS],
                                                  const double *__restrict__ partial, double (&out)[NS], bool &owner) {
   __shared__ double red[32][8][NS];
   const int ex = threadIdx.x & 7, sl = threadIdx.x >> 3;      // 8 channels (64 contiguous bytes) x 32 slices
-  const int ch = blockIdx.x * 8 + ex;
+  const int ch = cb * 8 + ex;                                  // cb: this workgroup's block of 8 channels
   double acc[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = 0.0;
@@ -1261,7 +1261,7 @@ bn_finalize_kernel(int c, long long rows, int nblk, const double *__restrict__ p
   const int which[2] = {0, 1};
   double sq[2];
   bool owner;
-  reduce_stat_rows<2>(c, nblk, 2, which, partial, sq, owner);
+  reduce_stat_rows<2>(blockIdx.x, c, nblk, 2, which, partial, sq, owner);
   if (!owner) return;
   const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
   const double mean = sq[0] / (double)rows;
@@ -1290,7 +1290,7 @@ bn_bwd_finalize_kernel(int c, long long rows, int nblk, int nstat, int which, co
   const int sel[2] = {0, which};
   double v[2];
   bool owner;
-  reduce_stat_rows<2>(c, nblk, nstat, sel, partial, v, owner);
+  reduce_stat_rows<2>(blockIdx.x, c, nblk, nstat, sel, partial, v, owner);
   if (!owner) return;
   const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
   const double db = v[0], dg = v[1];
@@ -1321,7 +1321,7 @@ bn_bwd_finalize_reduce_kernel(int c, long long rows, int nblk, int nstat, int wh
   const int sel[2] = {0, which};
   double v[2];
   bool owner;
-  reduce_stat_rows<2>(c, nblk, nstat, sel, partial, v, owner);
+  reduce_stat_rows<2>(blockIdx.x, c, nblk, nstat, sel, partial, v, owner);
   if (!owner) return;
   const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
   const double db = v[0], dg = v[1];
@@ -1332,6 +1332,74 @@ bn_bwd_finalize_reduce_kernel(int c, long long rows, int nblk, int nstat, int wh
   r[ch] = (float)(-s * db / m - qq * mu);
   if (dgamma) dgamma[ch] = (float)dg;
   if (dbeta) dbeta[ch] = (float)db;
+}
+
+// ---- several of those small jobs in ONE launch ---------------------------------------------------------------------
+// Every one of them is a few microseconds of work behind ~5 us of graph-node latency, and a stack's backward issues them
+// in pairs (the two BatchNorms of a two-branch first layer, the two first-layer weight gradients): rs_backward_tail takes
+// up to RS_TAIL_FIN_MAX BatchNorm-backward finalizes and up to RS_TAIL_RED_MAX weight-gradient reductions, workgroup
+// ranges [start[i], start[i + 1]) per job; rs_bn_finalize_batch the forward statistics of up to RS_BN_BATCH_MAX layers.
+struct TailStarts { int fin[RS_TAIL_FIN_MAX + 1]; int red[RS_TAIL_RED_MAX + 1]; };
+
+__global__ void __launch_bounds__(256)
+backward_tail_kernel(rs_backward_tail_work w, TailStarts st) {
+  const int b = blockIdx.x;
+  if (b < st.fin[w.nfin]) {
+    int i = 0;
+    for (int k = 1; k < w.nfin; ++k) if (b >= st.fin[k]) i = k;
+    const rs_bn_bwd_item &it = w.fin[i];
+    const int cb = b - st.fin[i];
+    const int sel[2] = {0, it.which};
+    double v[2];
+    bool owner;
+    reduce_stat_rows<2>(cb, it.c, it.nblk, it.nstat, sel, it.partial, v, owner);
+    if (!owner) return;
+    const int ch = cb * 8 + (threadIdx.x & 7);
+    const double db = v[0], dg = v[1];
+    const double s = it.scale[ch], is = it.invstd[ch], mu = it.mean[ch], m = (double)it.rows;
+    const double qq = -s * is * dg / m;                 // dy = s * (dz - db/m - yhat * dg/m),  yhat = (y - mu) * is
+    it.p[ch] = (float)s;
+    it.q[ch] = (float)qq;
+    it.r[ch] = (float)(-s * db / m - qq * mu);
+    if (it.dgamma) it.dgamma[ch] = (float)dg;
+    if (it.dbeta) it.dbeta[ch] = (float)db;
+    return;
+  }
+  int j = 0;
+  for (int k = 1; k < w.nred; ++k) if (b >= st.red[k]) j = k;
+  reduce_partials_body(b - st.red[j], st.red[j + 1] - st.red[j], w.red[j].chunks, w.red[j].n, w.red[j].partial, w.red[j].out);
+}
+
+struct BnBatch { rs_bn_item it[RS_BN_BATCH_MAX]; int start[RS_BN_BATCH_MAX + 1]; int n; };
+
+__global__ void __launch_bounds__(256)
+bn_finalize_batch_kernel(BnBatch w) {
+  const int b = blockIdx.x;
+  int i = 0;
+  for (int k = 1; k < w.n; ++k) if (b >= w.start[k]) i = k;
+  const rs_bn_item &it = w.it[i];
+  const int cb = b - w.start[i];
+  const int which[2] = {0, 1};
+  double sq[2];
+  bool owner;
+  reduce_stat_rows<2>(cb, it.c, it.nblk, 2, which, it.partial, sq, owner);
+  if (!owner) return;
+  const int ch = cb * 8 + (threadIdx.x & 7);
+  const double rows = (double)it.rows;
+  const double mean = sq[0] / rows;
+  double var = sq[1] / rows - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)it.eps);
+  const double g = it.gamma ? (double)it.gamma[ch] : 1.0, bt = it.beta ? (double)it.beta[ch] : 0.0;
+  it.scale[ch] = (float)(g * invstd);
+  it.shift[ch] = (float)(bt - mean * g * invstd);
+  it.save_mean[ch] = (float)mean;
+  it.save_invstd[ch] = (float)invstd;
+  if (it.running_mean) {
+    const double unbiased = it.rows > 1 ? var * rows / (rows - 1.0) : var;
+    it.running_mean[ch] = (float)((1.0 - it.momentum) * (double)it.running_mean[ch] + it.momentum * mean);
+    it.running_var[ch] = (float)((1.0 - it.momentum) * (double)it.running_var[ch] + it.momentum * unbiased);
+  }
 }
 
 // element e of the pooled layer's pre-activation y: fp32, or bf16 (bf16 activation storage) behind the same pointer type
@@ -1882,6 +1950,57 @@ extern "C" int rs_bn_backward_finalize_reduce(int c, long long rows, int nblk, i
                      nstat, which, partial, scale, mean, invstd, p, q, r, dgamma, dbeta, nfin, red_chunks, red_n, red_partial,
                      red_out);
   RS_CHECK_LAUNCH("rs_bn_backward_finalize_reduce");
+  return RS_OK;
+}
+
+extern "C" int rs_backward_tail(const rs_backward_tail_work *work, void *stream) {
+  RS_REQUIRE(work, "rs_backward_tail: null pointer");
+  rs_backward_tail_work w = *work;
+  RS_REQUIRE(w.nfin >= 0 && w.nfin <= RS_TAIL_FIN_MAX && w.nred >= 0 && w.nred <= RS_TAIL_RED_MAX, "rs_backward_tail: %d finalizes / %d reductions exceed %d / %d",
+             w.nfin, w.nred, RS_TAIL_FIN_MAX, RS_TAIL_RED_MAX);
+  if (w.nfin == 0 && w.nred == 0) return RS_OK;
+  TailStarts st = {};
+  int at = 0;
+  for (int i = 0; i < w.nfin; ++i) {
+    const rs_bn_bwd_item &it = w.fin[i];
+    RS_REQUIRE(it.c > 0 && it.rows > 0 && it.nblk > 0 && it.nstat >= 2 && it.which >= 1 && it.which < it.nstat, "rs_backward_tail: bad size (finalize %d)", i);
+    RS_REQUIRE(it.partial && it.scale && it.mean && it.invstd && it.p && it.q && it.r, "rs_backward_tail: null pointer (finalize %d)", i);
+    st.fin[i] = at;
+    at += rs_cdiv(it.c, 8);
+  }
+  for (int i = w.nfin; i <= RS_TAIL_FIN_MAX; ++i) st.fin[i] = at;
+  for (int j = 0; j < w.nred; ++j) {
+    const rs_reduce_item &it = w.red[j];
+    RS_REQUIRE(it.chunks > 0 && it.n > 0 && it.partial && it.out, "rs_backward_tail: empty reduction %d", j);
+    long long rb = (it.n + 31) / 32;
+    if (rb > 2048 / (w.nred > 1 ? 2 : 1)) rb = 2048 / (w.nred > 1 ? 2 : 1);
+    st.red[j] = at;
+    at += (int)rb;
+  }
+  for (int j = w.nred; j <= RS_TAIL_RED_MAX; ++j) st.red[j] = at;
+  hipLaunchKernelGGL(backward_tail_kernel, dim3(at), dim3(256), 0, (hipStream_t)stream, w, st);
+  RS_CHECK_LAUNCH("rs_backward_tail");
+  return RS_OK;
+}
+
+extern "C" int rs_bn_finalize_batch(const rs_bn_item *items, int n, void *stream) {
+  RS_REQUIRE(items && n >= 0 && n <= RS_BN_BATCH_MAX, "rs_bn_finalize_batch: %d items (at most %d)", n, RS_BN_BATCH_MAX);
+  if (n == 0) return RS_OK;
+  BnBatch w = {};
+  int at = 0;
+  for (int i = 0; i < n; ++i) {
+    const rs_bn_item &it = items[i];
+    RS_REQUIRE(it.c > 0 && it.rows > 0 && it.nblk > 0, "rs_bn_finalize_batch: bad size (item %d)", i);
+    RS_REQUIRE(it.partial && it.scale && it.shift && it.save_mean && it.save_invstd, "rs_bn_finalize_batch: null pointer (item %d)", i);
+    RS_REQUIRE((it.running_mean == nullptr) == (it.running_var == nullptr), "rs_bn_finalize_batch: running_mean and running_var come together (item %d)", i);
+    w.it[i] = it;
+    w.start[i] = at;
+    at += rs_cdiv(it.c, 8);
+  }
+  for (int i = n; i <= RS_BN_BATCH_MAX; ++i) w.start[i] = at;
+  w.n = n;
+  hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3(at), dim3(256), 0, (hipStream_t)stream, w);
+  RS_CHECK_LAUNCH("rs_bn_finalize_batch");
   return RS_OK;
 }
 

@@ -46,6 +46,28 @@ class Epilogue(ctypes.Structure):            # rs_mlp_epilogue
                 ("row_mult", P), ("out_bf16", c_int), ("my1_bf16", c_int), ("my2_bf16", c_int)]
 
 
+class BnItem(ctypes.Structure):              # rs_bn_item
+    _fields_ = [("c", c_int), ("nblk", c_int), ("rows", c_ll), ("partial", P), ("gamma", P), ("beta", P), ("eps", ctypes.c_float),
+                ("momentum", ctypes.c_float), ("scale", P), ("shift", P), ("save_mean", P), ("save_invstd", P), ("running_mean", P),
+                ("running_var", P)]
+
+
+class BnBwdItem(ctypes.Structure):           # rs_bn_bwd_item
+    _fields_ = [("c", c_int), ("nblk", c_int), ("nstat", c_int), ("which", c_int), ("rows", c_ll), ("partial", P), ("scale", P),
+                ("mean", P), ("invstd", P), ("p", P), ("q", P), ("r", P), ("dgamma", P), ("dbeta", P)]
+
+
+class ReduceItem(ctypes.Structure):          # rs_reduce_item
+    _fields_ = [("chunks", c_int), ("n", c_ll), ("partial", P), ("out", P)]
+
+
+TAIL_FIN_MAX, TAIL_RED_MAX, BN_BATCH_MAX = 2, 4, 4
+
+
+class BackwardTail(ctypes.Structure):        # rs_backward_tail_work
+    _fields_ = [("nfin", c_int), ("nred", c_int), ("fin", BnBwdItem * TAIL_FIN_MAX), ("red", ReduceItem * TAIL_RED_MAX)]
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -271,7 +293,16 @@ def fused_pool_ok(cout, nsample):
     return rows_per_thread % nsample == 0
 
 
-def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, rs=None, wk=None, store_bf16=False):
+def bn_finalize_batch(items):
+    """rs_bn_finalize for several layers in one launch; items: what fwd_layer(finalize=False) returned (the item keeps its
+    tensors alive)."""
+    for i in range(0, len(items), BN_BATCH_MAX):
+        chunk = items[i:i + BN_BATCH_MAX]
+        arr = (BnItem * len(chunk))(*[it[0] for it in chunk])
+        _lib.call("rs_bn_finalize_batch", ctypes.cast(arr, P), len(chunk), _stream())
+
+
+def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, rs=None, wk=None, store_bf16=False, finalize=True):
     """y = E . W^T + bias with BN statistics; returns (y, BNVec[, pooled (out, arg)]).
     rs: RowSet of a compacted operand (device row count, per-row weights of the statistics).
     store_bf16: y is written as bf16 (rounded first; statistics and pooling see the rounded values)."""
@@ -300,6 +331,13 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
         if track:
             _pending_counters.append(bn_mod.num_batches_tracked)
         mom = bn_mod.momentum if bn_mod.momentum is not None else 0.1
+        if not finalize:       # the caller batches this layer's statistics with another layer's (bn_finalize_batch)
+            assert pool is None
+            item = BnItem(c=cout, nblk=PARTIAL_BLOCKS, rows=bn_rows, partial=part.data_ptr(), gamma=_ptr(bn_mod.weight), beta=_ptr(bn_mod.bias),
+                          eps=float(bn_mod.eps), momentum=float(mom), scale=_ptr(vec.scale), shift=_ptr(vec.shift), save_mean=_ptr(vec.mean),
+                          save_invstd=_ptr(vec.invstd), running_mean=_ptr(bn_mod.running_mean) if track else None,
+                          running_var=_ptr(bn_mod.running_var) if track else None)
+            return y, vec, (item, part, vec)
         _lib.call("rs_bn_finalize", cout, bn_rows, PARTIAL_BLOCKS, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
                   float(bn_mod.eps), float(mom), _ptr(vec.scale), _ptr(vec.shift), _ptr(vec.mean), _ptr(vec.invstd),
                   _ptr(bn_mod.running_mean) if track else None, _ptr(bn_mod.running_var) if track else None, _stream())
@@ -354,35 +392,52 @@ def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None, defer=False):
     return dw
 
 
+def _tail(fin_items, max_red=TAIL_RED_MAX):
+    """One rs_backward_tail launch: the given BatchNorm-backward finalizes plus up to `max_red` pending reductions."""
+    work = BackwardTail()
+    work.nfin = len(fin_items)
+    for i, it in enumerate(fin_items):
+        work.fin[i] = it
+    nred = min(len(_pending_reduce), max_red)
+    keep = [_pending_reduce.pop(0) for _ in range(nred)]
+    work.nred = nred
+    for j, (part, chunks, n, dw) in enumerate(keep):
+        work.red[j] = ReduceItem(chunks=chunks, n=n, partial=_ptr(part), out=_ptr(dw))
+    if work.nfin or work.nred:
+        _lib.call("rs_backward_tail", ctypes.byref(work), _stream())
+
+
 def flush_reduces():
     while _pending_reduce:
-        part, chunks, n, dw = _pending_reduce.pop(0)
-        _lib.call("rs_reduce_partials", chunks, n, _ptr(part), _ptr(dw), _stream())
+        _tail([])
+
+
+def bwd_coeffs_multi(specs, device):
+    """specs: [(c, rows, part, nstat, which, vec, nblk | None, frozen)] (at most TAIL_FIN_MAX) -> [(p, q, r, dgamma, dbeta)] from ONE
+    launch, which also sums the pending weight-gradient partials (up to TAIL_RED_MAX of them).
+    frozen (eval mode: the layer normalised with its running statistics, which are constants): dy = scale * dz, i.e.
+    p = scale, q = r = 0; dgamma / dbeta are the same sums (vec.mean / vec.invstd hold the running statistics)."""
+    items, outs = [], []
+    for c, rows, part, nstat, which, vec, nblk, frozen in specs:
+        buf = torch.empty((5, c), dtype=torch.float32, device=device)
+        items.append(BnBwdItem(c=c, nblk=PARTIAL_BLOCKS if nblk is None else nblk, nstat=nstat, which=which, rows=rows, partial=part.data_ptr(),
+                               scale=_ptr(vec.scale), mean=_ptr(vec.mean), invstd=_ptr(vec.invstd), p=_ptr(buf[0]), q=_ptr(buf[1]), r=_ptr(buf[2]),
+                               dgamma=_ptr(buf[3]), dbeta=_ptr(buf[4])))
+        outs.append((buf, vec, frozen, c))
+    _tail(items)
+    res = []
+    for buf, vec, frozen, c in outs:
+        if frozen:
+            zero = torch.zeros((2, c), dtype=torch.float32, device=device)
+            res.append((vec.scale, zero[0], zero[1], buf[3], buf[4]))
+        else:
+            res.append((buf[0], buf[1], buf[2], buf[3], buf[4]))
+    return res
 
 
 def bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk=None, frozen=False):
-    """BN backward sums (`nblk` partial rows, default PARTIAL_BLOCKS) -> (p, q, r, dgamma, dbeta).
-    frozen=True (eval mode: the layer normalised with its running statistics, which are constants): dy = scale * dz, i.e.
-    p = scale, q = r = 0; dgamma / dbeta are the same sums (vec.mean / vec.invstd hold the running statistics)."""
-    if frozen:
-        out = _bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk)
-        zero = torch.zeros((2, c), dtype=torch.float32, device=device)
-        return vec.scale, zero[0], zero[1], out[3], out[4]
-    return _bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk)
-
-
-def _bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk=None):
-    buf = torch.empty((5, c), dtype=torch.float32, device=device)
-    if _pending_reduce:
-        rpart, rchunks, rn, rdw = _pending_reduce.pop(0)
-        _lib.call("rs_bn_backward_finalize_reduce", c, rows, PARTIAL_BLOCKS if nblk is None else nblk, nstat, which, part.data_ptr(),
-                  _ptr(vec.scale), _ptr(vec.mean), _ptr(vec.invstd), _ptr(buf[0]), _ptr(buf[1]), _ptr(buf[2]), _ptr(buf[3]),
-                  _ptr(buf[4]), rchunks, rn, _ptr(rpart), _ptr(rdw), _stream())
-        return buf[0], buf[1], buf[2], buf[3], buf[4]
-    _lib.call("rs_bn_backward_finalize", c, rows, PARTIAL_BLOCKS if nblk is None else nblk, nstat, which, part.data_ptr(), _ptr(vec.scale),
-              _ptr(vec.mean), _ptr(vec.invstd), _ptr(buf[0]), _ptr(buf[1]), _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]),
-              _stream())
-    return buf[0], buf[1], buf[2], buf[3], buf[4]
+    """BN backward sums (`nblk` partial rows, default PARTIAL_BLOCKS) -> (p, q, r, dgamma, dbeta); see bwd_coeffs_multi."""
+    return bwd_coeffs_multi([(c, rows, part, nstat, which, vec, nblk, frozen)], device)[0]
 
 
 def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=None, rows_dev=None, wt=None):
@@ -467,9 +522,16 @@ class _SAStack(Function):
         if pos > 0:      # two-branch first layer (SurfaceAbstractionCD)
             wl, bl, wf, bf = params[0], params[1], params[4], params[5]
             wl2, wf2 = all_w2d[0], all_w2d[1]
-            yl, vl = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev, rs=rs, wk=wks[0], store_bf16=sb)
-            yf, vf = fwd_layer(rows, operand(OP_ID, x, cx, a_off=foff), fk, wf2, bf, bns[1], training, dev, rs=rs,
-                               wk=wks[1], store_bf16=sb)
+            if training:       # both GEMMs, then the statistics of both BatchNorms in one launch
+                yl, vl, fin_l = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev, rs=rs, wk=wks[0], store_bf16=sb,
+                                          finalize=False)
+                yf, vf, fin_f = fwd_layer(rows, operand(OP_ID, x, cx, a_off=foff), fk, wf2, bf, bns[1], training, dev, rs=rs,
+                                          wk=wks[1], store_bf16=sb, finalize=False)
+                bn_finalize_batch([fin_l, fin_f])
+            else:
+                yl, vl = fwd_layer(rows, operand(OP_ID, x, cx), pos, wl2, bl, bns[0], training, dev, rs=rs, wk=wks[0], store_bf16=sb)
+                yf, vf = fwd_layer(rows, operand(OP_ID, x, cx, a_off=foff), fk, wf2, bf, bns[1], training, dev, rs=rs,
+                                   wk=wks[1], store_bf16=sb)
             saved.update(yl=yl, vl=vl, yf=yf, vf=vf, wl2=wl2, wf2=wf2)
             prev_op = operand(OP_RELU2, yl, yl.shape[1], yf, yf.shape[1], vl.scale, vl.shift, vf.scale, vf.shift)
             prev_c = wl2.shape[0]
@@ -571,8 +633,8 @@ class _SAStack(Function):
             elif pos > 0:   # two-branch first layer: one masked gradient, two BatchNorms
                 dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], s["yl"], s["vl"], s["yf"], s["vf"],
                                                device=dev, rows_dev=rdev, wt=wts[("l", 0)])
-                pl, ql, rl, dgl, dbl = bwd_coeffs(cin, full, part, 3, 1, s["vl"], dev, frozen=frozen)
-                pf, qf, rf, dgf, dbf = bwd_coeffs(cin, full, part, 3, 2, s["vf"], dev, frozen=frozen)
+                (pl, ql, rl, dgl, dbl), (pf, qf, rf, dgf, dbf) = bwd_coeffs_multi(       # both BatchNorms (+ pending reductions): one launch
+                    [(cin, full, part, 3, 1, s["vl"], None, frozen), (cin, full, part, 3, 2, s["vf"], None, frozen)], dev)
                 if DEBUG is not None:
                     DEBUG.update(dz0=dz, part0=part, pl=pl, ql=ql, rl=rl, pf=pf, qf=qf, rf=rf, dgl=dgl, dbl=dbl,
                                  dgf=dgf, dbf=dbf, yl=s["yl"], yf=s["yf"], vl=s["vl"], vf=s["vf"])
@@ -757,12 +819,12 @@ class _UmbrellaFused(Function):
         desc = UmbrellaMLPDesc(x=_ptr(x), rows=rows, group=group, w0=_ptr(s["w0"]), w1=_ptr(s["w1"]), b1=_ptr(s["c1"]),
                                w2=_ptr(s["w2"]), b2=_ptr(s["c2"]), bn0=_ptr(v0.scale), bn1=_ptr(v1.scale), dout=_ptr(dout))
         part = torch.empty((UMB_BLOCKS_BWD, 2, 10), dtype=torch.float64, device=dev)
-        dwp = torch.empty((UMB_BLOCKS_BWD, 110), dtype=torch.float32, device=dev)
+        dwp = torch.empty((3, UMB_BLOCKS_BWD, 110), dtype=torch.float32, device=dev)
         res = torch.empty((3, 110), dtype=torch.float32, device=dev)
 
-        def run(pas, slot):
-            _lib.call("rs_umbrella_mlp_pass", pas, ctypes.byref(desc), 1.0, None, part.data_ptr(), _ptr(dwp), UMB_BLOCKS_BWD, _stream())
-            _lib.call("rs_reduce_partials", UMB_BLOCKS_BWD, 110, _ptr(dwp), _ptr(res[slot]), _stream())
+        def run(pas, slot):      # the fixed-order sum of the weight-gradient partials rides along with the next finalize launch
+            _lib.call("rs_umbrella_mlp_pass", pas, ctypes.byref(desc), 1.0, None, part.data_ptr(), _ptr(dwp[slot]), UMB_BLOCKS_BWD, _stream())
+            _pending_reduce.append((dwp[slot], UMB_BLOCKS_BWD, 110, res[slot]))
 
         run(3, 2)
         p1, q1, r1, g_g1, g_b1 = bwd_coeffs(10, rows, part, 2, 1, v1, dev, UMB_BLOCKS_BWD)
@@ -771,6 +833,7 @@ class _UmbrellaFused(Function):
         p0, q0, r0, g_g0, g_b0 = bwd_coeffs(10, rows, part, 2, 1, v0, dev, UMB_BLOCKS_BWD)
         desc.c0 = _ptr(p0)
         run(5, 0)
+        flush_reduces()
         shp = meta["shapes"]
         g_c1 = _zeros.take(10, dev)             # bias before BN: exactly 0
         return (None, None, res[0, :100].reshape(shp[0]), g_g0, g_b0, res[1, :100].reshape(shp[1]), g_c1, g_g1, g_b1,

@@ -478,6 +478,72 @@ def test_bf16_stored_activation_pools_exactly(groups, ns, c, relu):
     assert torch.allclose(res[0][0], ref, rtol=1e-6, atol=1e-6)
 
 
+def test_batched_small_launches_equal_the_single_ones():
+    """rs_bn_finalize_batch / rs_backward_tail (several BatchNorm finalizes and weight-gradient reductions in one launch)
+    against rs_bn_finalize / rs_bn_backward_finalize / rs_reduce_partials one at a time: bit-identical outputs."""
+    import ctypes
+    from repsurf_amd import mlp_hip as H, _lib
+    g = torch.Generator().manual_seed(21)
+    dev = torch.device("cuda")
+    rows = 70000
+    # forward statistics of three layers of different widths
+    single, items = [], []
+    for c in (64, 10, 200):
+        part = torch.randn(H.PARTIAL_BLOCKS, 2, c, generator=g, dtype=torch.float64).cuda()
+        part[:, 1].abs_().mul_(rows / H.PARTIAL_BLOCKS).add_(part[:, 0] ** 2)
+        gamma, beta = torch.randn(c, generator=g).cuda(), torch.randn(c, generator=g).cuda()
+        rm, rv = torch.randn(c, generator=g).cuda(), torch.rand(c, generator=g).cuda()
+        outs = []
+        for _ in range(2):
+            vec, rm_, rv_ = H.BNVec(c, dev), rm.clone(), rv.clone()
+            outs.append((vec, rm_, rv_))
+        vec, rm_, rv_ = outs[0]
+        _lib.call("rs_bn_finalize", c, rows, H.PARTIAL_BLOCKS, part.data_ptr(), H._ptr(gamma), H._ptr(beta), 1e-5, 0.1, H._ptr(vec.scale),
+                  H._ptr(vec.shift), H._ptr(vec.mean), H._ptr(vec.invstd), H._ptr(rm_), H._ptr(rv_), H._stream())
+        vec, rm_, rv_ = outs[1]
+        items.append((H.BnItem(c=c, nblk=H.PARTIAL_BLOCKS, rows=rows, partial=part.data_ptr(), gamma=H._ptr(gamma), beta=H._ptr(beta), eps=1e-5,
+                               momentum=0.1, scale=H._ptr(vec.scale), shift=H._ptr(vec.shift), save_mean=H._ptr(vec.mean),
+                               save_invstd=H._ptr(vec.invstd), running_mean=H._ptr(rm_), running_var=H._ptr(rv_)), part, gamma, beta))
+        single.append(outs)
+    H.bn_finalize_batch(items)
+    for (a, arm, arv), (b, brm, brv) in single:
+        for x, y in ((a.scale, b.scale), (a.shift, b.shift), (a.mean, b.mean), (a.invstd, b.invstd), (arm, brm), (arv, brv)):
+            assert torch.equal(x, y)
+        assert torch.isfinite(a.scale).all()
+    # backward: two finalizes from one three-statistic partial + three pending reductions
+    c = 128
+    part = torch.randn(H.PARTIAL_BLOCKS, 3, c, generator=g, dtype=torch.float64).cuda()
+    v1, v2 = H.BNVec(c, dev), H.BNVec(c, dev)
+    for v in (v1, v2):
+        for t in (v.scale, v.shift, v.mean, v.invstd):
+            t.copy_(torch.randn(c, generator=g))
+    reds = [(torch.randn(ch, n, generator=g).cuda(), ch, n) for ch, n in ((512, 64 * 6), (16, 512 * 1024), (37, 1000))]
+    ref_c = []
+    for which, v in ((1, v1), (2, v2)):
+        buf = torch.empty((5, c), device=dev)
+        _lib.call("rs_bn_backward_finalize", c, rows, H.PARTIAL_BLOCKS, 3, which, part.data_ptr(), H._ptr(v.scale), H._ptr(v.mean),
+                  H._ptr(v.invstd), H._ptr(buf[0]), H._ptr(buf[1]), H._ptr(buf[2]), H._ptr(buf[3]), H._ptr(buf[4]), H._stream())
+        ref_c.append(buf)
+    ref_r = []
+    for p_, ch, n in reds:
+        out = torch.empty(n, device=dev)
+        _lib.call("rs_reduce_partials", ch, n, H._ptr(p_), H._ptr(out), H._stream())
+        ref_r.append(out)
+    outs_r = [torch.empty(n, device=dev) for _, _, n in reds]
+    assert not H._pending_reduce
+    for (p_, ch, n), o in zip(reds, outs_r):
+        H._pending_reduce.append((p_, ch, n, o))
+    got = H.bwd_coeffs_multi([(c, rows, part, 3, 1, v1, None, False), (c, rows, part, 3, 2, v2, None, False)], dev)
+    assert not H._pending_reduce
+    for ref, tup in zip(ref_c, got):
+        for i in range(5):
+            assert torch.equal(ref[i], tup[i])
+    for a, b in zip(ref_r, outs_r):
+        assert torch.equal(a, b)
+    fin = H.bwd_coeffs(c, rows, part, 3, 2, v2, dev)                         # single finalize, nothing pending
+    assert all(torch.equal(ref_c[1][i], fin[i]) for i in range(5))
+
+
 @pytest.mark.parametrize("relu_last", [True, False])
 @pytest.mark.parametrize("rows,cin,widths", [(5000, 64, [128]), (777, 256, [256, 128]), (65536, 128, [128])])
 def test_row_stack_of_single_row_groups_matches_torch(rows, cin, widths, relu_last):
