@@ -349,7 +349,8 @@ def main_seg(args):
     coord, rgb, label = (torch.from_numpy(a).to(device) for a in (coord_h, rgb_h, label_h))
     offset = ops.offsets_tensor(off_h.tolist(), device)
     np.random.seed(rdist.rank_seed(13, rank))                  # numpy generator: the constructor's normal flips
-    criterion = torch.nn.functional.cross_entropy
+    from repsurf_amd.head import CrossEntropyLoss
+    criterion = CrossEntropyLoss(ignore_index=255)             # the train loop's nn.CrossEntropyLoss(ignore_index=255), 3 launches
     inputs = [coord, rgb, offset]
 
     def fence():

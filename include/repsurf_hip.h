@@ -414,6 +414,17 @@ int rs_head_input_backward(int rows, int n, int k, const float *dz, const float 
  * dlogp (R, classes) = -soft / R (d loss / d logp). */
 int rs_smooth_cls_loss(int rows, int classes, float eps, const float *logp, const long long *target,
                        float *loss, float *dlogp, void *stream);
+/* nn.CrossEntropyLoss(ignore_index) of the segmentation train loop (segmentation/tool/train.py:110,296) on logits (rows, classes):
+ * loss[0] = mean over rows with target != ignore_index of logsumexp(row) - row[target]; inv_count[0] = 1 / (number of such rows);
+ * dlogits (rows, classes) = softmax(row) - onehot(target) (zero rows where ignored): d loss / d logits = dlogits * inv_count[0].
+ * partial: 2 * ceil(rows / 256) doubles of scratch. */
+int rs_cross_entropy_forward(long long rows, int classes, long long ignore_index, const float *logits, const long long *target,
+                             float *loss, float *inv_count, float *dlogits, double *partial, void *stream);
+/* out[i] = x[i] * a[0] * (b ? b[0] : 1): a, b device scalars (the loss gradient times 1 / count and the incoming gradient) */
+int rs_scale_by_scalars(long long n, const float *x, const float *a, const float *b, float *out, void *stream);
+/* Column sums, stage 1: partial (nblk, n), row slab b of x (rows, n; rows ldx floats apart) summed per column; rs_reduce_partials
+ * (nblk, n) finishes in a fixed order (bias gradient of a row Linear, dout.sum(0)). */
+int rs_col_sum_partials(long long rows, int n, const float *x, long long ldx, float *partial, int nblk, void *stream);
 
 /* ---- optimizer step -------------------------------------------------------------------------------
  * torch.optim.Adam(lr, betas, eps, weight_decay) as the reference configures it

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -50,6 +50,9 @@ SIGNATURES = {
     "rs_pool_select": [c_ll, c_int, P, P, P, P, P, P, P, P, P],
     "rs_reduce_partials": [c_int, c_ll, P, P, P],
     "rs_backward_tail": [P, P],
+    "rs_cross_entropy_forward": [c_ll, c_int, c_ll, P, P, P, P, P, P, P],
+    "rs_scale_by_scalars": [c_ll, P, P, P, P, P],
+    "rs_col_sum_partials": [c_ll, c_int, P, c_ll, P, c_int, P],
     "rs_bn_finalize_batch": [P, c_int, P],
     "rs_bn_backward_finalize_reduce": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, c_ll, P, P, P],
     "rs_pack_weights": [P, P],

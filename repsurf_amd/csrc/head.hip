@@ -430,7 +430,146 @@ smooth_loss_kernel(int R, int classes, float eps, const float *__restrict__ logp
   if (tid == 0) loss[0] = -part[0] / (float)R;
 }
 
+// ---- nn.CrossEntropyLoss(ignore_index) on logits (rows, classes): segmentation/tool/train.py:110,296 -------------------------
+// loss = mean over the rows whose target != ignore_index of (logsumexp(row) - row[target]).  One thread per row: the row's
+// softmax minus the one-hot target goes out as the UNSCALED gradient (zero row when ignored; the 1 / count factor is known
+// only after the reduction and is applied by ce_scale_kernel in backward), the row losses and the valid-row count meet in a
+// fixed-order tree per workgroup -> partial[block] = {sum, count}.
+__global__ void __launch_bounds__(256)
+ce_rows_kernel(long long rows, int classes, long long ignore_index, const float *__restrict__ logits,
+               const long long *__restrict__ target, float *__restrict__ dlogits, double *__restrict__ partial) {
+  __shared__ double ps[256], pc[256];
+  const int tid = threadIdx.x;
+  const long long r = (long long)blockIdx.x * 256 + tid;
+  double loss = 0.0, cnt = 0.0;
+  if (r < rows) {
+    const float *x = logits + r * classes;
+    float *d = dlogits + r * classes;
+    const long long t = target[r];
+    if (t == ignore_index || t < 0 || t >= classes) {
+      for (int j = 0; j < classes; ++j) d[j] = 0.f;
+    } else {
+      float mx = x[0];
+      for (int j = 1; j < classes; ++j) mx = fmaxf(mx, x[j]);
+      float se = 0.f;
+      for (int j = 0; j < classes; ++j) se += expf(x[j] - mx);
+      const float lse = mx + logf(se);
+      for (int j = 0; j < classes; ++j) d[j] = expf(x[j] - lse) - (j == (int)t ? 1.f : 0.f);
+      loss = (double)(lse - x[t]);
+      cnt = 1.0;
+    }
+  }
+  ps[tid] = loss; pc[tid] = cnt;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { ps[tid] += ps[tid + off]; pc[tid] += pc[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) { partial[2 * (long long)blockIdx.x] = ps[0]; partial[2 * (long long)blockIdx.x + 1] = pc[0]; }
+}
+
+// loss[0] = sum / count (NaN for an all-ignored batch, like torch), inv_count[0] = 1 / count (0 when count = 0)
+__global__ void __launch_bounds__(256)
+ce_finalize_kernel(int nblk, const double *__restrict__ partial, float *__restrict__ loss, float *__restrict__ inv_count) {
+  __shared__ double ps[256], pc[256];
+  const int tid = threadIdx.x;
+  double s = 0.0, c = 0.0;
+  for (int b = tid; b < nblk; b += 256) { s += partial[2 * b]; c += partial[2 * b + 1]; }
+  ps[tid] = s; pc[tid] = c;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { ps[tid] += ps[tid + off]; pc[tid] += pc[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) { loss[0] = (float)(ps[0] / pc[0]); inv_count[0] = pc[0] > 0.0 ? (float)(1.0 / pc[0]) : 0.f; }
+}
+
+// out = x * a[0] * (b ? b[0] : 1): the cross-entropy gradient times 1 / count and the incoming scalar gradient
+__global__ void __launch_bounds__(256)
+ce_scale_kernel(long long n, const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out) {
+  const float f = a[0] * (b ? b[0] : 1.f);
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) out[e] = x[e] * f;
+}
+
+// column sums of x (rows, n) with row pitch ldx, stage 1: workgroup b sums rows [b * per, (b + 1) * per) -> partial[b][:]
+// (the bias gradient of a row Linear: dout.sum(0); stage 2 is rs_reduce_partials' fixed-order sum)
+__global__ void __launch_bounds__(256)
+col_sum_kernel(long long rows, int n, const float *__restrict__ x, long long ldx, long long per, float *__restrict__ partial) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const long long r0 = (long long)blockIdx.x * per, r1 = min(rows, r0 + per);
+  if (n <= 16) {      // few columns (13 classes): a thread walks whole rows, 256 consecutive rows per trip, sums in registers
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    for (long long r = r0 + tid; r < r1; r += 256)
+#pragma unroll
+      for (int c = 0; c < 16; ++c) if (c < n) acc[c] += x[r * ldx + c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c >= n) continue;                         // (n is uniform: the barriers below are met by all threads or none)
+      red[tid] = acc[c];
+      __syncthreads();
+      for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+      }
+      if (tid == 0) partial[(long long)blockIdx.x * n + c] = red[0];
+      __syncthreads();
+    }
+    return;
+  }
+  // lanes along the columns when there are many of them, along the rows otherwise
+  const int tc = n >= 256 ? 256 : (n >= 64 ? 64 : (n >= 16 ? 16 : 1)), tr = 256 / tc;
+  const int cx = tid % tc, rx = tid / tc;
+  for (int c0 = 0; c0 < n; c0 += tc) {
+    const int c = c0 + cx;
+    float s = 0.f;
+    if (c < n) for (long long r = r0 + rx; r < r1; r += tr) s += x[r * ldx + c];
+    red[tid] = s;
+    __syncthreads();
+    for (int off = tr / 2; off > 0; off >>= 1) {
+      if (rx < off) red[tid] += red[tid + off * tc];
+      __syncthreads();
+    }
+    if (rx == 0 && c < n) partial[(long long)blockIdx.x * n + c] = red[cx];
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+extern "C" int rs_cross_entropy_forward(long long rows, int classes, long long ignore_index, const float *logits, const long long *target,
+                                        float *loss, float *inv_count, float *dlogits, double *partial, void *stream) {
+  RS_REQUIRE(rows > 0 && classes > 0 && rows <= (1LL << 31) * 255, "rs_cross_entropy_forward: bad size");
+  RS_REQUIRE(logits && target && loss && inv_count && dlogits && partial, "rs_cross_entropy_forward: null pointer");
+  const int nblk = (int)((rows + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(nblk), dim3(256), 0, st, rows, classes, ignore_index, logits, target, dlogits, partial);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, nblk, partial, loss, inv_count);
+  RS_CHECK_LAUNCH("rs_cross_entropy_forward");
+  return RS_OK;
+}
+
+extern "C" int rs_scale_by_scalars(long long n, const float *x, const float *a, const float *b, float *out, void *stream) {
+  RS_REQUIRE(n >= 0, "rs_scale_by_scalars: negative size");
+  if (n == 0) return RS_OK;
+  RS_REQUIRE(x && a && out, "rs_scale_by_scalars: null pointer");
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ce_scale_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, n, x, a, b, out);
+  RS_CHECK_LAUNCH("rs_scale_by_scalars");
+  return RS_OK;
+}
+
+extern "C" int rs_col_sum_partials(long long rows, int n, const float *x, long long ldx, float *partial, int nblk, void *stream) {
+  RS_REQUIRE(rows > 0 && n > 0 && nblk > 0 && ldx >= n, "rs_col_sum_partials: bad size");
+  RS_REQUIRE(x && partial, "rs_col_sum_partials: null pointer");
+  const long long per = (rows + nblk - 1) / nblk;
+  hipLaunchKernelGGL(col_sum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, rows, n, x, ldx, per, partial);
+  RS_CHECK_LAUNCH("rs_col_sum_partials");
+  return RS_OK;
+}
 
 extern "C" int rs_head_layer_forward(const rs_head_layer *l, void *stream) {
   RS_REQUIRE(l && l->x && l->w && l->b && l->gamma && l->beta && l->y && l->h && l->mean && l->invstd && l->step,

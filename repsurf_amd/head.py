@@ -202,3 +202,62 @@ def unit_gradient(device):
 def smooth_cls_loss(logp, target, eps):
     """SmoothClsLoss (classification/util/utils.py:55-69) in one launch (+ one for the backward scale)."""
     return _SmoothLoss.apply(logp, target.to(torch.int64), eps)
+
+
+class _CrossEntropy(Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits = logits.contiguous()
+        rows, classes = logits.shape
+        dev = logits.device
+        out = torch.empty((2,), dtype=torch.float32, device=dev)             # loss, 1 / (rows that count)
+        d = torch.empty_like(logits)
+        part = torch.empty((2 * ((rows + 255) // 256),), dtype=torch.float64, device=dev)
+        _lib.call("rs_cross_entropy_forward", rows, classes, int(ignore_index), logits.data_ptr(), target.contiguous().data_ptr(),
+                  out.data_ptr(), out.data_ptr() + 4, d.data_ptr(), part.data_ptr(), _stream())
+        ctx.save_for_backward(d, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        d, out = ctx.saved_tensors
+        one = _unit.get(str(d.device))
+        unit = one is not None and gout.data_ptr() == one.data_ptr()          # loss.backward(unit_gradient(device)): d loss = 1
+        g = torch.empty_like(d)
+        _lib.call("rs_scale_by_scalars", d.numel(), d.data_ptr(), out.data_ptr() + 4, None if unit else gout.contiguous().data_ptr(),
+                  g.data_ptr(), _stream())
+        return g, None, None
+
+
+def cross_entropy(logits, target, ignore_index=-100):
+    """F.cross_entropy(logits (rows, classes), target (rows,), ignore_index=...) with mean reduction -- the criterion of the
+    segmentation train loop (nn.CrossEntropyLoss(ignore_index=args.ignore_label), segmentation/tool/train.py:110,296) -- in two
+    launches forward and one backward (torch: log_softmax, a single-workgroup nll reduction, two backward kernels)."""
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2):
+        return torch.nn.functional.cross_entropy(logits, target, ignore_index=ignore_index)
+    return _CrossEntropy.apply(logits, target.to(torch.int64), ignore_index)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """Drop-in for the train loop's `nn.CrossEntropyLoss(ignore_index=...)` (mean reduction, no class weights)."""
+
+    def __init__(self, ignore_index=-100):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, logits, target):
+        return cross_entropy(logits, target, self.ignore_index)
+
+
+def col_sum(x):
+    """x (rows, n) -> x.sum(0) in two launches with a fixed summation order (bias gradient of a row Linear)."""
+    rows, n = x.shape
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    nblk = max(1, min(256, rows // 256))
+    part = torch.empty((nblk, n), dtype=torch.float32, device=x.device)
+    out = torch.empty((n,), dtype=torch.float32, device=x.device)
+    _lib.call("rs_col_sum_partials", rows, n, x.data_ptr(), x.stride(0), part.data_ptr(), nblk, _stream())
+    _lib.call("rs_reduce_partials", nblk, n, part.data_ptr(), out.data_ptr(), _stream())
+    return out
+

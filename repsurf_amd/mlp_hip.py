@@ -942,7 +942,8 @@ class _RowLinear(torch.autograd.Function):
             else:
                 dw = wgrad(rows, n, k, operand(OP_ID, dout, n), operand(OP_ID, x, k), x.device)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dout.sum(0)
+            from . import head as _head
+            db = _head.col_sum(dout)
         return dx, dw, db
 
 

@@ -369,3 +369,41 @@ def test_scene_grid_knn_equals_scan(ops, kind, n, k):
     ri, rd = ops.knnquery_offset(k, x, dev(qs), off, ops.offsets_tensor([qn], x.device))
     assert torch.equal(qi, ri) and torch.equal(qd, rd), qstats
     print("scene kNN", kind, n, k, stats, "queries elsewhere:", qstats)
+
+
+@pytest.mark.parametrize("rows,classes,ignored", [(65536, 13, 0), (1000, 13, 137), (257, 40, 5), (3, 2, 0), (512, 13, 512)])
+def test_cross_entropy_matches_torch(rows, classes, ignored):
+    """repsurf_amd.head.CrossEntropyLoss against nn.CrossEntropyLoss(ignore_index=255) (segmentation/tool/train.py:110): loss and
+    d loss / d logits, with ignored rows, with a non-unit incoming gradient, and an all-ignored batch (NaN, zero gradient --
+    torch gives NaN gradients there; a zero one keeps the optimizer state finite)."""
+    from repsurf_amd import head
+    g = torch.Generator().manual_seed(rows + classes)
+    x = (torch.randn(rows, classes, generator=g) * 3).cuda()
+    t = torch.randint(0, classes, (rows,), generator=g)
+    t[torch.randperm(rows, generator=g)[:ignored]] = 255
+    t = t.cuda()
+    crit, ref_crit = head.CrossEntropyLoss(ignore_index=255), torch.nn.CrossEntropyLoss(ignore_index=255)
+    for scale in (None, 0.37):
+        a, b = x.clone().requires_grad_(), x.clone().requires_grad_()
+        la, lb = crit(a, t), ref_crit(b, t)
+        if ignored == rows:
+            assert torch.isnan(la) and torch.isnan(lb)
+            la.backward()
+            assert float(a.grad.abs().max()) == 0.0
+            continue
+        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb))), (float(la), float(lb))
+        if scale is None:
+            la.backward(head.unit_gradient(x.device)); lb.backward()
+        else:
+            (la * scale).backward(); (lb * scale).backward()
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-9), (a.grad - b.grad).abs().max().item()
+
+
+@pytest.mark.parametrize("rows,n", [(65536, 13), (1000, 1), (777, 16), (5000, 40), (300, 300), (4096, 1024)])
+def test_col_sum_matches_torch(rows, n):
+    from repsurf_amd import head
+    g = torch.Generator().manual_seed(rows + n)
+    x = torch.randn(rows, n + 3, generator=g).cuda()[:, 1:n + 1]              # a column slice: row pitch n + 3
+    got, ref = head.col_sum(x), x.double().sum(0)
+    assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-3 * max(1.0, rows ** 0.5 / 30))
+    assert torch.equal(got, head.col_sum(x.contiguous()))                    # fixed summation order, pitch-independent
