@@ -422,9 +422,9 @@ int rs_cross_entropy_forward(long long rows, int classes, long long ignore_index
                              float *loss, float *inv_count, float *dlogits, double *partial, void *stream);
 /* out[i] = x[i] * a[0] * (b ? b[0] : 1): a, b device scalars (the loss gradient times 1 / count and the incoming gradient) */
 int rs_scale_by_scalars(long long n, const float *x, const float *a, const float *b, float *out, void *stream);
-/* Column sums, stage 1: partial (nblk, n), row slab b of x (rows, n; rows ldx floats apart) summed per column; rs_reduce_partials
- * (nblk, n) finishes in a fixed order (bias gradient of a row Linear, dout.sum(0)). */
-int rs_col_sum_partials(long long rows, int n, const float *x, long long ldx, float *partial, int nblk, void *stream);
+/* Column sums, stage 1: partial (nblk, n), row slab b of x (rows, n; rows ldx floats apart) summed per column and multiplied by
+ * `scale`; rs_reduce_partials (nblk, n) finishes in a fixed order (bias gradient of a row Linear, dout.sum(0)). */
+int rs_col_sum_partials(long long rows, int n, const float *x, long long ldx, float scale, float *partial, int nblk, void *stream);
 
 /* ---- optimizer step -------------------------------------------------------------------------------
  * torch.optim.Adam(lr, betas, eps, weight_decay) as the reference configures it

@@ -52,7 +52,7 @@ SIGNATURES = {
     "rs_backward_tail": [P, P],
     "rs_cross_entropy_forward": [c_ll, c_int, c_ll, P, P, P, P, P, P, P],
     "rs_scale_by_scalars": [c_ll, P, P, P, P, P],
-    "rs_col_sum_partials": [c_ll, c_int, P, c_ll, P, c_int, P],
+    "rs_col_sum_partials": [c_ll, c_int, P, c_ll, ctypes.c_float, P, c_int, P],
     "rs_bn_finalize_batch": [P, c_int, P],
     "rs_bn_backward_finalize_reduce": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, c_ll, P, P, P],
     "rs_pack_weights": [P, P],

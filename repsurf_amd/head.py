@@ -249,15 +249,15 @@ class CrossEntropyLoss(torch.nn.Module):
         return cross_entropy(logits, target, self.ignore_index)
 
 
-def col_sum(x):
-    """x (rows, n) -> x.sum(0) in two launches with a fixed summation order (bias gradient of a row Linear)."""
+def col_sum(x, scale=1.0):
+    """x (rows, n) -> scale * x.sum(0) in two launches with a fixed summation order (bias gradient of a row Linear)."""
     rows, n = x.shape
     if x.stride(1) != 1:
         x = x.contiguous()
     nblk = max(1, min(256, rows // 256))
     part = torch.empty((nblk, n), dtype=torch.float32, device=x.device)
     out = torch.empty((n,), dtype=torch.float32, device=x.device)
-    _lib.call("rs_col_sum_partials", rows, n, x.data_ptr(), x.stride(0), part.data_ptr(), nblk, _stream())
+    _lib.call("rs_col_sum_partials", rows, n, x.data_ptr(), x.stride(0), float(scale), part.data_ptr(), nblk, _stream())
     _lib.call("rs_reduce_partials", nblk, n, part.data_ptr(), out.data_ptr(), _stream())
     return out
 

@@ -876,12 +876,15 @@ class _UmbrellaStack2(Function):
         dout = dout.contiguous()
         c1n, c0n = s["w1"].shape[0], s["w0"].shape[0]
         p1 = operand(OP_BCAST, dout, c1n, ns=group)
-        g_c1 = dout.sum(0) * group
-        g_w1 = wgrad(rows, c1n, c0n, p1, operand(OP_RELU1, y0, c0n, s1=v0.scale, t1=v0.shift), dev)
+        from . import head as _head
+        g_c1 = _head.col_sum(dout, scale=group)
+        flush_reduces()
+        g_w1 = wgrad(rows, c1n, c0n, p1, operand(OP_RELU1, y0, c0n, s1=v0.scale, t1=v0.shift), dev, defer=True)     # summed with the finalize below
         dz0, part0, nstat0 = dgrad_masked(rows, c1n, c0n, p1, s["w1"], y0, v0, device=dev)
         pb, qb, rb, g_g0, g_b0 = bwd_coeffs(c0n, rows, part0, nstat0, 1, v0, dev, frozen=frozen)
         p0 = operand(OP_AFF2, dz0, c0n, y0, c0n, s1=pb, t1=rb, s2=qb)
-        g_w0 = wgrad(rows, c0n, cx, p0, operand(OP_ID, x, cx), dev)
+        g_w0 = wgrad(rows, c0n, cx, p0, operand(OP_ID, x, cx), dev, defer=True)
+        flush_reduces()
         shp = meta["shapes"]
         g_c0 = v0.scale * g_b0 if frozen else _zeros.take(c0n, dev)   # bias before BN
         return None, None, g_w0.reshape(shp[0]), g_c0, g_g0, g_b0, g_w1.reshape(shp[1]), g_c1

@@ -69,6 +69,10 @@ class Model(nn.Module):
         return SegGeoState(feat, stages, fps)
 
     def forward(self, pos_feat_off0, geo=None):
+        with _mlp.deferred_counters():                 # num_batches_tracked += 1 of all 30 BatchNorms: one launch, not one per stack
+            return self._forward(pos_feat_off0, geo)
+
+    def _forward(self, pos_feat_off0, geo=None):
         coord, feat, offset = pos_feat_off0            # (N,3), (N,C_in-3), (B,) running row ends
         if coord.is_cuda and self.training and torch.is_grad_enabled():
             _mlp.prepack(self._packed_layers())        # ~23 weight-pack launches of the step in one

@@ -391,7 +391,7 @@ def test_cross_entropy_matches_torch(rows, classes, ignored):
             la.backward()
             assert float(a.grad.abs().max()) == 0.0
             continue
-        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb))), (float(la), float(lb))
+        assert abs(la.item() - lb.item()) <= 1e-6 * max(1.0, abs(lb.item())), (la.item(), lb.item())
         if scale is None:
             la.backward(head.unit_gradient(x.device)); lb.backward()
         else:
