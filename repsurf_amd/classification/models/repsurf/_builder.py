@@ -24,19 +24,22 @@ class GeoState:
     stage, FPS picks, their coordinates, ball-query indices and distinct-neighbour counts.  `UmbrellaClassifier.geometry`
     computes it; a training loop that knows its next batch can do that while the previous batch is still in backward
     (repsurf_amd.graph.PipelinedStep)."""
-    __slots__ = ("feat", "stages")
+    __slots__ = ("feat", "stages", "xyz")
 
-    def __init__(self, feat, stages):
-        self.feat, self.stages = feat, stages
+    def __init__(self, feat, stages, xyz=None):
+        """xyz: the channels-last (B, N, 3) copy of the coordinates the geometry worked on (the stages group from it)"""
+        self.feat, self.stages, self.xyz = feat, stages, xyz
+        for i, g in enumerate(stages):       # every stage samples from the previous stage's centres
+            g.center = (xyz if i == 0 else stages[i - 1].new_center)
 
     def tensors(self):
-        out = [self.feat]
+        out = [self.feat] + ([self.xyz] if self.xyz is not None else [])
         for g in self.stages:
             out += g.tensors()
         return out
 
     def clone(self):
-        return GeoState(self.feat.clone(), [g.clone() for g in self.stages])
+        return GeoState(self.feat.clone(), [g.clone() for g in self.stages], None if self.xyz is None else self.xyz.clone())
 
     def copy_(self, other):
         torch._foreach_copy_(self.tensors(), other.tensors())       # one launch per dtype instead of one per tensor
@@ -92,7 +95,7 @@ class UmbrellaClassifier(nn.Module):
         else:           # one serial branch next to another batch's network: full-chip kNN first (under the light
             feat = sc.features(center, flip)    # head of that forward), the 32-workgroup FPS chains afterwards (1.98 vs 2.00 ms)
             plan = GeometryPlan(xyz, self._sampling, fork=False, compact=self._compact())
-        return GeoState(feat, [plan.stage(i) for i in range(len(self._sampling))])
+        return GeoState(feat, [plan.stage(i) for i in range(len(self._sampling))], xyz)
 
     def _compact(self):
         """the SA stages take the compacted-groups path (training mode): their bookkeeping belongs to the geometry"""

@@ -166,6 +166,8 @@ def _sa_forward_compact(self, center, normal, feature, geometry):
         idx, cnt = ops.ballquery(self.radius, self.nsample, center, new_center, return_count=True)
     else:
         fps_idx, new_center, idx, cnt = geometry.fps_idx, geometry.new_center, geometry.idx, geometry.cnt
+        if getattr(geometry, "center", None) is not None:
+            center = geometry.center           # the geometry's channels-last copy: no transpose of the (B, 3, N) view here
     # the centres' own normal rows (index_points(normal, fps_idx), reference :31) come out of the grouping launches
     groups, new_normal = ops.group_features_compact(center, new_center, normal, feature, idx, cnt, polar=self.return_polar,
                                                     index=getattr(geometry, "index", None), fps_idx=fps_idx)

@@ -24,10 +24,11 @@ def _side_stream(device):
 class StageGeometry:
     """index: the compacted groups' bookkeeping (ops.CompactIndex) when the plan was asked for it -- like everything here it
     depends on coordinates only, and the grouped MLP of the stage would otherwise build it on the critical path."""
-    __slots__ = ("fps_idx", "new_center", "idx", "cnt", "index")
+    __slots__ = ("fps_idx", "new_center", "idx", "cnt", "index", "center")
 
-    def __init__(self, fps_idx, new_center, idx, cnt=None, index=None):
+    def __init__(self, fps_idx, new_center, idx, cnt=None, index=None, center=None):
         self.fps_idx, self.new_center, self.idx, self.cnt, self.index = fps_idx, new_center, idx, cnt, index
+        self.center = center       # the (B, n, 3) contiguous coordinates this stage sampled from (the owner's tensor, not copied here)
 
     def tensors(self):
         out = [self.fps_idx, self.new_center, self.idx, self.cnt]
@@ -93,6 +94,7 @@ class GeometryPlan:
                     ci = g.index
                     _lib.call("rs_compact_index", b, n, npoint, nsample, g.idx.data_ptr(), g.cnt.data_ptr(), ci.offsets.data_ptr(),
                               ci.grp.data_ptr(), ci.slot.data_ptr(), ci.src.data_ptr(), ci.mult.data_ptr(), st_ptr)
+                g.center = center
                 center, n = g.new_center, npoint
                 if fork:
                     self.events.append(side.record_event())      # stage i is usable as soon as ITS kernels are done
