@@ -42,7 +42,11 @@ class GeoState:
         return GeoState(self.feat.clone(), [g.clone() for g in self.stages], None if self.xyz is None else self.xyz.clone())
 
     def copy_(self, other):
-        torch._foreach_copy_(self.tensors(), other.tensors())       # one launch per dtype instead of one per tensor
+        dst, src = self.tensors(), other.tensors()
+        for dt in (torch.float32, torch.int32):          # one multi-tensor launch per dtype instead of one copy per tensor
+            pairs = [(d, s_) for d, s_ in zip(dst, src) if d.dtype == dt]
+            if pairs:
+                torch._foreach_copy_([p[0] for p in pairs], [p[1] for p in pairs])
         return self
 
 
