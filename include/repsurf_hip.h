@@ -456,13 +456,18 @@ int rs_adam_step(const rs_adam_table *t, const double *hyper, int *step, int *do
  *   4: dw_partial = {dW1, 0}, stat_partial = {sum dz0, sum dz0*yhat0}     (needs c1 = p,q,r of BN1 backward)
  *   5: dw_partial = {dW0, 0}                                               (needs c0)
  * bn0/bn1: (4,10) = scale, shift, mean, invstd as written by rs_bn_finalize; c0/c1: (>=3,10) = p,q,r as
- * written by rs_bn_backward_finalize.  dout: (rows/group, 10), already scaled for 'avg'. */
+ * written by rs_bn_backward_finalize.  dout: (rows/group, 10), already scaled for 'avg'.
+ * layers = 2: the segmentation constructor's Conv1d(10,10)-BN-ReLU-Conv1d(10,10) + sum over the fan
+ * (segmentation/modules/repsurface_utils.py:298-303,323-327), y0 = W0 x + b0: passes 0 (stats of y0), 2 (out = sum of y1),
+ * 4 (dw_partial = {dW1, db1}, stat_partial = {sum dz0, sum dz0*yhat0}), 5 (dw_partial = {dW0, 0}; needs c0). */
 typedef struct rs_umbrella_mlp {
   const float *x; long long rows; int group;
   const float *w0, *w1, *b1, *w2, *b2;
   const float *bn0, *bn1;
   const float *c0, *c1;
   const float *dout;
+  const float *b0;          /* bias of the first conv (two-layer variant; NULL = none) */
+  int layers;               /* 3 (0 = 3) or 2 */
 } rs_umbrella_mlp;
 int rs_umbrella_mlp_pass(int pass, const rs_umbrella_mlp *m, float out_scale, float *out,
                          double *stat_partial, float *dw_partial, int nblk, void *stream);

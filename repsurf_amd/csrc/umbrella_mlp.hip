@@ -28,7 +28,7 @@ struct UmbWeights {             // LDS image
   float w2t[UM_C * UM_CP];
   float w1n[UM_C * UM_CP];      // natural: w1n[j][k] = w1[j][k]   (data gradient)
   float w2n[UM_C * UM_CP];
-  float b1[UM_CP], b2[UM_CP];
+  float b0[UM_CP], b1[UM_CP], b2[UM_CP];
   float bn0[4 * UM_CP], bn1[4 * UM_CP];    // scale, shift, mean, invstd
   float c0[3 * UM_CP], c1[3 * UM_CP];      // p, q, r of BatchNorm backward
 };
@@ -44,6 +44,7 @@ __device__ void load_weights(UmbWeights &L, const rs_umbrella_mlp &m) {
     L.w2n[e] = (ok && m.w2) ? m.w2[a * UM_C + b] : 0.f;
   }
   for (int e = threadIdx.x; e < UM_CP; e += UM_THREADS) {
+    L.b0[e] = (e < UM_C && m.b0) ? m.b0[e] : 0.f;
     L.b1[e] = (e < UM_C && m.b1) ? m.b1[e] : 0.f;
     L.b2[e] = (e < UM_C && m.b2) ? m.b2[e] : 0.f;
   }
@@ -192,6 +193,90 @@ umbrella_mlp_rows_kernel(rs_umbrella_mlp m, double *__restrict__ stat_partial, f
   if (PASS >= 3) block_reduce_store<UM_C * UM_C + UM_C, float>(dw, scratch, dw_partial);
 }
 
+// ---- two-layer variant: the segmentation constructor's mlps = Conv1d(10,10)-BN-ReLU-Conv1d(10,10), summed over the fan
+// (segmentation/modules/repsurface_utils.py:298-303,323-327).  PASS 0: stats(y0), y0 = W0 x + b0;  4: {dW1, db1} + BN0-backward
+// sums (dy1 = dout[point]);  5: dW0 (needs c0).  Same register-resident scheme, one stage shorter.
+template <int PASS>
+__global__ void __launch_bounds__(UM_THREADS)
+umbrella_mlp2_rows_kernel(rs_umbrella_mlp m, double *__restrict__ stat_partial, float *__restrict__ dw_partial) {
+  __shared__ UmbWeights L;
+  __shared__ float scratch[(UM_THREADS / 64) * (UM_C * UM_C + UM_C)];
+  load_weights(L, m);
+  float st[2 * UM_C];
+  float dw[UM_C * UM_C + UM_C];
+#pragma unroll
+  for (int i = 0; i < 2 * UM_C; ++i) st[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < UM_C * UM_C + UM_C; ++i) dw[i] = 0.f;
+  for (long long r = (long long)blockIdx.x * UM_THREADS + threadIdx.x; r < m.rows; r += (long long)gridDim.x * UM_THREADS) {
+    asm volatile("" ::: "memory");                 // (weights stay in LDS: see umbrella_mlp_rows_kernel)
+    float x[UM_C], y0[UM_C];
+    load_row(m.x, r, x);
+    matvec_t(L.w0t, L.b0, x, y0);
+    if (PASS == 0) {
+#pragma unroll
+      for (int j = 0; j < UM_C; ++j) { st[j] += y0[j]; st[UM_C + j] = fmaf(y0[j], y0[j], st[UM_C + j]); }
+      continue;
+    }
+    float a0[UM_C], dy1[UM_C], da0[UM_C], dz0[UM_C];
+    bn_relu(L.bn0, y0, a0);
+    load_row(m.dout, (long long)((unsigned)r / (unsigned)m.group), dy1);
+    matvec_n(L.w1n, dy1, da0);
+#pragma unroll
+    for (int k = 0; k < UM_C; ++k) dz0[k] = a0[k] > 0.f ? da0[k] : 0.f;
+    if (PASS == 4) {
+#pragma unroll
+      for (int j = 0; j < UM_C; ++j) {
+#pragma unroll
+        for (int k = 0; k < UM_C; ++k) dw[j * UM_C + k] = fmaf(dy1[j], a0[k], dw[j * UM_C + k]);
+        dw[UM_C * UM_C + j] += dy1[j];                                          // bias of the last conv
+      }
+#pragma unroll
+      for (int k = 0; k < UM_C; ++k) {
+        st[k] += dz0[k];
+        st[UM_C + k] = fmaf(dz0[k], (y0[k] - L.bn0[2 * UM_CP + k]) * L.bn0[3 * UM_CP + k], st[UM_C + k]);
+      }
+      continue;
+    }
+    // PASS 5
+    float dy0[UM_C];
+#pragma unroll
+    for (int j = 0; j < UM_C; ++j) dy0[j] = fmaf(L.c0[j], dz0[j], fmaf(L.c0[UM_CP + j], y0[j], L.c0[2 * UM_CP + j]));
+#pragma unroll
+    for (int j = 0; j < UM_C; ++j)
+#pragma unroll
+      for (int k = 0; k < UM_C; ++k) dw[j * UM_C + k] = fmaf(dy0[j], x[k], dw[j * UM_C + k]);
+  }
+  if (PASS != 5) block_reduce_store<2 * UM_C, double>(st, scratch, stat_partial);
+  if (PASS >= 4) block_reduce_store<UM_C * UM_C + UM_C, float>(dw, scratch, dw_partial);
+}
+
+// two-layer PASS 2: out[p] = scale * sum_g y1[p*group + g]
+__global__ void __launch_bounds__(UM_THREADS)
+umbrella_mlp2_out_kernel(rs_umbrella_mlp m, float scale, float *__restrict__ out) {
+  __shared__ UmbWeights L;
+  load_weights(L, m);
+  const long long points = m.rows / m.group;
+  for (long long p = (long long)blockIdx.x * UM_THREADS + threadIdx.x; p < points; p += (long long)gridDim.x * UM_THREADS) {
+    float acc[UM_C];
+#pragma unroll
+    for (int j = 0; j < UM_C; ++j) acc[j] = 0.f;
+    for (int g = 0; g < m.group; ++g) {
+      asm volatile("" ::: "memory");
+      float x[UM_C], y0[UM_C], a0[UM_C], y1[UM_C];
+      load_row(m.x, p * m.group + g, x);
+      matvec_t(L.w0t, L.b0, x, y0);
+      bn_relu(L.bn0, y0, a0);
+      matvec_t(L.w1t, L.b1, a0, y1);
+#pragma unroll
+      for (int j = 0; j < UM_C; ++j) acc[j] += y1[j];
+    }
+    float2 *o = reinterpret_cast<float2 *>(out + p * UM_C);
+#pragma unroll
+    for (int i = 0; i < UM_C / 2; ++i) o[i] = make_float2(acc[2 * i] * scale, acc[2 * i + 1] * scale);
+  }
+}
+
 // PASS 2: out[p] = scale * sum_g y2[p*group + g]     (one thread per point)
 __global__ void __launch_bounds__(UM_THREADS)
 umbrella_mlp_out_kernel(rs_umbrella_mlp m, float scale, float *__restrict__ out) {
@@ -230,6 +315,25 @@ extern "C" int rs_umbrella_mlp_pass(int pass, const rs_umbrella_mlp *m, float ou
   if (m->rows == 0) return RS_OK;
   RS_REQUIRE(((uintptr_t)m->x % 8) == 0 && (m->dout == nullptr || ((uintptr_t)m->dout % 8) == 0),
              "rs_umbrella_mlp_pass: rows must be 8-byte aligned");
+  RS_REQUIRE(m->layers == 0 || m->layers == 2 || m->layers == 3, "rs_umbrella_mlp_pass: layers = %d (2 or 3)", m->layers);
+  if (m->layers == 2) {
+    RS_REQUIRE(pass == 0 || pass == 2 || pass == 4 || pass == 5, "rs_umbrella_mlp_pass: the two-layer MLP has passes 0, 2, 4, 5 (not %d)", pass);
+    if (pass >= 2) RS_REQUIRE(m->bn0 && m->w1, "rs_umbrella_mlp_pass: pass %d needs bn0 and w1", pass);
+    if (pass == 2) RS_REQUIRE(out, "rs_umbrella_mlp_pass: pass 2 needs an output");
+    if (pass >= 4) RS_REQUIRE(m->dout && dw_partial, "rs_umbrella_mlp_pass: backward passes need dout and dw_partial");
+    if (pass == 5) RS_REQUIRE(m->c0, "rs_umbrella_mlp_pass: pass 5 needs the BN0 backward coefficients");
+    if (pass == 0 || pass == 4) RS_REQUIRE(stat_partial, "rs_umbrella_mlp_pass: pass %d needs stat_partial", pass);
+    hipStream_t st2 = (hipStream_t)stream;
+    const dim3 grid2(nblk), block2(UM_THREADS);
+    switch (pass) {
+      case 0: hipLaunchKernelGGL(umbrella_mlp2_rows_kernel<0>, grid2, block2, 0, st2, *m, stat_partial, dw_partial); break;
+      case 2: hipLaunchKernelGGL(umbrella_mlp2_out_kernel, grid2, block2, 0, st2, *m, out_scale, out); break;
+      case 4: hipLaunchKernelGGL(umbrella_mlp2_rows_kernel<4>, grid2, block2, 0, st2, *m, stat_partial, dw_partial); break;
+      default: hipLaunchKernelGGL(umbrella_mlp2_rows_kernel<5>, grid2, block2, 0, st2, *m, stat_partial, dw_partial); break;
+    }
+    RS_CHECK_LAUNCH("rs_umbrella_mlp_pass");
+    return RS_OK;
+  }
   if (pass >= 1) RS_REQUIRE(m->bn0 && m->w1, "rs_umbrella_mlp_pass: pass %d needs bn0 and w1", pass);
   if (pass >= 2) RS_REQUIRE(m->bn1 && m->w2, "rs_umbrella_mlp_pass: pass %d needs bn1 and w2", pass);
   if (pass == 2) RS_REQUIRE(out, "rs_umbrella_mlp_pass: pass 2 needs an output");

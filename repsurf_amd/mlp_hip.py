@@ -766,7 +766,7 @@ class _UmbrellaStack(Function):
 
 class UmbrellaMLPDesc(ctypes.Structure):      # rs_umbrella_mlp
     _fields_ = [("x", P), ("rows", c_ll), ("group", c_int), ("w0", P), ("w1", P), ("b1", P), ("w2", P), ("b2", P),
-                ("bn0", P), ("bn1", P), ("c0", P), ("c1", P), ("dout", P)]
+                ("bn0", P), ("bn1", P), ("c0", P), ("c1", P), ("dout", P), ("b0", P), ("layers", c_int)]
 
 
 UMB_BLOCKS = 512
@@ -890,10 +890,71 @@ class _UmbrellaStack2(Function):
         return None, None, g_w0.reshape(shp[0]), g_c0, g_g0, g_b0, g_w1.reshape(shp[1]), g_c1
 
 
+class _UmbrellaFused2(Function):
+    """The segmentation constructor's conv-BN-ReLU-conv + sum over the fan on the register-resident passes of
+    csrc/umbrella_mlp.hip (two-layer variant): forward = statistics pass, finalize, output pass; backward = {dW1, db1} +
+    BatchNorm-backward sums, finalize (+ the fixed-order sum of the dW1 partials), dW0.  The generic row-GEMM path
+    (_UmbrellaStack2: 10 of 32 MFMA columns, every intermediate through HBM) took 0.31 ms of a 5.2 ms step for this."""
+
+    @staticmethod
+    def forward(ctx, x, meta, w0, c0, g0, b0, w1, c1):
+        dev = x.device
+        x = x.contiguous()
+        rows = x.shape[0]
+        group, bn0 = meta["group"], meta["bn"]
+        w0_, w1_ = _w2d(w0), _w2d(w1)
+        c0_, c1_ = c0.detach().contiguous(), c1.detach().contiguous()
+        v0 = BNVec(10, dev)
+        desc = UmbrellaMLPDesc(x=_ptr(x), rows=rows, group=group, w0=_ptr(w0_), w1=_ptr(w1_), b1=_ptr(c1_), bn0=_ptr(v0.scale),
+                               b0=_ptr(c0_), layers=2)
+        part = torch.empty((UMB_BLOCKS, 2, 10), dtype=torch.float64, device=dev)
+        _lib.call("rs_umbrella_mlp_pass", 0, ctypes.byref(desc), 1.0, None, part.data_ptr(), None, UMB_BLOCKS, _stream())
+        track = bn0.track_running_stats and bn0.running_mean is not None
+        if track:
+            _pending_counters.append(bn0.num_batches_tracked)
+        mom = bn0.momentum if bn0.momentum is not None else 0.1
+        _lib.call("rs_bn_finalize", 10, rows, UMB_BLOCKS, part.data_ptr(), _ptr(bn0.weight), _ptr(bn0.bias), float(bn0.eps), float(mom),
+                  _ptr(v0.scale), _ptr(v0.shift), _ptr(v0.mean), _ptr(v0.invstd), _ptr(bn0.running_mean) if track else None,
+                  _ptr(bn0.running_var) if track else None, _stream())
+        out = torch.empty((rows // group, 10), dtype=torch.float32, device=dev)
+        _lib.call("rs_umbrella_mlp_pass", 2, ctypes.byref(desc), 1.0, _ptr(out), None, None, UMB_BLOCKS, _stream())
+        ctx.saved = dict(x=x, w0=w0_, w1=w1_, c0=c0_, c1=c1_, v0=v0)
+        ctx.meta = meta
+        _flush_counters()
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s, meta = ctx.saved, ctx.meta
+        x, v0 = s["x"], s["v0"]
+        dev = x.device
+        rows, group = x.shape[0], meta["group"]
+        dout = dout.contiguous()
+        desc = UmbrellaMLPDesc(x=_ptr(x), rows=rows, group=group, w0=_ptr(s["w0"]), w1=_ptr(s["w1"]), b1=_ptr(s["c1"]), bn0=_ptr(v0.scale),
+                               b0=_ptr(s["c0"]), dout=_ptr(dout), layers=2)
+        part = torch.empty((UMB_BLOCKS_BWD, 2, 10), dtype=torch.float64, device=dev)
+        dwp = torch.empty((2, UMB_BLOCKS_BWD, 110), dtype=torch.float32, device=dev)
+        res = torch.empty((2, 110), dtype=torch.float32, device=dev)
+        flush_reduces()
+        _lib.call("rs_umbrella_mlp_pass", 4, ctypes.byref(desc), 1.0, None, part.data_ptr(), _ptr(dwp[1]), UMB_BLOCKS_BWD, _stream())
+        _pending_reduce.append((dwp[1], UMB_BLOCKS_BWD, 110, res[1]))
+        p0, q0, r0, g_g0, g_b0 = bwd_coeffs(10, rows, part, 2, 1, v0, dev, UMB_BLOCKS_BWD)
+        desc.c0 = _ptr(p0)
+        _lib.call("rs_umbrella_mlp_pass", 5, ctypes.byref(desc), 1.0, None, None, _ptr(dwp[0]), UMB_BLOCKS_BWD, _stream())
+        _pending_reduce.append((dwp[0], UMB_BLOCKS_BWD, 110, res[0]))
+        flush_reduces()
+        shp = meta["shapes"]
+        g_c0 = _zeros.take(10, dev)             # bias before BN: exactly 0
+        return (None, None, res[0, :100].reshape(shp[0]), g_c0, g_g0, g_b0, res[1, :100].reshape(shp[1]), res[1, 100:])
+
+
 def umbrella_mlp2(x, mlps, group):
     conv0, bn0, _, conv1 = mlps
     meta = {"group": group, "bn": bn0, "training": bn0.training, "shapes": [conv0.weight.shape, conv1.weight.shape]}
-    return _UmbrellaStack2.apply(x, meta, conv0.weight, conv0.bias, bn0.weight, bn0.bias, conv1.weight, conv1.bias)
+    fused = (x.shape[1] == 10 and tuple(conv0.weight.shape[:2]) == (10, 10) and tuple(conv1.weight.shape[:2]) == (10, 10)
+             and conv0.bias is not None and conv1.bias is not None and bn0.training and FUSED_UMBRELLA)
+    fn = _UmbrellaFused2 if fused else _UmbrellaStack2
+    return fn.apply(x, meta, conv0.weight, conv0.bias, bn0.weight, bn0.bias, conv1.weight, conv1.bias)
 
 
 def umbrella_mlp(x, mlps, group, aggr):

@@ -695,3 +695,40 @@ def test_constructor_stacks_eval_mode_forward_and_backward(kind):
     assert rel(res["hip"][0], res["torch"][0]) < 2e-5
     for name, gt in res["torch"][1].items():
         assert rel_l2(res["hip"][1][name], gt) < 3e-3, name
+
+
+@pytest.mark.parametrize("points", [200, 7000])
+def test_seg_constructor_fused_two_layer_mlp_training(points):
+    """mlp.umbrella_mlp2 in training mode (the fused two-layer passes of csrc/umbrella_mlp.hip) against the PyTorch executor AND
+    against the generic row-GEMM path it replaces: output, running statistics and every gradient (the bias in front of the
+    BatchNorm: exactly 0 here, rounding noise in torch)."""
+    from repsurf_amd import mlp, mlp_hip as H
+    torch.manual_seed(11)
+    mlps = nn.Sequential(nn.Conv1d(10, 10, 1), nn.BatchNorm1d(10), nn.ReLU(True), nn.Conv1d(10, 10, 1)).cuda()
+    nn.init.uniform_(mlps[1].weight, 0.5, 1.5)
+    nn.init.uniform_(mlps[1].bias, -0.3, 0.3)
+    nn.init.uniform_(mlps[0].bias, -0.5, 0.5)
+    mlps.train()
+    group = 9
+    x = torch.randn(points * group, 10).cuda()
+    w = torch.randn(points, 10).cuda()
+    res = {}
+    for name in ("torch", "generic", "fused"):
+        torch_executor.set_backend("torch" if name == "torch" else "hip")
+        H.FUSED_UMBRELLA = name == "fused"
+        try:
+            m = copy.deepcopy(mlps)
+            out = mlp.umbrella_mlp2(x, m, group)
+            (out * w).sum().backward()
+        finally:
+            H.FUSED_UMBRELLA = True
+        res[name] = (out.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}, m[1].running_mean.clone(), m[1].running_var.clone())
+    torch_executor.set_backend("hip")
+    for other in ("torch", "generic"):
+        assert rel(res["fused"][0], res[other][0]) < 2e-5, other
+        assert torch.allclose(res["fused"][2], res[other][2], rtol=1e-5, atol=1e-6) and torch.allclose(res["fused"][3], res[other][3], rtol=1e-5, atol=1e-6)
+        for pname, gt in res[other][1].items():
+            if pname == "0.bias":
+                assert res["fused"][1][pname].abs().max() == 0 and gt.abs().max() < 1e-3
+                continue
+            assert rel_l2(res["fused"][1][pname], gt) < 3e-3, (other, pname)
