@@ -337,6 +337,8 @@ int rs_backward_tail(const rs_backward_tail_work *work, void *stream);
 /* offsets (optional, (groups+1) int32): ragged groups of a compacted row set (rows [offsets[g], offsets[g+1]));
  * NULL = dense groups of nsample rows. */
 /* y_bf16 != 0: y is a bf16 tensor (bf16 activation storage, written by rs_mlp_gemm_rows_bf16 with out_bf16). */
+/* nsample = 1 (ungrouped rows: the Linear-BN-ReLU rows of the segmentation decoder): arg may be NULL -- nothing is selected,
+ * the kernel is the BatchNorm + ReLU pass and rs_pool_max_backward takes arg = NULL as all zeros. */
 int rs_pool_max(long long groups, int nsample, int c, int relu, const int *offsets, const float *y, int y_bf16,
                 const float *scale, const float *shift, float *out, int *arg, void *stream);
 /* Resolves the fused pooling of rs_mlp_gemm_rows: out = relu(scale * (scale >= 0 ? ymax : ymin) + shift),

@@ -1428,7 +1428,8 @@ pool_max_kernel(long long groups, int ns, int c, int relu, const int *__restrict
       if (relu) z = fmaxf(z, 0.f);
       if (z > best) { best = z; bi = k; }
     }
-    out[e] = best; arg[e] = bi;
+    out[e] = best;
+    if (arg) arg[e] = bi;
   }
 }
 
@@ -1509,7 +1510,7 @@ pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ off
       const long long e = g * c + ch;
       const float val = (!out || out[e] > 0.f) ? dout[g * ldd + ch] : 0.f;      // out == NULL: the pooled layer ended without a ReLU
       v[e] = val;
-      const float yy = ldy<BF>(y, ((offsets ? (long long)offsets[g] : g * ns) + arg[e]) * c + ch);
+      const float yy = ldy<BF>(y, ((offsets ? (long long)offsets[g] : g * ns) + (arg ? arg[e] : 0)) * c + ch);
       s0 += (double)val;
       s1 += (double)(val * ((yy - mu) * is));
     }
@@ -2008,7 +2009,7 @@ extern "C" int rs_pool_max(long long groups, int nsample, int c, int relu, const
                            int y_bf16, const float *scale, const float *shift, float *out, int *arg, void *stream) {
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0, "rs_pool_max: bad size");
   if (groups == 0 || c == 0) return RS_OK;
-  RS_REQUIRE(y && out && arg, "rs_pool_max: null pointer");
+  RS_REQUIRE(y && out && (arg || nsample == 1), "rs_pool_max: null pointer (arg may be NULL for nsample = 1 only)");
   if (!offsets && nsample >= 64 && groups <= 65535 && groups * c <= (1 << 18)) {
     if (y_bf16) hipLaunchKernelGGL(pool_max_long_kernel<true>, dim3((int)groups, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, (hipStream_t)stream,
                                    nsample, c, relu, y, scale, shift, out, arg);
@@ -2046,7 +2047,7 @@ extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const 
                                     const float *invstd, float *v, double *partial, int partial_blocks, void *stream) {
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0 && partial_blocks > 0, "rs_pool_max_backward: bad size");
   if (groups == 0 || c == 0) return RS_OK;
-  RS_REQUIRE(dout && arg && y && mean && invstd && v && partial, "rs_pool_max_backward: null pointer");
+  RS_REQUIRE(dout && (arg || (nsample == 1 && !offsets)) && y && mean && invstd && v && partial, "rs_pool_max_backward: null pointer (arg may be NULL for dense groups of one row only)");
   if (ldd <= 0) ldd = c;
   RS_REQUIRE(ldd >= c, "rs_pool_max_backward: row stride of dout %lld < %d channels", ldd, c);
   const long long want = (groups + 3) / 4;

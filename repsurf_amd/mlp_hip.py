@@ -558,9 +558,10 @@ class _SAStack(Function):
         elif ys:
             y_last, v_last = ys[-1], vecs[-1]
             out = torch.empty((groups, prev_c), dtype=torch.float32, device=dev)
-            arg = torch.empty((groups, prev_c), dtype=torch.int32, device=dev)
+            # groups of ONE row (row stacks of the segmentation decoder): nothing is selected, no index tensor is written or read
+            arg = None if (ns == 1 and rs.dev is None) else torch.empty((groups, prev_c), dtype=torch.int32, device=dev)
             _lib.call("rs_pool_max", groups, ns, prev_c, int(meta.get("relu_last", True)), _ptr(rs.offsets), _ptr(y_last), _bf(y_last), _ptr(v_last.scale),
-                      _ptr(v_last.shift), _ptr(out), arg.data_ptr(), _stream())
+                      _ptr(v_last.shift), _ptr(out), None if arg is None else arg.data_ptr(), _stream())
         else:
             raise NotImplementedError("a stack needs at least one layer after the first")
         saved.update(ys=ys, vecs=vecs, w2ds=w2ds, out=out, arg=arg)
@@ -592,10 +593,13 @@ class _SAStack(Function):
         v = torch.empty(dout.shape, dtype=torch.float32, device=dev)
         part = torch.empty((PARTIAL_BLOCKS, 2, c_last), dtype=torch.float64, device=dev)
         _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), dout.stride(0), _ptr(s["out"]) if meta.get("relu_last", True) else None,
-                  s["arg"].data_ptr(), _ptr(ys[-1]), _bf(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
+                  None if s["arg"] is None else s["arg"].data_ptr(), _ptr(ys[-1]), _bf(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
                   PARTIAL_BLOCKS, _stream())
         p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev, frozen=frozen)
-        p_op = operand(OP_POOLED, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, arg=s["arg"], ns=ns, rs=rs)
+        if s["arg"] is None:      # one-row groups: the pooled-gradient operand IS the two-tensor BatchNorm-backward affine (no index compare)
+            p_op = operand(OP_AFF2, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, rs=rs)
+        else:
+            p_op = operand(OP_POOLED, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, arg=s["arg"], ns=ns, rs=rs)
         dx = None
         fork = _Fork(dev)
         fork.keep += [v, p, q, r]

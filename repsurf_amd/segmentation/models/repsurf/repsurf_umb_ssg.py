@@ -47,7 +47,7 @@ class Model(nn.Module):
             out += [sa.mlp_l0, sa.mlp_f0] + list(sa.mlp_convs)
         for fp in (self.fp4, self.fp3, self.fp2, self.fp1):
             out += [fp.mlp_f0] + ([fp.mlp_s0] if fp.skip else []) + list(fp.mlp_convs)
-        return out + [self.classifier[0]]
+        return out + [self.classifier[0], self.classifier[4]]
 
     def geometry(self, pos_feat_off0, fork=False):
         """Everything of a forward that reads coordinates only (no learned parameter): the constructor's kNN + fan

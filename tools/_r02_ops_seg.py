@@ -39,17 +39,12 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-class Spy(TorchDispatchMode):
-    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
-        full = str(func)
-        skip = ("aten.view", "aten.empty", "aten._unsafe_view", "aten.permute", "aten.transpose", "aten.detach", "aten.slice", "aten.select", "aten.as_strided",
-                "aten.reshape", "aten.t.", "aten.unsqueeze", "aten.squeeze", "aten.expand", "aten.alias", "aten.is_", "aten.sym_", "aten._local_scalar", "aten.lift",
-                "aten.unbind", "aten.split", "aten.narrow", "prim.", "aten.stride", "aten.size", "aten.storage_offset", "aten.numel", "aten.dim", "aten._to_copy")
-        if not any(k in full for k in skip):
-            shapes = [tuple(a.shape) for a in args if torch.is_tensor(a)][:3]
-            st = [f"{os.path.relpath(f.filename, ROOT)}:{f.lineno} {f.name}" for f in traceback.extract_stack() if ("repsurf_amd" in f.filename) ]
-            print(full, shapes, " <- ", " | ".join(st[-2:]) if st else "(autograd engine)")
-        return func(*args, **(kwargs or {}))
-with Spy():
-    step()
+from repsurf_amd import mlp_hip as H
+_orig = H._pack_items
+def _dbg(items, device):
+    st = [f"{os.path.relpath(f.filename, ROOT)}:{f.lineno} {f.name}" for f in traceback.extract_stack() if "repsurf_amd" in f.filename]
+    print("PACK", [(tuple(w.shape), bool(tr)) for w, tr in items][:6], len(items), "<-", " | ".join(st[-4:-1]))
+    return _orig(items, device)
+H._pack_items = _dbg
+step()
 torch.cuda.synchronize()
