@@ -48,3 +48,34 @@ def test_argument_errors_are_reported_not_fatal():
         _lib.call("rs_knnquery", 1, 100, 1, 65, 1, 1, 1, None, None)
     # zero-sized problems are valid no-ops
     _lib.call("rs_ballquery", 0, 0, 0, 0.1, 0, None, None, None, None, None)
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Every struct the binding passes by pointer has the size and field offsets the C compiler gives the header's
+    definition (gcc on include/repsurf_hip.h): a field added on one side only would shift everything behind it silently."""
+    import ctypes
+    import subprocess
+    from repsurf_amd import head, mlp_hip, optim
+    pairs = {"rs_row_operand": mlp_hip.RowOperand, "rs_mlp_epilogue": mlp_hip.Epilogue, "rs_pack_weights_args": mlp_hip.PackArgs,
+             "rs_umbrella_mlp": mlp_hip.UmbrellaMLPDesc, "rs_bn_item": mlp_hip.BnItem, "rs_bn_bwd_item": mlp_hip.BnBwdItem,
+             "rs_reduce_item": mlp_hip.ReduceItem, "rs_backward_tail_work": mlp_hip.BackwardTail, "rs_head_layer": head.HeadLayer,
+             "rs_head_layer_bwd": head.HeadLayerBwd, "rs_adam_table": optim.AdamTable}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "repsurf_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        cname, fname, value = line.split()
+        cls = pairs[cname]
+        expect = ctypes.sizeof(cls) if fname == "size" else getattr(cls, fname).offset
+        assert int(value) == expect, (cname, fname, int(value), expect)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in pairs.values())
