@@ -27,6 +27,16 @@ EPI_STORE, EPI_STATS, EPI_MASK = range(3)
 FUSED_UMBRELLA = True     # 10-channel constructor MLP through csrc/umbrella_mlp.hip (False: generic row-GEMM path)
 DEBUG = None              # set to a dict to capture backward intermediates (tools/mlp_debug.py)
 PARTIAL_BLOCKS = int(os.environ.get("REPSURF_PARTIAL_BLOCKS", "512"))      # rows of the BatchNorm partial-sum buffers (>= persistent workgroups)
+
+
+def partial_rows(rows, per_block=64):
+    """Rows of a BatchNorm partial-sum buffer for a launch over `rows` rows: one per workgroup that can exist (a workgroup
+    takes >= 64 rows; the pooled backward 4 groups), at most PARTIAL_BLOCKS.  The producing kernel zeroes the rows it does not
+    own and the finalize kernel reads all of them: a 4 096-row launch with the full 512 rows wrote and re-read 7 MB of zeros
+    per 1 024-channel layer."""
+    return max(1, min(PARTIAL_BLOCKS, -(-int(rows) // per_block)))
+
+
 WGRAD_CHUNKS = int(os.environ.get("REPSURF_WGRAD_CHUNKS", "512"))        # workgroups of one weight-gradient launch (row slabs x output blocks)
 WGRAD_MIN_ROWS = int(os.environ.get("REPSURF_WGRAD_MIN_ROWS", "128"))   # rows per row-workgroup of the weight gradient, at least
 
@@ -313,9 +323,10 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
     vec = BNVec(cout, device)
     pool = None
     if training:
-        part = torch.empty((PARTIAL_BLOCKS, 2, cout), dtype=torch.float64, device=device)
+        nblk = partial_rows(rows)
+        part = torch.empty((nblk, 2, cout), dtype=torch.float64, device=device)
         epi = Epilogue(bias=_ptr(bias), out=_ptr(y), ldo=cout, mode=EPI_STATS, partial=part.data_ptr(),
-                       partial_blocks=PARTIAL_BLOCKS, out_bf16=_bf(y))
+                       partial_blocks=nblk, out_bf16=_bf(y))
         if rs is not None and rs.mult is not None:
             epi.row_mult = _ptr(rs.mult)
         if pool_ns:
@@ -333,12 +344,12 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
         mom = bn_mod.momentum if bn_mod.momentum is not None else 0.1
         if not finalize:       # the caller batches this layer's statistics with another layer's (bn_finalize_batch)
             assert pool is None
-            item = BnItem(c=cout, nblk=PARTIAL_BLOCKS, rows=bn_rows, partial=part.data_ptr(), gamma=_ptr(bn_mod.weight), beta=_ptr(bn_mod.bias),
+            item = BnItem(c=cout, nblk=nblk, rows=bn_rows, partial=part.data_ptr(), gamma=_ptr(bn_mod.weight), beta=_ptr(bn_mod.bias),
                           eps=float(bn_mod.eps), momentum=float(mom), scale=_ptr(vec.scale), shift=_ptr(vec.shift), save_mean=_ptr(vec.mean),
                           save_invstd=_ptr(vec.invstd), running_mean=_ptr(bn_mod.running_mean) if track else None,
                           running_var=_ptr(bn_mod.running_var) if track else None)
             return y, vec, (item, part, vec)
-        _lib.call("rs_bn_finalize", cout, bn_rows, PARTIAL_BLOCKS, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
+        _lib.call("rs_bn_finalize", cout, bn_rows, nblk, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
                   float(bn_mod.eps), float(mom), _ptr(vec.scale), _ptr(vec.shift), _ptr(vec.mean), _ptr(vec.invstd),
                   _ptr(bn_mod.running_mean) if track else None, _ptr(bn_mod.running_var) if track else None, _stream())
         if pool is not None:
@@ -420,7 +431,7 @@ def bwd_coeffs_multi(specs, device):
     items, outs = [], []
     for c, rows, part, nstat, which, vec, nblk, frozen in specs:
         buf = torch.empty((5, c), dtype=torch.float32, device=device)
-        items.append(BnBwdItem(c=c, nblk=PARTIAL_BLOCKS if nblk is None else nblk, nstat=nstat, which=which, rows=rows, partial=part.data_ptr(),
+        items.append(BnBwdItem(c=c, nblk=part.shape[0] if nblk is None else nblk, nstat=nstat, which=which, rows=rows, partial=part.data_ptr(),
                                scale=_ptr(vec.scale), mean=_ptr(vec.mean), invstd=_ptr(vec.invstd), p=_ptr(buf[0]), q=_ptr(buf[1]), r=_ptr(buf[2]),
                                dgamma=_ptr(buf[3]), dbeta=_ptr(buf[4])))
         outs.append((buf, vec, frozen, c))
@@ -436,7 +447,7 @@ def bwd_coeffs_multi(specs, device):
 
 
 def bwd_coeffs(c, rows, part, nstat, which, vec, device, nblk=None, frozen=False):
-    """BN backward sums (`nblk` partial rows, default PARTIAL_BLOCKS) -> (p, q, r, dgamma, dbeta); see bwd_coeffs_multi."""
+    """BN backward sums (`nblk` partial rows, default: all rows of `part`) -> (p, q, r, dgamma, dbeta); see bwd_coeffs_multi."""
     return bwd_coeffs_multi([(c, rows, part, nstat, which, vec, nblk, frozen)], device)[0]
 
 
@@ -444,10 +455,11 @@ def dgrad_masked(rows, kdim, cols, p_op, w2d, y1, v1, y2=None, v2=None, device=N
     """dz_prev = (P . W) * relu'(z_prev) and the BN-backward sums of the previous layer(s)."""
     dz = torch.empty((rows, cols), dtype=torch.float32, device=device)
     nstat = 3 if y2 is not None else 2
-    part = torch.empty((PARTIAL_BLOCKS, nstat, cols), dtype=torch.float64, device=device)
+    nblk = partial_rows(rows)
+    part = torch.empty((nblk, nstat, cols), dtype=torch.float64, device=device)
     epi = Epilogue(bias=None, out=_ptr(dz), ldo=cols, mode=EPI_MASK,
                    my1=_ptr(y1), ldm1=cols, ms1=_ptr(v1.scale), mt1=_ptr(v1.shift), mean1=_ptr(v1.mean), invstd1=_ptr(v1.invstd),
-                   partial=part.data_ptr(), partial_blocks=PARTIAL_BLOCKS, my1_bf16=_bf(y1), my2_bf16=_bf(y2))
+                   partial=part.data_ptr(), partial_blocks=nblk, my1_bf16=_bf(y1), my2_bf16=_bf(y2))
     if y2 is not None:
         epi.my2, epi.ldm2 = _ptr(y2), cols
         epi.ms2, epi.mt2, epi.mean2, epi.invstd2 = _ptr(v2.scale), _ptr(v2.shift), _ptr(v2.mean), _ptr(v2.invstd)
@@ -591,10 +603,11 @@ class _SAStack(Function):
         # ---- pooled layer: BN-backward sums from (groups, c) data only
         c_last = ys[-1].shape[1]
         v = torch.empty(dout.shape, dtype=torch.float32, device=dev)
-        part = torch.empty((PARTIAL_BLOCKS, 2, c_last), dtype=torch.float64, device=dev)
+        pool_blk = partial_rows(groups, 4)
+        part = torch.empty((pool_blk, 2, c_last), dtype=torch.float64, device=dev)
         _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), dout.stride(0), _ptr(s["out"]) if meta.get("relu_last", True) else None,
                   None if s["arg"] is None else s["arg"].data_ptr(), _ptr(ys[-1]), _bf(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
-                  PARTIAL_BLOCKS, _stream())
+                  pool_blk, _stream())
         p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev, frozen=frozen)
         if s["arg"] is None:      # one-row groups: the pooled-gradient operand IS the two-tensor BatchNorm-backward affine (no index compare)
             p_op = operand(OP_AFF2, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, rs=rs)
