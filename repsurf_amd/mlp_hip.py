@@ -38,7 +38,7 @@ def partial_rows(rows, per_block=64):
 
 
 WGRAD_CHUNKS = int(os.environ.get("REPSURF_WGRAD_CHUNKS", "512"))        # workgroups of one weight-gradient launch (row slabs x output blocks)
-WGRAD_MIN_ROWS = int(os.environ.get("REPSURF_WGRAD_MIN_ROWS", "128"))   # rows per row-workgroup of the weight gradient, at least
+WGRAD_MIN_ROWS = int(os.environ.get("REPSURF_WGRAD_MIN_ROWS", "64"))    # rows per row-workgroup of the weight gradient, at least (sweep: 32..128, profiles/r02/wgrad_chunk_sweep.txt)
 
 
 class RowOperand(ctypes.Structure):          # rs_row_operand
