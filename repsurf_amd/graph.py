@@ -44,8 +44,9 @@ class GraphedStep:
         else:
             for p in self.net.parameters():
                 p.grad = None
-        loss = self.criterion(self.net(self.points), self.label)
-        loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
+        with mlp_hip.owned_pass():        # gradients start as None and are read only after backward (mlp_hip.owned_pass)
+            loss = self.criterion(self.net(self.points), self.label)
+            loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
         if self.optimizer is not None:
             self.optimizer.step()
         return loss
@@ -173,8 +174,9 @@ class PipelinedStep:
         else:
             for q in self.net.parameters():
                 q.grad = None
-        loss = self.criterion(self.net(self.points[p], geo=self.state[p]), self.label[p])
-        loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
+        with mlp_hip.owned_pass():        # gradients start as None and are read only after backward (mlp_hip.owned_pass)
+            loss = self.criterion(self.net(self.points[p], geo=self.state[p]), self.label[p])
+            loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
         if self.sharded:
             self.grads.pack()
         elif self.optimizer is not None:
@@ -350,8 +352,9 @@ class ShardedGraphedStep:
 
     def _fwd_bwd(self):
         self.grads.clear()
-        loss = self.criterion(self.net(self.points), self.label)
-        loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
+        with mlp_hip.owned_pass():        # gradients start as None and are read only after backward (mlp_hip.owned_pass)
+            loss = self.criterion(self.net(self.points), self.label)
+            loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
         self.grads.pack()
         return loss
 

@@ -423,6 +423,55 @@ def flush_reduces():
         _tail([])
 
 
+# A stack's backward ends with weight-gradient partials whose sum is still pending (its first-layer weights).  Summing them
+# there costs one more small launch per stack; left pending, they ride along with the NEXT stack's first finalize launch.
+# That is only sound when nothing reads a gradient before the backward pass is over -- no `.grad` to accumulate into, no
+# gradient hooks (DistributedDataParallel reads gradients as they appear) -- so it is opt-in: the graphed training steps of
+# repsurf_amd.graph own their pass (gradients start as None, consumed by the optimizer / the flat-buffer pack after
+# backward) and wrap it in `owned_pass()`; whatever is still pending when the autograd engine finishes is summed by an
+# end-of-pass callback.
+OWNED_PASS = 0
+_flush_armed = False
+
+
+class owned_pass:
+    def __enter__(self):
+        global OWNED_PASS
+        OWNED_PASS += 1
+        return self
+
+    def __exit__(self, *exc):
+        global OWNED_PASS
+        OWNED_PASS -= 1
+        flush_reduces()            # (nothing after a completed backward; an aborted one must not leak into the next pass)
+
+
+def _end_of_pass_flush():
+    global _flush_armed
+    _flush_armed = False
+    flush_reduces()
+
+
+def _stack_begins():
+    if not OWNED_PASS:
+        flush_reduces()      # (nothing, unless an earlier backward call was interrupted between a wgrad and its reduction)
+
+
+def _stack_ends():
+    global _flush_armed
+    if not _pending_reduce:
+        return
+    if OWNED_PASS:
+        if not _flush_armed:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass_flush)
+                _flush_armed = True
+            except RuntimeError:       # not inside a backward pass
+                flush_reduces()
+        return
+    flush_reduces()
+
+
 def bwd_coeffs_multi(specs, device):
     """specs: [(c, rows, part, nstat, which, vec, nblk | None, frozen)] (at most TAIL_FIN_MAX) -> [(p, q, r, dgamma, dbeta)] from ONE
     launch, which also sums the pending weight-gradient partials (up to TAIL_RED_MAX of them).
@@ -598,7 +647,7 @@ class _SAStack(Function):
             dout = dout.contiguous()
         grads = [None] * ctx.nparams
         nl = len(ys)
-        flush_reduces()      # (nothing, unless an earlier backward call was interrupted between a wgrad and its reduction)
+        _stack_begins()      # (nothing, unless an earlier backward call was interrupted between a wgrad and its reduction)
         first = 8 if pos > 0 else 0
         # ---- pooled layer: BN-backward sums from (groups, c) data only
         c_last = ys[-1].shape[1]
@@ -674,7 +723,7 @@ class _SAStack(Function):
                 dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
                 epi = Epilogue(bias=None, out=_ptr(dx), ldo=cx, mode=EPI_STORE)
                 gemm_rows(rows, cout, cx, p_op, wts[("l", 0)], epi, rdev)
-        flush_reduces()
+        _stack_ends()
         fork.join()
         out_grads = [None if g is None else g.reshape(shape) for g, shape in zip(grads, meta["shapes"])]
         return (dx, None) + tuple(out_grads)
@@ -850,7 +899,7 @@ class _UmbrellaFused(Function):
         p0, q0, r0, g_g0, g_b0 = bwd_coeffs(10, rows, part, 2, 1, v0, dev, UMB_BLOCKS_BWD)
         desc.c0 = _ptr(p0)
         run(5, 0)
-        flush_reduces()
+        _stack_ends()
         shp = meta["shapes"]
         g_c1 = _zeros.take(10, dev)             # bias before BN: exactly 0
         return (None, None, res[0, :100].reshape(shp[0]), g_g0, g_b0, res[1, :100].reshape(shp[1]), g_c1, g_g1, g_b1,
@@ -895,13 +944,13 @@ class _UmbrellaStack2(Function):
         p1 = operand(OP_BCAST, dout, c1n, ns=group)
         from . import head as _head
         g_c1 = _head.col_sum(dout, scale=group)
-        flush_reduces()
+        _stack_begins()
         g_w1 = wgrad(rows, c1n, c0n, p1, operand(OP_RELU1, y0, c0n, s1=v0.scale, t1=v0.shift), dev, defer=True)     # summed with the finalize below
         dz0, part0, nstat0 = dgrad_masked(rows, c1n, c0n, p1, s["w1"], y0, v0, device=dev)
         pb, qb, rb, g_g0, g_b0 = bwd_coeffs(c0n, rows, part0, nstat0, 1, v0, dev, frozen=frozen)
         p0 = operand(OP_AFF2, dz0, c0n, y0, c0n, s1=pb, t1=rb, s2=qb)
         g_w0 = wgrad(rows, c0n, cx, p0, operand(OP_ID, x, cx), dev, defer=True)
-        flush_reduces()
+        _stack_ends()
         shp = meta["shapes"]
         g_c0 = v0.scale * g_b0 if frozen else _zeros.take(c0n, dev)   # bias before BN
         return None, None, g_w0.reshape(shp[0]), g_c0, g_g0, g_b0, g_w1.reshape(shp[1]), g_c1
@@ -952,14 +1001,14 @@ class _UmbrellaFused2(Function):
         part = torch.empty((UMB_BLOCKS_BWD, 2, 10), dtype=torch.float64, device=dev)
         dwp = torch.empty((2, UMB_BLOCKS_BWD, 110), dtype=torch.float32, device=dev)
         res = torch.empty((2, 110), dtype=torch.float32, device=dev)
-        flush_reduces()
+        _stack_begins()
         _lib.call("rs_umbrella_mlp_pass", 4, ctypes.byref(desc), 1.0, None, part.data_ptr(), _ptr(dwp[1]), UMB_BLOCKS_BWD, _stream())
         _pending_reduce.append((dwp[1], UMB_BLOCKS_BWD, 110, res[1]))
         p0, q0, r0, g_g0, g_b0 = bwd_coeffs(10, rows, part, 2, 1, v0, dev, UMB_BLOCKS_BWD)
         desc.c0 = _ptr(p0)
         _lib.call("rs_umbrella_mlp_pass", 5, ctypes.byref(desc), 1.0, None, None, _ptr(dwp[0]), UMB_BLOCKS_BWD, _stream())
         _pending_reduce.append((dwp[0], UMB_BLOCKS_BWD, 110, res[0]))
-        flush_reduces()
+        _stack_ends()
         shp = meta["shapes"]
         g_c0 = _zeros.take(10, dev)             # bias before BN: exactly 0
         return (None, None, res[0, :100].reshape(shp[0]), g_c0, g_g0, g_b0, res[1, :100].reshape(shp[1]), res[1, 100:])
