@@ -732,3 +732,32 @@ def test_seg_constructor_fused_two_layer_mlp_training(points):
                 assert res["fused"][1][pname].abs().max() == 0 and gt.abs().max() < 1e-3
                 continue
             assert rel_l2(res["fused"][1][pname], gt) < 3e-3, (other, pname)
+
+
+def test_owned_pass_carries_pending_reductions_across_stacks_with_identical_gradients():
+    """mlp_hip.owned_pass(): the weight-gradient partials a stack leaves pending are summed by the next stack's first finalize
+    launch or by the end-of-pass callback -- every gradient bit-identical to the default (each stack completes its own), and
+    nothing is left pending when backward returns."""
+    from repsurf_amd import mlp, mlp_hip as H
+    torch_executor.set_backend("hip")
+    g = torch.Generator().manual_seed(31)
+    m1, m2 = make_cd(6, 10, [32, 32, 64], 4), make_cd(6, 64, [64, 128], 5)
+    groups, ns = 48, 16
+    x1 = torch.randn(groups * ns, 16, generator=g).cuda()
+    pos2 = torch.randn(groups, 6, generator=g).cuda()
+    w = torch.randn(groups // 8, 128, generator=g).cuda()
+
+    def run(owned):
+        a, b = copy.deepcopy(m1), copy.deepcopy(m2)
+        ctx = H.owned_pass() if owned else contextlib.nullcontext()
+        with ctx:
+            h1 = mlp.sa_mlp_cd(x1, 6, a.mlp_l0, a.bn_l0, a.mlp_f0, a.bn_f0, a.convs, a.bns, ns)            # (groups, 64)
+            x2 = torch.cat([pos2, h1], 1)                                                                    # second stack: 8 rows per group
+            out = mlp.sa_mlp_cd(x2, 6, b.mlp_l0, b.bn_l0, b.mlp_f0, b.bn_f0, b.convs, b.bns, 8)
+            (out * w).sum().backward()
+            assert not H._pending_reduce and not H._flush_armed
+        return [p.grad.clone() for p in list(a.parameters()) + list(b.parameters())]
+    import contextlib
+    ga, gb = run(False), run(True)
+    assert len(ga) == len(gb) and all(torch.equal(p, q) for p, q in zip(ga, gb))
+    assert H.OWNED_PASS == 0
