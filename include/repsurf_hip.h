@@ -165,7 +165,8 @@ int rs_group_features_backward(int b, int n, int m, int nsample, int cn, int cf,
  * (nsample-cnt+1 for slot 0, else 1), grp[row], slot[row], src[row] = cloud*n + idx (gather/scatter address). */
 int rs_exclusive_scan(int n, const int *in, int *out, void *stream);
 /* The bookkeeping alone (offsets by rs_exclusive_scan of cnt, then mult / grp / slot / src): it needs the ball query's
- * (idx, cnt) only, so a pipelined step builds it in its geometry stage, off the critical path. */
+ * (idx, cnt) only -- query_ball_point's padded rows, classification/modules/pointnet2_utils.py:78-99 -- so a pipelined step
+ * builds it in its geometry stage, off the critical path. */
 int rs_compact_index(int b, int n, int m, int nsample, const int *idx, const int *cnt, int *offsets, int *grp, int *slot,
                      int *src, float *mult, void *stream);
 /* have_index != 0: offsets / mult / grp / slot / src come from rs_compact_index (read, not written); 0: `offsets` is given
@@ -425,7 +426,9 @@ int rs_cross_entropy_forward(long long rows, int classes, long long ignore_index
 /* out[i] = x[i] * a[0] * (b ? b[0] : 1): a, b device scalars (the loss gradient times 1 / count and the incoming gradient) */
 int rs_scale_by_scalars(long long n, const float *x, const float *a, const float *b, float *out, void *stream);
 /* Column sums, stage 1: partial (nblk, n), row slab b of x (rows, n; rows ldx floats apart) summed per column and multiplied by
- * `scale`; rs_reduce_partials (nblk, n) finishes in a fixed order (bias gradient of a row Linear, dout.sum(0)). */
+ * `scale`; rs_reduce_partials (nblk, n) finishes in a fixed order: dout.sum(0), the bias gradient autograd forms for the
+ * classifier's output nn.Linear (segmentation/models/repsurf/repsurf_umb_ssg.py:36-41) and the constructor's last Conv1d
+ * (segmentation/modules/repsurface_utils.py:298-303). */
 int rs_col_sum_partials(long long rows, int n, const float *x, long long ldx, float scale, float *partial, int nblk, void *stream);
 
 /* ---- optimizer step -------------------------------------------------------------------------------
