@@ -27,4 +27,5 @@ ls -la $D | head -40
 tail -q -n 2 $D/*.log
 # keep what is judged small: the stats CSVs, summaries, traffic table (the raw traces stay in scratch)
 mkdir -p $R/gpurun_out/keep_${TAG}_$WL
+python tools/kernel_stats_by_grid.py $D/graph_kernel_trace.csv > $D/graph_kernel_stats_by_grid.csv 2>/dev/null    # per shape (the --stats summary mixes an instance's shapes)
 cp $D/*kernel_stats.csv $D/traffic.json $D/pmc_summary.csv $D/*.log $R/gpurun_out/keep_${TAG}_$WL/ 2>/dev/null
