@@ -43,6 +43,7 @@ class GeoState:
 
     def copy_(self, other):
         dst, src = self.tensors(), other.tensors()
+        assert len(dst) == len(src) and all(d.dtype in (torch.float32, torch.int32) and d.dtype == s_.dtype for d, s_ in zip(dst, src))
         for dt in (torch.float32, torch.int32):          # one multi-tensor launch per dtype instead of one copy per tensor
             pairs = [(d, s_) for d, s_ in zip(dst, src) if d.dtype == dt]
             if pairs:
