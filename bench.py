@@ -359,6 +359,37 @@ def main_seg(args):
             rdist.barrier()
         torch.cuda.synchronize()
 
+    if args.no_graph:
+        # eager launches in program order, one dispatch per instrumented call: what the PMC passes of tools/gpu_profile.sh align
+        # with the launch log (--launch-log); not a throughput configuration
+        def eager():
+            for q in model.parameters():
+                q.grad = None
+            loss = criterion(model(inputs), label)
+            loss.backward()
+            if optim is not None:
+                optim.step()
+            return loss
+        for _ in range(args.warmup):
+            eager()
+        fence()
+        _lib.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = eager()
+        fence()
+        dt = time.perf_counter() - t0
+        _lib.profile_enable(False)
+        _lib.profile_collect()
+        if rank == 0:
+            if args.launch_log:
+                os.makedirs(os.path.dirname(os.path.abspath(args.launch_log)), exist_ok=True)
+                json.dump([[n_, list(d)] for n_, d in _lib.profile_sequence()], open(args.launch_log, "w"))
+            print(json.dumps({"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, 4096-pt clouds @ B=16 per GPU (EAGER launches: profiling aid)",
+                              "value": round(clouds * world * args.steps / dt, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+                              "config": {"workload": "configs[3], eager launches", "launch": "eager"}, "loss": round(float(loss.item()), 5)}))
+        return
     pstep = PipelinedStep(model, criterion, optim, inputs, label, warmup=max(2, args.warmup), sharded=world > 1)
     step = lambda: pstep(sync=False)      # noqa: E731
     mode = "2 hipgraphs on 2 streams: geometry (kNN, FPS, 3-NN weights) of batch s+1 under the network of batch s" + (

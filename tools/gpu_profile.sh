@@ -22,6 +22,15 @@ if [ "$WL" = "cls" ]; then
     --write-log $D/launch_WRITE_SIZE.json --write-csv $D/pmc_WRITE_SIZE_counter_collection.csv --out $D/traffic.json > $D/traffic.log 2>&1
   python tools/pmc_summary.py $D > $D/pmc_summary.log 2>&1
 fi
+if [ "$WL" = "seg" ]; then      # HBM traffic of the segmentation step's launch classes (distinct keys: merged into profiles/traffic.json)
+  cd /tmp
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d $D -o pmc_$C -- $BENCH --steps 2 --warmup 1 --no-graph --launch-log $D/launch_$C.json > $D/pmc_$C.log 2>&1; echo "pmc $C rc=$?" >> $D/pmc_$C.log
+  done
+  cd $R
+  python tools/traffic_from_pmc.py --fetch-log $D/launch_FETCH_SIZE.json --fetch-csv $D/pmc_FETCH_SIZE_counter_collection.csv \
+    --write-log $D/launch_WRITE_SIZE.json --write-csv $D/pmc_WRITE_SIZE_counter_collection.csv --out $D/traffic.json > $D/traffic.log 2>&1
+fi
 cd $R
 ls -la $D | head -40
 tail -q -n 2 $D/*.log
