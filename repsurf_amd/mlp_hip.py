@@ -2,11 +2,14 @@
 
 Orchestrates the kernels of repsurf_amd/csrc/mlp.hip through the C ABI:
   forward  per layer: rs_mlp_gemm_rows (previous BN+ReLU fused into the operand load, BN sums in the
-           epilogue) -> rs_bn_finalize;  last layer -> rs_pool_max (BN+ReLU+max over nsample)
+           epilogue) -> rs_bn_finalize (both BatchNorms of a two-branch first layer in one
+           rs_bn_finalize_batch launch);  last layer -> rs_pool_max (BN+ReLU+max over nsample)
   backward per layer: rs_mlp_wgrad + rs_mlp_gemm_rows (BN-backward affine fused into the operand
-           load, ReLU mask + BN-backward sums in the epilogue) -> rs_bn_backward_finalize
-Only the pre-BatchNorm conv outputs and per-channel vectors are saved for backward; the gradient
-through the max-pool is never materialised (RS_OP_POOLED operand).
+           load, ReLU mask + BN-backward sums in the epilogue) -> rs_backward_tail (the BatchNorm-backward
+           finalize(s) of the layer below plus the fixed-order sums of up to four pending weight-gradient
+           partials in one launch)
+Only the pre-BatchNorm conv outputs (bf16 tensors in bf16 mode, `stores_bf16`) and per-channel vectors are
+saved for backward; the gradient through the max-pool is never materialised (RS_OP_POOLED operand).
 
 Gradients of conv biases that feed a BatchNorm are returned as exact zeros: BatchNorm removes any
 per-channel constant, so the analytic gradient is 0 (the reference's autograd produces rounding
