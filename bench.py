@@ -65,6 +65,13 @@ def parse():
     ap.add_argument("--launch-log", default="", help="write the ordered (abi call, sizes) list of the timing pass "
                                                      "(tools/traffic_from_pmc.py matches it to a rocprofv3 --pmc run)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--data", default="uniform", choices=["uniform", "real"],
+                    help="uniform: synthetic uniform clouds in [-1,1]^3 (the metric's data); real: the 4 scanned objects of "
+                         "tests/golden/geom_real.npz (first 1024 rows of the reference's visualization/*.txt clouds) tiled to the batch "
+                         "-- surfaces, not volumes: 4-6x more DISTINCT ball-query slots, i.e. more shared-MLP rows (DESIGN 6/7)")
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the timed region replays max(--steps, ceil(min-seconds / step time)) steps (`steps_timed` on the line): "
+                         "a 20-step sample of a 1.6 ms step is 32 ms, one clock wobble wide")
     return ap.parse_args()
 
 
@@ -78,6 +85,53 @@ def synthetic_batch(seed, b, n, device):
     xyz = (torch.rand(b, n, 3, generator=g) * 2 - 1)
     label = torch.randint(0, 15, (b,), generator=g)
     return xyz.permute(0, 2, 1).contiguous().to(device), label.to(device)
+
+
+def real_batch(seed, b, n, device):
+    """The 4 real scans of tests/golden/geom_real.npz (1024 rows each, unit-sphere normalised like the reference's loader)
+    tiled to b clouds; every copy gets its own rotation about the up axis and a small jitter so that no two clouds of the
+    batch are identical (the reference's train-time augmentation, classification/tool/train_cls_scanobjectnn.py)."""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "geom_real.npz"))["xyz"].astype(np.float32)
+    assert n == fx.shape[1], f"--data real holds {fx.shape[1]}-point clouds"
+    r = np.random.RandomState(seed)
+    out = np.empty((b, n, 3), np.float32)
+    for i in range(b):
+        a = r.rand() * 2 * np.pi
+        rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+        out[i] = fx[i % fx.shape[0]] @ rot + (0.002 * r.randn(n, 3)).astype(np.float32)
+    label = torch.from_numpy(r.randint(0, 15, (b,)))
+    return torch.from_numpy(out).permute(0, 2, 1).contiguous().to(device), label.to(device)
+
+
+def distinct_slot_fraction(points, stages=((512, 0.2, 32), (128, 0.4, 64))):
+    """Fraction of ball-query slots holding a DISTINCT neighbour at the model's two grouped stages: what the compacted
+    shared-MLP stacks process relative to the dense (B*S*nsample)-row formulation."""
+    from repsurf_amd import ops
+    xyz = points.permute(0, 2, 1).contiguous()
+    out = []
+    for s_, r, ns in stages:
+        start = torch.zeros(xyz.shape[0], dtype=torch.int32, device=xyz.device)
+        centres = ops.gather_rows(xyz, ops.furthestsampling(xyz, s_, start))
+        _, cnt = ops.ballquery(r, ns, xyz, centres, return_count=True)
+        out.append(round(float(cnt.float().mean().item()) / ns, 4))
+        xyz = centres
+    return out
+
+
+def reference_cpu_baseline(args, threads):
+    """the REFERENCE's own classification CPU path (its unmodified model + modules files, cuda_ops=False,
+    pointops_cuda stubbed) timed on this host by oracle/ref_cls_cpu.py in a process of its own (its package names collide
+    with this package's mirrors).  The files are /root/reference's in the build container and the copy oracle/Makefile.ref
+    stages under the git-ignored oracle/_ref/dropin/ on the GPU box.  None when they are not there."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_cls_cpu.py"), "--batch", str(min(args.batch, args.cpu_batch)),
+           "--points", str(args.points), "--steps", str(args.cpu_steps), "--threads", str(threads), "--model", args.model]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**os.environ, "OMP_NUM_THREADS": str(threads)})
+        rec = json.loads(res.stdout.strip().splitlines()[-1])
+        return None if "error" in rec else rec
+    except (subprocess.SubprocessError, OSError, ValueError, IndexError):
+        return None
 
 
 def cpu_baseline(args, state):
@@ -119,12 +173,24 @@ def cpu_baseline(args, state):
                  f"understates the ratio to the reference)")
     except (OSError, ValueError, KeyError):
         pass
-    return {"value": round(nb / dt, 3), "unit": "clouds/s", "cores": torch.get_num_threads(),
+    port = {"value": round(nb / dt, 3), "unit": "clouds/s", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"{args.cpu_steps} timed steps (after 1 warm-up) of B={nb}x{args.points} clouds, fwd+loss+bwd; "
                       f"dense ops torch {torch.__version__} CPU, geometry C/OpenMP, {threads} threads; "
                       f"host CPU: {cpu}" + calib,
             "s_per_step": round(dt, 4), "steps_s": [round(t, 4) for t in times[1:]]}
+    ref = reference_cpu_baseline(args, threads)
+    if ref is None:
+        return port
+    # the reference's own code is the baseline; the port's number rides along for comparison
+    return {"value": ref["clouds_per_s"], "unit": "clouds/s", "cores": ref["threads"], "kind": "reference",
+            "sample": f"the reference's own CPU path ({ref['source']}: classification/models/repsurf/{args.model}.py over its modules/, "
+                      f"cuda_ops=False, pointops_cuda stubbed), {args.cpu_steps} timed steps (after 1 warm-up) of B={ref['batch']}x{ref['points']} "
+                      f"uniform clouds, zero_grad+fwd+SmoothClsLoss+bwd, dense uniform-cube data (no compaction on either CPU leg), "
+                      f"torch {ref['torch']} CPU, {ref['threads']} threads; host CPU: {cpu}",
+            "s_per_step": ref["s_per_step"], "steps_s": ref["steps_s"][1:],
+            "port": {"value": port["value"], "s_per_step": port["s_per_step"], "kind": "port",
+                     "what": "oracle/torch_ref.py + oracle/geom_oracle.c (C/OpenMP geometry), same batch shape and thread count"}}
 
 
 def geometry_lines(device, points):
@@ -394,9 +460,10 @@ def main_seg(args):
     step = lambda: pstep(sync=False)      # noqa: E731
     mode = "2 hipgraphs on 2 streams: geometry (kNN, FPS, 3-NN weights) of batch s+1 under the network of batch s" + (
         " + rccl all-reduce + Adam graph" if world > 1 else "")
+    steps_timed = timed_step_count(args, step, fence, world, device, rdist)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps_timed):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
@@ -424,7 +491,7 @@ def main_seg(args):
     dt = rdist.max_over_ranks(dt, device)
     prof = _lib.profile_collect()
     if rank == 0:
-        ms = dt / args.steps * 1e3
+        ms = dt / steps_timed * 1e3
         roofline, table = roofline_from_profile(prof, timed_steps, args.dtype) if timing else (None, [])
         if args.breakdown:
             os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
@@ -448,8 +515,8 @@ def main_seg(args):
                              f"{threads} threads).  The reference's segmentation path has no CPU implementation (pointops_cuda only), "
                              f"so there is no reference timing to calibrate this port against.",
                    "s_per_step": round(cdt, 4)}
-        out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, 4096-pt clouds @ B=16 per GPU", "value": round(clouds * world * args.steps / dt, 2),
-               "unit": "clouds/s", "points_per_s": round(n * world * args.steps / dt), "n_gpus": world, "steps": args.steps,
+        out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, 4096-pt clouds @ B=16 per GPU", "value": round(clouds * world * steps_timed / dt, 2),
+               "unit": "clouds/s", "points_per_s": round(n * world * steps_timed / dt), "n_gpus": world, "steps": args.steps, "steps_timed": steps_timed,
                "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.dtype == "fp32" else "bf16 MFMA operands + bf16 conv-output storage, f32 accumulate / BatchNorm sums / gradients / parameters",
                "data": "synthetic uniform [-1,1]^3 clouds + uniform rgb, random-init weights",
@@ -499,7 +566,8 @@ def main():
     net = model if use_graph else rdist.wrap(model, device)
     criterion = SmoothClsLoss()
     optim = None if args.no_optim else Adam(model.parameters(), lr=1e-3)
-    points, label = synthetic_batch(rdist.rank_seed(125, rank), args.batch, args.points, device)
+    batch_of = real_batch if args.data == "real" else synthetic_batch
+    points, label = batch_of(rdist.rank_seed(125, rank), args.batch, args.points, device)
     torch.manual_seed(rdist.rank_seed(13, rank))   # CPU generator: FPS starts / normal flips differ per rank
 
     def step():
@@ -530,7 +598,8 @@ def main():
             # same synthetic batch here (both input buffers hold it)
             pstep = PipelinedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
             step = lambda: pstep(sync=False)      # noqa: E731 - the loop synchronises the device around the timed region
-            mode = "2 hipgraphs on 2 streams: geometry of batch s+1 under the network of batch s"
+            mode = ("2 hipgraphs on 2 streams: geometry of batch s+1 under the network of batch s; the SAME synthetic batch "
+                    "sits in both pipeline buffers (every replay still runs one full geometry pass and one full network pass)")
         elif world == 1:
             step = GraphedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup))
             mode = "hipgraph"
@@ -560,9 +629,10 @@ def main():
         if timing:
             args.timed_steps = args.steps
             _lib.profile_enable(True)
+    steps_timed = timed_step_count(args, step, fence, world, device, rdist) if use_graph else args.steps
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps_timed):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
@@ -596,8 +666,8 @@ def main():
     prof = _lib.profile_collect()            # {abi name: [(ms, dims), ...]} from HIP events on the launch stream
 
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        value = args.batch * world * args.steps / dt
+        ms = dt / steps_timed * 1e3
+        value = args.batch * world * steps_timed / dt
         roofline, table = roofline_from_profile(prof, getattr(args, "timed_steps", args.steps), args.dtype)
         if args.launch_log:
             os.makedirs(os.path.dirname(os.path.abspath(args.launch_log)), exist_ok=True)
@@ -611,14 +681,19 @@ def main():
         # (skipped under --launch-log: a PMC pass matches dispatches to the logged calls, extra launches would shift them)
         ball_line, fps_line = geometry_lines(device, args.points) if (timing and not args.launch_log) else (None, None)
         out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U 1024-pt cls @ B=32 per GPU", "value": round(value, 2),
-               "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "steps_timed": steps_timed, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.dtype == "fp32" else "bf16 MFMA operands + bf16 conv-output storage, f32 accumulate / BatchNorm sums / gradients / parameters", "data": "synthetic uniform [-1,1]^3 clouds, random-init weights",
+               "dtype": "f32" if args.dtype == "fp32" else "bf16 MFMA operands + bf16 conv-output storage, f32 accumulate / BatchNorm sums / gradients / parameters",
+               "data": ("synthetic uniform [-1,1]^3 clouds" if args.data == "uniform" else
+                        "the reference's 4 scanned objects (tests/golden/geom_real.npz) tiled to the batch, rotated + jittered per copy") + ", random-init weights",
                "config": {"workload": f"configs[{1 if args.dtype == 'fp32' else 4}]: RepSurf-U ({args.model}) classifier, B={args.batch}x{args.points} pts "
                                       f"per GPU, {args.dtype}, full encoder + head, fwd+loss+bwd"
                                       + ("" if args.no_optim else "+Adam step"),
                           "global_batch": args.batch * world, "points": args.points,
                           "parallelism": f"dp{world}", "mlp_backend": "hip", "launch": mode,
+                          "grouped_rows": ("compacted: distinct ball-query slots only (exact; DESIGN 6)" if mlp.COMPACT_GROUPS else
+                                           "dense: every ball-query slot (REPSURF_COMPACT=0)"),
+                          "distinct_slot_fraction_sa1_sa2": distinct_slot_fraction(points),
                           "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5),
                           "allreduce_us": None if allreduce_us is None else round(allreduce_us, 1),
                           "allreduce_bytes": 4 * sum(p.numel() for p in model.parameters()) if world > 1 else None},
@@ -627,6 +702,19 @@ def main():
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out), flush=True)
     rdist.finish()
+
+
+def timed_step_count(args, step, fence, world, device, rdist):
+    """max(--steps, ceil(--min-seconds / step time)): the step time comes from a short untimed probe (also warm-up), the
+    count is agreed over the ranks so that every rank replays the same number of steps."""
+    fence()
+    t0 = time.perf_counter()
+    probe = max(3, min(args.steps, 10))
+    for _ in range(probe):
+        step()
+    fence()
+    est = rdist.max_over_ranks((time.perf_counter() - t0) / probe, device)
+    return max(args.steps, int(np.ceil(args.min_seconds / max(est, 1e-6))))
 
 
 def traffic_key(kernel, dims):

@@ -94,14 +94,16 @@ int rs_ballquery(int b, int n, int m, float radius2, int nsample, const float *n
  * (classification/modules/pointops/src/knnquery/knnquery_cuda_kernel.h:14) with the
  * semantics of query_knn_point(cuda=False) (classification/modules/pointnet2_utils.py:102-111):
  * expanded-formula distances, ascending by (distance, index).  dist2 may be NULL.
- * nsample <= 64. */
+ * Any nsample <= n: register-list kernels up to 64, one wave per query by repeated minimum beyond (the reference
+ * operator accepts up to 200, knnquery_cuda_kernel.cu:21-22; 100 in knnquery_heap_cuda_kernel.cu:67-68). */
 int rs_knnquery(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz,
                 int *idx, float *dist2, void *stream);
 
 /* Packed-batch kNN of the segmentation path: replaces knnquery_cuda_launcher
  * (segmentation/modules/pointops/src/knnquery/knnquery_cuda_kernel.cu:65-108):
  * direct-difference distances, strict '<' replacement, ascending output,
- * dist2 (m, nsample) holds squared distances (Python takes the sqrt). */
+ * dist2 (m, nsample) holds squared distances (Python takes the sqrt).  Any nsample (the reference: <= 100, :86-87);
+ * a cloud with fewer rows leaves the tail of a list at (1e10, first row of the cloud) like the reference. */
 int rs_knnquery_offset(int m, int nsample, const float *xyz, const float *new_xyz,
                        const int *offset, const int *new_offset, int b,
                        int *idx, float *dist2, void *stream);

@@ -7,9 +7,10 @@ Follows the reference's segmentation path function by function:
   sample_and_group              segmentation/modules/repsurface_utils.py:15-51
   SurfaceAbstractionCD          segmentation/modules/repsurface_utils.py:176-230
   SurfaceFeaturePropagationCD   segmentation/modules/repsurface_utils.py:233-284
-Geometry comes from oracle/geom_oracle.c (packed-batch FPS and kNN restate the reference's CUDA kernels,
-which cannot run here: PARITY UNPINNED for those two; everything downstream of them is pinned against the
-reference's own torch code executed on CPU, tests/golden/make_golden_seg.py -> tests/golden/seg_model.npz).
+Geometry comes from oracle/geom_oracle.c (packed-batch FPS and kNN restate the reference's CUDA kernels and are pinned
+against those kernels executed as host code, oracle/_ref + tests/test_oracle_ref.py; everything downstream of them is
+pinned against the reference's own torch code run over its own kernels on CPU, tests/golden/make_golden_seg.py ->
+tests/golden/seg_model.npz).
 Dense part: PyTorch fp32 CPU ops, BatchNorm statistics in fp64 (see oracle/torch_ref.py:_bn_train).
 
 Parameters come from a state_dict with the reference's key names.
@@ -57,7 +58,7 @@ def sample_and_group(stride, nsample, center, normal, feature, offset, return_po
     new_normal = _rows(normal, fidx)
     gidx, _ = G.knn_offset(nsample, center, new_center, offset, new_offset)
     m = new_center.shape[0]
-    g = torch.from_numpy(center[gidx.reshape(-1)].reshape(m, nsample, 3) - new_center[:, None, :])
+    g = torch.from_numpy(center[gidx.reshape(-1)].reshape(m, nsample, 3) - new_center[:, None, :]).to(normal.dtype)
     parts = [g]
     if return_polar:
         parts.append(xyz2sphere(g))
@@ -78,10 +79,13 @@ def xyz2sphere(xyz):
     return torch.cat([rho, theta / np.pi, phi / (2 * np.pi) + .5], dim=-1)
 
 
-def step(state, coord, feat, offset, label=None, inv_sign=None, k=9, return_polar=False, want_grads=True):
+def step(state, coord, feat, offset, label=None, inv_sign=None, k=9, return_polar=False, want_grads=True,
+         dtype=torch.float32):
     """One training step on CPU.  coord (N,3), feat (N,Cin-3) float32 numpy, offset (B,) int32 running ends,
-    inv_sign (B,) +-1 or None, label (N,) int.  Returns logits, loss, stage outputs and {name: grad}."""
-    p = {k_: v.detach().clone().float().requires_grad_(v.dtype.is_floating_point and want_grads)
+    inv_sign (B,) +-1 or None, label (N,) int.  Returns logits, loss, stage outputs and {name: grad}.
+    dtype=torch.float64: the TRUTH leg of the three-way parity tests -- the same indices, fan features and interpolation
+    weights (fp32 outputs of the geometry oracle, widened exactly), every dense operation of the network in float64."""
+    p = {k_: v.detach().clone().to(dtype).requires_grad_(v.dtype.is_floating_point and want_grads)
          for k_, v in state.items() if "running" not in k_ and "num_batches" not in k_}
     coord = np.ascontiguousarray(coord, np.float32)
     offset = np.ascontiguousarray(offset, np.int32)
@@ -91,12 +95,12 @@ def step(state, coord, feat, offset, label=None, inv_sign=None, k=9, return_pola
     ufeat, _, tie = umbrella_rows(coord, offset, inv_sign, k)
     out["umb_feat"], out["near_tie"] = ufeat, tie
     n = coord.shape[0]
-    h = torch.from_numpy(ufeat.reshape(n * k, 10))
+    h = torch.from_numpy(ufeat.reshape(n * k, 10)).to(dtype)
     h = F.relu(_bn_train(_lin(h, p, "surface_constructor.mlps.0"), p["surface_constructor.mlps.1.weight"],
                          p["surface_constructor.mlps.1.bias"]))
     normal = _lin(h, p, "surface_constructor.mlps.3").view(n, k, -1).sum(dim=1)          # (N,10)
     out["normal"] = normal
-    feature = torch.cat([torch.from_numpy(coord), torch.from_numpy(np.ascontiguousarray(feat, np.float32))], 1)
+    feature = torch.cat([torch.from_numpy(coord), torch.from_numpy(np.ascontiguousarray(feat, np.float32))], 1).to(dtype)
     levels = [(coord, feature, offset)]
     center = coord
     for si, st in enumerate(SA, 1):
@@ -120,9 +124,9 @@ def step(state, coord, feat, offset, label=None, inv_sign=None, k=9, return_pola
         xyz1, pts1, off1 = lvl1
         xyz2, pts2, off2 = lvl2
         idx, d2 = G.knn_offset(3, xyz2, xyz1, off2, off1)                               # (:261)
-        w = torch.from_numpy(G.interp_weights(d2))
+        w = torch.from_numpy(G.interp_weights(d2)).to(dtype)
         pts2 = _bn_train(_lin(pts2, p, pre + ".mlp_f0"), p[pre + ".norm_f0.weight"], p[pre + ".norm_f0.bias"])
-        interp = torch.zeros(xyz1.shape[0], pts2.shape[1])
+        interp = torch.zeros(xyz1.shape[0], pts2.shape[1], dtype=dtype)
         for i in range(3):
             interp = interp + _rows(pts2, idx[:, i]) * w[:, i].unsqueeze(-1)
         if skip:

@@ -36,8 +36,8 @@ def _bn_train(y, w, b, eps=1e-5):
     are restated here in float64 and applied as y*alpha + beta like the CPU kernel does."""
     mean = y.mean(0, dtype=torch.float64)                       # fp64 accumulation, no fp64 copy of y
     var = ((y * y).mean(0, dtype=torch.float64) - mean * mean).clamp_min(0)
-    alpha = (w.double() / torch.sqrt(var + eps)).float()
-    beta = (b.double() - mean * (w.double() / torch.sqrt(var + eps))).float()
+    alpha = (w.double() / torch.sqrt(var + eps)).to(y.dtype)
+    beta = (b.double() - mean * (w.double() / torch.sqrt(var + eps))).to(y.dtype)
     return y * alpha + beta
 
 

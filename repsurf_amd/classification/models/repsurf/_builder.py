@@ -43,7 +43,10 @@ class GeoState:
 
     def copy_(self, other):
         dst, src = self.tensors(), other.tensors()
-        assert len(dst) == len(src) and all(d.dtype in (torch.float32, torch.int32) and d.dtype == s_.dtype for d, s_ in zip(dst, src))
+        if len(dst) != len(src) or any(d is None or s_ is None or d.dtype not in (torch.float32, torch.int32) or d.dtype != s_.dtype
+                                       for d, s_ in zip(dst, src)):
+            # (an exception, not an assert: `python -O` must not turn a tensor of another dtype into a silently skipped copy)
+            raise RuntimeError("GeoState.copy_: the two states do not hold the same float32 / int32 tensors")
         for dt in (torch.float32, torch.int32):          # one multi-tensor launch per dtype instead of one copy per tensor
             pairs = [(d, s_) for d, s_ in zip(dst, src) if d.dtype == dt]
             if pairs:

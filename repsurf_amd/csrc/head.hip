@@ -446,8 +446,15 @@ ce_rows_kernel(long long rows, int classes, long long ignore_index, const float 
     const float *x = logits + r * classes;
     float *d = dlogits + r * classes;
     const long long t = target[r];
-    if (t == ignore_index || t < 0 || t >= classes) {
+    if (t == ignore_index) {
       for (int j = 0; j < classes; ++j) d[j] = 0.f;
+    } else if (t < 0 || t >= classes) {
+      // a label outside [0, classes) that is NOT the ignore label is a data bug (torch traps it with a device assert): it must
+      // not train as a silently masked row -- the row's loss and gradient become NaN, which the mean carries to the caller
+      const float qnan = __builtin_nanf("");
+      for (int j = 0; j < classes; ++j) d[j] = qnan;
+      loss = (double)qnan;
+      cnt = 1.0;
     } else {
       float mx = x[0];
       for (int j = 1; j < classes; ++j) mx = fmaxf(mx, x[j]);

@@ -276,11 +276,11 @@ extern "C" int rs_knnquery(int b, int n, int m, int nsample, const float *xyz, c
                            int *idx, float *dist2, void *stream) {
   RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "rs_knnquery: negative size");
   if (b == 0 || m == 0 || nsample == 0) return RS_OK;
-  RS_REQUIRE(nsample <= 64, "rs_knnquery: nsample=%d exceeds the supported maximum of 64", nsample);
   RS_REQUIRE(n >= nsample, "rs_knnquery: cloud of %d points cannot supply %d neighbours", n, nsample);
   RS_REQUIRE(xyz && new_xyz && idx, "rs_knnquery: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (nsample <= 4) launch_knn<4>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
+  if (nsample > 64) rs_launch_knn_wide_dense(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);   // the reference operator: up to 200
+  else if (nsample <= 4) launch_knn<4>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
   else if (nsample <= 9) launch_knn<9>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
   else if (nsample <= 16) launch_knn<16>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);
   else if (nsample <= 32) launch_knn1<32>(b, n, m, nsample, xyz, new_xyz, idx, dist2, st);

@@ -119,3 +119,9 @@ __device__ __forceinline__ void rs_xcd_remap(int bid, int groups, int per_group,
   }
   (void)total;
 }
+
+// csrc/knn_wide.hip: the nsample > 64 route of rs_knnquery / rs_knnquery_offset (one wave per query, repeated minimum)
+void rs_launch_knn_wide_dense(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx,
+                              float *dist2, hipStream_t st);
+void rs_launch_knn_wide_packed(int m, int nsample, int b, const float *xyz, const float *new_xyz, const int *offset,
+                               const int *new_offset, int *idx, float *dist2, hipStream_t st);

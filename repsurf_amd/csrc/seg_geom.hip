@@ -331,9 +331,13 @@ extern "C" int rs_knnquery_offset(int m, int nsample, const float *xyz, const fl
                                   void *stream) {
   RS_REQUIRE(m >= 0 && nsample >= 0 && b >= 0, "rs_knnquery_offset: negative size");
   if (m == 0 || nsample == 0 || b == 0) return RS_OK;
-  RS_REQUIRE(nsample <= 64, "rs_knnquery_offset: nsample=%d exceeds the supported maximum of 64", nsample);
   RS_REQUIRE(xyz && new_xyz && offset && new_offset && idx, "rs_knnquery_offset: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (nsample > 64) {                                     // the reference operator: up to 100 (csrc/knn_wide.hip)
+    rs_launch_knn_wide_packed(m, nsample, b, xyz, new_xyz, offset, new_offset, idx, dist2, st);
+    RS_CHECK_LAUNCH("rs_knnquery_offset");
+    return RS_OK;
+  }
   const dim3 grid(rs_cdiv(m, SG_QPB)), block(SG_THREADS);
 #define RS_LAUNCH_KP(K, LM)                                                                               \
   hipLaunchKernelGGL((knn_packed_kernel<K, LM>), grid, block, 0, st, m, nsample, b, xyz, new_xyz, offset, \

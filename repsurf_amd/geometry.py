@@ -34,9 +34,10 @@ class StageGeometry:
         out = [self.fps_idx, self.new_center, self.idx, self.cnt]
         if self.index is not None:
             # (grp, slot, src are rows of one (3, capacity) allocation: copied as that one tensor)
-            out += [self.index.offsets, self.index.mult, self.index.grp._base if self.index.grp._base is not None else self.index.grp]
-            if self.index.grp._base is None:
-                out += [self.index.slot, self.index.src]
+            out += [self.index.offsets, self.index.mult]
+            out += [self.index.meta] if self.index.meta is not None else [self.index.grp, self.index.slot, self.index.src]
+        if any(t is None for t in out):
+            raise RuntimeError("StageGeometry.tensors: a stage without ball-query counts cannot be part of a pipelined state set")
         return out
 
     def clone(self):
@@ -44,9 +45,8 @@ class StageGeometry:
         index = None
         if self.index is not None:
             i = self.index
-            if i.grp._base is not None:
-                meta = i.grp._base.clone()
-                index = CompactIndex(i.offsets.clone(), i.mult.clone(), meta[0], meta[1], meta[2])
+            if i.meta is not None:
+                index = CompactIndex.from_meta(i.offsets.clone(), i.mult.clone(), i.meta.clone())
             else:
                 index = CompactIndex(i.offsets.clone(), i.mult.clone(), i.grp.clone(), i.slot.clone(), i.src.clone())
         return StageGeometry(self.fps_idx.clone(), self.new_center.clone(), self.idx.clone(), self.cnt.clone(), index)

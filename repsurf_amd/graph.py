@@ -44,6 +44,7 @@ class GraphedStep:
         else:
             for p in self.net.parameters():
                 p.grad = None
+        mlp_hip.owned_pass.check(self.net.parameters())
         with mlp_hip.owned_pass():        # gradients start as None and are read only after backward (mlp_hip.owned_pass)
             loss = self.criterion(self.net(self.points), self.label)
             loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
@@ -60,21 +61,52 @@ class GraphedStep:
         return self.loss
 
 
+def _offset_slot(x):
+    """Position of the packed batch's offsets in a list input -- the LAST element by the reference's collate convention
+    ([coord, feat, offset], segmentation/util/data_util.py:15-23) -- or None for a plain tensor input.  Identified by
+    position, never by dtype: any other int32 tensor of an input is data and is copied like the rest."""
+    if torch.is_tensor(x):
+        return None
+    last = x[-1]
+    if not (torch.is_tensor(last) and last.dtype == torch.int32 and last.dim() == 1):
+        raise TypeError("PipelinedStep: a list input must end with the packed batch's (B,) int32 offsets")
+    return len(x) - 1
+
+
 def _clone_inputs(x):
     """A model input for one of the two buffer sets: a tensor, or a list of tensors (segmentation: [coord, feat, offset]).
-    int32 tensors are the packed batch's offsets -- shapes the captured graphs bake in -- and stay shared."""
+    The offsets are SHAPES of the captured graphs (cloud boundaries decide grids, BatchNorm groups and the derived offsets
+    of every stage): they stay shared and constant; `_check_offsets` refuses a batch whose offsets differ."""
     if torch.is_tensor(x):
         return x.clone()
-    return [t if t.dtype == torch.int32 else t.clone() for t in x]
+    slot = _offset_slot(x)
+    return [t if i == slot else t.clone() for i, t in enumerate(x)]
 
 
 def _copy_inputs(dst, src):
     if torch.is_tensor(dst):
         dst.copy_(src, non_blocking=True)
         return
-    for d, s_ in zip(dst, src):
-        if d.dtype != torch.int32:
+    slot = _offset_slot(dst)
+    for i, (d, s_) in enumerate(zip(dst, src)):
+        if i != slot:
             d.copy_(s_, non_blocking=True)
+
+
+def _check_offsets(captured, batch):
+    """The captured graphs bake the per-cloud row ranges in: a packed batch with the same total row count but other
+    cloud boundaries would silently run kNN, FPS and BatchNorm grouping with STALE offsets.  The host copy of an offset
+    tensor travels with it (ops.host_offsets: one device->host read per tensor object, none when the collate function built
+    it through ops.offsets_tensor), so the comparison costs no synchronisation in a steady loop."""
+    slot = _offset_slot(captured)
+    if slot is None:
+        return
+    from . import ops
+    have, want = ops.host_offsets(batch[slot]), ops.host_offsets(captured[slot])
+    if have != want:
+        raise ValueError(f"PipelinedStep was captured for packed batches with row ends {want[:4]}...{want[-1:]} "
+                         f"({len(want)} clouds); this batch has {have[:4]}...{have[-1:]} ({len(have)} clouds).  Cloud boundaries "
+                         "are shapes of the captured graphs: build a PipelinedStep per batch layout (or pad the clouds to a fixed size).")
 
 
 class PipelinedStep:
@@ -174,6 +206,7 @@ class PipelinedStep:
         else:
             for q in self.net.parameters():
                 q.grad = None
+        mlp_hip.owned_pass.check(self.net.parameters())
         with mlp_hip.owned_pass():        # gradients start as None and are read only after backward (mlp_hip.owned_pass)
             loss = self.criterion(self.net(self.points[p], geo=self.state[p]), self.label[p])
             loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
@@ -207,6 +240,8 @@ class PipelinedStep:
         sync=True also orders the caller's current stream after this step (the returned loss can be read right away);
         a loop that reads the loss only now and then passes sync=False and synchronises when it does."""
         p = self.parity
+        if next_points is not None:
+            _check_offsets(self.points[1 - p], next_points)      # before anything is enqueued: a refused batch leaves the step as it was
         caller = torch.cuda.current_stream()
         self.geo_done[p].synchronize()                     # state[p], points[p], label[p]: written by the previous call
         with torch.cuda.stream(self.main):
@@ -352,6 +387,7 @@ class ShardedGraphedStep:
 
     def _fwd_bwd(self):
         self.grads.clear()
+        mlp_hip.owned_pass.check(self.net.parameters())
         with mlp_hip.owned_pass():        # gradients start as None and are read only after backward (mlp_hip.owned_pass)
             loss = self.criterion(self.net(self.points), self.label)
             loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()

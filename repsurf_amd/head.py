@@ -233,7 +233,8 @@ def cross_entropy(logits, target, ignore_index=-100):
     """F.cross_entropy(logits (rows, classes), target (rows,), ignore_index=...) with mean reduction -- the criterion of the
     segmentation train loop (nn.CrossEntropyLoss(ignore_index=args.ignore_label), segmentation/tool/train.py:110,296) -- in two
     launches forward and one backward (torch: log_softmax, a single-workgroup nll reduction, two backward kernels)."""
-    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2):
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2) or logits.shape[0] == 0:
+        # not this kernel's case (other dtype / layout, or an EMPTY batch, where torch defines the result as NaN)
         return torch.nn.functional.cross_entropy(logits, target, ignore_index=ignore_index)
     return _CrossEntropy.apply(logits, target.to(torch.int64), ignore_index)
 

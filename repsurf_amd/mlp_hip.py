@@ -402,7 +402,14 @@ def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None, defer=False):
     _lib.call("rs_mlp_wgrad_bf16" if _mlp.PRECISION == "bf16" else "rs_mlp_wgrad", rows, rows_dev, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), chunks,
               None if defer else _ptr(dw), _stream())
     if defer:
-        _pending_reduce.append((part, chunks, ncols * kcols, dw))
+        # the queue is ONE per process and is drained on the current stream: this package runs one process per GPU
+        # (repsurf_amd.dist); a second device in the same process (autograd runs its backward on a thread of its own) must not
+        # interleave with it -- its sums are launched at once instead of being carried
+        if _pending_reduce and _pending_reduce[0][0].device != part.device:
+            flush_reduces()
+            _lib.call("rs_reduce_partials", chunks, ncols * kcols, _ptr(part), _ptr(dw), _stream())
+        else:
+            _pending_reduce.append((part, chunks, ncols * kcols, dw))
     return dw
 
 
@@ -438,6 +445,19 @@ _flush_armed = False
 
 
 class owned_pass:
+    """Contract of the caller (the graphed steps of repsurf_amd.graph keep it): every parameter's `.grad` is None when
+    backward starts, no parameter carries gradient hooks / post-accumulate hooks, no `create_graph`, and nothing reads a
+    gradient before backward returns -- a weight gradient handed to autograd is COMPLETE only once the pass has ended (its
+    fixed-order sum rides with a later launch on the same stream).  `check(params)` verifies the first two."""
+
+    @staticmethod
+    def check(params):
+        for p in params:
+            if p.grad is not None:
+                raise RuntimeError("owned_pass: a parameter already holds a .grad (autograd would read the incomplete sum to accumulate)")
+            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+                raise RuntimeError("owned_pass: a parameter carries gradient hooks (they would see an incomplete weight gradient)")
+
     def __enter__(self):
         global OWNED_PASS
         OWNED_PASS += 1

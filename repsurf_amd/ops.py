@@ -400,17 +400,23 @@ class CompactGroups:
 class CompactIndex:
     """The bookkeeping of compacted groups (rs_compact_index): offsets (groups + 1), mult / grp / slot / src (capacity).  It
     depends on the ball query's (idx, cnt) only, so the geometry stage of a pipelined step builds it ahead of time."""
-    __slots__ = ("offsets", "mult", "grp", "slot", "src")
+    __slots__ = ("offsets", "mult", "grp", "slot", "src", "meta")
 
-    def __init__(self, offsets, mult, grp, slot, src):
-        self.offsets, self.mult, self.grp, self.slot, self.src = offsets, mult, grp, slot, src
+    def __init__(self, offsets, mult, grp, slot, src, meta=None):
+        """meta: the (3, capacity) int32 allocation grp / slot / src are rows of, when they were allocated that way (copied and
+        cloned as ONE tensor by the pipelined step's state sets); None when they are three separate tensors."""
+        self.offsets, self.mult, self.grp, self.slot, self.src, self.meta = offsets, mult, grp, slot, src, meta
+
+    @staticmethod
+    def from_meta(offsets, mult, meta):
+        return CompactIndex(offsets, mult, meta[0], meta[1], meta[2], meta)
 
     @staticmethod
     def empty(groups, nsample, dev):
         cap = groups * nsample
         meta = torch.empty((3, cap), dtype=torch.int32, device=dev)
-        return CompactIndex(torch.empty((groups + 1,), dtype=torch.int32, device=dev), torch.empty((cap,), dtype=torch.float32, device=dev),
-                            meta[0], meta[1], meta[2])
+        return CompactIndex.from_meta(torch.empty((groups + 1,), dtype=torch.int32, device=dev),
+                                      torch.empty((cap,), dtype=torch.float32, device=dev), meta)
 
 
 def compact_index(idx, cnt, n, out=None, stream=None):

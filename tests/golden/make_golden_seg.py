@@ -22,6 +22,8 @@ Fixtures:
                   so that the sector branch runs on small clouds.
   seg_model.npz   repsurf_umb_ssg on 2 packed clouds (2048 + 1536 points): logits, loss, stage outputs
                   (subsampled), parameter-gradient norms + subsampled gradients; name-seeded weights, dropout 0.
+  seg_pointnet2.npz  the reference's PointNet++ baseline (models/pointnet2/pointnet2_ssg.py over modules/pointnet2_utils.py)
+                  on the same clouds: logits, loss, gradient norms + subsampled gradients.
 """
 import argparse
 import os
@@ -173,6 +175,27 @@ def main():
     out["buffers"] = np.array(sorted(n for n, _ in model.named_buffers()))
     np.savez_compressed(os.path.join(HERE, "seg_model.npz"), **out)
     print("wrote seg_geom.npz, seg_model.npz; loss", loss.item())
+
+    # ---------------- PointNet++ baseline over the same pointops boundary (models/pointnet2/pointnet2_ssg.py over
+    # modules/pointnet2_utils.py:13-135): same clouds / labels / weight rule as the model fixture above
+    from models.pointnet2.pointnet2_ssg import Model as PointNet2
+    torch.manual_seed(0)
+    pn = PointNet2(args).train()
+    name_seeded_init(pn)
+    for m in pn.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    logits = pn([coord, rgb.clone(), offset])
+    loss = torch.nn.functional.cross_entropy(logits, label)
+    loss.backward()
+    out = {"coord": coord.numpy(), "rgb": rgb.numpy(), "offset": offset.numpy(), "label": label.numpy().astype(np.int16),
+           "logits": logits.detach().numpy(), "loss": np.float32(loss.item())}
+    for name, p in pn.named_parameters():
+        out["shape/" + name] = np.array(p.shape, np.int32)
+        out["gnorm/" + name] = np.float32(p.grad.norm().item())
+        out["gsub/" + name] = sub(p.grad, 7 if p.numel() > 4096 else 1)
+    np.savez_compressed(os.path.join(HERE, "seg_pointnet2.npz"), **out)
+    print("wrote seg_pointnet2.npz; loss", loss.item())
 
 
 if __name__ == "__main__":

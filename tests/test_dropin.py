@@ -16,6 +16,7 @@ from tests.util import (GOLDEN, disable_dropout, is_pre_bn_bias, load_by_path, n
 CLS = staged_reference_file("classification", "models/repsurf/repsurf_ssg_umb.py")
 CLS2X = staged_reference_file("classification", "models/repsurf/repsurf_ssg_umb_2x.py")
 SEG = staged_reference_file("segmentation", "models/repsurf/repsurf_umb_ssg.py")
+PN2 = staged_reference_file("segmentation", "models/pointnet2/pointnet2_ssg.py")
 need = pytest.mark.skipif(CLS is None or SEG is None, reason="reference model files not staged (make -f oracle/Makefile.ref)")
 
 
@@ -92,3 +93,48 @@ def test_reference_segmentation_file_forward_backward_matches_its_cpu_fixture():
     parity_report("dropin_seg_reference_file", logits_max_abs=err, loss_abs=abs(loss.item() - float(fx["loss"])),
                   grad_rel_l2_worst=worst)
     assert err <= 2e-5 * max(1.0, float(np.abs(fx["logits"]).max())) and abs(loss.item() - float(fx["loss"])) <= 5e-5 and not bad, (err, bad)
+
+
+@pytest.mark.skipif(PN2 is None, reason="reference pointnet2_ssg.py not staged (make -f oracle/Makefile.ref)")
+def test_reference_pointnet2_file_constructs_over_the_mirror_module():
+    """segmentation/models/pointnet2/pointnet2_ssg.py:8 imports PointNetSetAbstraction / PointNetFeaturePropagation from
+    modules.pointnet2_utils (SURVEY 8(b) names it as a caller of the boundary): it must import and build over the mirror, with
+    the reference's parameter names and shapes (tests/golden/seg_pointnet2.npz records them)."""
+    fx = np.load(os.path.join(GOLDEN, "seg_pointnet2.npz"))
+    with subproject("segmentation"):
+        model = load_by_path("ref_pn2_model", PN2).Model(seg_args())
+    want = {k[6:]: tuple(fx[k]) for k in fx.files if k.startswith("shape/")}
+    assert {k: tuple(v.shape) for k, v in model.named_parameters()} == want
+
+
+@pytest.mark.skipif(PN2 is None, reason="reference pointnet2_ssg.py not staged (make -f oracle/Makefile.ref)")
+@pytest.mark.gpu
+def test_reference_pointnet2_file_forward_backward_matches_its_cpu_fixture():
+    """The reference's PointNet++ baseline, UNMODIFIED, over modules.pointnet2_utils (sample_and_group with sectorized FPS,
+    PointNetSetAbstraction, PointNetFeaturePropagation on the HIP kernels) against the fixture the same file produced over the
+    reference's own modules and kernels on CPU (tests/golden/make_golden_seg.py)."""
+    fx = np.load(os.path.join(GOLDEN, "seg_pointnet2.npz"))
+    with subproject("segmentation"):
+        model = load_by_path("ref_pn2_model", PN2).Model(seg_args())
+        name_seeded_init(model)
+        disable_dropout(model)
+        model = model.cuda().train()
+        logits = model([torch.from_numpy(fx["coord"]).cuda(), torch.from_numpy(fx["rgb"]).cuda(),
+                        torch.from_numpy(fx["offset"]).cuda()])
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(fx["label"].astype(np.int64)).cuda())
+    loss.backward()
+    err = np.abs(logits.detach().cpu().numpy() - fx["logits"]).max()
+    scale = float(np.abs(fx["logits"]).max())
+    bad, worst = [], 0.0
+    for name, p in model.named_parameters():
+        ref = fx["gsub/" + name]
+        if float(fx["gnorm/" + name]) < 1e-5:                     # biases in front of a BatchNorm: analytically zero
+            continue
+        got = p.grad.detach().cpu().numpy().reshape(-1)[::(7 if p.numel() > 4096 else 1)]
+        rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-12)
+        worst = max(worst, rel)
+        if rel > 3e-2:
+            bad.append((name, rel))
+    parity_report("dropin_seg_pointnet2_reference_file", logits_max_abs=err, logits_scale=scale,
+                  loss_abs=abs(loss.item() - float(fx["loss"])), grad_rel_l2_worst=worst)
+    assert err <= 2e-5 * max(1.0, scale) and abs(loss.item() - float(fx["loss"])) <= 5e-5 and not bad, (err, bad)

@@ -79,7 +79,10 @@ def test_ballquery_empty_ball_gives_zeros(ops):
 
 KNN_CASES = [("uniform", 2, 1024, 1024, 9), ("uniform", 2, 1000, 300, 3), ("uniform", 1, 3000, 500, 16),
              ("uniform", 2, 512, 512, 32), ("grid", 1, 729, 729, 9), ("uniform", 1, 200, 200, 64),
-             ("clustered", 2, 1024, 1024, 9)]
+             ("clustered", 2, 1024, 1024, 9),
+             # nsample > 64: the reference operators' full width (200 / 100), csrc/knn_wide.hip
+             ("uniform", 2, 1024, 200, 100), ("uniform", 1, 700, 64, 200), ("grid", 1, 729, 100, 128), ("dup", 1, 512, 80, 65),
+             ("uniform", 1, 200, 200, 200)]
 
 
 @pytest.mark.parametrize("kind,b,n,s,k", KNN_CASES)

@@ -43,6 +43,14 @@ def test_reference_classification_operators_over_the_hip_library():
     assert np.array_equal(grp.detach().cpu().numpy(), fx["grouping"])
     (grp * dev(fx["grouping_w"])).sum().backward()
     assert np.abs(f2.grad.cpu().numpy() - fx["grouping_grad"]).max() <= 2e-5
+    # grouping_int (int64 payload, grouping_int_cuda_kernel.cu:33-49) and the operator's full kNN width (knnquery_cuda_kernel.cu:21-22)
+    lab = torch.arange(feats.shape[0] * 2 * feats.shape[2], device="cuda").view(feats.shape[0], 2, feats.shape[2]) * 7 - 3 + (1 << 40)
+    gi = P.grouping_int(lab, dev(fx["ball_16"]))
+    want = torch.gather(lab, 2, dev(fx["ball_16"]).long().reshape(lab.shape[0], 1, -1).expand(-1, 2, -1)).view(gi.shape)
+    assert gi.dtype == torch.int64 and torch.equal(gi, want)
+    wide = P.knnquery(200, xyz, new_xyz)
+    wide = (wide[0] if isinstance(wide, tuple) else wide)
+    assert wide.shape[-1] == 200 and torch.equal(wide[..., :9].cpu(), torch.from_numpy(knn))
     dist, nidx = P.nearestneighbor(xyz, new_xyz)
     assert np.array_equal(nidx.cpu().numpy(), fx["nn_idx"])
     assert (np.abs(dist.cpu().numpy() - fx["nn_dist"]) <= np.spacing(fx["nn_dist"])).all()

@@ -81,3 +81,23 @@ def test_segmentation_recons_utils_match_reference():
     assert torch.allclose(ours.cal_const(b, cen), pos, atol=1e-6, equal_nan=True)
     for x, y in zip(ours.check_nan_umb(b, cen, pos), ref.check_nan_umb(b, cen, pos)):
         assert torch.allclose(x, y, atol=1e-7, equal_nan=True)
+
+
+def test_pipelined_step_identifies_offsets_by_position_and_refuses_other_boundaries():
+    """repsurf_amd.graph: the packed batch's offsets are the LAST element of a list input (not 'any int32 tensor'); other
+    int32 tensors are data; a batch with other cloud boundaries is refused."""
+    import pytest
+    from repsurf_amd import graph
+    coord, lab32 = torch.zeros(10, 3), torch.arange(10, dtype=torch.int32)
+    off = torch.tensor([4, 10], dtype=torch.int32)
+    x = [coord, lab32, off]
+    c = graph._clone_inputs(x)
+    assert c[2] is off and c[1] is not lab32 and c[0] is not coord
+    graph._copy_inputs(c, [coord + 1, lab32 + 1, torch.tensor([5, 10], dtype=torch.int32)])
+    assert torch.equal(c[1], lab32 + 1) and torch.equal(c[0], coord + 1) and torch.equal(c[2], off)
+    graph._check_offsets(c, [coord, lab32, torch.tensor([4, 10], dtype=torch.int32)])
+    with pytest.raises(ValueError):
+        graph._check_offsets(c, [coord, lab32, torch.tensor([5, 10], dtype=torch.int32)])
+    with pytest.raises(TypeError):
+        graph._clone_inputs([coord, off, coord])
+    graph._check_offsets(coord, coord)            # plain tensor inputs: nothing to check

@@ -41,7 +41,7 @@ def ops():
     return _ops
 
 
-@pytest.mark.parametrize("k", [3, 9, 16, 32, 64])
+@pytest.mark.parametrize("k", [3, 9, 16, 32, 64, 65, 100])     # > 64: the reference operator's full width, csrc/knn_wide.hip
 @pytest.mark.parametrize("kind", ["uniform", "grid", "dup"])
 def test_knnquery_offset_matches_oracle(ops, k, kind):
     sizes = [700, 40, 1300, 5, 257, 2100]                 # clouds smaller than k (padding) and > one LDS tile
@@ -376,6 +376,13 @@ def test_seg_pipelined_step_matches_eager(monkeypatch):
             loss.backward()
             want.append(loss.item())
     assert np.allclose(got, want, atol=3e-5), (got, want)
+    # a packed batch with the same total row count but other cloud boundaries must be refused, not run with the
+    # captured (stale) offsets -- and the refusal must leave the step usable
+    other = _ops.offsets_tensor([896, sum(sizes)], torch.device("cuda"))
+    with pytest.raises(ValueError, match="row ends"):
+        step([batches[0][0], batches[0][1], other], labels[0])
+    with subproject("segmentation"):
+        assert np.isfinite(step(batches[0], labels[0]).item())
 
 
 def test_scene_scale_knn_and_median_filter():
@@ -456,6 +463,21 @@ def test_cross_entropy_matches_torch(rows, classes, ignored):
         else:
             (la * scale).backward(); (lb * scale).backward()
         assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-9), (a.grad - b.grad).abs().max().item()
+
+
+def test_cross_entropy_flags_labels_outside_the_class_range():
+    """a label that is neither a class nor the ignore label (an unmapped class, a wrong --ignore_label) must not train
+    as a silently masked row -- torch traps it with a device assert; here the loss (and that row's gradient) is NaN.  An empty
+    batch goes to torch (NaN by definition)."""
+    from repsurf_amd import head
+    x = torch.randn(300, 13, generator=torch.Generator().manual_seed(1)).cuda().requires_grad_()
+    t = torch.randint(0, 13, (300,), generator=torch.Generator().manual_seed(2)).cuda()
+    t[7], t[100] = 13, -1
+    loss = head.cross_entropy(x, t, ignore_index=255)
+    assert torch.isnan(loss)
+    loss.backward()
+    assert torch.isnan(x.grad[7]).all() and torch.isnan(x.grad[100]).all()
+    assert torch.isnan(head.cross_entropy(x[:0], t[:0], ignore_index=255))
 
 
 @pytest.mark.parametrize("rows,n", [(65536, 13), (1000, 1), (777, 16), (5000, 40), (300, 300), (4096, 1024)])

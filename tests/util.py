@@ -203,3 +203,14 @@ def load_by_path(name, path):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def three_way(got, ref32, ref64, rel_l2=False):
+    """Three-way comparison of one tensor: the HIP result and the fp32 CPU oracle, each against the SAME network evaluated in
+    float64 (the truth leg).  Returns (error of the HIP path, error of the fp32 oracle, scale of the truth).  With
+    rel_l2 the errors are relative L2 norms (gradients), otherwise maximum absolute differences (activations)."""
+    got, ref32, ref64 = (np.asarray(a, np.float64).reshape(-1) for a in (got, ref32, ref64))
+    if rel_l2:
+        nrm = max(np.linalg.norm(ref64), 1e-300)
+        return np.linalg.norm(got - ref64) / nrm, np.linalg.norm(ref32 - ref64) / nrm, nrm
+    return np.abs(got - ref64).max(), np.abs(ref32 - ref64).max(), np.abs(ref64).max()
