@@ -51,12 +51,39 @@ def install_stubs():
             def __new__(cls, *a):
                 if len(a) == 1 and isinstance(a[0], (list, tuple)):
                     return torch.tensor(a[0], dtype=dtype)
-                return torch.empty(*a, dtype=dtype)
+                # float buffers the MODULES allocate (interpolation accumulators, pointnet2_utils.py:114,
+                # repsurface_utils.py:268) follow FLOAT_DTYPE -- float64 in the truth runs below; buffers the operator file
+                # hands to the kernels (pointops.py: FPS distances, kNN dist2) are always float32
+                import inspect
+                mine = dtype
+                if dtype == torch.float32 and "pointops" not in inspect.stack()[1].filename:
+                    mine = FLOAT_DTYPE[0]
+                return torch.empty(*a, dtype=mine)
         return _T
     torch.cuda.IntTensor = ctor(torch.int32)
     torch.cuda.FloatTensor = ctor(torch.float32)
     if REF not in sys.path:
         sys.path.insert(0, REF)
+
+
+FLOAT_DTYPE = [torch.float32]
+
+
+def truth_run(build, inputs, label):
+    """The reference's OWN code evaluated in float64 (same indices: coordinates and the kernels stay float32; parameters,
+    features and every dense operation in double): the truth leg of the three-way parity tests.  -> logits, {name: grad}"""
+    FLOAT_DTYPE[0] = torch.float64
+    try:
+        model = build().double()
+        for mod in model.modules():      # float32 geometry (fan features, coordinate offsets) enters the double network exactly
+            if isinstance(mod, (torch.nn.Conv1d, torch.nn.Linear)):
+                mod.register_forward_pre_hook(lambda m_, a: tuple(t.double() for t in a))
+        logits = model(inputs(torch.float64))
+        loss = torch.nn.functional.cross_entropy(logits, label)
+        loss.backward()
+        return logits.detach().numpy(), float(loss.item()), {n: p.grad.detach() for n, p in model.named_parameters()}
+    finally:
+        FLOAT_DTYPE[0] = torch.float32
 
 
 def name_seeded_init(model):
@@ -173,6 +200,22 @@ def main():
         out["gnorm/" + name] = np.float32(p.grad.norm().item())
         out["gsub/" + name] = sub(p.grad, 7 if p.numel() > 4096 else 1)
     out["buffers"] = np.array(sorted(n for n, _ in model.named_buffers()))
+
+    def build_repsurf():
+        m_ = Model(args).train()
+        name_seeded_init(m_)
+        for mod in m_.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        np.random.seed(9)
+        return m_
+    l64, loss64, g64 = truth_run(build_repsurf, lambda dt: [coord, rgb.clone().to(dt), offset], label)
+    truth = {"logits64": l64, "loss64": np.float64(loss64)}
+    for name, g in g64.items():
+        truth["gsub64/" + name] = sub(g, 7 if g.numel() > 4096 else 1)
+        truth["gnorm64/" + name] = np.float64(g.norm().item())
+    np.savez_compressed(os.path.join(HERE, "seg_model_fp64.npz"), **truth)
+    print("reference fp32 vs its own fp64: logits", np.abs(out["logits"] - l64).max())
     np.savez_compressed(os.path.join(HERE, "seg_model.npz"), **out)
     print("wrote seg_geom.npz, seg_model.npz; loss", loss.item())
 
@@ -194,6 +237,19 @@ def main():
         out["shape/" + name] = np.array(p.shape, np.int32)
         out["gnorm/" + name] = np.float32(p.grad.norm().item())
         out["gsub/" + name] = sub(p.grad, 7 if p.numel() > 4096 else 1)
+
+    def build_pn2():
+        m_ = PointNet2(args).train()
+        name_seeded_init(m_)
+        for mod in m_.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m_
+    l64, loss64, g64 = truth_run(build_pn2, lambda dt: [coord, rgb.clone().to(dt), offset], label)
+    out["logits64"], out["loss64"] = l64, np.float64(loss64)
+    for name, g in g64.items():
+        out["gsub64/" + name] = sub(g, 7 if g.numel() > 4096 else 1)
+    print("reference PointNet++ fp32 vs its own fp64: logits", np.abs(out["logits"] - l64).max())
     np.savez_compressed(os.path.join(HERE, "seg_pointnet2.npz"), **out)
     print("wrote seg_pointnet2.npz; loss", loss.item())
 

@@ -110,9 +110,11 @@ def test_umbrella_features(ops, kind, b, n, k):
     assert np.array_equal(np.isnan(got), np.isnan(of))
     # fp32 tolerance of the north-star: 1e-5 (acos/atan2 of ocml vs glibc differ in the last ulp;
     # near-degenerate fans amplify that through the normalisation, hence the relative term)
+    # measured (tools/umbrella_outliers.py, profiles/r03/umbrella_outliers.txt): 1.8e-7 at most on every case, near-ties included
+    # (kernel and oracle resolve them with the same exact predicate) -- no outlier allowance
     err = np.nan_to_num(np.abs(got - of))
-    assert (err <= 1e-5 + 1e-5 * np.nan_to_num(np.abs(of))).mean() > 0.9999
-    assert np.median(err) < 1e-7
+    assert (err <= 1e-5 + 1e-5 * np.nan_to_num(np.abs(of))).all(), float(err.max())
+    assert err.max() <= 2e-6 and np.median(err) < 1e-7
 
 
 @pytest.mark.parametrize("tag", ["seed0", "seed1", "seed2", "seed3", "real"])
@@ -135,7 +137,12 @@ def test_against_reference_fixtures(ops, tag):
     ref = g["umb_feat"]
     assert np.array_equal(np.isnan(feat), np.isnan(ref))
     err = np.nan_to_num(np.abs(feat - ref)).reshape(ref.shape[1], -1).max(-1)
-    assert (err > 1e-5).sum() <= 16 and np.median(err) < 1e-6
+    # the tie-aware form of tests/test_oracle_golden.py: a mismatch against the reference's own output needs an azimuth
+    # near-tie (oracle flag) or an exact kNN distance tie (fixture flag); every other point within 1e-6 (measured: 4.8e-7)
+    _, _, near_tie = G.umbrella(g["xyz"][:1], 9, g["umb_inv_sign"])
+    flagged = near_tie[0] | g["knn9_tie_rows"][0]
+    assert err[~flagged].max() <= 1e-6, float(err[~flagged].max())
+    assert (err > 1e-5).sum() <= flagged.sum() and np.median(err) < 1e-6
 
 
 def test_group_features_forward_backward(ops):

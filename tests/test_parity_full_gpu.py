@@ -85,8 +85,9 @@ def _seg_three_way(tag, coord, rgb, offset, label, np_seed, flips, factor=1.5):
     """HIP step, fp32 CPU oracle and float64 truth on one batch.  The north-star's 1e-5 is a bound on single fp32 operators;
     a 13-BatchNorm-deep fp32 network evaluated by ANY fp32 arithmetic sits further than that from its exact value, so the
     model-level claim is stated against the truth: the HIP path is no further from the float64 evaluation of the network than
-    `factor` x the reference's own fp32 arithmetic (the CPU oracle, torch fp32 kernels) is -- for the logits, the stage
-    outputs and every gradient tensor.  All three numbers go to the parity report."""
+    `factor` x the reference's own fp32 arithmetic (the CPU oracle, torch fp32 kernels) is -- for the logits and the stage
+    outputs; gradient tensors by tests.util.gradient_noise_check (they are discontinuous in the rounding noise: see there).
+    All three numbers of every tensor go to the parity report."""
     from tests.util import three_way
     feats = {}
     with subproject("segmentation"):
@@ -125,8 +126,10 @@ def _seg_three_way(tag, coord, rgb, offset, label, np_seed, flips, factor=1.5):
         e_hip, e_ref, nrm = three_way(p.grad.detach().cpu().numpy(), ref["grads"][name].numpy(), t, rel_l2=True)
         grads[name] = [float("%.3g" % e_hip), float("%.3g" % e_ref)]
         worst = max(worst, (e_hip, name))
-        if e_hip > factor * e_ref + 1e-4:
-            bad.append((name, e_hip, e_ref))
+    from tests.util import gradient_noise_check
+    bad += gradient_noise_check(grads)
+    nums["grad_rel_l2_median_vs_fp64__hip_oracle"] = [float(np.median([v[0] for v in grads.values()])),
+                                                      float(np.median([v[1] for v in grads.values()]))]
     nums["grad_rel_l2_worst_vs_fp64"], nums["grad_worst_name"] = worst
     nums["grad_rel_l2_vs_fp64__hip_oracle"] = grads
     nums["outside_bound"] = [b[0] for b in bad]
@@ -158,7 +161,12 @@ def test_segmentation_fixture_three_way():
     truth = seg_ref.step(seg_state(), fx["coord"], fx["rgb"], fx["offset"], label, fx["inv_sign"], dtype=torch.float64,
                          want_grads=False)
     ref_err = np.abs(fx["logits"] - truth["logits"].detach().numpy()).max()
-    parity_report("seg_fixture_reference_fp32_vs_fp64", logits_max_abs=ref_err)
+    # ... and the truth itself cross-checked: the oracle in float64 against the REFERENCE's own code in float64
+    t64 = np.load(os.path.join(GOLDEN, "seg_model_fp64.npz"))
+    truth_gap = np.abs(truth["logits"].detach().numpy() - t64["logits64"]).max()
+    parity_report("seg_fixture_reference_fp32_vs_fp64", logits_max_abs=ref_err, oracle_fp64_vs_reference_fp64=truth_gap,
+                  reference_fp32_vs_its_own_fp64=np.abs(fx["logits"] - t64["logits64"]).max())
+    assert truth_gap <= 2e-6, truth_gap        # (6e-7: the fan features enter both as fp32, last-ulp atan2 / acos differences)
     assert not bad, bad
     assert nums["logits"]["hip_vs_fp64"] <= 1.5 * max(ref_err, nums["logits"]["fp32_oracle_vs_fp64"])
 
