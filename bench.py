@@ -459,7 +459,8 @@ def main_seg(args):
     pstep = PipelinedStep(model, criterion, optim, inputs, label, warmup=max(2, args.warmup), sharded=world > 1)
     step = lambda: pstep(sync=False)      # noqa: E731
     mode = "2 hipgraphs on 2 streams: geometry (kNN, FPS, 3-NN weights) of batch s+1 under the network of batch s" + (
-        " + rccl all-reduce + Adam graph" if world > 1 else "")
+        "" if world == 1 else ("; RCCL all-reduce + Adam inside the network graph" if pstep.collective_captured else
+                               " + eager rccl all-reduce + Adam graph"))
     steps_timed = timed_step_count(args, step, fence, world, device, rdist)
     fence()
     t0 = time.perf_counter()
@@ -611,7 +612,9 @@ def main():
                 else:
                     pstep = PipelinedStep(net, criterion, optim, points, label, warmup=max(2, args.warmup), sharded=True)
                     step = lambda: pstep(sync=False)      # noqa: E731
-                    mode = "2 hipgraphs on 2 streams (geometry of batch s+1 under the network of batch s) + rccl all-reduce + Adam graph"
+                    mode = ("2 hipgraphs on 2 streams (geometry of batch s+1 under the network of batch s); " +
+                            ("the network graph holds forward + backward + gradient pack + RCCL all-reduce + Adam: one replay per rank-step"
+                             if pstep.collective_captured else "network graph -> eager rccl all-reduce -> Adam graph"))
             except Exception as e:  # noqa: BLE001 - keep the scaling run alive: eager DDP is slower but equivalent
                 print(f"[bench rank {rank}] graph capture failed ({e!r}); falling back to eager DDP", file=sys.stderr)
                 for p in model.parameters():

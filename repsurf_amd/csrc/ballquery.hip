@@ -308,15 +308,13 @@ ballquery_grid_kernel(int b, int n, int m, float radius2, int nsample, int wpc, 
 //     the cell counts is a wave scan + one LDS hop (2 barriers instead of 16);
 //   * a thread keeps up to BC_HCAP hits in its LDS row and sorts them in REGISTERS with a Batcher network (19 / 63
 //     compare-exchanges for <= 8 / <= 16 hits: straight-line v_min/v_max, no LDS round trips);
-//   * rows with more hits (dense clusters) are redone by their thread into a small per-workgroup arena (one more walk),
-//     rows beyond the arena by the repeated-minimum walk; both write their row to global memory themselves;
+//   * rows with more hits (dense clusters) are redone by their WAVE, one row at a time (round 3): 64 lanes over the row's
+//     candidates, ranks by counting; rows with more than 64 hits by a cooperative repeated minimum;
 //   * the other rows leave through one coalesced sweep over the (centres x nsample) block, padding expanded on the fly.
 // Same distance arithmetic and threshold as the scan kernel: bit-identical neighbour lists (tests/test_geometry_gpu.py).
 // Phase costs at B = 2048 x 1024 points x 512 centres, r = 0.2 (RS_BALLQUERY_DBG builds, profiles/r02/): see DESIGN.md §5.
-constexpr int BC_THREADS = 512;
 constexpr int BC_HCAP = 16;
-constexpr int BC_PP = BG_MAXN / BC_THREADS;              // points a thread carries in registers (8)
-constexpr int BC_OVF_ROWS = 16, BC_OVF_CAP = 64;         // arena for rows with BC_HCAP < hits <= BC_OVF_CAP
+constexpr int BC_SLACK = 4;                              // float4 entries behind the sorted cloud a 4-candidate step may read
 
 __device__ __forceinline__ void bc_cx(int &a, int &b) { const int lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
 template <int N> __device__ __forceinline__ void bc_sort(int (&v)[16]) {
@@ -333,19 +331,21 @@ template <int N> __device__ __forceinline__ void bc_sort(int (&v)[16]) {
   }
 }
 
-__global__ void __launch_bounds__(BC_THREADS)
+template <int BC_THREADS, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(BC_THREADS, WAVES_PER_SIMD)
 ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
                        const float *__restrict__ xyz, int *__restrict__ idx, int *__restrict__ cnt_out, int dbg) {
+  constexpr int BC_PP = BG_MAXN / BC_THREADS;                  // points a thread carries in registers (8 / 16)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float4 *sp4 = reinterpret_cast<float4 *>(lds);               // (x, y, z, |p|^2) sorted by cell
-  int *sid = reinterpret_cast<int *>(lds + 4 * n);
+  float4 *sp4 = reinterpret_cast<float4 *>(lds);               // (x, y, z, |p|^2) sorted by cell (+ BC_SLACK entries)
+  int *sid = reinterpret_cast<int *>(lds + 4 * (n + BC_SLACK));
   int *cstart = sid + n;                                        // ncell + 1 running starts
-  int *cursor = cstart + BG_MAXCELLS + 1;                       // scatter cursors; later the per-centre hit counts
-  int *hits = cursor + BG_MAXCELLS;                             // BC_THREADS rows of BC_HCAP + 1
-  int *ovf = hits + BC_THREADS * (BC_HCAP + 1);                 // BC_OVF_ROWS rows of BC_OVF_CAP
+  int *hcount = cstart + BG_MAXCELLS + 1;                       // one hit count per thread / centre
+  int *arena = hcount + BC_THREADS;                             // BC_THREADS / 64 rows of 64: a wave's cooperative overflow row
+  int *cursor = arena + BC_THREADS;                             // scatter cursors (build) ...
+  unsigned short *hits = reinterpret_cast<unsigned short *>(cursor);   // ... then BC_THREADS rows of BC_HCAP + 1 hits (16-bit: n <= 4096)
   __shared__ float red[6][BC_THREADS / 64];
   __shared__ int wsum[BC_THREADS / 64];
-  __shared__ int ovf_used;
 
   const int cloud = blockIdx.x;
   const float *pts = xyz + (size_t)cloud * n * 3;
@@ -430,15 +430,13 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
   __syncthreads();
   if (dbg == 1) return;                                         // (experiment: cost of the build alone)
 
-  // F. centres, BC_THREADS at a time
-  int *hcount = cursor;                                         // the cursors are spent: one count per thread / centre
-  int *row = hits + tid * (BC_HCAP + 1);
+  // F. centres, BC_THREADS at a time (the cursors are spent: their LDS now holds the hit rows)
+  unsigned short *row = hits + tid * (BC_HCAP + 1);
   for (int qb = 0; qb < m; qb += BC_THREADS) {
     const int q = qb + tid;
     int count = 0;
     float qx = 0.f, qy = 0.f, qz = 0.f, qq = 0.f;
     int x0 = 1, x1 = 0, y0 = 0, z0 = 0, ny = 0, nrows = 0;
-    if (tid == 0) ovf_used = 0;
     if (q < m) {
       const float *c = new_xyz + ((size_t)cloud * m + q) * 3;
       qx = c[0]; qy = c[1]; qz = c[2]; qq = rs_sqnorm(qx, qy, qz);
@@ -452,21 +450,6 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
       ny = y1 - y0 + 1;
       nrows = (x0 <= x1 && ny > 0 && z1 >= z0) ? ny * (z1 - z0 + 1) : 0;
     }
-    // one flattened candidate stream: (row r, position j); a lane leaves when its rows are exhausted.
-    // visit(j) is called once per candidate of the centre's <= 27 cells.
-    auto walk = [&](auto &&visit) {
-      int r = 0, ry = 0, rz = 0, j = 0, jend = 0;
-      while (true) {
-        while (j >= jend && r < nrows) {
-          const int cb = ((z0 + rz) * g[1] + (y0 + ry)) * g[0];
-          j = cstart[cb + x0]; jend = cstart[cb + x1 + 1];
-          ++r; if (++ry == ny) { ry = 0; ++rz; }
-        }
-        if (j >= jend) break;
-        visit(j);
-        ++j;
-      }
-    };
     // Main pass: the centre's <= 9 rows of cells, FOUR candidates per step.  The row ranges are fetched up front (18
     // independent LDS reads), a step issues four 16-byte candidate reads behind one wait and evaluates them branch-free;
     // the (rare: ~5 hits among ~28 candidates) hit bookkeeping runs only when some lane of the wave has a hit (one
@@ -490,7 +473,7 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
           float4 c4[4];
           bool hit[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) c4[i] = sp4[min(j + i, n - 1)];
+          for (int i = 0; i < 4; ++i) c4[i] = sp4[j + i];                 // j <= n: at most BC_SLACK entries past the cloud (never valid)
           bool any = false;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -502,13 +485,17 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               if (hit[i]) {
-                if (count < BC_HCAP) row[count] = sid[j + i];
+                if (count < BC_HCAP) row[count] = (unsigned short)sid[j + i];
                 ++count;
               }
           }
           j += 4;
         }
       }
+      // (tried, round 3: reading a slot only where it holds a candidate -- exec-masked ds_read_b128, 27 of ~80 slots -- and
+      //  storing a hit's POSITION with the sid lookup deferred to the sort phase: walk 69.5 -> 70.8 us, sort 6 -> 9.6 us,
+      //  launch 93 -> 101 us; the LDS pipe is not relieved by masked lanes and the deferred lookup is a second dependent
+      //  round trip in front of the sorting network)
     }
     if (dbg == 2) { if (count == 12345) idx[0] = count; continue; }      // (experiment: build + walk)
     if (q < m && cnt_out) cnt_out[(size_t)cloud * m + q] = count > 0 ? min(count, nsample) : 1;
@@ -523,7 +510,7 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
         if (wmax > 8) bc_sort<16>(v); else bc_sort<8>(v);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if ((i < 8 || wmax > 8) && i < kept) row[i] = v[i];
+          if ((i < 8 || wmax > 8) && i < kept) row[i] = (unsigned short)v[i];
       }
     }
     hcount[tid] = q < m ? count : 0;
@@ -532,13 +519,32 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
     // coalesced write-out of the rows with <= BC_HCAP hits; padding = the lowest hit (an empty ball yields zeros)
     const int nq = min(BC_THREADS, m - qb);
     int *dst = idx + ((size_t)cloud * m + qb) * nsample;
-    if (dbg != 5) {
+    if (dbg != 5 && (nsample & 3) == 0) {
+      // 16 bytes per thread and trip: a row is nsample / 4 groups of four slots; a wave stores 1 KB of consecutive output
+      const int gpr = nsample >> 2;
+      int4 *dst4 = reinterpret_cast<int4 *>(dst);
+      for (int e = tid; e < nq * gpr; e += BC_THREADS) {
+        const int ql = e / gpr, g4 = (e - ql * gpr) << 2;
+        const int c = hcount[ql];
+        if (c <= BC_HCAP) {
+          const unsigned short *h = hits + ql * (BC_HCAP + 1);
+          const int take = min(c, nsample);
+          const int first = c > 0 ? h[0] : 0;
+          int4 v;
+          v.x = g4 + 0 < take ? h[min(g4 + 0, BC_HCAP)] : first;
+          v.y = g4 + 1 < take ? h[min(g4 + 1, BC_HCAP)] : first;
+          v.z = g4 + 2 < take ? h[min(g4 + 2, BC_HCAP)] : first;
+          v.w = g4 + 3 < take ? h[min(g4 + 3, BC_HCAP)] : first;
+          dst4[e] = v;
+        }
+      }
+    } else if (dbg != 5) {
       int ql = tid / nsample, sl = tid - ql * nsample;
       const int dq = BC_THREADS / nsample, ds = BC_THREADS - dq * nsample;
       for (int e = tid; e < nq * nsample; e += BC_THREADS) {
         const int c = hcount[ql];
         if (c <= BC_HCAP) {
-          const int *h = hits + ql * (BC_HCAP + 1);
+          const unsigned short *h = hits + ql * (BC_HCAP + 1);
           const int take = min(c, nsample);
           dst[e] = c > 0 ? h[sl < take ? sl : 0] : 0;
         }
@@ -546,45 +552,64 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
         if (sl >= nsample) { sl -= nsample; ++ql; }
       }
     }
-    // rows with more than BC_HCAP hits (dense clusters): straight to global memory by their own thread
-    if (dbg != 4 && q < m && count > BC_HCAP) {
-      int *out = idx + ((size_t)cloud * m + q) * nsample;
-      const int want = min(count, nsample);
-      const int slot = count <= BC_OVF_CAP ? atomicAdd(&ovf_used, 1) : BC_OVF_ROWS;
-      if (slot < BC_OVF_ROWS) {
-        // one more walk collects every hit into the arena, an insertion sort orders them (<= 64, rare)
-        int *o = ovf + slot * BC_OVF_CAP;
-        int c2 = 0;
-        walk([&](int j) {
+    // Rows with more than BC_HCAP hits (dense clusters; ~1e-5 of the rows of a uniform cloud): the WAVE redoes them
+    // together, one row at a time -- 64 lanes over the row's candidates, hits through a ballot into the wave's arena, ranks by
+    // counting (<= 64 hits) or the nsample lowest indices by repeated minimum (more).  A single thread walking and
+    // insertion-sorting such a row in LDS took ~12 us of dependent latency, and the launch ended with the unluckiest
+    // workgroup: 13 us of a 113 us launch for a dozen rows in a million (profiles/r02/ballquery_cells_phase_costs.txt).
+    if (dbg != 4) {
+      unsigned long long todo = __ballot(q < m && count > BC_HCAP);
+      int *mine = arena + wave * 64;
+      while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const float cqx = __shfl(qx, src, 64), cqy = __shfl(qy, src, 64), cqz = __shfl(qz, src, 64), cqq = __shfl(qq, src, 64);
+        const int cx0 = __shfl(x0, src, 64), cx1 = __shfl(x1, src, 64), cy0 = __shfl(y0, src, 64), cz0 = __shfl(z0, src, 64);
+        const int cny = __shfl(ny, src, 64), cnrows = __shfl(nrows, src, 64);
+        int *out = idx + ((size_t)cloud * m + (qb + (wave << 6) + src)) * nsample;
+        // candidates of row r of the centre, 64 at a time: visit(j, valid) in every lane
+        auto sweep_rows = [&](auto &&visit) {
+          for (int r = 0; r < cnrows; ++r) {
+            const int rz = r / cny, ry = r - rz * cny;
+            const int cb = ((cz0 + rz) * g[1] + (cy0 + ry)) * g[0];
+            const int jb = cstart[cb + cx0], je = cstart[cb + cx1 + 1];
+            for (int j0 = jb; j0 < je; j0 += 64) visit(min(j0 + lane, n - 1), j0 + lane < je);
+          }
+        };
+        int total = 0;
+        sweep_rows([&](int j, bool valid) {
           const float4 c4 = sp4[j];
-          const float d = rs_sqdist_expanded(qx, qy, qz, qq, c4.x, c4.y, c4.z, c4.w);
-          if (!(d > radius2)) o[c2++] = sid[j];
+          const float d = rs_sqdist_expanded(cqx, cqy, cqz, cqq, c4.x, c4.y, c4.z, c4.w);
+          const bool hit = valid && !(d > radius2);
+          const unsigned long long mask = __ballot(hit);
+          const int slot = total + rs_mbcnt(mask);
+          if (hit && slot < 64) mine[slot] = sid[j];
+          total += __popcll(mask);
         });
-        for (int i = 1; i < c2; ++i) {
-          const int v = o[i];
-          int t = i - 1;
-          while (t >= 0 && o[t] > v) { o[t + 1] = o[t]; --t; }
-          o[t + 1] = v;
+        if (total <= 64) {
+          const int v = lane < total ? mine[lane] : 0x7fffffff;
+          int rank = 0;
+          for (int k = 0; k < total; ++k) rank += mine[k] < v ? 1 : 0;       // (broadcast reads; indices are distinct)
+          if (lane < total && rank < nsample) out[rank] = v;
+          const int first = (int)rs_wave_min_u32((unsigned)v);
+          for (int s2 = total + lane; s2 < nsample; s2 += 64) out[s2] = first;
+        } else {
+          int last = -1;
+          for (int s2 = 0; s2 < nsample; ++s2) {
+            int best = 0x7fffffff;
+            sweep_rows([&](int j, bool valid) {
+              const int p = sid[j];
+              if (valid && p > last && p < best) {
+                const float4 c4 = sp4[j];
+                const float d = rs_sqdist_expanded(cqx, cqy, cqz, cqq, c4.x, c4.y, c4.z, c4.w);
+                if (!(d > radius2)) best = p;
+              }
+            });
+            best = (int)rs_wave_min_u32((unsigned)best);
+            if (lane == 0) out[s2] = best;
+            last = best;
+          }
         }
-        for (int s2 = 0; s2 < nsample; ++s2) out[s2] = o[s2 < want ? s2 : 0];
-      } else {
-        // arena exhausted / more than BC_OVF_CAP hits: the nsample lowest indices by repeated minimum over the candidates
-        int last = -1, first = 0;
-        for (int s2 = 0; s2 < want; ++s2) {
-          int best = 0x7fffffff;
-          walk([&](int j) {
-            const int p = sid[j];
-            if (p > last && p < best) {
-              const float4 c4 = sp4[j];
-              const float d = rs_sqdist_expanded(qx, qy, qz, qq, c4.x, c4.y, c4.z, c4.w);
-              if (!(d > radius2)) best = p;
-            }
-          });
-          out[s2] = best;
-          if (s2 == 0) first = best;
-          last = best;
-        }
-        for (int s2 = want; s2 < nsample; ++s2) out[s2] = first;
       }
     }
     __syncthreads();
@@ -608,10 +633,22 @@ extern "C" int rs_ballquery(int b, int n, int m, float radius2, int nsample, con
   const bool use_grid = grid_mode > 0 || (grid_mode < 0 && (long long)b * m >= 65536 && n >= 1024 && nsample <= 32);
   // 2 (default where the grid applies): the register-carried, cell-sorted variant; 1: the first cell-list kernel
   static const int cells_on = getenv("RS_BALLQUERY_CELLS") ? atoi(getenv("RS_BALLQUERY_CELLS")) : 1;
-  if (use_grid && grid_ok && cells_on && nsample >= 1 && nsample <= BC_THREADS) {
-    const size_t lds = (size_t)n * 20 + sizeof(int) * (2 * BG_MAXCELLS + 1 + (size_t)BC_THREADS * (BC_HCAP + 1) + BC_OVF_ROWS * BC_OVF_CAP);
+  if (use_grid && grid_ok && cells_on && nsample >= 1 && nsample <= 256) {
     static const int dbg = getenv("RS_BALLQUERY_DBG") ? atoi(getenv("RS_BALLQUERY_DBG")) : 0;
-    hipLaunchKernelGGL(ballquery_cells_kernel, dim3(b), dim3(BC_THREADS), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
+    // threads per cloud: 512 (256 = two passes over the centres with half the waves: 154 against 114 us, profiles/r03/)
+    static const int threads = getenv("RS_BALLQUERY_THREADS") ? atoi(getenv("RS_BALLQUERY_THREADS")) : 512;
+    const int t = threads == 512 ? 512 : 256;
+    const size_t hit_bytes = (size_t)t * (BC_HCAP + 1) * 2, cursor_bytes = sizeof(int) * BG_MAXCELLS;
+    const size_t lds = (size_t)(n + BC_SLACK) * 16 + (size_t)n * 4 + sizeof(int) * (BG_MAXCELLS + 1 + 2 * (size_t)t) +
+                       (hit_bytes > cursor_bytes ? hit_bytes : cursor_bytes);
+    // 6 waves per SIMD (<= 80 VGPRs) lets three 512-thread workgroups share a CU when their LDS (45 KB at n = 1024) allows it
+    static const int occ = getenv("RS_BALLQUERY_OCC") ? atoi(getenv("RS_BALLQUERY_OCC")) : 6;
+    if (t == 512 && occ >= 6)
+      hipLaunchKernelGGL((ballquery_cells_kernel<512, 6>), dim3(b), dim3(512), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
+    else if (t == 512)
+      hipLaunchKernelGGL((ballquery_cells_kernel<512, 4>), dim3(b), dim3(512), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
+    else
+      hipLaunchKernelGGL((ballquery_cells_kernel<256, 4>), dim3(b), dim3(256), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
     RS_CHECK_LAUNCH("rs_ballquery");
     return RS_OK;
   }

@@ -3,8 +3,11 @@
 The hot path shards by cloud with no data-path collective: every rank runs the whole model on its
 own B clouds (per-GPU BatchNorm statistics, the reference's default — segmentation/tool/train.py:141-146)
 and the only exchange is ONE gradient all-reduce per step.  The 1.48 M-parameter classifier is
-5.9 MB of fp32 gradients, so a single DDP bucket (64 MB cap) carries all of it: one RCCL ring
-all-reduce, latency-bound (≈10 MB per xGMI link), overlapped with the tail of backward.
+5.9 MB of fp32 gradients: ONE RCCL ring all-reduce of one flat buffer, latency-bound (< 1 MB per xGMI link and hop).
+Graphed steps (repsurf_amd.graph): the collective is recorded INSIDE the step's hipGraph between the gradient pack and the
+Adam kernels -- one replay per rank-step, no host hop; it runs after the whole backward (it is not overlapped with it:
+DESIGN.md 8 prices that).  Eager steps (`wrap`): DistributedDataParallel with a single 64 MB bucket, whose all-reduce starts
+when the last gradient of the bucket is ready, i.e. at the end of backward too.
 """
 import os
 

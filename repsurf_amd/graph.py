@@ -166,25 +166,58 @@ class PipelinedStep:
         self.side.wait_stream(self.main)
         torch.cuda.current_stream().wait_stream(self.main)
         torch.cuda.synchronize()
+        # With a process group alive, its watchdog thread polls the events of the collectives issued so far (the warm-up's
+        # all-reduces, the parameter broadcast): a poll that lands inside a capture in the default (global) error mode aborts
+        # the process (seen: a second PipelinedStep of one process crashed in the watchdog thread while the geometry graphs
+        # were being captured).  So every capture of a sharded step is thread-local, and the watchdog gets one poll period to
+        # retire what has already completed.
+        mode = {"capture_error_mode": "thread_local"} if sharded else {}
+        if sharded:
+            import time
+            time.sleep(0.3)
         # geometry graphs and network graphs run concurrently: separate memory pools
         self.g_geo, self.g_net, self.loss = [], [], []
         for p in (0, 1):
             g = torch.cuda.CUDAGraph()
             with self.draws:
                 self.draws.begin_pass()
-                with torch.cuda.graph(g, pool=self.g_geo[0].pool() if self.g_geo else None, stream=self.side):
+                with torch.cuda.graph(g, pool=self.g_geo[0].pool() if self.g_geo else None, stream=self.side, **mode):
                     self._geometry(p)
             self.g_geo.append(g)
-        for p in (0, 1):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, stream=self.main):
-                self.loss.append(self._network(p))
-            self.g_net.append(g)
+        # Sharded: ONE replay per rank-step when RCCL accepts stream capture -- network + gradient pack + all-reduce + Adam in the
+        # same graph, no host hop between them (round 2: network graph -> eager collective -> Adam graph, two launches and a
+        # host-paced gap per step).  capture_error_mode="thread_local": the process group's watchdog thread polls events while
+        # this thread captures.  If the capture throws (a build without capturable collectives, gloo in the CPU / one-device
+        # tests) the round-2 form is built instead; `self.collective_captured` says which one runs.
+        self.collective_captured = False
+        if sharded and os.environ.get("REPSURF_CAPTURE_ALLREDUCE", "1") != "0" and self._collective_capturable():
+            try:
+                nets, losses = [], []
+                for p in (0, 1):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=nets[0].pool() if nets else None, stream=self.main, **mode):
+                        losses.append(self._network(p))
+                        self._reduce()
+                        if optimizer is not None:
+                            optimizer.step()
+                    nets.append(g)
+                self.g_net, self.loss, self.collective_captured = nets, losses, True
+            except Exception as e:  # noqa: BLE001 - any capture failure: fall back to the three-part form below
+                import sys
+                print(f"[repsurf_amd.graph] the collective could not be captured ({e!r}); using network graph -> eager all-reduce -> Adam graph", file=sys.stderr)
+                torch.cuda.synchronize()
+                self.g_net, self.loss = [], []
         self.graph_opt = None
-        if sharded and optimizer is not None:
-            self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.g_net[0].pool(), stream=self.main):
-                optimizer.step()
+        if not self.collective_captured:
+            for p in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, stream=self.main, **mode):
+                    self.loss.append(self._network(p))
+                self.g_net.append(g)
+            if sharded and optimizer is not None:
+                self.graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_opt, pool=self.g_net[0].pool(), stream=self.main, **mode):
+                    optimizer.step()
         torch.cuda.synchronize()
         self.geo_done = [torch.cuda.Event(), torch.cuda.Event()]    # geo_done[q]: state[q] / points[q] are ready
         self.net_done = [torch.cuda.Event(), torch.cuda.Event()]    # net_done[q]: the network finished reading them
@@ -220,9 +253,15 @@ class PipelinedStep:
         if self.sharded and self.dist.is_initialized():
             self.grads.all_reduce_mean(self.dist, self.group)
 
+    def _collective_capturable(self):
+        """RCCL (backend "nccl") collectives can be recorded into a hipGraph; gloo's run on the host and cannot."""
+        d = self.dist
+        return d.is_available() and d.is_initialized() and d.get_backend(self.group) == "nccl"
+
     def _finish(self):
-        """what follows the network graph in sharded mode (eagerly during warm-up, as a graph afterwards)"""
-        if not self.sharded:
+        """what follows the network graph in sharded mode (eagerly during warm-up, as a graph afterwards; nothing when the
+        collective and the optimizer were captured into the network graph)"""
+        if not self.sharded or getattr(self, "collective_captured", False):
             return
         self._reduce()
         if self.optimizer is not None:
@@ -314,7 +353,9 @@ class FlatGrads:
 
     def all_reduce_mean(self, dist, group=None):
         world = dist.get_world_size(group)
-        if world <= 1:
+        # (REPSURF_FORCE_ALLREDUCE=1: issue the collective on a 1-rank group too -- what lets a single-GPU box exercise the
+        #  captured-collective path end to end; a 1-rank all-reduce is the identity)
+        if world <= 1 and os.environ.get("REPSURF_FORCE_ALLREDUCE", "0") == "0":
             return
         if dist.get_backend(group) == "nccl" and getattr(self, "_avg_ok", True):    # RCCL averages in the collective
             try:

@@ -155,20 +155,28 @@ def test_pipelined_sharded_step_single_rank_process_group():
         pts = torch.from_numpy(cloud(3, 8, 1024)).cuda().permute(0, 2, 1).contiguous()
         lab = torch.arange(8).cuda() % 15
         losses = {}
-        for sharded in (False, True):
+        # round 3: the all-reduce (forced on this 1-rank group: REPSURF_FORCE_ALLREDUCE) and Adam are recorded INSIDE the network
+        # graph -- "captured" -- against the round-2 form (network graph -> eager collective -> Adam graph) and the N = 1 step
+        os.environ["REPSURF_FORCE_ALLREDUCE"] = "1"
+        for kind in ("single", "captured", "between"):
+            os.environ["REPSURF_CAPTURE_ALLREDUCE"] = "0" if kind == "between" else "1"
             m = Model(ref_args())
             name_seeded_init(m)
             disable_dropout(m)
             m = m.cuda().train()
             opt = Adam(m.parameters(), lr=1e-3)
             torch.manual_seed(21)
-            step = PipelinedStep(m, SmoothClsLoss(), opt, pts, lab, warmup=2, sharded=sharded)
-            losses[sharded] = [step().item() for _ in range(3)]
-            if sharded:
+            step = PipelinedStep(m, SmoothClsLoss(), opt, pts, lab, warmup=2, sharded=kind != "single")
+            losses[kind] = [step().item() for _ in range(3)]
+            if kind != "single":
                 assert step.flat.abs().sum() > 0
-        assert np.allclose(losses[True], losses[False], atol=2e-2), losses
-        assert losses[True][2] < losses[True][0] + 0.5
+                assert step.collective_captured == (kind == "captured"), kind
+        assert np.allclose(losses["captured"], losses["single"], atol=2e-2), losses
+        assert np.allclose(losses["captured"], losses["between"], atol=2e-2), losses
+        assert losses["captured"][2] < losses["captured"][0] + 0.5
     finally:
+        os.environ.pop("REPSURF_FORCE_ALLREDUCE", None)
+        os.environ.pop("REPSURF_CAPTURE_ALLREDUCE", None)
         dist.destroy_process_group()
 
 
