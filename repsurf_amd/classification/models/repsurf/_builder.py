@@ -105,6 +105,12 @@ class UmbrellaClassifier(nn.Module):
             plan = GeometryPlan(xyz, self._sampling, fork=False, compact=self._compact())
         return GeoState(feat, [plan.stage(i) for i in range(len(self._sampling))], xyz)
 
+    def early_gradient_modules(self):
+        """The modules whose parameter gradients are complete first in backward (the last SA stage, then the head): bucket 0
+        of the sharded step's gradient all-reduce (repsurf_amd.graph.PipelinedStep, REPSURF_GRAD_BUCKETS=2).  The first entry
+        is the one whose INPUT gradient marks that moment."""
+        return [getattr(self, self._stage_names[-1]), self.classfier]
+
     def _compact(self):
         """the SA stages take the compacted-groups path (training mode): their bookkeeping belongs to the geometry"""
         return bool(_mlp.COMPACT_GROUPS and self.training)

@@ -140,7 +140,17 @@ class PipelinedStep:
             import torch.distributed as dist
             self.dist = dist
             sync_replicas(net, dist, group)
-            self.grads = FlatGrads(list(net.parameters()))
+            # REPSURF_GRAD_BUCKETS=2 (opt-in, measured in DESIGN.md 8): the gradients of the layers closest to the loss
+            # (net.early_gradient_modules(): the last SA stage + the head) form bucket 0, whose all-reduce is issued from a
+            # tensor hook on that stage's input gradient -- i.e. as soon as they are complete -- and runs on the process
+            # group's stream under the rest of the backward pass; bucket 1 follows the backward as before.
+            early, self._early_work = None, None
+            if (os.environ.get("REPSURF_GRAD_BUCKETS", "1") == "2" and hasattr(net, "early_gradient_modules")
+                    and os.environ.get("REPSURF_CAPTURE_ALLREDUCE", "1") != "0" and self._collective_capturable()):
+                mods = net.early_gradient_modules()
+                early = [p for m_ in mods for p in m_.parameters()]
+                mods[0].register_forward_pre_hook(self._arm_early_bucket)
+            self.grads = FlatGrads(list(net.parameters()), early=early)
             self.flat = self.grads.flat
         dev = label.device
         self.points = [_clone_inputs(points), _clone_inputs(points)]
@@ -244,14 +254,36 @@ class PipelinedStep:
             loss = self.criterion(self.net(self.points[p], geo=self.state[p]), self.label[p])
             loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
         if self.sharded:
-            self.grads.pack()
+            self.grads.pack(1 if len(self.grads.buckets) == 2 else None)
         elif self.optimizer is not None:
             self.optimizer.step()
         return loss
 
     def _reduce(self):
         if self.sharded and self.dist.is_initialized():
-            self.grads.all_reduce_mean(self.dist, self.group)
+            if len(self.grads.buckets) == 2:
+                self.grads.all_reduce_mean(self.dist, self.group, bucket=1)
+                if self._early_work is not None:
+                    self._early_work.wait()          # the current stream joins bucket 0's collective
+                    self._early_work = None
+            else:
+                self.grads.all_reduce_mean(self.dist, self.group)
+
+    def _arm_early_bucket(self, module, args):
+        """forward pre-hook of the first early-gradient module: its feature input's gradient marks the moment every gradient
+        of bucket 0 exists (autograd runs AccumulateGrad nodes ahead of everything else that is ready)."""
+        if not (torch.is_grad_enabled() and len(self.grads.buckets) == 2):
+            return
+        feats = [t for t in args if torch.is_tensor(t) and t.requires_grad]
+        if feats:
+            feats[-1].register_hook(self._early_bucket)
+
+    def _early_bucket(self, grad):
+        mlp_hip.flush_reduces()                      # weight-gradient sums still riding with a later launch (owned_pass)
+        self.grads.pack(0)
+        if self.dist.is_initialized():
+            self._early_work = self.grads.all_reduce_mean(self.dist, self.group, bucket=0, async_op=True)
+        return None
 
     def _collective_capturable(self):
         """RCCL (backend "nccl") collectives can be recorded into a hipGraph; gloo's run on the host and cannot."""
@@ -325,46 +357,63 @@ class FlatGrads:
     what the collective reduces and the optimizer reads.  Under graph capture the copy is part of the network graph and
     the slices' addresses are what the optimizer graph bakes in."""
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, early=None):
+        """early: parameters whose gradients are complete FIRST in backward (the layers closest to the loss): they lead the flat
+        buffer as bucket 0, the rest is bucket 1 -- reverse execution order, so bucket 0's collective can run under the rest of
+        the backward pass (PipelinedStep, REPSURF_GRAD_BUCKETS=2)."""
+        params = [p for p in params if p.requires_grad]
+        early_ids = {id(p) for p in (early or [])}
+        lead = [p for p in params if id(p) in early_ids]
+        self.params = lead + [p for p in params if id(p) not in early_ids]
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=self.params[0].dtype, device=self.params[0].device)
         self.views, off = [], 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        n0 = sum(p.numel() for p in lead)
+        self.split = len(lead)                                    # params [0, split) form bucket 0
+        self.buckets = [self.flat[:n0], self.flat[n0:]] if 0 < n0 < total else [self.flat]
 
     def clear(self):
         for p in self.params:
             p.grad = None
 
-    def pack(self):
+    def pack(self, bucket=None):
+        """bucket None: every parameter; 0 / 1: the parameters of that bucket only (bucket 0 mid-backward: a gradient that is
+        not there yet is an ordering bug of the caller, not a zero)."""
+        lo, hi = (0, len(self.params)) if bucket is None or len(self.buckets) == 1 else ((0, self.split) if bucket == 0 else (self.split, len(self.params)))
         src, dst = [], []
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             if p.grad is None:
+                if bucket == 0:
+                    raise RuntimeError("FlatGrads.pack(0): an early-bucket gradient has not been produced yet")
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
         if src:
             torch._foreach_copy_(dst, src)
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             p.grad = v
 
-    def all_reduce_mean(self, dist, group=None):
+    def all_reduce_mean(self, dist, group=None, bucket=None, async_op=False):
+        """Average the flat buffer (or one bucket of it) over the ranks; async_op=True returns the work handle (its wait()
+        orders the current stream after the collective)."""
         world = dist.get_world_size(group)
         # (REPSURF_FORCE_ALLREDUCE=1: issue the collective on a 1-rank group too -- what lets a single-GPU box exercise the
         #  captured-collective path end to end; a 1-rank all-reduce is the identity)
         if world <= 1 and os.environ.get("REPSURF_FORCE_ALLREDUCE", "0") == "0":
-            return
+            return None
+        buf = self.flat if bucket is None or len(self.buckets) == 1 else self.buckets[bucket]
         if dist.get_backend(group) == "nccl" and getattr(self, "_avg_ok", True):    # RCCL averages in the collective
             try:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
-                return
+                return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
             except (RuntimeError, ValueError):           # a build without ncclAvg refuses at call time: sum and scale
                 self._avg_ok = False
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.div_(world)
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=False)
+        buf.div_(world)
+        return None if not async_op else work
 
 
 def attach_flat_grads(params):

@@ -139,3 +139,56 @@ def test_flatgrads_pack_and_allreduce():
         (f0, l0, g0), (f1, l1, g1) = out[0], out[1]
     assert torch.allclose(f0, f1) and torch.allclose(f0, (l0 + l1) / 2, atol=1e-6)
     assert torch.equal(g0, f0)
+
+
+def _bucket_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from repsurf_amd import dist as rdist
+    from repsurf_amd.graph import FlatGrads
+    rdist.init(backend="gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    early = list(model[2].parameters())        # the layer closest to the loss: its gradients exist first
+    grads = FlatGrads(list(model.parameters()), early=early)
+    assert len(grads.buckets) == 2 and grads.buckets[0].numel() == 16 * 3 + 3 and grads.params[:2] == early
+    g = torch.Generator().manual_seed(rdist.rank_seed(5, rank))
+    x = torch.randn(32, 8, generator=g)
+    import copy
+    twin = copy.deepcopy(model)                # the rank's own gradient, computed the plain way, in the flat buffer's order
+    twin(x).pow(2).mean().backward()
+    plain = torch.cat([p.grad.flatten() for p in list(twin[2].parameters()) + list(twin[0].parameters())])
+    h = model[1](model[0](x))
+    seen = {}
+
+    def early_bucket(grad):                    # what PipelinedStep._early_bucket does, from a tensor hook mid-backward
+        assert model[0].weight.grad is None    # the rest of the backward has not run yet
+        grads.pack(0)
+        seen["work"] = grads.all_reduce_mean(dist, bucket=0, async_op=True)
+    h.register_hook(early_bucket)
+    grads.clear()
+    model[2](h).pow(2).mean().backward()
+    local = torch.cat([p.grad.flatten() for p in grads.params[:2]] + [p.grad.flatten() for p in grads.params[2:]])
+    local_early = local[:grads.buckets[0].numel()].clone()    # (bucket 0 is already averaged in place when the wait returns)
+    grads.pack(1)
+    grads.all_reduce_mean(dist, bucket=1)
+    if seen.get("work") is not None:
+        seen["work"].wait()
+    out[rank] = (grads.flat.clone(), torch.cat([p.grad.flatten() for p in grads.params]),
+                 torch.cat([p.grad.flatten() for p in model.parameters()]), plain)
+    rdist.finish()
+
+
+def test_flatgrads_two_buckets_in_reverse_execution_order():
+    """FlatGrads(early=...): bucket 0 packed and all-reduced from a tensor hook in the middle of backward (asynchronously),
+    bucket 1 after it, on 2 gloo ranks: both ranks end with the same averaged gradient in every parameter's view."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+        (f0, v0, m0, p0), (f1, v1, m1, p1) = out[0], out[1]
+    assert torch.allclose(f0, f1) and torch.equal(f0, v0) and torch.allclose(m0, m1)
+    assert torch.allclose(f0, (p0 + p1) / 2, atol=1e-6) and f0.abs().sum() > 0

@@ -158,8 +158,9 @@ def test_pipelined_sharded_step_single_rank_process_group():
         # round 3: the all-reduce (forced on this 1-rank group: REPSURF_FORCE_ALLREDUCE) and Adam are recorded INSIDE the network
         # graph -- "captured" -- against the round-2 form (network graph -> eager collective -> Adam graph) and the N = 1 step
         os.environ["REPSURF_FORCE_ALLREDUCE"] = "1"
-        for kind in ("single", "captured", "between"):
+        for kind in ("single", "captured", "between", "buckets"):
             os.environ["REPSURF_CAPTURE_ALLREDUCE"] = "0" if kind == "between" else "1"
+            os.environ["REPSURF_GRAD_BUCKETS"] = "2" if kind == "buckets" else "1"    # bucket 0 (sa3 + head) all-reduced from a backward hook
             m = Model(ref_args())
             name_seeded_init(m)
             disable_dropout(m)
@@ -170,13 +171,16 @@ def test_pipelined_sharded_step_single_rank_process_group():
             losses[kind] = [step().item() for _ in range(3)]
             if kind != "single":
                 assert step.flat.abs().sum() > 0
-                assert step.collective_captured == (kind == "captured"), kind
+                assert step.collective_captured == (kind != "between"), kind
+                assert len(step.grads.buckets) == (2 if kind == "buckets" else 1)
         assert np.allclose(losses["captured"], losses["single"], atol=2e-2), losses
+        assert np.allclose(losses["buckets"], losses["single"], atol=2e-2), losses
         assert np.allclose(losses["captured"], losses["between"], atol=2e-2), losses
         assert losses["captured"][2] < losses["captured"][0] + 0.5
     finally:
         os.environ.pop("REPSURF_FORCE_ALLREDUCE", None)
         os.environ.pop("REPSURF_CAPTURE_ALLREDUCE", None)
+        os.environ.pop("REPSURF_GRAD_BUCKETS", None)
         dist.destroy_process_group()
 
 
