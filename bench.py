@@ -223,12 +223,18 @@ def geometry_lines(device, points):
                         "algorithmic_bytes": nbytes}
         del xyz, centres
     fps = {}
+    # A pick is a dependent reduction inside ONE workgroup (one cloud = one CU): the launch time does not depend on the
+    # number of clouds until the chip is full.  The *_x3 entry is the sa1 chain of THREE batches of 32 clouds in one
+    # launch (96 of 256 CUs) with its cost amortised per batch of 32 -- what a loader that is three batches ahead pays;
+    # the step itself hides the chain of ONE batch under the previous batch's network (config.launch).
     for name, (b, nn, m) in {"sa1_1024_to_512": (32, points, 512), "sa2_512_to_128": (32, 512, 128),
-                             "sample_2048_to_1024": (32, 2048, 1024)}.items():
+                             "sample_2048_to_1024": (32, 2048, 1024), "sa1_1024_to_512_x3": (96, points, 512)}.items():
         xyz = (torch.rand(b, nn, 3, generator=g) * 2 - 1).to(device)
         start = torch.zeros(b, dtype=torch.int32, device=device)
         t = timed(lambda: ops.furthestsampling(xyz, m, start))
         fps[name] = {"us": round(t * 1e6, 1), "us_per_pick": round(t * 1e6 / (m - 1), 4), "clouds": b}
+        if b > 32:
+            fps[name]["us_per_pick_per_batch_of_32"] = round(t * 1e6 / (m - 1) / (b / 32), 4)
     return ({"kernel": "rs_ballquery", "shape": f"N={n} S={s_} nsample={ns} r={r}", "bound": "hbm", "unit": "GB/s",
              "peak": PEAK_HBM_GBS, "clouds_per_launch": ball}, fps)
 

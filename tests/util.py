@@ -216,13 +216,15 @@ def three_way(got, ref32, ref64, rel_l2=False):
     return np.abs(got - ref64).max(), np.abs(ref32 - ref64).max(), np.abs(ref64).max()
 
 
-def gradient_noise_check(table, per_tensor=3.0, median=2.0, floor=1e-4):
+def gradient_noise_check(table, per_tensor=4.0, median=2.0, floor=1e-4):
     """table: {parameter: (relative-L2 error of the HIP gradient, of the fp32 reference gradient)}, both against the float64
     evaluation of the same network.  Activations are continuous in the rounding noise and are held to 1.5 x the reference's
     error elsewhere; GRADIENTS are not: a ReLU input or a max-pool runner-up within ~1e-6 of the decision flips between two
     valid fp32 evaluations and re-routes a whole row, so a tensor's error is a handful of such quanta and varies by 2-4 x
     between two correct fp32 runs (profiles/r03/seg_fp32_spread.txt: the SAME CPU oracle on two hosts: median 0.0044 / 0.0078,
-    max 0.012 / 0.018; with torch's fp32 BatchNorm kernel 0.020 / 0.10).  The statement is therefore: every tensor within
+    max 0.012 / 0.018; with torch's fp32 BatchNorm kernel 0.020 / 0.10; single tensors move by 3x between the two hosts --
+    surface_constructor.mlps.1.weight at configs[3]: oracle 0.0060 on the GPU host, 0.0184 on the build host, HIP 0.0194).
+    The statement is therefore: every tensor within
     `per_tensor` x the larger of its own reference error and the network's typical (median) reference error, and the median
     over tensors within `median` x the reference's median.  -> list of offending (name, hip, ref)."""
     ref_med = float(np.median([v[1] for v in table.values()]))
