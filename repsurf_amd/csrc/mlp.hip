@@ -282,8 +282,23 @@ __device__ __forceinline__ void frag_store(float *stage, int plane, int k0, int 
 // of its row to MFMA step s, so a 32-deep chunk is FOUR planes p = k >> 3 of [row][4 dwords = 8 bf16]: one
 // ds_read_b128 per operand per step, two steps per chunk (16 fp32 steps otherwise); plane pad 16 dwords keeps the
 // 8-byte commit stores of a half-wave (4 rows x 4 planes x 2 halves) on distinct banks.
-template <int BM, int BN, int V, int MODE, bool BF>
-__global__ void __launch_bounds__(GM_THREADS, 2)     // >= 2 workgroups per CU: one computes while another stages
+//
+// WS = true (round 3, 64-row tiles; an EXPERIMENT kept behind RS_GEMM_WS=1, off by default): WAVE SPECIALISATION.  The workgroup has 8 waves: waves 0-3 only read fragments and issue
+// MFMAs (and write the tile out), waves 4-7 only move data -- global loads two chunks ahead (two register sets), the operand
+// prologue, the LDS commit.  One barrier per chunk joins them: the loaders arrive when chunk g is in LDS, the MFMA waves when they
+// are done with chunk g - 1, so commit(g) runs under the MFMAs of g - 1 and the matrix pipe never waits for a global load or a
+// prologue of its own wave.  (Without it a wave alternates between the two roles; two workgroups per CU were meant to cover each
+// other's staging phases, but workgroups launched together run their phases in lockstep -- the loop issued MFMAs 27-40 % of a
+// tile's cycles)  The stage a chunk uses is the parity of a RUNNING chunk count across tiles, so the loaders start
+// the next tile while the MFMA waves are still in the epilogue of this one.
+// What the per-role cycle stamps showed (tools/gemm_bench.py timing, profiles/r03/gemm_ws_timing.txt): the loaders are the
+// bottleneck -- issuing one chunk's ~50 address / load instructions takes 3 600 cycles beside running MFMAs and 800 with the
+// MFMAs compiled out, whatever the loaders' priority (s_setprio 3) or age (waves 0-3 or 4-7).  v_mfma_f32_32x32x2_f32 holds its
+// SIMD's issue for 64 cycles (MI355X_MICROARCH.md) and leaves about one slot per MFMA to everything else on that SIMD, so
+// on fp32 MFMAs "a wave that only loads" does not run BESIDE the matrix stream, it runs in its gaps: the kernel's
+// efficiency is 64 / (64 + issue cycles of the non-MFMA instructions per MFMA) whichever wave executes them.
+template <int BM, int BN, int V, int MODE, bool BF, bool WS = false>
+__global__ void __launch_bounds__(WS ? 2 * GM_THREADS : GM_THREADS, WS ? 4 : 2)     // >= 2 workgroups per CU: one computes while another stages
 gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim, int cols, RowOperand E,
                  const float *__restrict__ w, int ldw, Epilogue ep) {
   // compacted inputs carry their row count on the device (no host sync); rows_arg is then the capacity
@@ -317,13 +332,22 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *As0 = smem, *As1 = smem + AStage<BM>::SIZE;
   float *Ws0 = smem + 2 * AStage<BM>::SIZE, *Ws1 = Ws0 + WStage<BN>::SIZE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(!WS || BM == 64, "wave specialisation is built for the 64-row tiles (direct epilogue)");
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+#ifdef RS_EXP_WS_LOADERS_LAST
+  const bool loader = WS && tid >= GM_THREADS;              // waves 4-7 of a specialised workgroup
+#else
+  // the loaders are waves 0-3: VALU / VMEM issue on a SIMD is arbitrated by priority, then AGE (MI355X_MICROARCH.md), and the
+  // few instructions that keep the matrix pipe fed must not queue behind the MFMA waves' fragment reads
+  const bool loader = WS && tid < GM_THREADS;
+#endif
+  const int ltid = tid & (GM_THREADS - 1);                  // position among the 256 threads of a role
   const int n0 = blockIdx.y * BN;
   const long long tiles = (rows + BM - 1) / BM;
   const int lrow = lane & 31, lk = lane >> 5;
   const int wave_r = wave % WR, wave_c = wave / WR;
-  const int a_kq = (tid % A_TPR) * V, a_r = tid / A_TPR;
-  const int w_kq = (tid & 7) * 4, w_n = tid >> 3;           // weights: 8 threads x float4 cover the 32 k of a column
+  const int a_kq = (ltid % A_TPR) * V, a_r = ltid / A_TPR;
+  const int w_kq = (ltid & 7) * 4, w_n = ltid >> 3;         // weights: 8 threads x float4 cover the 32 k of a column
   const int nchunks = (kdim + GM_BK - 1) / GM_BK;
 
   // epilogue geometry: the finished tile goes through LDS so that global traffic is row-major float4
@@ -333,38 +357,43 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   const bool ep_vec = (((uintptr_t)ep.out | (uintptr_t)ep.my1 | (uintptr_t)ep.my2) % 16 == 0) && (ep.ldo % 4 == 0) &&
                       (ep.ldm1 % 4 == 0) && (ep.ldm2 % 4 == 0) && (cols % 4 == 0);
 
-  RawVec<V> araw[A_VECS];
-  float4 wraw[W_VECS];
-  ColCoef<V> coef;
+  constexpr int NSET = WS ? 2 : 1;                          // WS: the loaders keep two chunks of raw operands in flight
+  RawVec<V> araw[NSET][A_VECS];
+  float4 wraw[NSET][W_VECS];
+  ColCoef<V> coef[NSET];
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, NSET - 1>;
 
   // Loads are never predicated: out-of-range rows / k are CLAMPED to the last valid element (always in bounds,
   // finite) and zeroed when the values are committed to LDS -- straight-line code, no exec-mask branches.
   // `part` < 0 issues the whole chunk.  (Spreading the parts 0..3 over the four MFMA groups of the running chunk was
   // measured and is worse: a load that cannot issue stalls the wave in front of its next MFMA -- in-order issue --
   // 126 us against 116 us at 262144 x 128 x 128, weight gradient 410 us against 320 us.)
-  auto prefetch = [&](long long r0, int k0, int part) {
+  auto prefetch = [&](auto set_, long long r0, int k0, int part) {
+    constexpr int S = decltype(set_)::value;
     const int k = min(k0 + a_kq, kdim - V);                 // kdim % V == 0
     const int rlast = (int)min((long long)BM - 1, rows - 1 - r0);
-    if (part <= 0) op_coef<V, MODE>(E, k, true, coef);
+    if (part <= 0) op_coef<V, MODE>(E, k, true, coef[S]);
 #pragma unroll
     for (int p = 0; p < A_VECS; ++p)
-      if (part < 0 || (p * 4) / A_VECS == part) op_load<V, MODE>(E, r0, min(p * A_RPP + a_r, rlast), k, true, araw[p]);
+      if (part < 0 || (p * 4) / A_VECS == part) op_load<V, MODE>(E, r0, min(p * A_RPP + a_r, rlast), k, true, araw[S][p]);
     const int kw = min(k0 + w_kq, ldw - 4);
 #pragma unroll
     for (int p = 0; p < W_VECS; ++p)
       if (part < 0 || (p * 4) / W_VECS == part) {
         const int n = min(n0 + p * 32 + w_n, cols - 1);
-        wraw[p] = *reinterpret_cast<const float4 *>(w + (long long)n * ldw + kw);
+        wraw[S][p] = *reinterpret_cast<const float4 *>(w + (long long)n * ldw + kw);
       }
   };
-  auto commit = [&](float *As, float *Ws, long long r0, int k0) {
+  auto commit = [&](auto set_, float *As, float *Ws, long long r0, int k0) {
+    constexpr int S = decltype(set_)::value;
     const bool kok = (k0 + a_kq) < kdim;
 #pragma unroll
     for (int p = 0; p < A_VECS; ++p) {
       const int rl = p * A_RPP + a_r;
       const long long r = r0 + rl;
       float v[V];
-      op_finish<V, MODE>(E, coef, araw[p], r, kok && r < rows, v);
+      op_finish<V, MODE>(E, coef[S], araw[S][p], r, kok && r < rows, v);
       if constexpr (BF) {                                     // k = a_kq .. a_kq + V - 1 -> plane k >> 3, dword (k & 7) >> 1
         float *b = As + (a_kq >> 3) * PLANE_A + rl * 4 + ((a_kq & 7) >> 1);
         if constexpr (V == 4) *reinterpret_cast<float2 *>(b) = make_float2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
@@ -378,7 +407,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
     for (int p = 0; p < W_VECS; ++p) {
       const int nl = p * 32 + w_n;
       const bool ok = wk_ok && (n0 + nl < cols);
-      const float v[4] = {ok ? wraw[p].x : 0.f, ok ? wraw[p].y : 0.f, ok ? wraw[p].z : 0.f, ok ? wraw[p].w : 0.f};
+      const float v[4] = {ok ? wraw[S][p].x : 0.f, ok ? wraw[S][p].y : 0.f, ok ? wraw[S][p].z : 0.f, ok ? wraw[S][p].w : 0.f};
       if constexpr (BF)
         *reinterpret_cast<float2 *>(Ws + (w_kq >> 3) * PLANE_W + nl * 4 + ((w_kq & 7) >> 1)) =
             make_float2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
@@ -395,26 +424,9 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   float st0[CT], st1[CT], st2[CT];                          // DIRECT: this lane's column sums over all its tiles
 #pragma unroll
   for (int c = 0; c < CT; ++c) { st0[c] = 0.f; st1[c] = 0.f; st2[c] = 0.f; }
-  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const long long r0 = tile * BM;
-    f32x16 acc[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
-    // DIRECT: the first chunk of this tile was requested in front of the previous tile's epilogue (below)
-    if (!EARLY_PREFETCH || tile == (long long)blockIdx.x) prefetch(r0, 0, -1);
-    RS_T(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-      float *As = (ch & 1) ? As1 : As0;
-      float *Ws = (ch & 1) ? Ws1 : Ws0;
-      commit(As, Ws, r0, ch * GM_BK);
-      RS_T(1);
-      __syncthreads();                                        // tile chunk visible; stage ch-1 free again
-      RS_T(2);
-      if (ch + 1 < nchunks) prefetch(r0, (ch + 1) * GM_BK, -1);   // loads fly under the MFMAs below
-      RS_T(3);
+  // MFMAs of one 32-deep chunk staged at (As, Ws) into acc[]
+  auto mma = [&](f32x16 (&acc)[CT], const float *As, const float *Ws, int ch) {
       if constexpr (BF) {
         // both steps' fragments first (2 + 2 CT ds_read_b128), then 2 x CT MFMAs; k beyond kdim was committed as zero
         const float *ap = As + lk * PLANE_A + (wave_r * 32 + lrow) * 4;
@@ -463,7 +475,82 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         }
       }
       }
+  };
+
+  long long gchunk = 0;                                     // WS: chunks this workgroup has consumed so far (stage parity)
+  const long long ws_total = ((long long)blockIdx.x < tiles ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0) * nchunks;   // chunks of this workgroup
+  if (WS && loader) {
+    // ---- loader waves: (tile, chunk) pairs in the order the MFMA waves consume them, raw operands two chunks ahead.
+    // Every prefetch is UNCONDITIONAL (past the last chunk it re-reads the last tile: wasted, harmless): with a prefetch
+    // under `if (more work)` the compiler's s_waitcnt pass merges the two paths and makes commit(set 0) wait for the loads
+    // of set 1 as well (seen in the ISA: vmcnt(5..0) where vmcnt(13..8) was meant) -- the two-chunk distance collapsed to one.
+    // The loaders run at raised priority: they issue ~50 instructions per chunk against ~100 of an MFMA wave, and an
+    // arbiter that serves the MFMA waves first lets each of those instructions wait for a gap in the matrix stream.
+    // The loop body is branch-free: two chunks per trip (set 0 -> stage 0, set 1 -> stage 1), an odd total is padded with
+    // one dummy chunk (its barrier is matched by the MFMA waves below) -- a `break` between the halves rejoined the latch
+    // in the structurised CFG and had the same effect on the wait counts as the conditional prefetch.
+    __builtin_amdgcn_s_setprio(3);
+    auto adv = [&](long long &t, int &c) { if (++c == nchunks) { c = 0; t += gridDim.x; } };
+    auto rbase = [&](long long t) { return (t < tiles ? t : tiles - 1) * BM; };
+    long long t0 = blockIdx.x, t1 = blockIdx.x;               // the chunk set 0 / set 1 holds (or is loading)
+    int c0 = 0, c1 = 0;
+    adv(t1, c1);
+    const long long pairs = (ws_total + 1) >> 1;
+    if (pairs > 0) {
+      prefetch(S0{}, rbase(t0), c0 * GM_BK, -1);
+      prefetch(S1{}, rbase(t1), c1 * GM_BK, -1);
+    }
+    for (long long pr = 0; pr < pairs; ++pr) {
+      commit(S0{}, As0, Ws0, rbase(t0), c0 * GM_BK);
+      RS_T(1);
+      __syncthreads();
+      RS_T(2);
+      adv(t0, c0); adv(t0, c0);
+      prefetch(S0{}, rbase(t0), c0 * GM_BK, -1);
+      RS_T(3);
+      commit(S1{}, As1, Ws1, rbase(t1), c1 * GM_BK);
+      RS_T(1);
+      __syncthreads();
+      RS_T(2);
+      adv(t1, c1); adv(t1, c1);
+      prefetch(S1{}, rbase(t1), c1 * GM_BK, -1);
+      RS_T(3);
+    }
+  } else
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long long r0 = tile * BM;
+    f32x16 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+    if constexpr (WS) {
+      for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();                                        // chunk gchunk is in LDS (the loaders passed the same barrier)
+        RS_T(2);
+#ifndef RS_EXP_WS_NOMFMA
+        mma(acc, (gchunk & 1) ? As1 : As0, (gchunk & 1) ? Ws1 : Ws0, ch);
+#endif
+        RS_T(4);
+        ++gchunk;
+      }
+    } else {
+    // DIRECT: the first chunk of this tile was requested in front of the previous tile's epilogue (below)
+    if (!EARLY_PREFETCH || tile == (long long)blockIdx.x) prefetch(S0{}, r0, 0, -1);
+    RS_T(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      float *As = (ch & 1) ? As1 : As0;
+      float *Ws = (ch & 1) ? Ws1 : Ws0;
+      commit(S0{}, As, Ws, r0, ch * GM_BK);
+      RS_T(1);
+      __syncthreads();                                        // tile chunk visible; stage ch-1 free again
+      RS_T(2);
+      if (ch + 1 < nchunks) prefetch(S0{}, r0, (ch + 1) * GM_BK, -1);   // loads fly under the MFMAs below
+      RS_T(3);
+      mma(acc, As, Ws, ch);
       RS_T(4);
+    }
     }
     if constexpr (DIRECT) {
       // ---- epilogue straight from the accumulators (64-row tiles).  D[i][j]: j = lane & 31 is the output column,
@@ -475,7 +562,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       RS_T(5);
       // the next tile's first operand chunk travels while this tile's results leave: the epilogue needs no LDS and few
       // registers, and the loads have the whole write-out to land (they used to be issued behind it and waited for in full)
-      if (EARLY_PREFETCH && tile + gridDim.x < tiles) prefetch((tile + gridDim.x) * BM, 0, -1);
+      if (EARLY_PREFETCH && tile + gridDim.x < tiles) prefetch(S0{}, (tile + gridDim.x) * BM, 0, -1);
       const int EPI = ep.mode;
       int rbase = wave_r * 32 + 4 * lk;
       asm volatile("" : "+v"(rbase));                         // opaque per tile: the 16 x 3 row offsets below are recomputed here,
@@ -589,7 +676,8 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         }
         st0[c] += t0; st1[c] += t1; st2[c] += t2;
       }
-      __syncthreads();   // every wave is past its fragment reads: the next tile may overwrite the staging buffers
+      if (!WS) __syncthreads();   // every wave is past its fragment reads: the next tile may overwrite the staging buffers
+                                  // (WS: the stage parity runs across tiles and the chunk barrier orders the overwrite)
     } else {
       __syncthreads();   // all fragment reads of this tile done: the staging buffers become the C tile
       RS_T(5);
@@ -727,9 +815,10 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
     }
     RS_T(6);
   }
+  if (WS && !loader && (ws_total & 1)) __syncthreads();     // the loaders' padding chunk (two chunks per trip)
 #ifdef RS_EXP_TIMING
-  if (tid == 0 && ep.pool_amax) {
-    long long *o = reinterpret_cast<long long *>(ep.pool_amax) + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 10;
+  if ((tid == 0 || (WS && tid == GM_THREADS)) && ep.pool_amax) {      // WS: the first loader wave reports 4096 rows further down
+    long long *o = reinterpret_cast<long long *>(ep.pool_amax) + ((long long)blockIdx.y * gridDim.x + blockIdx.x + (loader ? 4096 : 0)) * 10;
     for (int i = 0; i < 7; ++i) o[i] = tacc[i];
     o[7] = clock64() - tstart;
     o[8] = 0;
@@ -743,12 +832,14 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       double *red = reinterpret_cast<double *>(smem);         // [stat][4][BN] doubles <= 12 KB (staging is idle: barrier below)
       const int nstat = (ep.mode == EPI_MASK && ep.my2) ? 3 : 2;
       __syncthreads();
+      if (!loader) {
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        const int cl = (wave_c * CT + c) * 32 + lrow, slot = wave_r * 2 + lk;
-        red[(0 * 4 + slot) * BN + cl] = (double)st0[c];
-        red[(1 * 4 + slot) * BN + cl] = (double)st1[c];
-        if (nstat == 3) red[(2 * 4 + slot) * BN + cl] = (double)st2[c];
+        for (int c = 0; c < CT; ++c) {
+          const int cl = (wave_c * CT + c) * 32 + lrow, slot = wave_r * 2 + lk;
+          red[(0 * 4 + slot) * BN + cl] = (double)st0[c];
+          red[(1 * 4 + slot) * BN + cl] = (double)st1[c];
+          if (nstat == 3) red[(2 * 4 + slot) * BN + cl] = (double)st2[c];
+        }
       }
       __syncthreads();
       if (tid < BN && n0 + tid < cols)
@@ -1589,6 +1680,23 @@ template <int BM, int BN, int V, bool BF>
 void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                    const float *w, int ldw, const Epilogue &ep) {
   const size_t lds = sizeof(float) * (2 * AStage<BM>::SIZE + 2 * WStage<BN>::SIZE);
+  // wave-specialised instances (8 waves: 4 MFMA + 4 loader, see the kernel): fp32, 64-row tiles, vector operands
+  static const int ws_on = env_int("RS_GEMM_WS", 0);       // measured slower on the fused backward instances and equal on the forward ones: DESIGN.md 5
+  if constexpr (BM == 64 && !BF && V >= 2) {
+    if (ws_on) {
+#define RS_GW(M_) hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, V, M_, BF, true>), grid, dim3(2 * GM_THREADS), lds, st, rows, rows_dev, kdim, cols, E, w, ldw, ep)
+      switch (E.mode) {
+        case OPM_ID: RS_GW(OPM_ID); break;
+        case OPM_RELU1: RS_GW(OPM_RELU1); break;
+        case OPM_RELU2: RS_GW(OPM_RELU2); break;
+        case OPM_AFF2: RS_GW(OPM_AFF2); break;
+        case OPM_POOLED: RS_GW(OPM_POOLED); break;
+        default: RS_GW(OPM_BCAST); break;
+      }
+#undef RS_GW
+      return;
+    }
+  }
 #define RS_G(M_) hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, V, M_, BF>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, kdim, cols, E, w, ldw, ep)
   if (V == 1) { RS_G(-1); return; }                 // odd sizes: one generic (runtime-mode) kernel
   switch (E.mode) {

@@ -7,7 +7,8 @@ cd "$(dirname "$0")/.."
 mkdir -p build_exp
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -munsafe-fp-atomics -Wno-unused-function"
 for v in "$@"; do
-  ( /opt/rocm/bin/hipcc $FL -DRS_EXP_$v -DRS_MLP_TU=2 -x hip -c repsurf_amd/csrc/mlp.hip -o build_exp/mlp_$v.o &&
+  defs=""; for d in ${v//+/ }; do defs="$defs -DRS_EXP_$d"; done      # NAME1+NAME2: several RS_EXP_ switches in one variant
+  ( /opt/rocm/bin/hipcc $FL $defs -DRS_MLP_TU=2 -x hip -c repsurf_amd/csrc/mlp.hip -o build_exp/mlp_$v.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_exp/librepsurf_$v.so $(ls build/*.o | grep -v "^build/mlp") build_exp/mlp_$v.o ) &
 done
 wait

@@ -124,7 +124,7 @@ if __name__ == "__main__":
         x = torch.randn(rows, k, device=dev); w = torch.randn(n, k, device=dev) / k ** 0.5
         out = torch.empty(rows, n, device=dev); s_ = torch.rand(k, device=dev) + 0.5; t_ = torch.randn(k, device=dev) * 0.1
         part = torch.empty((H.PARTIAL_BLOCKS, 3, n), dtype=torch.float64, device=dev)
-        dbg = torch.zeros((4096, 10), dtype=torch.int64, device=dev)
+        dbg = torch.zeros((8192, 10), dtype=torch.int64, device=dev)
         rd = torch.tensor([int(rows * frac)], dtype=torch.int32, device=dev) if frac else None
         op = H.operand(H.OP_RELU1, x, k, s1=s_, t1=t_)
         ep = H.Epilogue(bias=None, out=H._ptr(out), ldo=n, mode=H.EPI_STATS, partial=part.data_ptr(), partial_blocks=H.PARTIAL_BLOCKS)
@@ -133,12 +133,15 @@ if __name__ == "__main__":
             H.gemm_rows(rows, k, n, op, H.w_fwd(w), ep, rd.data_ptr() if frac else None)
         torch.cuda.synchronize()
         d = dbg.cpu().numpy()
-        act = d[d[:, 7] > 0]
         names = ["first prefetch issue", "commit (wait loads + transform + LDS writes)", "barrier", "next prefetch issue",
                  "fragment reads + MFMA issue", "barrier before epilogue", "epilogue (C tile, stats, stores)", "TOTAL"]
-        print(f"rows={rows} k={k} n={n} frac={frac}: {len(act)} workgroups reported, tiles={act[0, 9]}")
-        for i, nm in enumerate(names):
-            print(f"  {nm:48s} {act[:, i].mean():10.0f} cycles  ({100 * act[:, i].mean() / act[:, 7].mean():5.1f}%)")
+        for tag, blk in (("wave 0 (MFMA wave of a specialised workgroup)", d[:4096]), ("first LOADER wave (wave-specialised instances only)", d[4096:])):
+            act = blk[blk[:, 7] > 0]
+            if len(act) == 0:
+                continue
+            print(f"{tag}: rows={rows} k={k} n={n} frac={frac}: {len(act)} workgroups reported, tiles={act[0, 9]}")
+            for i, nm in enumerate(names):
+                print(f"  {nm:48s} {act[:, i].mean():10.0f} cycles  ({100 * act[:, i].mean() / act[:, 7].mean():5.1f}%)")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "one":        # one shape, for PMC runs: one <rows> <k> <n> [frac]
         rows, k, n = (int(v) for v in sys.argv[2:5])
