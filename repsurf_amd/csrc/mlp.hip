@@ -188,14 +188,26 @@ __device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int r
     case OPM_POOLED: {
       unsigned g;
       if (o.grp) { g = (unsigned)o.grp[r0 + rl]; raw.k = o.slot[r0 + rl]; }           // compacted (ragged) groups
-      else { g = (unsigned)(r0 + rl) / (unsigned)o.ns; raw.k = (int)((unsigned)(r0 + rl) - g * (unsigned)o.ns); }
+      else {
+        // dense groups: row / nsample.  nsample is a power of two in every shipped stack but the 2x classifier's (24): a
+        // shift instead of the ~20-instruction 32-bit division sequence, per operand vector and chunk -- on fp32 MFMAs every
+        // VALU instruction of the staging code comes straight out of the matrix pipe's issue slots
+        const unsigned ns = (unsigned)o.ns, r = (unsigned)(r0 + rl);
+        g = (ns & (ns - 1)) == 0 ? r >> (31 - __clz((int)ns)) : r / ns;
+        raw.k = (int)(r - g * ns);
+      }
       ldx<V>(o.a, (long long)g * o.lda + c, sb_a(OPM_POOLED), raw.a);
       ldvi<V>(o.arg + (long long)g * o.lda + c, raw.g);
       ldx<V>(o.b, r0 * o.ldb + offb, sb_b(OPM_POOLED), raw.b);
       if (o.mult) raw.m = o.mult[r0 + rl];
       break;
     }
-    default: ldx<V>(o.a, (long long)((unsigned)(r0 + rl) / (unsigned)o.ns) * o.lda + c, sb_a(OPM_BCAST), raw.a); break;
+    default: {
+      const unsigned ns = (unsigned)o.ns, r = (unsigned)(r0 + rl);
+      const unsigned g = (ns & (ns - 1)) == 0 ? r >> (31 - __clz((int)ns)) : r / ns;
+      ldx<V>(o.a, (long long)g * o.lda + c, sb_a(OPM_BCAST), raw.a);
+      break;
+    }
   }
 }
 

@@ -101,3 +101,34 @@ def test_pipelined_step_identifies_offsets_by_position_and_refuses_other_boundar
     with pytest.raises(TypeError):
         graph._clone_inputs([coord, off, coord])
     graph._check_offsets(coord, coord)            # plain tensor inputs: nothing to check
+
+
+def test_bench_real_batch_and_step_count():
+    """bench.py helpers (CPU side): `--data real` tiles the 4 scanned objects of tests/golden/geom_real.npz to the batch -- every copy
+    a rotated, jittered version of its source (no two clouds equal), deterministic in the seed -- and the timed region replays
+    max(--steps, ceil(min-seconds / step)) steps."""
+    import argparse
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    pts, lab = bench.real_batch(7, 8, 1024, torch.device("cpu"))
+    pts2, _ = bench.real_batch(7, 8, 1024, torch.device("cpu"))
+    assert pts.shape == (8, 3, 1024) and lab.shape == (8,) and torch.equal(pts, pts2)
+    flat = pts.reshape(8, -1)
+    assert all(not torch.equal(flat[i], flat[j]) for i in range(8) for j in range(i))
+    src = np.load(os.path.join(root, "tests", "golden", "geom_real.npz"))["xyz"]
+    # a rotation about the y axis + 0.002 jitter: the heights (y) of copy 5 are those of scan 5 % 4 = 1 up to the jitter
+    assert np.abs(pts[5, 1].numpy() - src[1, :, 1]).max() < 0.02
+
+    class Dist:
+        @staticmethod
+        def max_over_ranks(v, device=None):
+            return v
+    calls = []
+    args = argparse.Namespace(steps=20, min_seconds=0.5)
+    n = bench.timed_step_count(args, lambda: calls.append(1), lambda: None, 1, None, Dist)
+    assert n >= 20 and len(calls) == 10            # a fast step: thousands of replays to fill 0.5 s, probed with 10
+    args = argparse.Namespace(steps=20, min_seconds=0.0)
+    assert bench.timed_step_count(args, lambda: None, lambda: None, 1, None, Dist) == 20
