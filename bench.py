@@ -10,13 +10,16 @@ zero_grad -> Model.forward (umbrella constructor, 3 SurfaceAbstractionCD stages,
 SmoothClsLoss -> backward (+ the RCCL gradient all-reduce when N > 1) -> optimizer step
 (BASELINE.md's definition stops at backward; the Adam step is kept inside the timed region so no
 part of a training step is skipped — `--no-optim` reproduces the BASELINE.md definition exactly).
-Batches shard across ranks (one process per GPU, weak scaling: B=32 per rank), gradients are
-averaged by DistributedDataParallel over RCCL/xGMI in one bucket.
+Batches shard across ranks (one process per GPU, weak scaling: B=32 per rank); the gradients are averaged by ONE
+RCCL all-reduce of a flat 5.9 MB buffer over xGMI, recorded inside the step's hipGraph (repsurf_amd.graph.PipelinedStep;
+eager launches: DistributedDataParallel with a single bucket).
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
   "roofline":     the dominant instrumented HIP kernel, timed live with HIP events on the launch stream,
-  "cpu_baseline": the CPU oracle (oracle/torch_ref.py + oracle/geom_oracle.c) on the same workload,
-                  timed on this host (rank 0, N=1 only).
+  "cpu_baseline": the REFERENCE's own CPU path (its unmodified model + modules files, cuda_ops=False; oracle/ref_cls_cpu.py in
+                  a process of its own) timed on this host on the same workload, rank 0, N=1 only -- kind "reference"; the
+                  oracle port (oracle/torch_ref.py + oracle/geom_oracle.c) rides along as cpu_baseline.port, and is the
+                  baseline itself (kind "port") where the reference files are not staged.
 """
 import argparse
 import json
