@@ -1186,6 +1186,142 @@ gemm_small_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim
   }
 }
 
+// ---- narrow row GEMM on the matrix pipe, no LDS (round 3): kdim <= 16, plain operand with 16-byte aligned rows ----------------
+// The first-layer branches of every stack (3 / 6 / 10 input channels -> 32 ... 128 columns) move one wide tensor OUT and almost
+// nothing in: 24.6 MB at 48 k x 128 is 3 us of HBM time.  Through the tiled kernel they took 13-23 us -- 1.5 tiles per workgroup,
+// each a chain of exposed round trips (operand prefetch -> LDS commit -> barrier -> 8 MFMAs -> row-multiplicity loads -> a
+// chip-wide store burst) that 2 workgroups per CU cannot overlap.  Here a WAVE owns 32 rows at a time: ONE 16-byte load per lane is
+// the whole operand of the block (lane (r, h) reads x[r][4 h .. 4 h + 3] (+ 8 .. 11 for kdim > 8): v_mfma_f32_32x32x2_f32 is free in
+// the order of the k's as long as both operands agree, so half-wave h feeds k = 4 h + i to step i), the weights of the wave's
+// column tiles live in registers for the whole launch, the next block's operand is requested before this block's MFMAs, and the
+// 32 x cols block leaves straight from the accumulators (128-byte row segments) with the BatchNorm sums lane-local in fp32 across
+// all blocks of the wave -- no LDS, no barrier until the one fixed-order reduction at the end.  4 waves per SIMD (<= 128 VGPRs).
+template <int CT, int KL>      // CT column tiles of 32 (cols <= 32 CT), KL float4 per lane and row (kdim <= 8 KL)
+__global__ void __launch_bounds__(GM_THREADS, CT > 2 ? 3 : 4)     // 128 columns: ~170 VGPRs (3 waves per SIMD), else <= 128 (4)
+gemm_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim, int cols, RowOperand E,
+                   const float *__restrict__ w, int ldw, Epilogue ep) {
+  const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
+  __shared__ double red[2][GM_THREADS / 32][CT * 32];          // [stat][wave x lane half][column]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, h = lane >> 5;
+  // weights + bias of this lane's columns (w is n-major, zero in [kdim, ldw), ldw >= 8 KL: checked by the launcher)
+  float4 wq[CT][KL];
+  float bias[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const int col = c * 32 + lrow;
+    const bool cok = col < cols;
+    bias[c] = (ep.bias && cok) ? ep.bias[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < KL; ++j)      // ldw % 4 == 0: a lane's four k are inside the row or all beyond it
+      wq[c][j] = (cok && 8 * j + 4 * h + 4 <= ldw) ? *reinterpret_cast<const float4 *>(w + (long long)col * ldw + 8 * j + 4 * h)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const bool stats = ep.mode == EPI_STATS;
+  float st0[CT], st1[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) { st0[c] = 0.f; st1[c] = 0.f; }
+  const long long nblk = (rows + 31) >> 5, bstep = (long long)gridDim.x * (GM_THREADS / 64);
+  auto load_a = [&](long long blk, float4 (&a)[KL]) {
+    const long long r = min(blk * 32 + lrow, rows - 1);              // clamped: always in bounds, the row is discarded below
+    const float *src = E.a + r * E.lda + 4 * h;
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+      const int k0 = 8 * j + 4 * h;      // channels [kdim, ...) of the row belong to other tensors / padding: never multiplied
+      float4 v = (k0 + 4 <= (int)E.lda) ? *reinterpret_cast<const float4 *>(src + 8 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v.x = k0 + 0 < kdim ? v.x : 0.f; v.y = k0 + 1 < kdim ? v.y : 0.f; v.z = k0 + 2 < kdim ? v.z : 0.f; v.w = k0 + 3 < kdim ? v.w : 0.f;
+      a[j] = v;
+    }
+  };
+  long long blk = (long long)blockIdx.x * (GM_THREADS / 64) + wave;
+  float4 a[KL], an[KL];
+  if (blk < nblk) load_a(blk, a);
+  for (; blk < nblk; blk += bstep) {
+    if (blk + bstep < nblk) load_a(blk + bstep, an);
+    const long long r0 = blk * 32;
+    // D[i][j]: column j = lane & 31, row (reg & 3) + 8 (reg >> 2) + 4 h
+    const bool full = r0 + 32 <= rows;
+    int rbase = 4 * h;
+    asm volatile("" : "+v"(rbase));                             // opaque per block: the 16 row offsets are recomputed here, not hoisted
+                                                                // out of the block loop into ~100 long-lived VGPRs (as in the tiled kernel)
+    const float *mw_t = ep.row_mult ? ep.row_mult + r0 : nullptr;
+    float mw[16];
+    if (stats) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rl = rbase + (i & 3) + 8 * (i >> 2);
+        mw[i] = (mw_t && (full || r0 + rl < rows)) ? mw_t[rl] : 1.f;
+      }
+    }
+    float *out_t = ep.out + r0 * ep.ldo;
+    const int ldo = (int)ep.ldo;
+    // column tiles two at a time (32 accumulator registers live): with all four the 128-column instances spilled at 128 VGPRs.
+    // (Tried: a 4 x 4 transpose inside the quads by DPP and 16-byte stores, 4 per column tile instead of 16 dword stores --
+    //  48 234 x 6 -> 128: 18.7 against 12.1 us; the rows are 128-byte segments either way and the shuffles cost more than the stores.)
+    constexpr int CP = CT > 2 ? 2 : CT;
+#pragma unroll
+    for (int cb = 0; cb < CT; cb += CP) {
+      f32x16 acc[CP];
+#pragma unroll
+      for (int c = 0; c < CP; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < KL; ++j) {
+        const float a4[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < CP; ++c) {
+            const float4 wv = wq[cb + c][j];
+            const float b = i == 0 ? wv.x : (i == 1 ? wv.y : (i == 2 ? wv.z : wv.w));
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], b, acc[c], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        const int col = (cb + c) * 32 + lrow;
+        const bool cok = col < cols;
+        float t0 = 0.f, t1 = 0.f;
+        float y[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int rl = rbase + (i & 3) + 8 * (i >> 2);
+          const bool ok = cok && (full || r0 + rl < rows);
+          y[i] = acc[c][i] + bias[cb + c];
+          if (ok) out_t[rl * ldo + col] = y[i];
+          if (stats) {
+            const float yy = ok ? y[i] : 0.f;
+            t0 = fmaf(mw[i], yy, t0);
+            t1 = fmaf(mw[i] * yy, yy, t1);
+          }
+        }
+        st0[cb + c] += t0; st1[cb + c] += t1;
+      }
+      __builtin_amdgcn_sched_barrier(0);                       // the next pair's MFMAs stay behind this pair's stores (register budget)
+    }
+#pragma unroll
+    for (int j = 0; j < KL; ++j) a[j] = an[j];
+  }
+  if (stats) {
+    const int slot = wave * 2 + h;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { red[0][slot][c * 32 + lrow] = (double)st0[c]; red[1][slot][c * 32 + lrow] = (double)st1[c]; }
+    __syncthreads();
+    for (int e = tid; e < 2 * CT * 32; e += GM_THREADS) {
+      const int sidx = e / (CT * 32), col = e - sidx * (CT * 32);
+      if (col < cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < GM_THREADS / 32; ++g) t += red[sidx][g][col];
+        ep.partial[((long long)blockIdx.x * 2 + sidx) * cols + col] = t;
+        // the finalize kernel sums `partial_blocks` rows: the ones no workgroup owns read as zero (no memset launch)
+        for (int pb = blockIdx.x + gridDim.x; pb < ep.partial_blocks; pb += gridDim.x)
+          ep.partial[((long long)pb * 2 + sidx) * cols + col] = 0.0;
+      }
+    }
+  }
+}
+
 // ---- narrow weight gradient: kcols <= 16 (first-layer branches: 3 / 6 / 10 / 16 input channels) ---------------------
 // dw[n][k] = sum_r P[r][n] * Q[r][k] is a pure streaming reduction here: 2 * 16 flop per byte of P.  No LDS, no
 // barriers, no matrix pipe in the loop: thread (tn, tr) owns 4 columns of P and every k for the rows tr, tr + RG, ...
@@ -1830,6 +1966,25 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
     else hipLaunchKernelGGL(gemm_small_kernel<128>, grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep);
     RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
     return RS_OK;
+  }
+  // kdim <= 16, plain operand, rows 16-byte aligned and at least 8 / 16 floats long, fp32 output: the LDS-free wave-per-32-rows kernel
+  static const int narrow_on = env_int("RS_GEMM_NARROW", 1);
+  if (narrow_on && !RS_STORE_BF16 && !bf && kdim <= 16 && cols <= 128 && E.mode == OPM_ID && epi_mode != EPI_MASK && ep.pool_ns == 0) {
+    const int kl = kdim <= 8 ? 1 : 2;
+    if (aligned_to(E.a, 16) && E.lda % 4 == 0 && E.lda >= 4 && rows > 0) {
+      int gxn = (int)((rows + 127) / 128);
+      if (gxn > 1024) gxn = 1024;
+      if (epi_mode != EPI_STORE && gxn > ep.partial_blocks) gxn = ep.partial_blocks;
+      if (gxn < 1) gxn = 1;
+      const dim3 grid(gxn);
+      const int ct = cols <= 32 ? 1 : (cols <= 64 ? 2 : 4);
+#define RS_GN(CT_, KL_) hipLaunchKernelGGL((gemm_narrow_kernel<CT_, KL_>), grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep)
+      if (kl == 1) { if (ct == 1) RS_GN(1, 1); else if (ct == 2) RS_GN(2, 1); else RS_GN(4, 1); }
+      else { if (ct == 1) RS_GN(1, 2); else if (ct == 2) RS_GN(2, 2); else RS_GN(4, 2); }
+#undef RS_GN
+      RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
+      return RS_OK;
+    }
   }
   const int v = pick_vec(E, kdim);
   // tile height: 64-row tiles (2 x 2 waves) wherever the layout allows -- twice the workgroups, three per CU
