@@ -1322,6 +1322,81 @@ gemm_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdi
   }
 }
 
+// ---- narrow weight gradient on the matrix pipe, no LDS in the loop (round 3): kcols <= 32 ------------------------------------
+// dw[n][k] = sum_r P[r][n] Q[r][k] with the ROWS as the MFMA reduction index: lane (l = lane & 31, h = lane >> 5) holds
+// P[r][n0 + l] as the A operand and Q[r][l] (l < kcols) as the B operand of v_mfma_f32_32x32x2_f32 for the rows r = r0 + 4 h + i
+// of step i -- consecutive lanes read consecutive columns of one row (128-byte segments), a wave takes 8 rows per trip and keeps
+// the (32 CT) x 32 block of dw in its accumulators over all its rows; the 4 waves of a workgroup meet in LDS once, in a fixed order,
+// and the workgroup leaves one partial like the other weight-gradient kernels.  (The streaming form above spends ~110 VALU
+// instructions per thread and row -- 16 predicated scalar loads + 64 FMAs whatever kcols is -- and measured 14-21 us where its
+// 34 MB are 5 us of HBM time.)
+template <int CT, int PM, int QM>
+__global__ void __launch_bounds__(GM_THREADS, 4)
+wgrad_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, int kcols, RowOperand P, RowOperand Q,
+                    float *__restrict__ partial) {
+  const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
+  __shared__ float red[GM_THREADS / 64][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * (32 * CT);
+  ColCoef<1> pc[CT], qc;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) op_coef<1, PM>(P, n0 + c * 32 + l, n0 + c * 32 + l < ncols, pc[c]);
+  op_coef<1, QM>(Q, l, l < kcols, qc);
+  f32x16 acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+  const long long nblk = (rows + 7) >> 3, bstep = (long long)gridDim.x * (GM_THREADS / 64);
+  for (long long blk = (long long)blockIdx.x * (GM_THREADS / 64) + wave; blk < nblk; blk += bstep) {
+    const long long r0 = blk * 8;
+    RawVec<1> praw[CT][4], qraw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = 4 * h + i;
+      const bool rok = r0 + rl < rows;
+      const int rc = rok ? rl : 0;                                  // (a row beyond the end: any valid address, discarded)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int n = n0 + c * 32 + l;
+        op_load<1, PM>(P, r0, rc, n < ncols ? n : 0, rok && n < ncols, praw[c][i]);
+      }
+      op_load<1, QM>(Q, r0, rc, l < kcols ? l : 0, rok && l < kcols, qraw[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = 4 * h + i;
+      const bool rok = r0 + rl < rows;
+      float qv[1];
+      op_finish<1, QM>(Q, qc, qraw[i], r0 + rl, rok && l < kcols, qv);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        float pv[1];
+        op_finish<1, PM>(P, pc[c], praw[c][i], r0 + rl, rok && n0 + c * 32 + l < ncols, pv);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[0], qv[0], acc[c], 0, 0, 0);
+      }
+    }
+  }
+  // D[i][j]: j = lane & 31 is the k index, row (reg & 3) + 8 (reg >> 2) + 4 h the column n of P
+  float *dst = partial + (long long)blockIdx.x * ncols * kcols;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][(i & 3) + 8 * (i >> 2) + 4 * h][l] = acc[c][i];
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += GM_THREADS) {
+      const int nl = e >> 5, k = e & 31, n = n0 + c * 32 + nl;
+      if (n < ncols && k < kcols) {
+        float t = red[0][nl][k];
+#pragma unroll
+        for (int w2 = 1; w2 < GM_THREADS / 64; ++w2) t += red[w2][nl][k];
+        dst[(long long)n * kcols + k] = t;
+      }
+    }
+  }
+}
+
 // ---- narrow weight gradient: kcols <= 16 (first-layer branches: 3 / 6 / 10 / 16 input channels) ---------------------
 // dw[n][k] = sum_r P[r][n] * Q[r][k] is a pure streaming reduction here: 2 * 16 flop per byte of P.  No LDS, no
 // barriers, no matrix pipe in the loop: thread (tn, tr) owns 4 columns of P and every k for the rows tr, tr + RG, ...
@@ -2069,6 +2144,21 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
   hipStream_t st = (hipStream_t)stream;
   const int vp = pick_vec(P, ncols), vq = pick_vec(Q, kcols);
   static const int small_on = env_int("RS_WGRAD_SMALL", 1);
+  static const int wnarrow_on = env_int("RS_WGRAD_NARROW", 1);
+  if (wnarrow_on && !RS_STORE_BF16 && !bf && kcols <= WS_KP && (Q.mode == OPM_ID || Q.mode == OPM_RELU1) &&
+      (P.mode == OPM_AFF2 || P.mode == OPM_POOLED || P.mode == OPM_BCAST || P.mode == OPM_ID)) {
+    // narrow gradient on the matrix pipe (rows = MFMA k), 64 columns of P per workgroup
+    const int ct = ncols <= 32 ? 1 : 2;
+    const dim3 grid(chunks, rs_cdiv(ncols, 32 * ct));
+#define RS_WN(CT_, PM_, QM_) hipLaunchKernelGGL((wgrad_narrow_kernel<CT_, PM_, QM_>), grid, dim3(GM_THREADS), 0, st, rows, rows_dev, ncols, kcols, P, Q, partial)
+#define RS_WNQ(CT_, PM_) do { if (Q.mode == OPM_ID) RS_WN(CT_, PM_, OPM_ID); else RS_WN(CT_, PM_, OPM_RELU1); } while (0)
+#define RS_WNP(CT_) do { if (P.mode == OPM_AFF2) RS_WNQ(CT_, OPM_AFF2); else if (P.mode == OPM_POOLED) RS_WNQ(CT_, OPM_POOLED); \
+                         else if (P.mode == OPM_BCAST) RS_WNQ(CT_, OPM_BCAST); else RS_WNQ(CT_, OPM_ID); } while (0)
+    if (ct == 1) RS_WNP(1); else RS_WNP(2);
+#undef RS_WNP
+#undef RS_WNQ
+#undef RS_WN
+  } else
   if (small_on && kcols <= WS_KP && vp == 4 && (Q.mode == OPM_ID || Q.mode == OPM_RELU1) &&
       (P.mode == OPM_AFF2 || P.mode == OPM_POOLED || P.mode == OPM_BCAST || P.mode == OPM_ID)) {
     // narrow gradient (first-layer branches): streaming kernel, no matrix pipe
