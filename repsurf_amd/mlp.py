@@ -5,6 +5,10 @@ the group pool folded into the last layer.  There is no other executor in this p
 reference the kernels are tested against lives in tests/torch_executor.py.
 
 Rows are (group, sample) pairs, channels last: x is (groups*nsample, C).
+
+This module is deliberately thin: it is the SEAM between the reference-named modules and the executor -- the two run-time
+switches (compacted groups, fp32 / bf16 arithmetic) live here, and the parity tests swap the stack functions below for the
+plain-PyTorch executor of tests/torch_executor.py (`set_backend`) to compare the two on identical modules.
 """
 import os
 
