@@ -1221,13 +1221,29 @@ gemm_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdi
 #pragma unroll
   for (int c = 0; c < CT; ++c) { st0[c] = 0.f; st1[c] = 0.f; }
   const long long nblk = (rows + 31) >> 5, bstep = (long long)gridDim.x * (GM_THREADS / 64);
+  const bool a16 = (((uintptr_t)E.a) % 16 == 0) && (E.lda % 4 == 0);     // else 8-byte aligned rows (checked by the launcher)
   auto load_a = [&](long long blk, float4 (&a)[KL]) {
     const long long r = min(blk * 32 + lrow, rows - 1);              // clamped: always in bounds, the row is discarded below
     const float *src = E.a + r * E.lda + 4 * h;
 #pragma unroll
     for (int j = 0; j < KL; ++j) {
       const int k0 = 8 * j + 4 * h;      // channels [kdim, ...) of the row belong to other tensors / padding: never multiplied
-      float4 v = (k0 + 4 <= (int)E.lda) ? *reinterpret_cast<const float4 *>(src + 8 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 < kdim) {
+        if (r == rows - 1) {                 // the last row: a vector load may run past the end of the tensor
+          v.x = src[8 * j];
+          if (k0 + 1 < kdim) v.y = src[8 * j + 1];
+          if (k0 + 2 < kdim) v.z = src[8 * j + 2];
+          if (k0 + 3 < kdim) v.w = src[8 * j + 3];
+        } else if (a16) {
+          v = *reinterpret_cast<const float4 *>(src + 8 * j);
+        } else {                             // rows on 8-byte boundaries only (a column slice starting at channel 6 of the
+          const float2 lo = *reinterpret_cast<const float2 *>(src + 8 * j);      // compacted classification rows; the
+          float2 hi = make_float2(0.f, 0.f);                                     // constructor's 10-float rows)
+          if (k0 + 2 < kdim) hi = *reinterpret_cast<const float2 *>(src + 8 * j + 2);
+          v = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+      }
       v.x = k0 + 0 < kdim ? v.x : 0.f; v.y = k0 + 1 < kdim ? v.y : 0.f; v.z = k0 + 2 < kdim ? v.z : 0.f; v.w = k0 + 3 < kdim ? v.w : 0.f;
       a[j] = v;
     }
@@ -2042,11 +2058,11 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
     RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
     return RS_OK;
   }
-  // kdim <= 16, plain operand, rows 16-byte aligned and at least 8 / 16 floats long, fp32 output: the LDS-free wave-per-32-rows kernel
+  // kdim <= 16, plain operand, rows on 16- or 8-byte boundaries, fp32 output: the LDS-free wave-per-32-rows kernel
   static const int narrow_on = env_int("RS_GEMM_NARROW", 1);
   if (narrow_on && !RS_STORE_BF16 && !bf && kdim <= 16 && cols <= 128 && E.mode == OPM_ID && epi_mode != EPI_MASK && ep.pool_ns == 0) {
     const int kl = kdim <= 8 ? 1 : 2;
-    if (aligned_to(E.a, 16) && E.lda % 4 == 0 && E.lda >= 4 && rows > 0) {
+    if (aligned_to(E.a, 8) && E.lda % 2 == 0 && E.lda >= 4 && rows > 0) {
       int gxn = (int)((rows + 127) / 128);
       if (gxn > 1024) gxn = 1024;
       if (epi_mode != EPI_STORE && gxn > ep.partial_blocks) gxn = ep.partial_blocks;
