@@ -11,16 +11,35 @@ PEAK = 157.3
 
 
 def timeit(fn, iters=20):
+    """GPU time per launch: `iters` launches recorded into a hipGraph and replayed (a ctypes call costs ~10 us of host time,
+    more than the kernels under test; the training step replays a graph too).  GEMM_BENCH_EAGER=1: plain back-to-back calls."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if os.environ.get("GEMM_BENCH_EAGER", "0") == "1":
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3   # us
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(iters):
+                fn()
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(5):
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3   # us
+    return e0.elapsed_time(e1) / (5 * iters) * 1e3   # us
 
 
 def bench(rows, k, n, rows_dev_frac=None):
@@ -147,6 +166,11 @@ if __name__ == "__main__":
         rows, k, n = (int(v) for v in sys.argv[2:5])
         frac = float(sys.argv[5]) if len(sys.argv) > 5 else None
         bench(rows, k, n, frac)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mid":         # 64 ... 128 channels on both sides (gemm_mid_kernel; RS_GEMM_MID=0: the tiled kernel)
+        for rows, k, n, frac in [(524288, 64, 64, 0.127), (524288, 64, 128, 0.127), (524288, 128, 64, 0.127), (262144, 128, 64, 0.184),
+                                 (262144, 64, 128, 0.184), (65536, 64, 64, None)]:
+            bench(rows, k, n, frac)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "small":       # narrow first-layer GEMMs (kdim <= 16)
         for rows, k, n, frac in [(524288, 6, 64, 0.127), (524288, 10, 64, 0.127), (262144, 6, 128, 0.184), (4096, 6, 256, None),
