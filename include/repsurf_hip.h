@@ -440,7 +440,7 @@ int rs_col_sum_partials(long long rows, int n, const float *x, long long ldx, fl
  * hyper (device, 5 DOUBLES) = {lr, beta1, beta2, eps, weight_decay}; step (device int) = number of updates done so far,
  * t = *step + 1; with advance != 0 the launch stores t back when its last workgroup retires (`done` = device int, 0
  * between launches) -- pass advance = 0 on all but the last launch of one optimizer step. */
-#define RS_ADAM_MAX 40
+#define RS_ADAM_MAX 80      /* the table travels in the kernel arguments: 80 x 44 bytes, under the 4 KB limit */
 typedef struct rs_adam_table {
   float *p[RS_ADAM_MAX];         /* parameters, updated in place */
   const float *g[RS_ADAM_MAX];   /* gradients */

@@ -1,4 +1,4 @@
-// adam.hip — torch.optim.Adam step over a list of fp32 parameter tensors in one launch per 40 tensors (gfx950).
+// adam.hip — torch.optim.Adam step over a list of fp32 parameter tensors in one launch per 80 tensors (gfx950).
 //
 // The reference trains with torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=decay_rate)
 // (classification/tool/train_cls_scanobjectnn.py:179-185).  The model has ~70 small parameter tensors (1.5 M floats);
@@ -24,6 +24,8 @@ struct AdamTable {
   int blk_end[RS_ADAM_MAX];               // running number of workgroups up to and including tensor i
   int count;
 };
+
+static_assert(sizeof(AdamTable) + 32 <= 4096, "the table rides in the kernel arguments (4 KB)");
 
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float wd, float omb1, float b2, float omb2,
                                          float eps, float step_size, float bc2_sqrt) {

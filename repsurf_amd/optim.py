@@ -3,7 +3,7 @@
 `Adam(params, lr, betas, eps, weight_decay)` has torch.optim.Adam's update rule, defaults, `param_groups` (LR schedulers
 work on it) and state-dict layout (`step`, `exp_avg`, `exp_avg_sq` per parameter; classification/tool/
 train_cls_scanobjectnn.py:179-185 builds it, :166-170 / :261-271 resume from / save its state dict).  The ~70 parameter
-tensors of a RepSurf-U classifier are updated by two launches (rs_adam_step takes 40 tensors per launch) instead of the
+tensors of a RepSurf-U classifier are updated by one launch (rs_adam_step takes 80 tensors per launch) instead of the
 framework's chunked multi-tensor kernels; learning rate and step count are read from device memory, so a captured step
 (graph.GraphedStep) follows a scheduler -- call `sync_hyper()` before each replay, GraphedStep does.
 """
@@ -14,7 +14,7 @@ import torch
 from . import _lib, mlp_hip
 
 P, c_int = ctypes.c_void_p, ctypes.c_int
-MAX_TENSORS = 40
+MAX_TENSORS = 80          # RS_ADAM_MAX
 
 
 class AdamTable(ctypes.Structure):           # rs_adam_table
