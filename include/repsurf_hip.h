@@ -437,7 +437,9 @@ int rs_col_sum_partials(long long rows, int n, const float *x, long long ldx, fl
  * torch.optim.Adam(lr, betas, eps, weight_decay) as the reference configures it
  * (classification/tool/train_cls_scanobjectnn.py:179-185), for up to RS_ADAM_MAX fp32 tensors per launch:
  *   g += wd * p;  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
- * hyper (device, 5 DOUBLES) = {lr, beta1, beta2, eps, weight_decay}; step (device int) = number of updates done so far,
+ * hyper (device, 10 DOUBLES): [0..4] = {lr, beta1, beta2, eps, weight_decay}, written by the caller; [5..9] belong to the
+ * kernel (zero them once): the bias corrections of the NEXT step, left by a step's last workgroup so that the next launch
+ * does not recompute two fp64 powers in every thread.  step (device int) = number of updates done so far,
  * t = *step + 1; with advance != 0 the launch stores t back when its last workgroup retires (`done` = device int, 0
  * between launches) -- pass advance = 0 on all but the last launch of one optimizer step. */
 #define RS_ADAM_MAX 80      /* the table travels in the kernel arguments: 80 x 44 bytes, under the 4 KB limit */
@@ -449,7 +451,7 @@ typedef struct rs_adam_table {
   int n[RS_ADAM_MAX];            /* elements */
   int count;
 } rs_adam_table;
-int rs_adam_step(const rs_adam_table *t, const double *hyper, int *step, int *done, int advance, void *stream);
+int rs_adam_step(const rs_adam_table *t, double *hyper, int *step, int *done, int advance, void *stream);
 
 /* ---- fused 10-channel MLP of UmbrellaSurfaceConstructor ---------------------------------------
  * self.mlps = Conv2d(10,10,bias=False)-BN-ReLU-Conv2d(10,10)-BN-ReLU-Conv2d(10,10) + sum/avg over the fan

@@ -37,9 +37,16 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 }
 
 __global__ void __launch_bounds__(AD_THREADS)
-adam_kernel(AdamTable T, const double *__restrict__ hyper, int *__restrict__ step, int *__restrict__ done, int advance) {
-  int ti = 0;
-  while (ti < T.count - 1 && (int)blockIdx.x >= T.blk_end[ti]) ++ti;
+adam_kernel(AdamTable T, double *hyper, int *__restrict__ step, int *__restrict__ done, int advance) {
+  // the tensor of this workgroup: first entry whose running block count exceeds blockIdx.x.  A bisection: every probe is a
+  // dependent scalar load from the kernel-argument segment, and the big tensors (the head, the last stage) sit at the END of the
+  // table -- the linear walk cost their workgroups ~70 round trips before the first operand load was issued.
+  int lo = 0, hi = T.count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= T.blk_end[mid]) lo = mid + 1; else hi = mid;
+  }
+  const int ti = lo;
   const int blk0 = ti ? T.blk_end[ti - 1] : 0;
   const int base = ((int)blockIdx.x - blk0) * AD_CHUNK;
   const int n = T.n[ti];
@@ -68,8 +75,15 @@ adam_kernel(AdamTable T, const double *__restrict__ hyper, int *__restrict__ ste
   const float eps = (float)hyper[3], wd = (float)hyper[4];
   const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
   const int t = *step + 1;                          // this update's step number (1-based)
-  const float step_size = (float)(lr / (1.0 - pow(beta1, (double)t)));
-  const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
+  // bias corrections 1 - beta1^t and sqrt(1 - beta2^t): ~330 fp64 instructions per THREAD for two numbers the whole launch
+  // shares (a thread's own update is ~100 fp32 instructions).  The last workgroup of a step leaves the pair for step t + 1 in
+  // hyper[5..9] = {t + 1, 1 - beta1^(t+1), sqrt(1 - beta2^(t+1)), beta1, beta2}; a launch that finds its own step number and betas
+  // there (a wave-uniform test) uses them, any other (first step, changed betas, loaded state) computes them as before.
+  double denom1, s2;
+  if (hyper[5] == (double)t && hyper[8] == beta1 && hyper[9] == beta2) { denom1 = hyper[6]; s2 = hyper[7]; }
+  else { denom1 = 1.0 - pow(beta1, (double)t); s2 = sqrt(1.0 - pow(beta2, (double)t)); }
+  const float step_size = (float)(lr / denom1);
+  const float bc2_sqrt = (float)s2;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int e = base + (u * AD_THREADS + (int)threadIdx.x) * 4;
@@ -90,19 +104,26 @@ adam_kernel(AdamTable T, const double *__restrict__ hyper, int *__restrict__ ste
       }
     }
   }
-  // the last workgroup to finish advances the step counter (every workgroup has read it by then)
+  // the last workgroup to finish advances the step counter (every workgroup has read it by then: a workgroup's read of *step
+  // feeds its stores, which precede the barrier and the counter increment).  No __threadfence(): at agent scope it is an L2
+  // write-back + invalidate (buffer_wbl2 / buffer_inv) -- 771 of them made the launch 33 us for 41 MB -- and nothing written
+  // here is read before the next launch.
   if (advance) {
     __syncthreads();
     if (threadIdx.x == 0) {
-      __threadfence();
-      if (atomicAdd(done, 1) == (int)gridDim.x - 1) { *done = 0; *step = t; }
+      if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
+        *done = 0; *step = t;
+        hyper[6] = 1.0 - pow(beta1, (double)(t + 1)); hyper[7] = sqrt(1.0 - pow(beta2, (double)(t + 1)));
+        hyper[8] = beta1; hyper[9] = beta2;
+        hyper[5] = (double)(t + 1);
+      }
     }
   }
 }
 
 }  // namespace
 
-extern "C" int rs_adam_step(const rs_adam_table *t, const double *hyper, int *step, int *done, int advance, void *stream) {
+extern "C" int rs_adam_step(const rs_adam_table *t, double *hyper, int *step, int *done, int advance, void *stream) {
   RS_REQUIRE(t && hyper && step && done, "rs_adam_step: null pointer");
   RS_REQUIRE(t->count > 0 && t->count <= RS_ADAM_MAX, "rs_adam_step: count=%d (1..%d)", t->count, RS_ADAM_MAX);
   AdamTable T;

@@ -33,7 +33,7 @@ class Adam(torch.optim.Optimizer):
     def _group_state(self, gi, group, device):
         st = self._dev.get(gi)
         if st is None:
-            st = dict(hyper=torch.zeros(5, dtype=torch.float64, device=device), host=None,
+            st = dict(hyper=torch.zeros(10, dtype=torch.float64, device=device), host=None,      # [5..9]: the kernel's (include/repsurf_hip.h)
                       step=torch.zeros(1, dtype=torch.int32, device=device),
                       done=torch.zeros(1, dtype=torch.int32, device=device))
             self._dev[gi] = st
@@ -52,7 +52,7 @@ class Adam(torch.optim.Optimizer):
                 continue
             vals = self._hyper_values(group)
             if st["host"] != vals:
-                st["hyper"].copy_(torch.tensor(vals, dtype=torch.float64))
+                st["hyper"][:5].copy_(torch.tensor(vals, dtype=torch.float64))
                 st["host"] = vals
 
     # ---- state dict in torch.optim.Adam's layout ------------------------------------------------------------------
