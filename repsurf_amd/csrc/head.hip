@@ -48,34 +48,63 @@ __device__ __forceinline__ int hd_drow(int i, int h) { return (i & 3) + 8 * (i >
 
 // acc[rb] (32 rows x 32 columns) += A[rb*32 + i][k] * B[c0 + j][k] over k in [kbeg, kend): both operands k-contiguous
 // (x . W^T).  v_mfma_f32_32x32x2_f32 takes, per step, lane (i = lane & 31, h = lane >> 5) -> A[i][k_h], B[i][k_h]; the order
-// of the k's is free as long as both operands agree, so a lane reads 4 consecutive k (one 16-B load per operand) for 4 steps.
+// of the k's is free as long as both operands agree, so a lane feeds 4 consecutive k (one 16-byte fragment per operand) to 4 steps.
+// The operands reach the lanes through a wave-private LDS buffer.  (Round 2 loaded the fragments straight from global memory:
+// a load instruction then has every lane on a different row -- 64 cache lines per instruction, 16 bytes used of each, and the next
+// three instructions come back for the same lines; with 8 waves x 2 operands x 64 lines in flight (128 KB against 32 KB of L1) they
+// were fetched from L2 again each time: 8 x the bytes, 5 us per 32-k trip, 25 us for the 32 x 1024 -> 512 layer whose weights
+// are 2 MB; 15.7 us now.)  Here 8 (4)
+// adjacent lanes read one whole 128-byte (64-byte) row segment, the chunk is written to LDS as planes of [k / 4][row] float4
+// (row XOR plane: the minimum of 4 bank passes per write), and the fragment read of lane (c, h) for the k group 2 g + h is one
+// conflict-free ds_read_b128.  The next chunk's loads fly under the current chunk's MFMAs.  `stage`: (1 + RB) * CK * 32 floats.
 template <int RB>
-__device__ __forceinline__ void hd_mma_nt(const float *__restrict__ A, int lda, int R, const float *__restrict__ B, int ldb,
-                                          int ncols, int c0, int K, int kbeg, int kend, hd_f16 (&acc)[RB]) {
+__device__ __forceinline__ void hd_mma_nt_lds(const float *__restrict__ A, int lda, int R, const float *__restrict__ B, int ldb,
+                                              int ncols, int c0, int K, int kbeg, int kend, hd_f16 (&acc)[RB], float *stage) {
+  constexpr int CK = RB == 1 ? 32 : 16;              // k per chunk (the stage aliases the 8 KB partial-tile slot of the wave)
+  constexpr int KG = CK / 4, RPI = 64 / KG, NB = 32 / RPI;     // 16-byte groups per row, rows per load instruction, instructions per 32 rows
   const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int seg = lane % KG, lr = lane / KG;
   const bool vec = (((lda | ldb | K) & 3) == 0) && ((((size_t)A | (size_t)B) & 15) == 0);
-  const bool bok = c0 + c < ncols;
-  const float *bp = B + (long long)(bok ? c0 + c : 0) * ldb;
-  constexpr int U = 4;                               // 4 x 8 k in flight per wave: the loads of a trip are issued together
-  for (int k0 = kbeg + 4 * h; k0 < kend; k0 += 8 * U) {
-    float4 b4[U], a4[U][RB];
+  float4 *Ws = reinterpret_cast<float4 *>(stage), *As = Ws + KG * 32;
+  const int kmax = min(kend, K);
+  float4 wv[NB], av[RB][NB];
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int kq = k0 + 8 * u, avail = min(kend, K) - kq;
-      b4[u] = hd_load4(bp + kq, bok ? avail : 0, vec);
+    for (int p = 0; p < NB; ++p) {
+      const int row = lr + RPI * p, col = c0 + row, kq = k0 + 4 * seg;
+      wv[p] = hd_load4(B + (long long)(col < ncols ? col : 0) * ldb + kq, col < ncols ? kmax - kq : 0, vec);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        const int r = rb * 32 + c;
-        a4[u][rb] = hd_load4(A + (long long)(r < R ? r : 0) * lda + kq, r < R ? avail : 0, vec);
+        const int r = rb * 32 + row;
+        av[rb][p] = hd_load4(A + (long long)(r < R ? r : 0) * lda + kq, r < R ? kmax - kq : 0, vec);
       }
     }
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += CK) {
+    __builtin_amdgcn_wave_barrier();                 // (compiler-only: LDS operations of a wave complete in order)
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int p = 0; p < NB; ++p) {
+      const int row = lr + RPI * p;
+      Ws[seg * 32 + (row ^ seg)] = wv[p];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) As[(rb * KG + seg) * 32 + (row ^ seg)] = av[rb][p];
+    }
+    if (k0 + CK < kend) fetch(k0 + CK);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < KG / 2; ++g) {
+      const int kg = 2 * g + h;
+      const float4 b4 = Ws[kg * 32 + (c ^ kg)];
+      float4 a4[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) a4[rb] = As[(rb * KG + kg) * 32 + (c ^ kg)];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
-          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(hd_get(a4[u][rb], i), hd_get(b4[u], i), acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(hd_get(a4[rb], i), hd_get(b4, i), acc[rb], 0, 0, 0);
+    }
   }
 }
 
@@ -165,15 +194,19 @@ head_layer_fwd_kernel(HeadLayer L) {
   __shared__ float part[HD_WAVES * HD_MAXR * HD_COLS];
   __shared__ float colred[(HD_THREADS / 32) * HD_COLS];
   const int tid = threadIdx.x, c = tid & 31, rg = tid >> 5, n0 = blockIdx.x * HD_COLS, n = n0 + c;
-  int kbeg, kend;
-  hd_wave_range(L.K, kbeg, kend);
+  // the waves' k ranges are multiples of 32 (whole staging chunks); a wave's staging buffer is its own slot of `part`
+  const int kper = ((L.K + 32 * HD_WAVES - 1) / (32 * HD_WAVES)) * 32, wv_ = tid >> 6;
+  const int kbeg = min(L.K, wv_ * kper), kend = min(L.K, kbeg + kper);
+  float *stage = part + wv_ * HD_MAXR * HD_COLS;
   if (L.R <= 32) {
     hd_f16 acc[1] = {};
-    hd_mma_nt<1>(L.x, L.ldx, L.R, L.w, L.K, L.N, n0, L.K, kbeg, kend, acc);
+    hd_mma_nt_lds<1>(L.x, L.ldx, L.R, L.w, L.K, L.N, n0, L.K, kbeg, kend, acc, stage);
+    __builtin_amdgcn_wave_barrier();
     hd_store_partials<1>(acc, part);
   } else {
     hd_f16 acc[2] = {};
-    hd_mma_nt<2>(L.x, L.ldx, L.R, L.w, L.K, L.N, n0, L.K, kbeg, kend, acc);
+    hd_mma_nt_lds<2>(L.x, L.ldx, L.R, L.w, L.K, L.N, n0, L.K, kbeg, kend, acc, stage);
+    __builtin_amdgcn_wave_barrier();
     hd_store_partials<2>(acc, part);
   }
   __syncthreads();

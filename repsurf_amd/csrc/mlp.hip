@@ -1753,10 +1753,16 @@ pool_max_kernel(long long groups, int ns, int c, int relu, const int *__restrict
     float best = -INFINITY; int bi = 0;
     const long long base = offsets ? offsets[g] : g * ns;             // ragged (compacted) or dense groups
     const int len = offsets ? offsets[g + 1] - offsets[g] : ns;
-    for (int k = 0; k < len; ++k) {
-      float z = fmaf(s, ldy<BF>(y, (base + k) * c + ch), t);
-      if (relu) z = fmaxf(z, 0.f);
-      if (z > best) { best = z; bi = k; }
+    for (int k0 = 0; k0 < len; k0 += 4) {                            // 4 rows in flight (one per trip was a chain of `len` round trips)
+      float z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) z[u] = ldy<BF>(y, (base + min(k0 + u, len - 1)) * c + ch);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float zz = fmaf(s, z[u], t);
+        if (relu) zz = fmaxf(zz, 0.f);
+        if (k0 + u < len && zz > best) { best = zz; bi = k0 + u; }
+      }
     }
     out[e] = best;
     if (arg) arg[e] = bi;
@@ -1836,13 +1842,28 @@ pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ off
   double s0 = 0.0, s1 = 0.0;
   if (ch < c) {
     const float mu = mean[ch], is = invstd[ch];
-    for (long long g = (long long)blockIdx.x * 4 + ty; g < groups; g += (long long)gridDim.x * 4) {
-      const long long e = g * c + ch;
-      const float val = (!out || out[e] > 0.f) ? dout[g * ldd + ch] : 0.f;      // out == NULL: the pooled layer ended without a ReLU
-      v[e] = val;
-      const float yy = ldy<BF>(y, ((offsets ? (long long)offsets[g] : g * ns) + (arg ? arg[e] : 0)) * c + ch);
-      s0 += (double)val;
-      s1 += (double)(val * ((yy - mu) * is));
+    // two groups per trip: a group is a chain of two dependent round trips (out / arg / offsets -> the y row they select), and a
+    // thread sees only 2-4 groups -- one after the other that was 4-8 exposed round trips per launch
+    const long long gstep = (long long)gridDim.x * 4;
+    for (long long g = (long long)blockIdx.x * 4 + ty; g < groups; g += 2 * gstep) {
+      const long long g1 = g + gstep;
+      const bool ok1 = g1 < groups;
+      const long long e0 = g * c + ch, e1 = (ok1 ? g1 : g) * c + ch;
+      const float o0 = out ? out[e0] : 1.f, o1 = out ? out[e1] : 1.f;
+      const float d0 = dout[g * ldd + ch], d1 = dout[(ok1 ? g1 : g) * ldd + ch];
+      const int a0 = arg ? arg[e0] : 0, a1 = arg ? arg[e1] : 0;
+      const long long b0 = offsets ? (long long)offsets[g] : g * ns, b1 = offsets ? (long long)offsets[ok1 ? g1 : g] : (ok1 ? g1 : g) * ns;
+      const float y0 = ldy<BF>(y, (b0 + a0) * c + ch), y1 = ldy<BF>(y, (b1 + a1) * c + ch);
+      const float v0 = o0 > 0.f ? d0 : 0.f;                        // out == NULL: the pooled layer ended without a ReLU
+      v[e0] = v0;
+      s0 += (double)v0;
+      s1 += (double)(v0 * ((y0 - mu) * is));
+      if (ok1) {                                                  // (same order of the sums as one group per trip)
+        const float v1 = o1 > 0.f ? d1 : 0.f;
+        v[e1] = v1;
+        s0 += (double)v1;
+        s1 += (double)(v1 * ((y1 - mu) * is));
+      }
     }
   }
   red[ty][tx][0] = s0; red[ty][tx][1] = s1;
