@@ -265,8 +265,26 @@ head_out_fwd_kernel(HeadOut O) {
   const int ldk = O.K + 1;
   float *hs = sm, *wsm = sm + O.R * ldk, *lg = wsm + O.classes * ldk;
   const int tid = threadIdx.x;
-  for (int e = tid; e < O.R * O.K; e += blockDim.x) { const int r = e / O.K, k = e - r * O.K; hs[r * ldk + k] = O.h[e]; }
-  for (int e = tid; e < O.classes * O.K; e += blockDim.x) { const int j = e / O.K, k = e - j * O.K; wsm[j * ldk + k] = O.w[e]; }
+  // both matrices are contiguous: one pass over (R + classes) * K elements, 4 loads in flight per thread (one per trip was a
+  // chain of ~12 round trips for 12 K floats -- most of this launch's 12 us)
+  {
+    const int nh = O.R * O.K, nall = nh + O.classes * O.K, st = (int)blockDim.x;
+    for (int e0 = tid; e0 < nall; e0 += 4 * st) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = min(e0 + u * st, nall - 1);
+        v[u] = e < nh ? O.h[e] : O.w[e - nh];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * st;
+        if (e >= nall) break;
+        const int row = e / O.K, k = e - row * O.K;                 // rows of h first, then rows of w: hs and wsm are adjacent, same pitch
+        hs[row * ldk + k] = v[u];
+      }
+    }
+  }
   __syncthreads();
   const int total = O.R * O.classes;
   for (int e = tid; e < total; e += blockDim.x) {
@@ -299,13 +317,18 @@ struct HeadOutBwd {
 
 __global__ void __launch_bounds__(1024)
 head_out_bwd_kernel(HeadOutBwd O) {
-  extern __shared__ float dl[];                      // (R, classes)
+  extern __shared__ float dl[];                      // dlogits | dlogp | logp, (R, classes) each
   const int tid = threadIdx.x;
+  // dlogp / logp rows meet in LDS first (one element per thread and trip: the per-row loops below read LDS, not a chain of
+  // 2 * classes global round trips per row)
+  float *gp = dl + O.R * O.classes, *lp = gp + O.R * O.classes;
+  for (int e = tid; e < O.R * O.classes; e += blockDim.x) { gp[e] = O.dlogp[e]; lp[e] = O.logp[e]; }
+  __syncthreads();
   for (int r = tid; r < O.R; r += blockDim.x) {
     float s = 0.f;
-    for (int j = 0; j < O.classes; ++j) s += O.dlogp[(long long)r * O.classes + j];
+    for (int j = 0; j < O.classes; ++j) s += gp[r * O.classes + j];
     for (int j = 0; j < O.classes; ++j) {
-      const float g = O.dlogp[(long long)r * O.classes + j] - expf(O.logp[(long long)r * O.classes + j]) * s;
+      const float g = gp[r * O.classes + j] - expf(lp[r * O.classes + j]) * s;
       dl[r * O.classes + j] = g;
       O.dlogits[(long long)r * O.classes + j] = g;
     }
@@ -643,7 +666,7 @@ extern "C" int rs_head_output_backward(int rows, int k, int classes, const float
   RS_REQUIRE(rows > 0 && rows <= HD_MAXR && k > 0 && classes > 0 && classes <= 256, "rs_head_output_backward: bad size");
   RS_REQUIRE(dlogp && logp && h && dlogits && dw && db, "rs_head_output_backward: null pointer");
   HeadOutBwd O{dlogp, logp, h, dlogits, dw, db, rows, k, classes};
-  hipLaunchKernelGGL(head_out_bwd_kernel, dim3(1), dim3(1024), sizeof(float) * (size_t)rows * classes, (hipStream_t)stream, O);
+  hipLaunchKernelGGL(head_out_bwd_kernel, dim3(1), dim3(1024), 3 * sizeof(float) * (size_t)rows * classes, (hipStream_t)stream, O);
   RS_CHECK_LAUNCH("rs_head_output_backward");
   return RS_OK;
 }
