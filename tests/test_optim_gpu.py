@@ -97,3 +97,29 @@ def test_adam_in_a_captured_graph_follows_the_schedule():
         ref.step()
     for x, y in zip(a, b):
         torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-7)
+
+
+def test_adam_two_launches_per_step_and_changed_betas():
+    """90 tensors are two launches per step (RS_ADAM_MAX = 80): only the last one advances the step counter and leaves the next
+    step's bias corrections on the device; after a change of betas those cached corrections belong to other betas and the
+    kernel has to compute its own (csrc/adam.hip)."""
+    from repsurf_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(33, 7), (64,), (5, 5, 1, 1)] * 30
+    a = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ours, ref = Adam(a, lr=1e-3, weight_decay=1e-4), torch.optim.Adam(b, lr=1e-3, weight_decay=1e-4)
+    for it in range(6):
+        if it == 3:
+            for opt in (ours, ref):
+                opt.param_groups[0]["betas"] = (0.8, 0.99)
+            ours._dev_reset_host()
+        gg = torch.Generator().manual_seed(100 + it)
+        for x, y in zip(a, b):
+            x.grad = torch.randn(x.shape, generator=gg).to(dev) * 0.1
+            y.grad = x.grad.clone()
+        ours.step(); ref.step()
+    for x, y in zip(a, b):
+        torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-7)
+    assert float(ours.state_dict()["state"][0]["step"]) == 6.0
