@@ -21,6 +21,13 @@ namespace {
 constexpr int UM_C = 10;        // channels (repsurf_channel)
 constexpr int UM_CP = 12;       // padded row length in LDS (float4 aligned)
 constexpr int UM_THREADS = 256;
+// register budget of the row kernels: left to the compiler (the backward passes then take 256 VGPRs + AGPRs, one wave per SIMD);
+// -DRS_UM_OCC=2 cuts it for two waves per SIMD: 20-34 spilled registers, 24-30 us per backward pass against 20-23
+#ifdef RS_UM_OCC
+#define RS_UM_BOUNDS __launch_bounds__(UM_THREADS, RS_UM_OCC)
+#else
+#define RS_UM_BOUNDS __launch_bounds__(UM_THREADS)
+#endif
 
 struct UmbWeights {             // LDS image
   float w0t[UM_C * UM_CP];      // k-major: w0t[k][j] = w0[j][k]   (forward)
@@ -89,30 +96,51 @@ __device__ __forceinline__ void load_row(const float *x, long long r, float (&v)
   for (int i = 0; i < UM_C / 2; ++i) { const float2 t = p[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
 }
 
-// workgroup reduction of NV per-thread values -> dst[blockIdx.x * NV + i] (T = float or double)
-template <int NV, typename T>
-__device__ void block_reduce_store(float (&v)[NV], float *scratch, T *dst) {
+// workgroup reduction of NV per-thread values -> dst[blockIdx.x * NV + i] (T = float or double), through LDS.
+// (Round 2 summed every value across the wave by DPP: ~29 instructions x 110 values = 3 200 instructions per wave for the weight-
+// gradient tiles -- more than the 4 rows x 740 instructions of the pass itself.)  The lanes write their values to LDS as [value][lane]
+// (pitch 68: conflict-free writes, 4-way = minimal on the 16-byte reads), four threads per value sum one wave's 64 lanes each
+// (16 ds_read_b128), the four meet by two quad shuffles; RED_H values per round (55 of the 110 weight-gradient values: 60 KB).
+// Order of the sum: lanes ascending within a wave, then the waves -- fixed, so the result is deterministic.
+// (The statistics-only passes reduce 20 values and size the buffer for those: a 60 KB buffer tells the register allocator that
+// two workgroups per CU is the most there can be, and it then takes 256 VGPRs where 60 do.)
+constexpr int RED_PITCH = 68;
+constexpr int red_floats(int h) { return (UM_THREADS / 64) * h * RED_PITCH; }
+
+template <int NV, int RED_H, typename T>
+__device__ void block_reduce_store(float (&v)[NV], float *red, T *dst) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const float s = rs_wave_sum_f32(v[i]);
-    if (lane == 0) scratch[wave * NV + i] = s;
+  for (int c0 = 0; c0 < NV; c0 += RED_H) {
+    const int n = NV - c0 < RED_H ? NV - c0 : RED_H;
+#pragma unroll
+    for (int i = 0; i < RED_H; ++i)
+      if (i < n) red[(wave * RED_H + i) * RED_PITCH + lane] = v[c0 + i];
+    __syncthreads();
+    const int i = threadIdx.x >> 2, w = threadIdx.x & 3;
+    float s = 0.f;
+    if (i < n) {
+      const float4 *src = reinterpret_cast<const float4 *>(red + (w * RED_H + i) * RED_PITCH);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { const float4 x = src[q]; s += x.x; s += x.y; s += x.z; s += x.w; }
+    }
+    T t = (T)s;                                                    // the four waves of value i sit in one quad
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    if (i < n && w == 0) dst[(long long)blockIdx.x * NV + c0 + i] = t;
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < NV; i += UM_THREADS) {
-    T t = (T)0;
-    for (int w = 0; w < UM_THREADS / 64; ++w) t += (T)scratch[w * NV + i];
-    dst[(long long)blockIdx.x * NV + i] = t;
-  }
-  __syncthreads();
 }
 
 // PASS 0: stats(y0)  1: stats(y1)  3: dW2,db2 + BN1-backward sums  4: dW1 + BN0-backward sums  5: dW0
+// (The backward passes take 256 VGPRs + 20-34 AGPRs: ONE wave per SIMD, so a second workgroup on a CU simply waits for the first
+//  -- 256 workgroups is the grid.  Cutting the budget for two waves spills and is slower: RS_UM_OCC.)
 template <int PASS>
-__global__ void __launch_bounds__(UM_THREADS)
+__global__ void RS_UM_BOUNDS
 umbrella_mlp_rows_kernel(rs_umbrella_mlp m, double *__restrict__ stat_partial, float *__restrict__ dw_partial) {
   __shared__ UmbWeights L;
-  __shared__ float scratch[(UM_THREADS / 64) * (UM_C * UM_C + UM_C)];
+  constexpr int RH = PASS >= 3 ? 55 : 2 * UM_C;               // values per reduction round (block_reduce_store)
+  __shared__ __attribute__((aligned(16))) float scratch[red_floats(RH)];
   load_weights(L, m);
   float st[2 * UM_C];
   float dw[UM_C * UM_C + UM_C];
@@ -189,18 +217,19 @@ umbrella_mlp_rows_kernel(rs_umbrella_mlp m, double *__restrict__ stat_partial, f
 #pragma unroll
       for (int k = 0; k < UM_C; ++k) dw[j * UM_C + k] = fmaf(dy0[j], x[k], dw[j * UM_C + k]);
   }
-  if (PASS != 5) block_reduce_store<2 * UM_C, double>(st, scratch, stat_partial);
-  if (PASS >= 3) block_reduce_store<UM_C * UM_C + UM_C, float>(dw, scratch, dw_partial);
+  if (PASS != 5) block_reduce_store<2 * UM_C, RH, double>(st, scratch, stat_partial);
+  if (PASS >= 3) block_reduce_store<UM_C * UM_C + UM_C, RH, float>(dw, scratch, dw_partial);
 }
 
 // ---- two-layer variant: the segmentation constructor's mlps = Conv1d(10,10)-BN-ReLU-Conv1d(10,10), summed over the fan
 // (segmentation/modules/repsurface_utils.py:298-303,323-327).  PASS 0: stats(y0), y0 = W0 x + b0;  4: {dW1, db1} + BN0-backward
 // sums (dy1 = dout[point]);  5: dW0 (needs c0).  Same register-resident scheme, one stage shorter.
 template <int PASS>
-__global__ void __launch_bounds__(UM_THREADS)
+__global__ void RS_UM_BOUNDS
 umbrella_mlp2_rows_kernel(rs_umbrella_mlp m, double *__restrict__ stat_partial, float *__restrict__ dw_partial) {
   __shared__ UmbWeights L;
-  __shared__ float scratch[(UM_THREADS / 64) * (UM_C * UM_C + UM_C)];
+  constexpr int RH = PASS >= 3 ? 55 : 2 * UM_C;               // values per reduction round (block_reduce_store)
+  __shared__ __attribute__((aligned(16))) float scratch[red_floats(RH)];
   load_weights(L, m);
   float st[2 * UM_C];
   float dw[UM_C * UM_C + UM_C];
@@ -247,8 +276,8 @@ umbrella_mlp2_rows_kernel(rs_umbrella_mlp m, double *__restrict__ stat_partial, 
 #pragma unroll
       for (int k = 0; k < UM_C; ++k) dw[j * UM_C + k] = fmaf(dy0[j], x[k], dw[j * UM_C + k]);
   }
-  if (PASS != 5) block_reduce_store<2 * UM_C, double>(st, scratch, stat_partial);
-  if (PASS >= 4) block_reduce_store<UM_C * UM_C + UM_C, float>(dw, scratch, dw_partial);
+  if (PASS != 5) block_reduce_store<2 * UM_C, RH, double>(st, scratch, stat_partial);
+  if (PASS >= 4) block_reduce_store<UM_C * UM_C + UM_C, RH, float>(dw, scratch, dw_partial);
 }
 
 // two-layer PASS 2: out[p] = scale * sum_g y1[p*group + g]
@@ -305,6 +334,41 @@ umbrella_mlp_out_kernel(rs_umbrella_mlp m, float scale, float *__restrict__ out)
   }
 }
 
+// PASS 2 for fans of 8 (the classification constructor): one thread per ROW.  With one thread per point only 32 768 threads exist
+// at B = 32 (half a wave per SIMD) and each walks 8 rows serially: 20 us.  Here the 8 rows of a point are 8 adjacent lanes, their
+// y2 vectors meet by three DPP steps (xor 1, xor 2, half-row mirror) and lane 0 of the octet stores the point.
+__global__ void __launch_bounds__(UM_THREADS)
+umbrella_mlp_out8_kernel(rs_umbrella_mlp m, float scale, float *__restrict__ out) {
+  __shared__ UmbWeights L;
+  load_weights(L, m);
+  const long long step = (long long)gridDim.x * UM_THREADS;
+  const long long rows_up = (m.rows + 63) & ~63LL;                 // whole waves: every lane takes part in the DPP steps
+  for (long long r = (long long)blockIdx.x * UM_THREADS + threadIdx.x; r < rows_up; r += step) {
+    asm volatile("" ::: "memory");                                // keep the LDS weight reads inside the loop (see rows kernel)
+    const bool ok = r < m.rows;
+    float x[UM_C], y0[UM_C], a0[UM_C], y1[UM_C], a1[UM_C], y2[UM_C];
+    load_row(m.x, ok ? r : m.rows - 1, x);
+    matvec_t(L.w0t, nullptr, x, y0);
+    bn_relu(L.bn0, y0, a0);
+    matvec_t(L.w1t, L.b1, a0, y1);
+    bn_relu(L.bn1, y1, a1);
+    matvec_t(L.w2t, L.b2, a1, y2);
+#pragma unroll
+    for (int j = 0; j < UM_C; ++j) {
+      unsigned v = __float_as_uint(ok ? y2[j] : 0.f);
+      v = __float_as_uint(__uint_as_float(v) + __uint_as_float(rs_dpp<RS_DPP_QUAD_XOR1>(v)));
+      v = __float_as_uint(__uint_as_float(v) + __uint_as_float(rs_dpp<RS_DPP_QUAD_XOR2>(v)));
+      v = __float_as_uint(__uint_as_float(v) + __uint_as_float(rs_dpp<RS_DPP_ROW_HALF_MIRROR>(v)));
+      y2[j] = __uint_as_float(v) * scale;
+    }
+    if (ok && (threadIdx.x & 7) == 0) {
+      float2 *o = reinterpret_cast<float2 *>(out + (r >> 3) * UM_C);
+#pragma unroll
+      for (int i = 0; i < UM_C / 2; ++i) o[i] = make_float2(y2[2 * i], y2[2 * i + 1]);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int rs_umbrella_mlp_pass(int pass, const rs_umbrella_mlp *m, float out_scale, float *out,
@@ -346,7 +410,10 @@ extern "C" int rs_umbrella_mlp_pass(int pass, const rs_umbrella_mlp *m, float ou
   switch (pass) {
     case 0: hipLaunchKernelGGL(umbrella_mlp_rows_kernel<0>, grid, block, 0, st, *m, stat_partial, dw_partial); break;
     case 1: hipLaunchKernelGGL(umbrella_mlp_rows_kernel<1>, grid, block, 0, st, *m, stat_partial, dw_partial); break;
-    case 2: hipLaunchKernelGGL(umbrella_mlp_out_kernel, grid, block, 0, st, *m, out_scale, out); break;
+    case 2:
+      if (m->group == 8 && m->rows % 8 == 0) hipLaunchKernelGGL(umbrella_mlp_out8_kernel, grid, block, 0, st, *m, out_scale, out);
+      else hipLaunchKernelGGL(umbrella_mlp_out_kernel, grid, block, 0, st, *m, out_scale, out);
+      break;
     case 3: hipLaunchKernelGGL(umbrella_mlp_rows_kernel<3>, grid, block, 0, st, *m, stat_partial, dw_partial); break;
     case 4: hipLaunchKernelGGL(umbrella_mlp_rows_kernel<4>, grid, block, 0, st, *m, stat_partial, dw_partial); break;
     default: hipLaunchKernelGGL(umbrella_mlp_rows_kernel<5>, grid, block, 0, st, *m, stat_partial, dw_partial); break;
