@@ -1347,7 +1347,7 @@ gemm_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdi
 // instructions per thread and row -- 16 predicated scalar loads + 64 FMAs whatever kcols is -- and measured 14-21 us where its
 // 34 MB are 5 us of HBM time.)
 template <int CT, int PM, int QM>
-__global__ void __launch_bounds__(GM_THREADS, 4)
+__global__ void __launch_bounds__(GM_THREADS, CT > 1 ? 3 : 4)      // two column tiles + the next trip's rows: 168 VGPRs
 wgrad_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, int kcols, RowOperand P, RowOperand Q,
                     float *__restrict__ partial) {
   const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
@@ -1364,22 +1364,33 @@ wgrad_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int nc
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
   const long long nblk = (rows + 7) >> 3, bstep = (long long)gridDim.x * (GM_THREADS / 64);
-  for (long long blk = (long long)blockIdx.x * (GM_THREADS / 64) + wave; blk < nblk; blk += bstep) {
-    const long long r0 = blk * 8;
-    RawVec<1> praw[CT][4], qraw[4];
+  // The next trip's rows are requested before this trip's MFMAs, and every load is UNCONDITIONAL (row and column clamped to a
+  // valid address, the value discarded by op_finish).  A predicated op_load is a branch around its loads: the compiler then
+  // cannot count the loads in flight and waits for all of them (s_waitcnt vmcnt(0)) -- including the ones just requested for the
+  // next trip -- and the zero-initialisation of a predicated destination waits for the previous load into that register: the
+  // 12 loads of a trip went out as 4 dependent groups.  Invisible with the compacted classification rows (a wave makes ~4
+  // trips: 11.7 us), 137 us per launch on the segmentation step's dense 524 288-row first layers (32 trips per wave).
+  auto request = [&](long long blk_, RawVec<1> (&pr)[CT][4], RawVec<1> (&qr)[4]) {
+    const long long r0_ = blk_ * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rl = 4 * h + i;
-      const bool rok = r0 + rl < rows;
-      const int rc = rok ? rl : 0;                                  // (a row beyond the end: any valid address, discarded)
+      const int rc = r0_ + rl < rows ? rl : 0;                      // (a row beyond the end: the block's first row, discarded)
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int n = n0 + c * 32 + l;
-        op_load<1, PM>(P, r0, rc, n < ncols ? n : 0, rok && n < ncols, praw[c][i]);
+        op_load<1, PM>(P, r0_, rc, n < ncols ? n : 0, true, pr[c][i]);
       }
-      op_load<1, QM>(Q, r0, rc, l < kcols ? l : 0, rok && l < kcols, qraw[i]);
+      op_load<1, QM>(Q, r0_, rc, l < kcols ? l : 0, true, qr[i]);
     }
-    // (requesting the next trip's rows ahead of this trip's MFMAs was measured: 11.7 us per launch either way)
+  };
+  RawVec<1> praw[CT][4], qraw[4], pnext[CT][4], qnext[4];
+  long long blk = (long long)blockIdx.x * (GM_THREADS / 64) + wave;
+  if (blk < nblk) request(blk, praw, qraw);
+  for (; blk < nblk; blk += bstep) {
+    const long long r0 = blk * 8;
+    const bool more = blk + bstep < nblk;
+    if (more) request(blk + bstep, pnext, qnext);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rl = 4 * h + i;
@@ -1391,6 +1402,14 @@ wgrad_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int nc
         float pv[1];
         op_finish<1, PM>(P, pc[c], praw[c][i], r0 + rl, rok && n0 + c * 32 + l < ncols, pv);
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[0], qv[0], acc[c], 0, 0, 0);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        qraw[i] = qnext[i];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) praw[c][i] = pnext[c][i];
       }
     }
   }

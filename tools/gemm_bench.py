@@ -172,6 +172,10 @@ if __name__ == "__main__":
                                  (262144, 64, 128, 0.184), (65536, 64, 64, None)]:
             bench(rows, k, n, frac)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "wnarrow":     # narrow weight gradients (kcols <= 16): dense segmentation shapes and compacted classification ones
+        for rows, n, k, frac in [(524288, 32, 16, None), (524288, 32, 6, None), (524288, 64, 10, None), (524288, 64, 10, 0.127), (262144, 128, 6, 0.184)]:
+            bench_wgrad(rows, n, k, frac)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "small":       # narrow first-layer GEMMs (kdim <= 16)
         for rows, k, n, frac in [(524288, 6, 64, 0.127), (524288, 10, 64, 0.127), (262144, 6, 128, 0.184), (4096, 6, 256, None),
                                  (524288, 3, 32, None), (524288, 16, 32, None)]:
