@@ -51,12 +51,39 @@ three_nn_kernel(int b, int n, int m, int blocks_per_cloud, const float *__restri
 }
 
 // out[b, j, :] = sum_t w[b,j,t] * points[b, idx[b,j,t], :]
+// Both kernels take FOUR elements per trip with all index / weight loads of the four first, then the gathers, then the stores /
+// atomics: an element is a chain of two dependent round trips (idx -> the rows it names), a thread of the widest decoder level sees
+// 32 of them, and one after the other that is what the launch took (46 us for the backward of 65 536 x 256).  32-bit index
+// arithmetic while the element count allows (two 64-bit divisions per element otherwise).
 __global__ void __launch_bounds__(IT_THREADS)
 interp_fwd_kernel(long long rows, int n, int m, int c, const float *__restrict__ points,
                   const int *__restrict__ idx, const float *__restrict__ weight, float *__restrict__ out) {
-  const long long total = rows * c;
-  for (long long e = (long long)blockIdx.x * IT_THREADS + threadIdx.x; e < total;
-       e += (long long)gridDim.x * IT_THREADS) {
+  const long long total = rows * c, stride = (long long)gridDim.x * IT_THREADS;
+  if (total < (1LL << 31) && rows * 3 < (1LL << 31)) {
+    const unsigned tot = (unsigned)total, st = (unsigned)stride, cu = (unsigned)c, nu = (unsigned)n;
+    for (unsigned e0 = blockIdx.x * IT_THREADS + threadIdx.x; e0 < tot; e0 += 4 * st) {
+      unsigned ch[4], cloud[4]; int id[4][3]; float w[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned e = e0 + k * st < tot ? e0 + k * st : e0, r = e / cu;
+        ch[k] = e - r * cu; cloud[k] = r / nu;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { id[k][t] = idx[r * 3 + t]; w[k][t] = weight[r * 3 + t]; }
+      }
+      float v[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float *base = points + (long long)cloud[k] * m * c + ch[k];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) v[k][t] = base[(long long)id[k][t] * c];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (e0 + k * st < tot) out[e0 + k * st] = (w[k][0] * v[k][0] + w[k][1] * v[k][1]) + w[k][2] * v[k][2];
+    }
+    return;
+  }
+  for (long long e = (long long)blockIdx.x * IT_THREADS + threadIdx.x; e < total; e += stride) {
     const long long r = e / c;
     const int ch = (int)(e - r * c);
     const long long cloud = r / n;
@@ -72,9 +99,31 @@ __global__ void __launch_bounds__(IT_THREADS)
 interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__ grad_out,
                   const int *__restrict__ idx, const float *__restrict__ weight,
                   float *__restrict__ grad_points) {
-  const long long total = rows * c;
-  for (long long e = (long long)blockIdx.x * IT_THREADS + threadIdx.x; e < total;
-       e += (long long)gridDim.x * IT_THREADS) {
+  const long long total = rows * c, stride = (long long)gridDim.x * IT_THREADS;
+  if (total < (1LL << 31) && rows * 3 < (1LL << 31)) {
+    const unsigned tot = (unsigned)total, st = (unsigned)stride, cu = (unsigned)c, nu = (unsigned)n;
+    for (unsigned e0 = blockIdx.x * IT_THREADS + threadIdx.x; e0 < tot; e0 += 4 * st) {
+      unsigned ch[4], cloud[4]; int id[4][3]; float w[4][3], g[4]; bool ok[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ok[k] = e0 + k * st < tot;
+        const unsigned e = ok[k] ? e0 + k * st : e0, r = e / cu;
+        ch[k] = e - r * cu; cloud[k] = r / nu;
+        g[k] = grad_out[e];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { id[k][t] = idx[r * 3 + t]; w[k][t] = weight[r * 3 + t]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!ok[k]) continue;
+        float *base = grad_points + (long long)cloud[k] * m * c + ch[k];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) atomicAdd(base + (long long)id[k][t] * c, g[k] * w[k][t]);
+      }
+    }
+    return;
+  }
+  for (long long e = (long long)blockIdx.x * IT_THREADS + threadIdx.x; e < total; e += stride) {
     const long long r = e / c;
     const int ch = (int)(e - r * c);
     const long long cloud = r / n;
