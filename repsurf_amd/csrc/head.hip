@@ -56,7 +56,7 @@ __device__ __forceinline__ int hd_drow(int i, int h) { return (i & 3) + 8 * (i >
 // are 2 MB; 15.7 us now.)  Here 8 (4)
 // adjacent lanes read one whole 128-byte (64-byte) row segment, the chunk is written to LDS as planes of [k / 4][row] float4
 // (row XOR plane: the minimum of 4 bank passes per write), and the fragment read of lane (c, h) for the k group 2 g + h is one
-// conflict-free ds_read_b128.  The next chunk's loads fly under the current chunk's MFMAs.  `stage`: (1 + RB) * CK * 32 floats.
+// conflict-free ds_read_b128.  `stage`: (1 + RB) * CK * 32 floats.
 template <int RB>
 __device__ __forceinline__ void hd_mma_nt_lds(const float *__restrict__ A, int lda, int R, const float *__restrict__ B, int ldb,
                                               int ncols, int c0, int K, int kbeg, int kend, hd_f16 (&acc)[RB], float *stage) {
@@ -67,43 +67,67 @@ __device__ __forceinline__ void hd_mma_nt_lds(const float *__restrict__ A, int l
   const bool vec = (((lda | ldb | K) & 3) == 0) && ((((size_t)A | (size_t)B) & 15) == 0);
   float4 *Ws = reinterpret_cast<float4 *>(stage), *As = Ws + KG * 32;
   const int kmax = min(kend, K);
-  float4 wv[NB], av[RB][NB];
-  auto fetch = [&](int k0) {
+  // PF chunks are requested together, then committed and multiplied one after the other: a wave's whole k range of the
+  // classifier's layers (1 024 / 8 waves = 4 chunks) is ONE round trip to the weights instead of one per chunk -- the MFMAs of a
+  // chunk (0.4 us) are far too short to cover the next chunk's HBM latency.
+  constexpr int PF = RB == 1 ? 4 : 2;
+  float4 wv[PF][NB], av[PF][RB][NB];
+  // whole chunks of aligned rows (the classifier: K = 1 024 / 512): plain 16-byte loads, rows / columns beyond the end clamped
+  // to valid ones (their products land in accumulator rows / columns nobody reads).  Left to hd_load4's partial-row handling
+  // the compiler scalarised EVERY load of this loop into predicated 4-byte loads (no dwordx4 in the ISA at all).
+  const bool fast = vec && kend <= K && ((kend - kbeg) % CK) == 0;
+  auto fetch = [&](int k0, float4 (&w_)[NB], float4 (&a_)[RB][NB]) {
+    if (fast) {
+#pragma unroll
+      for (int p = 0; p < NB; ++p) {
+        const int row = lr + RPI * p, col = min(c0 + row, ncols - 1), kq = k0 + 4 * seg;
+        w_[p] = *reinterpret_cast<const float4 *>(B + (long long)col * ldb + kq);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+          a_[rb][p] = *reinterpret_cast<const float4 *>(A + (long long)min(rb * 32 + row, R - 1) * lda + kq);
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int row = lr + RPI * p, col = c0 + row, kq = k0 + 4 * seg;
-      wv[p] = hd_load4(B + (long long)(col < ncols ? col : 0) * ldb + kq, col < ncols ? kmax - kq : 0, vec);
+      w_[p] = hd_load4(B + (long long)(col < ncols ? col : 0) * ldb + kq, col < ncols ? kmax - kq : 0, vec);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         const int r = rb * 32 + row;
-        av[rb][p] = hd_load4(A + (long long)(r < R ? r : 0) * lda + kq, r < R ? kmax - kq : 0, vec);
+        a_[rb][p] = hd_load4(A + (long long)(r < R ? r : 0) * lda + kq, r < R ? kmax - kq : 0, vec);
       }
     }
   };
-  if (kbeg < kend) fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += CK) {
-    __builtin_amdgcn_wave_barrier();                 // (compiler-only: LDS operations of a wave complete in order)
+  for (int kg = kbeg; kg < kend; kg += PF * CK) {
 #pragma unroll
-    for (int p = 0; p < NB; ++p) {
-      const int row = lr + RPI * p;
-      Ws[seg * 32 + (row ^ seg)] = wv[p];
+    for (int f = 0; f < PF; ++f)
+      if (kg + f * CK < kend) fetch(kg + f * CK, wv[f], av[f]);
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) As[(rb * KG + seg) * 32 + (row ^ seg)] = av[rb][p];
-    }
-    if (k0 + CK < kend) fetch(k0 + CK);
-    __builtin_amdgcn_wave_barrier();
+    for (int f = 0; f < PF; ++f) {
+      if (kg + f * CK >= kend) break;
+      __builtin_amdgcn_wave_barrier();               // (compiler-only: LDS operations of a wave complete in order)
 #pragma unroll
-    for (int g = 0; g < KG / 2; ++g) {
-      const int kg = 2 * g + h;
-      const float4 b4 = Ws[kg * 32 + (c ^ kg)];
-      float4 a4[RB];
+      for (int p = 0; p < NB; ++p) {
+        const int row = lr + RPI * p;
+        Ws[seg * 32 + (row ^ seg)] = wv[f][p];
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) a4[rb] = As[(rb * KG + kg) * 32 + (c ^ kg)];
+        for (int rb = 0; rb < RB; ++rb) As[(rb * KG + seg) * 32 + (row ^ seg)] = av[f][rb][p];
+      }
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int g = 0; g < KG / 2; ++g) {
+        const int kq = 2 * g + h;
+        const float4 b4 = Ws[kq * 32 + (c ^ kq)];
+        float4 a4[RB];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(hd_get(a4[rb], i), hd_get(b4, i), acc[rb], 0, 0, 0);
+        for (int rb = 0; rb < RB; ++rb) a4[rb] = As[(rb * KG + kq) * 32 + (c ^ kq)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb)
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(hd_get(a4[rb], i), hd_get(b4, i), acc[rb], 0, 0, 0);
+      }
     }
   }
 }
@@ -117,9 +141,22 @@ __device__ __forceinline__ void hd_mma_nn(const float *__restrict__ A, int lda, 
   const bool cok = c0 + c < ncols;
   const float *wp = W + (cok ? c0 + c : 0);
   constexpr int U = 4;
+  // whole trips of aligned rows: plain loads, rows / columns beyond the end clamped (their products are never read); see hd_mma_nt_lds
+  const bool fast = vec && nend <= N && ((nend - nbeg) % (8 * U)) == 0;
+  const int cc = min(c0 + c, ncols - 1);
   for (int n0 = nbeg + 4 * h; n0 < nend; n0 += 8 * U) {
     float b[U][4];
     float4 a4[U][RB];
+    if (fast) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int nq = n0 + 8 * u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[u][i] = W[(long long)(nq + i) * ldw + cc];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) a4[u][rb] = *reinterpret_cast<const float4 *>(A + (long long)min(rb * 32 + c, R - 1) * lda + nq);
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int nq = n0 + 8 * u, avail = min(nend, N) - nq;
@@ -130,6 +167,7 @@ __device__ __forceinline__ void hd_mma_nn(const float *__restrict__ A, int lda, 
         const int r = rb * 32 + c;
         a4[u][rb] = hd_load4(A + (long long)(r < R ? r : 0) * lda + nq, r < R ? avail : 0, vec);
       }
+    }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
