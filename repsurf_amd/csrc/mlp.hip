@@ -1202,7 +1202,9 @@ gemm_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdi
                    const float *__restrict__ w, int ldw, Epilogue ep) {
   const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
   __shared__ double red[2][GM_THREADS / 32][CT * 32];          // [stat][wave x lane half][column]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, lrow = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform for the compiler too: block bases and row predicates in SGPRs
+                                                                   // (as a VGPR value it made every address of the block a 64-bit per-lane computation)
   // weights + bias of this lane's columns (w is n-major, zero in [kdim, ldw), ldw >= 8 KL: checked by the launcher)
   float4 wq[CT][KL];
   float bias[CT];
@@ -1259,17 +1261,27 @@ gemm_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdi
     int rbase = 4 * h;
     asm volatile("" : "+v"(rbase));                             // opaque per block: the 16 row offsets are recomputed here, not hoisted
                                                                 // out of the block loop into ~100 long-lived VGPRs (as in the tiled kernel)
-    const float *mw_t = ep.row_mult ? ep.row_mult + r0 : nullptr;
+    // Addresses: a wave-uniform base (SGPRs) + an unsigned 32-bit byte offset per lane -- the form global loads / stores take
+    // without a 64-bit VGPR pair; row validity is one 32-bit compare against the block's last valid row.  (With 64-bit per-lane
+    // row arithmetic every one of the 32-64 stores of a block carried ~17 instructions, 8 MFMAs carried ~1 100.)
+    const int last = (int)min(31LL, rows - 1 - r0);
+    const char *mw_t = reinterpret_cast<const char *>(ep.row_mult ? ep.row_mult + r0 : nullptr);
     float mw[16];
     if (stats) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int rl = rbase + (i & 3) + 8 * (i >> 2);
-        mw[i] = (mw_t && (full || r0 + rl < rows)) ? mw_t[rl] : 1.f;
+      for (int i = 0; i < 16; ++i) mw[i] = 1.f;
+      if (mw_t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                              // unconditional: a row beyond the end reads the last valid one (unused)
+          const int rl = min(rbase + (i & 3) + 8 * (i >> 2), last);
+          mw[i] = *reinterpret_cast<const float *>(mw_t + 4u * (unsigned)rl);
+        }
       }
     }
-    float *out_t = ep.out + r0 * ep.ldo;
-    const int ldo = (int)ep.ldo;
+    char *out_t = reinterpret_cast<char *>(ep.out + r0 * ep.ldo);
+    const unsigned ldo = 4u * (unsigned)ep.ldo;
+    unsigned o_out = (unsigned)rbase * ldo;
+    asm volatile("" : "+v"(o_out));
     // column tiles two at a time (32 accumulator registers live): with all four the 128-column instances spilled at 128 VGPRs.
     // (Tried: a 4 x 4 transpose inside the quads by DPP and 16-byte stores, 4 per column tile instead of 16 dword stores --
     //  48 234 x 6 -> 128: 18.7 against 12.1 us; the rows are 128-byte segments either way and the shuffles cost more than the stores.)
@@ -1300,12 +1312,24 @@ gemm_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdi
         float t0 = 0.f, t1 = 0.f;
         float y[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int rl = rbase + (i & 3) + 8 * (i >> 2);
-          const bool ok = cok && (full || r0 + rl < rows);
-          y[i] = acc[c][i] + bias[cb + c];
-          if (ok) out_t[rl * ldo + col] = y[i];
-          if (stats) {
+        for (int i = 0; i < 16; ++i) y[i] = acc[c][i] + bias[cb + c];
+        const unsigned o_col = o_out + 4u * (unsigned)col;
+        if (full) {                                                 // all 32 rows valid (every block of a launch but its last): one
+          if (cok) {                                                // predicate around the 16 stores instead of one each
+#pragma unroll
+            for (int i = 0; i < 16; ++i) *reinterpret_cast<float *>(out_t + (o_col + (unsigned)((i & 3) + 8 * (i >> 2)) * ldo)) = y[i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int ri = (i & 3) + 8 * (i >> 2);
+            if (cok && rbase + ri <= last) *reinterpret_cast<float *>(out_t + (o_col + (unsigned)ri * ldo)) = y[i];
+          }
+        }
+        if (stats) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const bool ok = cok && (full || rbase + (i & 3) + 8 * (i >> 2) <= last);
             const float yy = ok ? y[i] : 0.f;
             t0 = fmaf(mw[i], yy, t0);
             t1 = fmaf(mw[i] * yy, yy, t1);
@@ -1352,7 +1376,8 @@ wgrad_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int nc
                     float *__restrict__ partial) {
   const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
   __shared__ float red[GM_THREADS / 64][32][33];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (wave-uniform: see gemm_narrow_kernel)
   const int n0 = blockIdx.y * (32 * CT);
   ColCoef<1> pc[CT], qc;
 #pragma unroll
