@@ -588,12 +588,20 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       // forward operand modes never come with the mask epilogue, backward ones never with the statistics one:
       // the dead branch (and its registers) vanishes from the specialised instances
       constexpr bool CAN_STATS = MODE < 0 || MODE <= OPM_RELU2, CAN_MASK = MODE < 0 || MODE >= OPM_AFF2;
+      // Row validity is ONE 32-bit compare against the tile's last valid row, and every address of the epilogue is a wave-uniform
+      // base (SGPRs) + an unsigned 32-bit byte offset per lane -- the form global loads / stores take without a 64-bit VGPR pair.
+      // (With `r0 + rl < rows` in 64 bits and int element indices each of the 16-32 stores and 16-64 mask loads of a tile carried
+      // ~17 instructions: 300-1 000 per wave and tile, as much as the K loop of the 64 ... 128-channel layers.)
+      const int last = (int)min((long long)(BM - 1), rows - 1 - r0);
       float mw[16];
       if (CAN_STATS && EPI == EPI_STATS) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int rl = rbase + (i & 3) + 8 * (i >> 2);
-          mw[i] = (ep.row_mult && r0 + rl < rows) ? ep.row_mult[r0 + rl] : 1.f;
+        for (int i = 0; i < 16; ++i) mw[i] = 1.f;
+        if (ep.row_mult) {
+          const char *mwp = reinterpret_cast<const char *>(ep.row_mult + r0);
+#pragma unroll
+          for (int i = 0; i < 16; ++i)                            // unconditional: a row beyond the end reads the last valid one (unused)
+            mw[i] = *reinterpret_cast<const float *>(mwp + 4u * (unsigned)min(rbase + (i & 3) + 8 * (i >> 2), last));
         }
       }
 #pragma unroll
@@ -603,27 +611,27 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         const int cc = cok ? col : cols - 1;
         float y1v[16], y2v[16];
         if (CAN_MASK && EPI == EPI_MASK) {                    // the 16 (32) mask loads of this column tile in flight at once
-          int mrl[16];
+          unsigned mrl[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            mrl[i] = full ? rbase + (i & 3) + 8 * (i >> 2) : (int)min((long long)(rbase + (i & 3) + 8 * (i >> 2)), rows - 1 - r0);
+          for (int i = 0; i < 16; ++i) mrl[i] = (unsigned)(full ? rbase + (i & 3) + 8 * (i >> 2) : min(rbase + (i & 3) + 8 * (i >> 2), last));
+          const char *m1c = reinterpret_cast<const char *>(my1_t), *m2c = reinterpret_cast<const char *>(my2_t);
           // bf16 tensors: raw half words first (one branch around all loads), widened once they are all requested
           if (SB_MASK) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y1v[i] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(my1_t)[mrl[i] * ldm1 + cc]);
+            for (int i = 0; i < 16; ++i) y1v[i] = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short *>(m1c + 2u * (mrl[i] * (unsigned)ldm1 + (unsigned)cc)));
           } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y1v[i] = my1_t[mrl[i] * ldm1 + cc];
+            for (int i = 0; i < 16; ++i) y1v[i] = *reinterpret_cast<const float *>(m1c + 4u * (mrl[i] * (unsigned)ldm1 + (unsigned)cc));
           }
           if (!my2_t) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) y2v[i] = 0.f;
           } else if (SB_MASK) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y2v[i] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(my2_t)[mrl[i] * ldm2 + cc]);
+            for (int i = 0; i < 16; ++i) y2v[i] = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short *>(m2c + 2u * (mrl[i] * (unsigned)ldm2 + (unsigned)cc)));
           } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y2v[i] = my2_t[mrl[i] * ldm2 + cc];
+            for (int i = 0; i < 16; ++i) y2v[i] = *reinterpret_cast<const float *>(m2c + 4u * (mrl[i] * (unsigned)ldm2 + (unsigned)cc));
           }
           if (SB_MASK) {
 #pragma unroll
@@ -641,11 +649,11 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
           if (my2_t) { ms2 = ep.ms2[cc]; mt2 = ep.mt2[cc]; mu2 = ep.mean2[cc]; is2 = ep.invstd2[cc]; }
         }
         float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-        float ykeep[16];                                        // (bf16 output only) the rounded values, stored in pairs below
+        float ykeep[16];                                        // the tile's values as stored (bf16 output: rounded, stored in pairs below)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int rl = rbase + (i & 3) + 8 * (i >> 2);
-          const bool ok = cok && (full || r0 + rl < rows);
+          const bool ok = cok && (full || rl <= last);
           float y = acc[c][i] + bias;
           if (obf) y = bf16_round(y);                           // the sums below see what the stored tensor holds
           if (CAN_MASK && EPI == EPI_MASK) {
@@ -660,8 +668,25 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
             t0 = fmaf(mw[i], yy, t0);
             t1 = fmaf(mw[i] * yy, yy, t1);
           }
-          if (RS_STORE_BF16) ykeep[i] = y;
-          if (ok && !obf) out_t[rl * ldo + col] = y;
+          ykeep[i] = y;
+        }
+        if (!obf) {
+          // the tile's 16 stores of this column tile behind ONE predicate when every row of the tile is valid (all tiles of a launch
+          // but its last); per-row predicates (an exec save / restore and a branch each) only there
+          char *ob = reinterpret_cast<char *>(out_t);
+          const unsigned o_col = 4u * ((unsigned)rbase * (unsigned)ldo + (unsigned)col);
+          if (full) {
+            if (cok) {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) *reinterpret_cast<float *>(ob + (o_col + 4u * (unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)ldo)) = ykeep[i];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int ri = (i & 3) + 8 * (i >> 2);
+              if (cok && rbase + ri <= last) *reinterpret_cast<float *>(ob + (o_col + 4u * (unsigned)ri * (unsigned)ldo)) = ykeep[i];
+            }
+          }
         }
         if (obf) {
           // two bf16 per store: lanes j, j + 1 (adjacent columns) trade one value per row pair (i, i + 1) -- the even lane
@@ -678,11 +703,11 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
             if (pair_ok) {
               const int rl = odd ? rl1 : rl0;
               const unsigned lo = __float_as_uint(odd ? recv : ykeep[i]), hi = __float_as_uint(odd ? ykeep[i + 1] : recv);
-              if (cok && (full || r0 + rl < rows))
+              if (cok && (full || rl <= last))
                 *reinterpret_cast<unsigned *>(o16 + rl * ldo + (col & ~1)) = (lo >> 16) | (hi & 0xffff0000u);
             } else {
-              if (cok && (full || r0 + rl0 < rows)) o16[rl0 * ldo + col] = (unsigned short)(__float_as_uint(ykeep[i]) >> 16);
-              if (cok && (full || r0 + rl1 < rows)) o16[rl1 * ldo + col] = (unsigned short)(__float_as_uint(ykeep[i + 1]) >> 16);
+              if (cok && (full || rl0 <= last)) o16[rl0 * ldo + col] = (unsigned short)(__float_as_uint(ykeep[i]) >> 16);
+              if (cok && (full || rl1 <= last)) o16[rl1 * ldo + col] = (unsigned short)(__float_as_uint(ykeep[i + 1]) >> 16);
             }
           }
         }
