@@ -113,6 +113,23 @@ template <int V> __device__ __forceinline__ void ldx(const float *base, long lon
     ldv<V>(base + e, d);
   }
 }
+// The same from a WAVE-UNIFORM base pointer and an unsigned 32-bit element offset: the address is an SGPR pair + a 32-bit VGPR byte
+// offset (the `saddr` form of global_load), where `base + (long long) e` costs a sign extension and a 64-bit add per load.
+// Offsets are tile-relative (< 2^30 elements).
+template <int V> __device__ __forceinline__ void ldxu(const float *ubase, unsigned off, bool bf, float (&d)[V]) {
+  if constexpr (RS_STORE_BF16) {
+    const char *p = reinterpret_cast<const char *>(ubase) + (bf ? off << 1 : off << 2);
+    if (bf) {
+      if constexpr (V == 4) { const uint2 u = *reinterpret_cast<const uint2 *>(p); d[0] = __uint_as_float(u.x); d[1] = __uint_as_float(u.y); }
+      else if constexpr (V == 2) d[0] = __uint_as_float(*reinterpret_cast<const unsigned *>(p));
+      else d[0] = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short *>(p));
+    } else {
+      ldv<V>(reinterpret_cast<const float *>(p), d);
+    }
+  } else {
+    ldv<V>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + (off << 2)), d);
+  }
+}
 // raw bits of ldx -> fp32 values, in place (exact: a bf16 is the upper half of an fp32)
 template <int V> __device__ __forceinline__ void bf16_expand(float (&d)[V], bool bf) {
   if (RS_STORE_BF16 && bf) {
@@ -176,18 +193,20 @@ __device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int r
   for (int i = 0; i < V; ++i) { raw.a[i] = 0.f; raw.b[i] = 0.f; raw.g[i] = -1; }
   raw.m = 1.f; raw.k = 0;
   if (!ok) return;
-  const int offa = rl * (int)o.lda + c, offb = rl * (int)o.ldb + c;
+  // (r0 is wave-uniform in every caller: the row part of an address stays in SGPRs, the lane part is an unsigned 32-bit offset)
+  const unsigned offa = (unsigned)(rl * (int)o.lda + c), offb = (unsigned)(rl * (int)o.ldb + c), url = (unsigned)rl;
+  const float *ua = tile_base(o.a, r0 * o.lda, sb_a(mode)), *ub = o.b ? tile_base(o.b, r0 * o.ldb, sb_b(mode)) : nullptr;
   switch (mode) {
-    case OPM_ID: ldx<V>(o.a, r0 * o.lda + offa, sb_a(OPM_ID), raw.a); break;
-    case OPM_RELU1: ldx<V>(o.a, r0 * o.lda + offa, sb_a(OPM_RELU1), raw.a); break;
-    case OPM_RELU2: ldx<V>(o.a, r0 * o.lda + offa, sb_a(OPM_RELU2), raw.a); ldx<V>(o.b, r0 * o.ldb + offb, sb_b(OPM_RELU2), raw.b); break;
+    case OPM_ID: ldxu<V>(ua, offa, sb_a(OPM_ID), raw.a); break;
+    case OPM_RELU1: ldxu<V>(ua, offa, sb_a(OPM_RELU1), raw.a); break;
+    case OPM_RELU2: ldxu<V>(ua, offa, sb_a(OPM_RELU2), raw.a); ldxu<V>(ub, offb, sb_b(OPM_RELU2), raw.b); break;
     case OPM_AFF2:
-      ldx<V>(o.a, r0 * o.lda + offa, sb_a(OPM_AFF2), raw.a); ldx<V>(o.b, r0 * o.ldb + offb, sb_b(OPM_AFF2), raw.b);
-      if (o.mult) raw.m = o.mult[r0 + rl];
+      ldxu<V>(ua, offa, sb_a(OPM_AFF2), raw.a); ldxu<V>(ub, offb, sb_b(OPM_AFF2), raw.b);
+      if (o.mult) raw.m = (o.mult + r0)[url];
       break;
     case OPM_POOLED: {
       unsigned g;
-      if (o.grp) { g = (unsigned)o.grp[r0 + rl]; raw.k = o.slot[r0 + rl]; }           // compacted (ragged) groups
+      if (o.grp) { g = (unsigned)(o.grp + r0)[url]; raw.k = (o.slot + r0)[url]; }       // compacted (ragged) groups
       else {
         // dense groups: row / nsample.  nsample is a power of two in every shipped stack but the 2x classifier's (24): a
         // shift instead of the ~20-instruction 32-bit division sequence, per operand vector and chunk -- on fp32 MFMAs every
@@ -198,8 +217,8 @@ __device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int r
       }
       ldx<V>(o.a, (long long)g * o.lda + c, sb_a(OPM_POOLED), raw.a);
       ldvi<V>(o.arg + (long long)g * o.lda + c, raw.g);
-      ldx<V>(o.b, r0 * o.ldb + offb, sb_b(OPM_POOLED), raw.b);
-      if (o.mult) raw.m = o.mult[r0 + rl];
+      ldxu<V>(ub, offb, sb_b(OPM_POOLED), raw.b);
+      if (o.mult) raw.m = (o.mult + r0)[url];
       break;
     }
     default: {
@@ -261,17 +280,20 @@ template <int BM> struct AStage { static constexpr int PLANE = BM * 4 + 8; stati
 template <int BN> struct WStage { static constexpr int PLANE = BN * 4 + 8; static constexpr int SIZE = 8 * PLANE; };
 
 // LDS offset of element k (0..31, chunk-relative) of row r inside a stage with `plane` floats per plane
+// Which k meets which MFMA step is free as long as both operands agree: of 4 consecutive k (one thread's vector), the first two
+// go to the lk = 0 plane and the last two to the lk = 1 plane, adjacent slots -- the two 8-byte LDS stores of a vector then take
+// their values from adjacent registers.  (Round 2 interleaved them, (k0, k0 + 2) | (k0 + 1, k0 + 3): 24 register moves per chunk
+// to pair the values up, a tenth of the K loop's instructions.)
 __device__ __forceinline__ int frag_off(int k, int r, int plane) {
-  const int ks = k >> 1;
-  return ((ks >> 2) * 2 + (k & 1)) * plane + r * 4 + (ks & 3);
+  return ((k >> 3) * 2 + ((k >> 1) & 1)) * plane + r * 4 + (2 * ((k >> 2) & 1) + (k & 1));
 }
 // store V consecutive k of one row (k0 % V == 0)
 template <int V>
 __device__ __forceinline__ void frag_store(float *stage, int plane, int k0, int r, const float (&v)[V]) {
-  if constexpr (V == 4) {          // (k0, k0+2) -> plane lk=0, slots i0, i0+1;  (k0+1, k0+3) -> plane lk=1
+  if constexpr (V == 4) {          // (k0, k0+1) -> plane lk=0, slots i0, i0+1;  (k0+2, k0+3) -> plane lk=1, same slots
     float *b = stage + frag_off(k0, r, plane);
-    *reinterpret_cast<float2 *>(b) = make_float2(v[0], v[2]);
-    *reinterpret_cast<float2 *>(b + plane) = make_float2(v[1], v[3]);
+    *reinterpret_cast<float2 *>(b) = make_float2(v[0], v[1]);
+    *reinterpret_cast<float2 *>(b + plane) = make_float2(v[2], v[3]);
   } else {
 #pragma unroll
     for (int i = 0; i < V; ++i) stage[frag_off(k0 + i, r, plane)] = v[i];
@@ -394,7 +416,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
     for (int p = 0; p < W_VECS; ++p)
       if (part < 0 || (p * 4) / W_VECS == part) {
         const int n = min(n0 + p * 32 + w_n, cols - 1);
-        wraw[S][p] = *reinterpret_cast<const float4 *>(w + (long long)n * ldw + kw);
+        wraw[S][p] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(w) + 4u * ((unsigned)n * (unsigned)ldw + (unsigned)kw));   // SGPR base + 32-bit offset
       }
   };
   auto commit = [&](auto set_, float *As, float *Ws, long long r0, int k0) {
