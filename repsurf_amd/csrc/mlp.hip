@@ -427,7 +427,9 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       const int rl = p * A_RPP + a_r;
       const long long r = r0 + rl;
       float v[V];
-      op_finish<V, MODE>(E, coef[S], araw[S][p], r, kok && r < rows, v);
+      // only k >= kdim has to read as zero: a row beyond the end was loaded from the tile's last valid row (finite) and feeds
+      // nothing but its own row of D, which no epilogue stores or sums
+      op_finish<V, MODE>(E, coef[S], araw[S][p], r, kok, v);
       if constexpr (BF) {                                     // k = a_kq .. a_kq + V - 1 -> plane k >> 3, dword (k & 7) >> 1
         float *b = As + (a_kq >> 3) * PLANE_A + rl * 4 + ((a_kq & 7) >> 1);
         if constexpr (V == 4) *reinterpret_cast<float2 *>(b) = make_float2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
@@ -436,12 +438,13 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         frag_store<V>(As, PLANE_A, a_kq, rl, v);
       }
     }
-    const bool wk_ok = (k0 + w_kq) < ldw;                   // [kdim, ldw) is zero in memory
+    // The weights go to LDS as loaded: k in [kdim, ldw) is zero in memory, k beyond ldw (clamped to the row's last vector) meets
+    // operand values that were committed as zero, and a column beyond `cols` (clamped to the last one: finite) feeds only its own
+    // column of D, which no epilogue stores or sums.  (16 selects per chunk, 7 % of the loop, until round 3.)
 #pragma unroll
     for (int p = 0; p < W_VECS; ++p) {
       const int nl = p * 32 + w_n;
-      const bool ok = wk_ok && (n0 + nl < cols);
-      const float v[4] = {ok ? wraw[S][p].x : 0.f, ok ? wraw[S][p].y : 0.f, ok ? wraw[S][p].z : 0.f, ok ? wraw[S][p].w : 0.f};
+      const float v[4] = {wraw[S][p].x, wraw[S][p].y, wraw[S][p].z, wraw[S][p].w};
       if constexpr (BF)
         *reinterpret_cast<float2 *>(Ws + (w_kq >> 3) * PLANE_W + nl * 4 + ((w_kq & 7) >> 1)) =
             make_float2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
