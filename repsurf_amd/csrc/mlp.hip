@@ -983,18 +983,21 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
   op_coef<VQ, QM>(Q, k0 + q_c, qc_ok, qcoef);
 
   // part 0..3: a quarter of the next stage's loads (issued between the MFMA steps, see gemm_rows_kernel); < 0: all
+  // Loads are never predicated (as in the row GEMM): rows beyond the slab's end and columns beyond the matrix are CLAMPED to valid
+  // ones and the values zeroed when they are committed -- a predicated load is an exec-mask branch per vector, and the compiler
+  // can neither cluster such loads nor count them in flight.
   auto prefetch = [&](long long r0, int part) {
+    const int rlast = (int)min((long long)WG_BR - 1, rend - 1 - r0);
+    const int pc = pc_ok ? n0 + p_c : n0, qc = qc_ok ? k0 + q_c : k0;
 #pragma unroll
     for (int p = 0; p < P_VECS; ++p) {
       if (part >= 0 && (p * 4) / P_VECS != part) continue;
-      const int rl = p_row(p);
-      op_load<VP, PM>(P, r0, rl, n0 + p_c, pc_ok && r0 + rl < rend, praw[p]);
+      op_load<VP, PM>(P, r0, min(p_row(p), rlast), pc, true, praw[p]);
     }
 #pragma unroll
     for (int p = 0; p < Q_VECS; ++p) {
       if (part >= 0 && (p * 4) / Q_VECS != part) continue;
-      const int rl = q_row(p);
-      op_load<VQ, QM>(Q, r0, rl, k0 + q_c, qc_ok && rl < WG_BR && r0 + rl < rend, qraw[p]);
+      op_load<VQ, QM>(Q, r0, min(q_row(p), rlast), qc, true, qraw[p]);
     }
   };
   auto commit = [&](float *Ps, float *Qs, long long r0) {
