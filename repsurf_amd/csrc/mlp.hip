@@ -1239,7 +1239,7 @@ gemm_small_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim
   }
 }
 
-// ---- narrow row GEMM on the matrix pipe, no LDS (round 3): kdim <= 16, plain operand with 16-byte aligned rows ----------------
+// ---- narrow row GEMM on the matrix pipe, no LDS (round 3): kdim <= 16, plain operand, rows on 16- or 8-byte boundaries ---------
 // The first-layer branches of every stack (3 / 6 / 10 input channels -> 32 ... 128 columns) move one wide tensor OUT and almost
 // nothing in: 24.6 MB at 48 k x 128 is 3 us of HBM time.  Through the tiled kernel they took 13-23 us -- 1.5 tiles per workgroup,
 // each a chain of exposed round trips (operand prefetch -> LDS commit -> barrier -> 8 MFMAs -> row-multiplicity loads -> a
