@@ -21,6 +21,44 @@ def make_head(c0=1024, classes=15, p=0.4, seed=0):
     return seq
 
 
+def make_odd_head(c0, n1, n2, classes, seed=3):
+    torch.manual_seed(seed)
+    seq = nn.Sequential(nn.Linear(c0, n1), nn.BatchNorm1d(n1), nn.ReLU(True), nn.Dropout(0.0),
+                        nn.Linear(n1, n2), nn.BatchNorm1d(n2), nn.ReLU(True), nn.Dropout(0.0),
+                        nn.Linear(n2, classes)).cuda().train()
+    with torch.no_grad():
+        for m in seq:
+            if isinstance(m, nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    return seq
+
+
+@pytest.mark.parametrize("rows,c0,n1,n2,classes", [(7, 70, 48, 40, 7), (33, 100, 96, 33, 3), (64, 36, 64, 72, 40)])
+def test_head_with_ragged_sizes(rows, c0, n1, n2, classes):
+    """Widths that are not multiples of 32 / 4: the partial-chunk and unaligned paths of the staged layer kernels (the aligned
+    whole-chunk path is what the classifier's own sizes take, test above)."""
+    import copy
+    from repsurf_amd import head
+    ref = make_odd_head(c0, n1, n2, classes)
+    mine = copy.deepcopy(ref)
+    x = torch.randn(rows, c0, device="cuda")
+    w = torch.randn(rows, classes, device="cuda")
+    xr, xm = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    assert head.usable(mine, xm)
+    lp_ref = F.log_softmax(ref(xr), -1)
+    (lp_ref * w).sum().backward()
+    lp = head.classifier_logprobs(mine, xm)
+    (lp * w).sum().backward()
+    assert (lp - lp_ref).abs().max().item() <= 2e-5
+    assert (xm.grad - xr.grad).abs().max().item() <= 2e-5 * max(1.0, xr.grad.abs().max().item())
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        if n in ("0.bias", "4.bias"):
+            continue
+        rel = (pm.grad - pr.grad).norm().item() / max(pr.grad.norm().item(), 1e-12)
+        assert rel <= 5e-4, (n, rel)
+
+
 @pytest.mark.parametrize("rows", [32, 5, 64])
 def test_head_matches_modules_without_dropout(rows):
     import copy
