@@ -72,6 +72,9 @@ def parse():
                     help="uniform: synthetic uniform clouds in [-1,1]^3 (the metric's data); real: the 4 scanned objects of "
                          "tests/golden/geom_real.npz (first 1024 rows of the reference's visualization/*.txt clouds) tiled to the batch "
                          "-- surfaces, not volumes: 4-6x more DISTINCT ball-query slots, i.e. more shared-MLP rows (DESIGN 6/7)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check: spawn / join the ranks, one all-reduce over the process group (gloo where there is no "
+                         "HIP device), rank 0 prints one JSON line; no model, no kernels (tests/test_ddp_gloo.py)")
     ap.add_argument("--min-seconds", type=float, default=0.5,
                     help="the timed region replays max(--steps, ceil(min-seconds / step time)) steps (`steps_timed` on the line): "
                          "a 20-step sample of a 1.6 ms step is 32 ms, one clock wobble wide")
@@ -387,9 +390,7 @@ def main_seg(args):
     zero_grad -> forward -> cross-entropy -> backward -> Adam, same contract as the classification line."""
     from repsurf_amd import dist as rdist
     rank, world, local = rdist.env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (one rank per GPU)")
+    if world != args.gpus:         # under a launcher the launcher's world size is the truth (no launcher: main() spawned --gpus ranks)
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if "REPSURF_BENCH_DEVICE" in os.environ:
@@ -541,15 +542,49 @@ def main_seg(args):
     rdist.finish()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` -- one rank per GPU, rank 0 prints the line
+    (the reference spawns its ranks from the entry script too: segmentation/tool/train.py:478-484).  Under a launcher
+    (RANK / WORLD_SIZE in the environment) this is never reached."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def dry_run(args):
+    """--dry-run: the ranks exist, found each other and can reduce; nothing else."""
+    from repsurf_amd import dist as rdist
+    rank, world, local = rdist.env()
+    cuda = torch.cuda.is_available()
+    device = torch.device("cuda", local % max(1, torch.cuda.device_count())) if cuda else torch.device("cpu")
+    rdist.init(backend=os.environ.get("REPSURF_DIST_BACKEND", "nccl" if cuda else "gloo"), device=device)
+    t = torch.tensor([float(rank + 1)], device=device)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "requested": args.gpus, "rank_sum": float(t.item()),
+                          "backend": dist.get_backend() if dist.is_initialized() else None}), flush=True)
+    rdist.finish()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    if args.dry_run:
+        return dry_run(args)
     if args.workload == "seg":
         return main_seg(args)
     from repsurf_amd import dist as rdist
     rank, world, local = rdist.env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (one rank per GPU)")
+    if world != args.gpus:         # under a launcher the launcher's world size is the truth (no launcher: main() spawned --gpus ranks)
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # test hooks (tests/test_graph_gpu.py runs the world_size-2 path on a ONE-GPU box): both ranks on one device, gloo

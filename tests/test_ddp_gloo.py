@@ -192,3 +192,21 @@ def test_flatgrads_two_buckets_in_reverse_execution_order():
         (f0, v0, m0, p0), (f1, v1, m1, p1) = out[0], out[1]
     assert torch.allclose(f0, f1) and torch.equal(f0, v0) and torch.allclose(m0, m1)
     assert torch.allclose(f0, (p0 + p1) / 2, atol=1e-6) and f0.abs().sum() > 0
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` PLAIN (no torch.distributed.run around it: the form a driver may use) re-executes itself under
+    the launcher on 127.0.0.1 with a free port, the ranks join and reduce, rank 0 prints exactly one JSON line.  --dry-run stops
+    before the model (no HIP device here); tests/test_graph_gpu.py runs the full plain form on the GPU box."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["REPSURF_DIST_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out == {"dry_run": True, "n_gpus": 2, "requested": 2, "rank_sum": 3.0, "backend": "gloo"}

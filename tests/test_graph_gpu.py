@@ -184,7 +184,7 @@ def test_pipelined_sharded_step_single_rank_process_group():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("extra", [[], ["--no-pipeline", "--no-kernel-timing"], ["--no-graph", "--no-kernel-timing"]])
+@pytest.mark.parametrize("extra", [[], ["--no-pipeline", "--no-kernel-timing"], ["--no-graph", "--no-kernel-timing"], ["PLAIN", "--no-kernel-timing"]])
 def test_bench_world_size_two_on_one_gpu(extra, tmp_path):
     """bench.py's N > 1 code (rank seeds, flat-gradient all-reduce between the captured graphs, Adam graph, barrier +
     max-over-ranks timing, rank-0 JSON line) launched the way the driver launches it, with two ranks sharing the one GPU of
@@ -204,6 +204,9 @@ def test_bench_world_size_two_on_one_gpu(extra, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
            "--no-cpu-baseline"] + extra        # extra = []: exactly the driver's flags (per-launch timing pass on rank 0)
+    if extra and extra[0] == "PLAIN":          # `python bench.py --gpus 2` with no launcher around it: bench.py spawns its own ranks
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"] + extra[1:]
+        env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
