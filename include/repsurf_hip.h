@@ -481,6 +481,49 @@ typedef struct rs_umbrella_mlp {
 int rs_umbrella_mlp_pass(int pass, const rs_umbrella_mlp *m, float out_scale, float *out,
                          double *stat_partial, float *dw_partial, int nblk, void *stream);
 
+/* ---- the same MLP on the fp32 matrix pipe (repsurf_amd/csrc/umbrella_mfma.hip, round 4) ---------------------
+ * A wave owns 16 points at a time and walks their `group` fan rows as 16-row v_mfma_f32_16x16x4_f32 tiles; weights and
+ * BatchNorm vectors live in registers, weight gradients are MFMA accumulators (rows = the reduction index).  The passes whose
+ * sums are linear in the input are replaced by the MOMENTS of x: rs_umbrella_moments writes moments (11, 16) fp64,
+ * S[m][n] = sum_rows x_m x_n with index 10 = the constant 1 (S[10][k] = sum x_k, S[10][10] = rows) -- a function of the
+ * geometry alone (the caller computes it in its geometry stage); `partial` (nblk, RS_UMB_MOM_ROW) floats is scratch.
+ * BatchNorm 0 (of y0 = W0 x + b0) follows from the moments; so does the part of dW0 that is not sum dz0 x^T.
+ * rs_umbrella_mfma_pass(pass, m, nblk, stream), one launch of nblk workgroups each (RS_UMB_FIN: 10 workgroups):
+ *   three layers (classification/modules/repsurface_utils.py:266-274,296-305):
+ *     RS_UMB_F1  stat (nblk, 2, 16) fp64 = {sum y1, sum y1^2}; publishes bn0 (+ running statistics 0)       [nblk_f1 = nblk]
+ *     RS_UMB_F2  out (rows / group, 10) = out_scale * sum over the fan of y2; publishes bn1 (+ running statistics 1)
+ *     RS_UMB_B1  part_b1 (nblk, RS_UMB_B1_ROW): dW2, db2, BatchNorm-1 backward sums, the sums dW1 is built from [nblk_b1 = nblk]
+ *     RS_UMB_B2  part_b2 (nblk, RS_UMB_B2_ROW): sum dz0 x^T, BatchNorm-0 backward sums                        [nblk_b2 = nblk]
+ *     RS_UMB_FIN grads (360): dW0 [0,100) dgamma0 [100,110) dbeta0 [110,120) dW1 [120,220) dbias1 [220,230) (two layers only)
+ *                dgamma1 [230,240) dbeta1 [240,250) dW2 [250,350) dbias2 [350,360) (three layers only)
+ *   two layers (segmentation/modules/repsurface_utils.py:298-303,323-327; y0 = W0 x + b0, the output is the sum of y1):
+ *     RS_UMB_F2 (publishes bn0), RS_UMB_B2 (also dW1 = sum dy1^T a0, db1), RS_UMB_FIN.
+ * bn0 / bn1: (4, 10) = scale, shift, mean, invstd (the layout rs_bn_finalize writes); dout (rows / group, 10), already
+ * scaled for 'avg'.  Sums: fp32 inside a workgroup, fp64 across workgroups, fixed order (deterministic). */
+#define RS_UMB_C 10
+#define RS_UMB_MOM_ROW 176
+#define RS_UMB_B1_ROW 544
+#define RS_UMB_B2_ROW 368
+#define RS_UMB_GRADS 360
+enum { RS_UMB_F1 = 1, RS_UMB_F2 = 2, RS_UMB_B1 = 3, RS_UMB_B2 = 4, RS_UMB_FIN = 5 };
+typedef struct rs_umbrella_mfma {
+  const float *x; long long rows; int group; int layers;
+  const float *w0, *b0, *w1, *b1, *w2, *b2;
+  const float *gamma0, *beta0, *gamma1, *beta1;
+  float eps0, eps1, mom0, mom1;
+  float *bn0, *bn1;
+  float *run_mean0, *run_var0, *run_mean1, *run_var1;      /* NULL: no running statistics */
+  const double *moments;
+  const float *dout;
+  double *stat; int nblk_f1;
+  float *part_b1; int nblk_b1;
+  float *part_b2; int nblk_b2;
+  float out_scale; float *out;
+  float *grads;
+} rs_umbrella_mfma;
+int rs_umbrella_moments(const float *x, long long rows, float *partial, int nblk, double *moments, void *stream);
+int rs_umbrella_mfma_pass(int pass, const rs_umbrella_mfma *m, int nblk, void *stream);
+
 /* ---- sectorized FPS on the device: pointops.sectorized_fps
  * (segmentation/modules/pointops/functions/pointops.py:52-108) without its host loop and read-backs.
  * rs_sectorize: per cloud, angle = atan2(x, y), S + 1 linspace boundaries over [min, max + 1e-4], stable partition of the

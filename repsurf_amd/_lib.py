@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -57,6 +57,8 @@ SIGNATURES = {
     "rs_bn_backward_finalize_reduce": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, c_ll, P, P, P],
     "rs_pack_weights": [P, P],
     "rs_umbrella_mlp_pass": [c_int, P, c_float, P, P, P, c_int, P],
+    "rs_umbrella_moments": [P, c_ll, P, c_int, P, P],
+    "rs_umbrella_mfma_pass": [c_int, P, c_int, P],
     "rs_head_layer_forward": [P, P],
     "rs_head_output_forward": [c_int, c_int, c_int, P, P, P, P, P, P],
     "rs_head_output_backward": [c_int, c_int, c_int, P, P, P, P, P, P, P],

@@ -24,30 +24,33 @@ class GeoState:
     stage, FPS picks, their coordinates, ball-query indices and distinct-neighbour counts.  `UmbrellaClassifier.geometry`
     computes it; a training loop that knows its next batch can do that while the previous batch is still in backward
     (repsurf_amd.graph.PipelinedStep)."""
-    __slots__ = ("feat", "stages", "xyz")
+    __slots__ = ("feat", "stages", "xyz", "moments")
 
-    def __init__(self, feat, stages, xyz=None):
-        """xyz: the channels-last (B, N, 3) copy of the coordinates the geometry worked on (the stages group from it)"""
-        self.feat, self.stages, self.xyz = feat, stages, xyz
+    def __init__(self, feat, stages, xyz=None, moments=None):
+        """xyz: the channels-last (B, N, 3) copy of the coordinates the geometry worked on (the stages group from it);
+        moments: (11, 16) fp64 first / second moments of the fan features (repsurf_amd.mlp.umbrella_moments): BatchNorm 0 of the
+        constructor MLP follows from them, and they are geometry"""
+        self.feat, self.stages, self.xyz, self.moments = feat, stages, xyz, moments
         for i, g in enumerate(stages):       # every stage samples from the previous stage's centres
             g.center = (xyz if i == 0 else stages[i - 1].new_center)
 
     def tensors(self):
-        out = [self.feat] + ([self.xyz] if self.xyz is not None else [])
+        out = [self.feat] + ([self.xyz] if self.xyz is not None else []) + ([self.moments] if self.moments is not None else [])
         for g in self.stages:
             out += g.tensors()
         return out
 
     def clone(self):
-        return GeoState(self.feat.clone(), [g.clone() for g in self.stages], None if self.xyz is None else self.xyz.clone())
+        return GeoState(self.feat.clone(), [g.clone() for g in self.stages], None if self.xyz is None else self.xyz.clone(),
+                        None if self.moments is None else self.moments.clone())
 
     def copy_(self, other):
         dst, src = self.tensors(), other.tensors()
-        if len(dst) != len(src) or any(d is None or s_ is None or d.dtype not in (torch.float32, torch.int32) or d.dtype != s_.dtype
+        if len(dst) != len(src) or any(d is None or s_ is None or d.dtype not in (torch.float32, torch.int32, torch.float64) or d.dtype != s_.dtype
                                        for d, s_ in zip(dst, src)):
             # (an exception, not an assert: `python -O` must not turn a tensor of another dtype into a silently skipped copy)
-            raise RuntimeError("GeoState.copy_: the two states do not hold the same float32 / int32 tensors")
-        for dt in (torch.float32, torch.int32):          # one multi-tensor launch per dtype instead of one copy per tensor
+            raise RuntimeError("GeoState.copy_: the two states do not hold the same float32 / int32 / float64 tensors")
+        for dt in (torch.float32, torch.int32, torch.float64):          # one multi-tensor launch per dtype instead of one copy per tensor
             pairs = [(d, s_) for d, s_ in zip(dst, src) if d.dtype == dt]
             if pairs:
                 torch._foreach_copy_([p[0] for p in pairs], [p[1] for p in pairs])
@@ -103,7 +106,8 @@ class UmbrellaClassifier(nn.Module):
         else:           # one serial branch next to another batch's network: full-chip kNN first (under the light
             feat = sc.features(center, flip)    # head of that forward), the 32-workgroup FPS chains afterwards (1.98 vs 2.00 ms)
             plan = GeometryPlan(xyz, self._sampling, fork=False, compact=self._compact())
-        return GeoState(feat, [plan.stage(i) for i in range(len(self._sampling))], xyz)
+        moments = sc.moments(feat) if self.training else None
+        return GeoState(feat, [plan.stage(i) for i in range(len(self._sampling))], xyz, moments)
 
     def early_gradient_modules(self):
         """The modules whose parameter gradients are complete first in backward (the last SA stage, then the head): bucket 0
@@ -128,7 +132,7 @@ class UmbrellaClassifier(nn.Module):
         if points.is_cuda and self.training:
             _mlp.prepack(self._sa_convs())      # padded / transposed weight copies of all stages: one launch
         if geo is not None:
-            normal = self.surface_constructor(center, feat=geo.feat)
+            normal = self.surface_constructor(center, feat=geo.feat, moments=geo.moments)
         elif self.overlap_geometry:
             # same CPU-generator order as the reference: the constructor's flip first, then one FPS start per stage
             sc = self.surface_constructor

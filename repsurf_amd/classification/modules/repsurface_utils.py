@@ -210,13 +210,22 @@ class UmbrellaSurfaceConstructor(nn.Module):
             flip = rng.draw("flip", b, 2, xyz.device)
         return ops.umbrella_features(xyz, self.k, flip)           # [centre, polar, normal, pos]
 
-    def forward(self, center, flip=None, feat=None):
-        """feat: the output of `features` for these points when it was computed ahead of time."""
+    def moments(self, feat):
+        """First / second moments of the fan features (geometry-only): what BatchNorm 0 of `mlps` is computed from on the
+        matrix-pipe path (csrc/umbrella_mfma.hip).  None where that path does not apply (9-channel features)."""
+        if not self.return_dist or not feat.is_cuda:
+            return None
+        return _mlp.umbrella_moments(feat.reshape(-1, feat.shape[-1]))
+
+    def forward(self, center, flip=None, feat=None, moments=None):
+        """feat: the output of `features` for these points when it was computed ahead of time (moments: of `moments`)."""
         if feat is None:
             feat = self.features(center, flip)
+            moments = None
         b, n = feat.shape[0], feat.shape[1]
         if not self.return_dist:
             feat = feat[..., :9]
+            moments = None
         g = self.k - 1
-        pooled = _mlp.umbrella_mlp(feat.reshape(b * n * g, feat.shape[-1]), self.mlps, g, self.aggr_type)
+        pooled = _mlp.umbrella_mlp(feat.reshape(b * n * g, feat.shape[-1]), self.mlps, g, self.aggr_type, moments=moments)
         return pooled.view(b, n, -1).permute(0, 2, 1)

@@ -50,18 +50,24 @@ def sa_mlp_plain(x, convs, bns, nsample, relu_last=True):
     return mlp_hip.sa_mlp_plain(x, convs, bns, nsample, relu_last)
 
 
-def umbrella_mlp(x, mlps, group, aggr):
+def umbrella_mlp(x, mlps, group, aggr, moments=None):
     """UmbrellaSurfaceConstructor.mlps + aggregation (repsurface_utils.py:296-305):
     conv-bn-relu-conv-bn-relu-conv then sum/max/avg over the `group` fan triangles.
-    x (P*group, C) -> (P, C)."""
-    return mlp_hip.umbrella_mlp(x, mlps, group, aggr)
+    x (P*group, C) -> (P, C).  moments: `umbrella_moments(x)` computed ahead of time (geometry stage), optional."""
+    return mlp_hip.umbrella_mlp(x, mlps, group, aggr, moments)
 
 
-def umbrella_mlp2(x, mlps, group):
+def umbrella_mlp2(x, mlps, group, moments=None):
     """Segmentation UmbrellaSurfaceConstructor.mlps + aggregation
     (segmentation/modules/repsurface_utils.py:298-303,323-327): conv-bn-relu-conv, sum over the `group`
-    fan triangles.  x (P*group, C) -> (P, Cout)."""
-    return mlp_hip.umbrella_mlp2(x, mlps, group)
+    fan triangles.  x (P*group, C) -> (P, Cout).  moments: as umbrella_mlp."""
+    return mlp_hip.umbrella_mlp2(x, mlps, group, moments)
+
+
+def umbrella_moments(x):
+    """First and second moments of the (rows, 10) constructor features, (11, 16) fp64 (csrc/umbrella_mfma.hip): what BatchNorm 0
+    of the constructor MLP and the linear part of its first weight gradient are computed from.  Geometry-only."""
+    return mlp_hip.umbrella_moments(x)
 
 
 def row_linear(x, linear):

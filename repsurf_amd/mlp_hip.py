@@ -929,6 +929,125 @@ class _UmbrellaFused(Function):
                 res[2, :100].reshape(shp[2]), res[2, 100:])
 
 
+# ------------------------------------------------------------------------------------------- constructor MLP on the matrix pipe
+class UmbrellaMFMADesc(ctypes.Structure):      # rs_umbrella_mfma
+    _fields_ = [("x", P), ("rows", c_ll), ("group", c_int), ("layers", c_int),
+                ("w0", P), ("b0", P), ("w1", P), ("b1", P), ("w2", P), ("b2", P),
+                ("gamma0", P), ("beta0", P), ("gamma1", P), ("beta1", P),
+                ("eps0", ctypes.c_float), ("eps1", ctypes.c_float), ("mom0", ctypes.c_float), ("mom1", ctypes.c_float),
+                ("bn0", P), ("bn1", P), ("run_mean0", P), ("run_var0", P), ("run_mean1", P), ("run_var1", P),
+                ("moments", P), ("dout", P), ("stat", P), ("nblk_f1", c_int), ("part_b1", P), ("nblk_b1", c_int),
+                ("part_b2", P), ("nblk_b2", c_int), ("out_scale", ctypes.c_float), ("out", P), ("grads", P)]
+
+
+UMB_F1, UMB_F2, UMB_B1, UMB_B2, UMB_FIN = 1, 2, 3, 4, 5
+UMB_MOM_ROW, UMB_B1_ROW, UMB_B2_ROW, UMB_GRADS = 176, 544, 368, 360
+UMB_MFMA = os.environ.get("REPSURF_UMB_MFMA", "1") != "0"         # 0: the register-resident VALU passes of csrc/umbrella_mlp.hip
+UMB_MFMA_BLOCKS = int(os.environ.get("REPSURF_UMB_MFMA_BLOCKS", "256"))
+
+
+def _umb_blocks(rows, group):
+    """workgroups of a constructor pass: 4 waves each, a wave takes tiles of 16 points; at least one tile per wave"""
+    tiles = -(-(rows // group) // 16)
+    return max(1, min(UMB_MFMA_BLOCKS, -(-tiles // 4)))
+
+
+def umbrella_moments(x):
+    """(11, 16) fp64 moments of the (rows, 10) constructor features: S[m][n] = sum x_m x_n, index 10 = the constant 1.  They depend
+    on the geometry only: the pipelined step computes them in the geometry stage (side stream), next to the features."""
+    rows = x.shape[0]
+    nblk = max(1, min(256, -(-rows // 1024)))
+    part = torch.empty((nblk, UMB_MOM_ROW), dtype=torch.float32, device=x.device)
+    mom = torch.empty((11, 16), dtype=torch.float64, device=x.device)
+    _lib.call("rs_umbrella_moments", _ptr(x), rows, _ptr(part), nblk, _ptr(mom), _stream())
+    return mom
+
+
+def _bn_track(bn_mod):
+    track = bn_mod.track_running_stats and bn_mod.running_mean is not None
+    if track:
+        _pending_counters.append(bn_mod.num_batches_tracked)
+    mom = bn_mod.momentum if bn_mod.momentum is not None else 0.1
+    return track, float(mom)
+
+
+class _UmbrellaMFMA(Function):
+    """The constructor MLP on v_mfma_f32_16x16x4_f32 (csrc/umbrella_mfma.hip): three layers (classification): F1, F2 forward,
+    B1, B2, FIN backward; two layers (segmentation): F2 | B2, FIN.  BatchNorm 0 and the linear part of dW0 come from the moments
+    of x; the BatchNorm finalizes are prologues of the consuming passes.
+    args: x, meta, moments | None, then the parameters in module order."""
+
+    @staticmethod
+    def forward(ctx, x, meta, moments, *params):
+        dev = x.device
+        x = x.contiguous()
+        rows, group, layers = x.shape[0], meta["group"], meta["layers"]
+        if moments is None:
+            moments = umbrella_moments(x)
+        if layers == 3:
+            w0, g0, b0, w1, c1, g1, b1, w2, c2 = params
+            bn0, bn1 = meta["bns"]
+            cb0 = None
+        else:
+            w0, cb0, g0, b0, w1, c1 = params
+            bn0, bn1 = meta["bns"][0], None
+            w2 = c2 = g1 = b1 = None
+        det = lambda t: None if t is None else t.detach().contiguous()      # noqa: E731
+        w0_, w1_, w2_ = _w2d(w0), _w2d(w1), (None if w2 is None else _w2d(w2))
+        v0 = BNVec(10, dev)
+        v1 = BNVec(10, dev) if layers == 3 else None
+        nblk = _umb_blocks(rows, group)
+        tr0, mom0 = _bn_track(bn0)
+        tr1, mom1 = _bn_track(bn1) if bn1 is not None else (False, 0.1)
+        desc = UmbrellaMFMADesc(x=_ptr(x), rows=rows, group=group, layers=layers, w0=_ptr(w0_), b0=_ptr(det(cb0)), w1=_ptr(w1_), b1=_ptr(det(c1)),
+                                w2=_ptr(w2_), b2=_ptr(det(c2)), gamma0=_ptr(det(g0)), beta0=_ptr(det(b0)), gamma1=_ptr(det(g1)), beta1=_ptr(det(b1)),
+                                eps0=float(bn0.eps), eps1=float(bn1.eps) if bn1 is not None else 0.0, mom0=mom0, mom1=mom1,
+                                bn0=_ptr(v0.scale), bn1=None if v1 is None else _ptr(v1.scale),
+                                run_mean0=_ptr(bn0.running_mean) if tr0 else None, run_var0=_ptr(bn0.running_var) if tr0 else None,
+                                run_mean1=_ptr(bn1.running_mean) if tr1 else None, run_var1=_ptr(bn1.running_var) if tr1 else None,
+                                moments=_ptr(moments))
+        out = torch.empty((rows // group, 10), dtype=torch.float32, device=dev)
+        desc.out, desc.out_scale = _ptr(out), (1.0 / group if meta.get("aggr") == "avg" else 1.0)
+        keep = [x, moments, w0_, w1_, w2_, v0, v1, out]
+        if layers == 3:
+            stat = torch.empty((nblk, 2, 16), dtype=torch.float64, device=dev)
+            desc.stat, desc.nblk_f1 = stat.data_ptr(), nblk
+            _lib.call("rs_umbrella_mfma_pass", UMB_F1, ctypes.byref(desc), nblk, _stream())
+            keep.append(stat)
+        _lib.call("rs_umbrella_mfma_pass", UMB_F2, ctypes.byref(desc), nblk, _stream())
+        ctx.saved = dict(x=x, moments=moments, w0=w0_, w1=w1_, w2=w2_, cb0=det(cb0), c1=det(c1), c2=det(c2), v0=v0, v1=v1, nblk=nblk)
+        ctx.meta = meta
+        _flush_counters()
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s, meta = ctx.saved, ctx.meta
+        x, v0, v1 = s["x"], s["v0"], s["v1"]
+        dev = x.device
+        rows, group, layers, nblk = x.shape[0], meta["group"], meta["layers"], s["nblk"]
+        dout = dout.contiguous()
+        if meta.get("aggr") == "avg":
+            dout = dout * (1.0 / group)
+        part_b2 = torch.empty((nblk, UMB_B2_ROW), dtype=torch.float32, device=dev)
+        grads = torch.empty((UMB_GRADS,), dtype=torch.float32, device=dev)
+        desc = UmbrellaMFMADesc(x=_ptr(x), rows=rows, group=group, layers=layers, w0=_ptr(s["w0"]), b0=_ptr(s["cb0"]), w1=_ptr(s["w1"]), b1=_ptr(s["c1"]),
+                                w2=_ptr(s["w2"]), b2=_ptr(s["c2"]), bn0=_ptr(v0.scale), bn1=None if v1 is None else _ptr(v1.scale),
+                                moments=_ptr(s["moments"]), dout=_ptr(dout), part_b2=_ptr(part_b2), nblk_b2=nblk, grads=_ptr(grads))
+        if layers == 3:
+            part_b1 = torch.empty((nblk, UMB_B1_ROW), dtype=torch.float32, device=dev)
+            desc.part_b1, desc.nblk_b1 = _ptr(part_b1), nblk
+            _lib.call("rs_umbrella_mfma_pass", UMB_B1, ctypes.byref(desc), nblk, _stream())
+        _lib.call("rs_umbrella_mfma_pass", UMB_B2, ctypes.byref(desc), nblk, _stream())
+        _lib.call("rs_umbrella_mfma_pass", UMB_FIN, ctypes.byref(desc), nblk, _stream())
+        shp = meta["shapes"]
+        zero = _zeros.take(10, dev)             # the bias in front of a BatchNorm: exactly 0
+        if layers == 3:
+            return (None, None, None, grads[0:100].reshape(shp[0]), grads[100:110], grads[110:120], grads[120:220].reshape(shp[1]), zero,
+                    grads[230:240], grads[240:250], grads[250:350].reshape(shp[2]), grads[350:360])
+        return (None, None, None, grads[0:100].reshape(shp[0]), zero, grads[100:110], grads[110:120], grads[120:220].reshape(shp[1]), grads[220:230])
+
+
 class _UmbrellaStack2(Function):
     """conv-BN-ReLU-conv, then the sum over the `group` fan triangles: the segmentation constructor's mlps
     (segmentation/modules/repsurface_utils.py:298-303,323-327).  The input (geometric features) never needs a
@@ -1037,21 +1156,30 @@ class _UmbrellaFused2(Function):
         return (None, None, res[0, :100].reshape(shp[0]), g_c0, g_g0, g_b0, res[1, :100].reshape(shp[1]), res[1, 100:])
 
 
-def umbrella_mlp2(x, mlps, group):
+def umbrella_mlp2(x, mlps, group, moments=None):
+    """moments: umbrella_moments(x) when the caller computed them ahead of time (geometry stage)."""
     conv0, bn0, _, conv1 = mlps
     meta = {"group": group, "bn": bn0, "training": bn0.training, "shapes": [conv0.weight.shape, conv1.weight.shape]}
     fused = (x.shape[1] == 10 and tuple(conv0.weight.shape[:2]) == (10, 10) and tuple(conv1.weight.shape[:2]) == (10, 10)
              and conv0.bias is not None and conv1.bias is not None and bn0.training and FUSED_UMBRELLA)
+    if fused and UMB_MFMA and bn0.weight is not None:
+        meta.update(layers=2, bns=(bn0,))
+        return _UmbrellaMFMA.apply(x, meta, moments, conv0.weight, conv0.bias, bn0.weight, bn0.bias, conv1.weight, conv1.bias)
     fn = _UmbrellaFused2 if fused else _UmbrellaStack2
     return fn.apply(x, meta, conv0.weight, conv0.bias, bn0.weight, bn0.bias, conv1.weight, conv1.bias)
 
 
-def umbrella_mlp(x, mlps, group, aggr):
+def umbrella_mlp(x, mlps, group, aggr, moments=None):
+    """moments: umbrella_moments(x) when the caller computed them ahead of time (geometry stage)."""
     conv0, bn0, _, conv1, bn1, _, conv2 = mlps
     meta = {"group": group, "aggr": aggr, "bns": (bn0, bn1), "training": bn0.training,
             "shapes": [conv0.weight.shape, conv1.weight.shape, conv2.weight.shape]}
     fused = (x.shape[1] == 10 and conv0.weight.shape[:2] == (10, 10) and conv1.weight.shape[:2] == (10, 10)
              and conv2.weight.shape[:2] == (10, 10) and aggr in ("sum", "avg") and bn0.training and FUSED_UMBRELLA)
+    if fused and UMB_MFMA and conv0.bias is None and bn0.weight is not None and bn1.weight is not None:
+        meta["layers"] = 3
+        return _UmbrellaMFMA.apply(x, meta, moments, conv0.weight, bn0.weight, bn0.bias, conv1.weight, conv1.bias, bn1.weight,
+                                   bn1.bias, conv2.weight, conv2.bias)
     fn = _UmbrellaFused if fused else _UmbrellaStack
     return fn.apply(x, meta, conv0.weight, bn0.weight, bn0.bias, conv1.weight, conv1.bias, bn1.weight,
                     bn1.bias, conv2.weight, conv2.bias)

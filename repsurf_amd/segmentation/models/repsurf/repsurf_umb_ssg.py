@@ -66,7 +66,8 @@ class Model(nn.Module):
         fps = []
         for fine, coarse in ((3, 4), (2, 3), (1, 2), (0, 1)):          # fp4, fp3, fp2, fp1
             fps.append(SurfaceFeaturePropagationCD.geometry(centers[fine], offsets[fine], centers[coarse], offsets[coarse]))
-        return SegGeoState(feat, stages, fps)
+        moments = _mlp.umbrella_moments(feat.reshape(-1, 10)) if (self.training and feat.is_cuda) else None
+        return SegGeoState(feat, stages, fps, moments)
 
     def forward(self, pos_feat_off0, geo=None):
         with _mlp.deferred_counters():                 # num_batches_tracked += 1 of all 30 BatchNorms: one launch, not one per stack
@@ -78,7 +79,8 @@ class Model(nn.Module):
             _mlp.prepack(self._packed_layers())        # ~23 weight-pack launches of the step in one
         sg = geo.stages if geo is not None else [None] * 4
         fg = geo.fps if geo is not None else [None] * 4
-        normal = self.surface_constructor(coord, offset, feat=None if geo is None else geo.feat)
+        normal = self.surface_constructor(coord, offset, feat=None if geo is None else geo.feat,
+                                          moments=None if geo is None else geo.moments)
         level0 = [coord, normal, torch.cat([coord, feat], 1), offset]
         level1 = self.sa1(level0, geometry=sg[0])
         level2 = self.sa2(level1, geometry=sg[1])
@@ -98,13 +100,14 @@ class Model(nn.Module):
 class SegGeoState:
     """Tensors `Model.geometry` produced (int32 indices, coordinates, weights): what a forward needs besides the
     features and the parameters.  Offsets of the sampled levels are host-known constants of the batch shape."""
-    __slots__ = ("feat", "stages", "fps")
+    __slots__ = ("feat", "stages", "fps", "moments")
 
-    def __init__(self, feat, stages, fps):
-        self.feat, self.stages, self.fps = feat, stages, fps
+    def __init__(self, feat, stages, fps, moments=None):
+        """moments: (11, 16) fp64 moments of the fan features (repsurf_amd.mlp.umbrella_moments), geometry like the features"""
+        self.feat, self.stages, self.fps, self.moments = feat, stages, fps, moments
 
     def tensors(self):
-        out = [self.feat]
+        out = [self.feat] + ([self.moments] if self.moments is not None else [])
         for g in self.stages:
             out += [t for t in (g.fps_idx, g.new_center, g.group_idx) if t is not None]
         for idx, w in self.fps:
@@ -116,7 +119,7 @@ class SegGeoState:
         return SegGeoState(self.feat.clone(),
                            [StageGeometry(None if g.fps_idx is None else g.fps_idx.clone(), g.new_center.clone(), g.new_offset,
                                           g.group_idx.clone()) for g in self.stages],
-                           [(i.clone(), w.clone()) for i, w in self.fps])
+                           [(i.clone(), w.clone()) for i, w in self.fps], None if self.moments is None else self.moments.clone())
 
     def copy_(self, other):
         for d, s_ in zip(self.tensors(), other.tensors()):

@@ -245,8 +245,10 @@ class UmbrellaSurfaceConstructor(nn.Module):
         idx, _ = ops.knnquery_offset(self.k, center, center, offset, offset)
         return ops.umbrella_fan_offset(center, center, idx, offset, flip, self._rotate)      # (N,k,10)
 
-    def forward(self, center, offset, flip=None, feat=None):
+    def forward(self, center, offset, flip=None, feat=None, moments=None):
+        """moments: repsurf_amd.mlp.umbrella_moments of `feat` when both were computed ahead of time (geometry stage)"""
         n = center.shape[0]
         if feat is None:
             feat = self.features(center, offset, flip)
-        return _mlp.umbrella_mlp2(feat.reshape(n * self.k, 10), self.mlps, self.k)
+            moments = None
+        return _mlp.umbrella_mlp2(feat.reshape(n * self.k, 10), self.mlps, self.k, moments=moments)

@@ -57,7 +57,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     import subprocess
     from repsurf_amd import head, mlp_hip, optim
     pairs = {"rs_row_operand": mlp_hip.RowOperand, "rs_mlp_epilogue": mlp_hip.Epilogue, "rs_pack_weights_args": mlp_hip.PackArgs,
-             "rs_umbrella_mlp": mlp_hip.UmbrellaMLPDesc, "rs_bn_item": mlp_hip.BnItem, "rs_bn_bwd_item": mlp_hip.BnBwdItem,
+             "rs_umbrella_mlp": mlp_hip.UmbrellaMLPDesc, "rs_umbrella_mfma": mlp_hip.UmbrellaMFMADesc, "rs_bn_item": mlp_hip.BnItem, "rs_bn_bwd_item": mlp_hip.BnBwdItem,
              "rs_reduce_item": mlp_hip.ReduceItem, "rs_backward_tail_work": mlp_hip.BackwardTail, "rs_head_layer": head.HeadLayer,
              "rs_head_layer_bwd": head.HeadLayerBwd, "rs_adam_table": optim.AdamTable}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "repsurf_hip.h"', 'int main(void) {']

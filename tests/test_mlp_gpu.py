@@ -761,3 +761,69 @@ def test_owned_pass_carries_pending_reductions_across_stacks_with_identical_grad
     ga, gb = run(False), run(True)
     assert len(ga) == len(gb) and all(torch.equal(p, q) for p, q in zip(ga, gb))
     assert H.OWNED_PASS == 0
+
+
+@pytest.mark.parametrize("layers,points,group", [(3, 300, 8), (3, 2048, 8), (3, 33, 5), (2, 200, 9), (2, 7000, 9), (2, 16, 8), (3, 1, 8)])
+def test_constructor_mlp_on_the_matrix_pipe(layers, points, group):
+    """csrc/umbrella_mfma.hip (v_mfma_f32_16x16x4_f32 tiles of 16 points, BatchNorm 0 from the moments of x, finalizes folded into the
+    consuming passes) against (a) the fp64 evaluation of the same modules, (b) the register-resident VALU passes it replaces
+    (csrc/umbrella_mlp.hip): output, both BatchNorms' running statistics, every gradient; point counts that are not a multiple of
+    the 16-point tile, fans of 5 / 8 / 9, a single point; the moments handed in ahead of time (the geometry stage does) or not."""
+    from repsurf_amd import mlp, mlp_hip as H
+    torch.manual_seed(31 + points)
+    if layers == 3:
+        mlps = nn.Sequential(nn.Conv2d(10, 10, 1, bias=False), nn.BatchNorm2d(10), nn.ReLU(True), nn.Conv2d(10, 10, 1),
+                             nn.BatchNorm2d(10), nn.ReLU(True), nn.Conv2d(10, 10, 1)).cuda()
+        bn_idx = (1, 4)
+    else:
+        mlps = nn.Sequential(nn.Conv1d(10, 10, 1), nn.BatchNorm1d(10), nn.ReLU(True), nn.Conv1d(10, 10, 1)).cuda()
+        nn.init.uniform_(mlps[0].bias, -0.5, 0.5)
+        bn_idx = (1,)
+    for i in bn_idx:
+        nn.init.uniform_(mlps[i].weight, 0.5, 1.5)
+        nn.init.uniform_(mlps[i].bias, -0.3, 0.3)
+    mlps.train()
+    x = (torch.randn(points * group, 10) * torch.linspace(0.3, 2.0, 10) + torch.linspace(-1, 1, 10)).cuda()
+    w = torch.randn(points, 10).cuda()
+    torch_executor.set_backend("hip")
+
+    def run(kind):
+        m = copy.deepcopy(mlps)
+        xx = x
+        if kind == "fp64":
+            m, xx = m.double(), x.double()
+            torch_executor.set_backend("torch")
+        H.UMB_MFMA = kind in ("mfma", "mfma+moments")
+        try:
+            mom = mlp.umbrella_moments(x) if kind == "mfma+moments" else None
+            if layers == 3:
+                out = mlp.umbrella_mlp(xx, m, group, "sum", moments=mom)
+            else:
+                out = mlp.umbrella_mlp2(xx, m, group, moments=mom)
+            (out * w.to(out.dtype)).sum().backward()
+        finally:
+            H.UMB_MFMA = True
+            torch_executor.set_backend("hip")
+        stats = [t.clone() for i in bn_idx for t in (m[i].running_mean, m[i].running_var)]
+        return out.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}, stats
+
+    ref, valu, new, new2 = run("fp64"), run("valu"), run("mfma"), run("mfma+moments")
+    assert torch.equal(new[0], new2[0]) and all(torch.equal(new[1][k], new2[1][k]) for k in new[1])
+    pre_bn_bias = "3.bias" if layers == 3 else "0.bias"
+    single = points * group < 2           # one row: the batch variance is 0 and every BatchNorm gradient degenerates
+    for name, got in (("valu", valu), ("mfma", new)):
+        assert rel(got[0].double(), ref[0]) < (1e-5 if not single else 1e-3), (name, rel(got[0].double(), ref[0]))
+        for a, b in zip(got[2], ref[2]):
+            assert torch.allclose(a.double(), b, rtol=2e-5, atol=1e-6), name
+        for pname, gt in ref[1].items():
+            if pname == pre_bn_bias:
+                assert got[1][pname].abs().max() == 0
+                continue
+            if single:
+                continue
+            assert rel_l2(got[1][pname].double(), gt) < 2e-3, (name, pname, rel_l2(got[1][pname].double(), gt))
+    # the matrix-pipe path is at least as close to the fp64 evaluation as the path it replaces (up to noise)
+    if not single:
+        for pname, gt in ref[1].items():
+            if pname != pre_bn_bias:
+                assert rel_l2(new[1][pname].double(), gt) < 3 * rel_l2(valu[1][pname].double(), gt) + 1e-5, pname

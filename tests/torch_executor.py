@@ -52,7 +52,7 @@ def sa_mlp_plain(x, convs, bns, nsample, relu_last=True):
     return h.view(-1, nsample, h.shape[1]).max(dim=1)[0]
 
 
-def umbrella_mlp(x, mlps, group, aggr):
+def umbrella_mlp(x, mlps, group, aggr, moments=None):
     conv0, bn0, _, conv1, bn1, _, conv2 = mlps
     h = F.relu(_bn(F.linear(x, _w2d(conv0), conv0.bias), bn0))
     h = F.relu(_bn(F.linear(h, _w2d(conv1), conv1.bias), bn1))
@@ -64,7 +64,7 @@ def umbrella_mlp(x, mlps, group, aggr):
     return h.sum(dim=1)
 
 
-def umbrella_mlp2(x, mlps, group):
+def umbrella_mlp2(x, mlps, group, moments=None):
     conv0, bn0, _, conv1 = mlps
     h = F.relu(_bn(F.linear(x, _w2d(conv0), conv0.bias), bn0))
     return F.linear(h, _w2d(conv1), conv1.bias).view(-1, group, conv1.weight.shape[0]).sum(dim=1)
