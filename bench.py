@@ -292,11 +292,74 @@ def algorithmic_bytes(name, dims):
     return None
 
 
-def roofline_from_profile(prof, timed_steps, dtype):
+def gemm_family_in_graph(forward_loss, net, replays=20):
+    """The matrix-pipe launches of ONE step (every rs_mlp_gemm_rows / rs_mlp_wgrad call of forward + backward) as they run inside
+    a replayed step: recorded during one eager pass, captured into ONE hipGraph, replayed `replays` times between two HIP events.
+    Per-launch events of the eager pass include ~5-10 us of idle device in front of every launch (the host is slower than the
+    kernels); a replay has none, which is what the training step's graph sees (rocprofv3 of the replayed step agrees:
+    profiles/r04/).  The loss is held until the replays are done, so every tensor the calls read is alive; what they WRITE are
+    buffers of that same pass (free blocks of the caching allocator by then: nothing else allocates in between).
+    -> {"ms_per_step": all launches, "launches": n, "by_class_us": {class key: avg us per launch}}"""
+    from repsurf_amd import _lib
+    for p in net.parameters():
+        p.grad = None
+    _lib.record_calls(True)
+    loss = forward_loss()
+    loss.backward()
+    calls = _lib.record_calls(False)
+    torch.cuda.synchronize()
+    if not calls:
+        return None
+
+    def timed_graph(subset):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            _lib.replay_calls(subset, torch.cuda.current_stream().cuda_stream)
+        for _ in range(3):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(replays):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / replays
+
+    out = {"ms_per_step": timed_graph(calls), "launches": len(calls), "replays": replays}
+    # per launch class (ABI call + sizes + operand / epilogue modes, as in roofline_from_profile): its launches alone, back to back
+    classes = {}
+    for name, a in calls:
+        ints = tuple(x for x, t in zip(a, _lib.SIGNATURES[name]) if t is _lib.c_int or t is _lib.c_ll)
+        if name.startswith("rs_mlp_gemm_rows"):
+            key = (name,) + ints + (f"op={a[4]._obj.mode}", f"epi={a[7]._obj.mode}{'+2' if a[7]._obj.my2 else ''}")
+        else:
+            key = (name,) + ints + (f"p={a[4]._obj.mode}", f"q={a[5]._obj.mode}")
+        classes.setdefault(key, []).append((name, a))
+    # a class IN its place in the step: the whole sequence minus the sequence without the class's launches (leave-one-out; a graph
+    # of one class alone would run it on a warm cache, back to back with itself)
+    total = out["ms_per_step"]
+    out["by_class_us"] = {}
+    for k, v in classes.items():
+        ids = {id(c[1]) for c in v}
+        rest = [c for c in calls if id(c[1]) not in ids]
+        out["by_class_us"][k] = max(0.0, total - (timed_graph(rest) if rest else 0.0)) * 1e3 / len(v)
+    del loss
+    return out
+
+
+def roofline_from_profile(prof, timed_steps, dtype, in_graph=None):
     """prof: {abi name: [(ms, dims)]} of an eager pass -> (roofline of the MFMA / byte-priced launch class with the largest
-    time per step, table of all classes)."""
+    time per step, table of all classes).  in_graph (gemm_family_in_graph): the same launches timed inside a replayed hipGraph --
+    when present, the GEMM-shaped classes are priced on THOSE durations (what the step runs at) and the per-launch HIP-event
+    figures of the eager pass ride along as `eager_*`."""
     roofline = None
     table = []
+    graph_us = {}
+    if in_graph:
+        for key, us in in_graph["by_class_us"].items():
+            graph_us[(key[0],) + tuple(str(d) for d in key[1:])] = us
     for name, recs in prof.items():
         by_dims = {}
         rows_of = {}
@@ -311,8 +374,14 @@ def roofline_from_profile(prof, timed_steps, dtype):
             if dims in rows_of:
                 dims = dims + (f"rows={float(np.mean(rows_of[dims])):.1f}",)
             unit, amount = algorithmic_cost(name, dims)
-            table.append({"kernel": name, "dims": list(dims), "launches": len(ts), "avg_us": float(np.mean(ts)) * 1e3,
-                          "total_ms_per_step": float(np.sum(ts)) / max(1, timed_steps), "unit": unit, "amount": amount})
+            row = {"kernel": name, "dims": list(dims), "launches": len(ts), "avg_us": float(np.mean(ts)) * 1e3,
+                   "total_ms_per_step": float(np.sum(ts)) / max(1, timed_steps), "unit": unit, "amount": amount}
+            gkey = (name,) + tuple(str(d) for d in dims if not (isinstance(d, str) and (d.startswith("rows=") or d.startswith("sb="))))
+            if gkey in graph_us:         # the class as it runs inside a replayed graph
+                row["eager_avg_us"] = row["avg_us"]
+                row["avg_us"] = graph_us[gkey]
+                row["total_ms_per_step"] = row["avg_us"] * 1e-3 * len(ts) / max(1, timed_steps)
+            table.append(row)
     table.sort(key=lambda r: -r["total_ms_per_step"])
     for row in table:
         if row["unit"] is None:
@@ -328,6 +397,11 @@ def roofline_from_profile(prof, timed_steps, dtype):
             roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "hbm", "achieved": round(ach, 2),
                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5)}
         roofline["avg_launch_us"] = round(row["avg_us"], 2)
+        if "eager_avg_us" in row:
+            roofline["timed"] = ("inside a replayed hipGraph, in its place in the step: (all GEMM-family launches of one recorded step as one graph) minus (the "
+                                 "same graph without this class), 20 replays each between two HIP events (gemm_family_in_graph); eager_avg_launch_us: "
+                                 "per-launch HIP events of the eager pass (host-paced)")
+            roofline["eager_avg_launch_us"] = round(row["eager_avg_us"], 2)
         roofline["launches_per_step"] = row["launches"] // max(1, timed_steps)
         roofline["traffic"] = traffic_from_profiles(row["kernel"], row["dims"])
         ab = algorithmic_bytes(row["kernel"], row["dims"])
@@ -342,12 +416,24 @@ def roofline_from_profile(prof, timed_steps, dtype):
         break
     # every MFMA launch of the step together (all shared-MLP GEMMs + weight-gradient GEMMs)
     fl = sum(r["amount"] * r["launches"] for r in table if r["unit"] == "flops")
-    tm = sum(r["avg_us"] * r["launches"] for r in table if r["unit"] == "flops") * 1e-6
+    tm = sum(r.get("eager_avg_us", r["avg_us"]) * r["launches"] for r in table if r["unit"] == "flops") * 1e-6      # (per-launch events of the eager pass)
     if roofline is not None and tm > 0:
         roofline["all_mfma_launches"] = {"achieved": round(fl / tm / 1e12, 2), "unit": "TFLOP/s",
                                          # (bf16 run: row GEMMs on the bf16 pipe, weight gradients on the fp32 one -- no single peak)
                                          "frac": round(fl / tm / 1e12 / PEAK_F32_MFMA_TF, 4) if dtype == "fp32" else None,
                                          "ms_per_step": round(tm * 1e3 / max(1, timed_steps), 4)}
+        if in_graph:
+            # every GEMM + weight-gradient launch of one step as ONE replayed graph (no idle device between launches)
+            fl_step = fl / max(1, timed_steps)
+            sec = in_graph["ms_per_step"] * 1e-3
+            eager = roofline["all_mfma_launches"]
+            roofline["all_mfma_launches"] = {
+                "achieved": round(fl_step / sec / 1e12, 2), "unit": "TFLOP/s",
+                "frac": round(fl_step / sec / 1e12 / PEAK_F32_MFMA_TF, 4) if dtype == "fp32" else None,
+                "ms_per_step": round(in_graph["ms_per_step"], 4), "launches_per_step": in_graph["launches"],
+                "timed": f"the {in_graph['launches']} GEMM-family launches of one recorded step captured as one hipGraph, {in_graph['replays']} replays between two HIP events",
+                "eager": {"achieved": eager["achieved"], "frac": eager["frac"], "ms_per_step": eager["ms_per_step"],
+                          "timed": "sum of per-launch HIP events of the eager pass"}}
     return roofline, table
 
 
@@ -631,6 +717,7 @@ def main():
         torch.cuda.synchronize()
 
     mode = "eager"
+    in_graph = None
     timing = not args.no_kernel_timing
     if use_graph:
         # Capture FIRST (an eager step on the default stream before capture leaves AccumulateGrad nodes on
@@ -704,6 +791,7 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         _lib.profile_enable(False)
+        in_graph = gemm_family_in_graph(lambda: criterion(twin(points), label), twin)
     dt = rdist.max_over_ranks(dt, device)
     allreduce_us = rdist.time_allreduce(sum(p.numel() for p in model.parameters()), device) if world > 1 else None
     if "REPSURF_BENCH_DUMP" in os.environ:       # test hook: every rank's parameters after the timed loop
@@ -715,7 +803,7 @@ def main():
     if rank == 0:
         ms = dt / steps_timed * 1e3
         value = args.batch * world * steps_timed / dt
-        roofline, table = roofline_from_profile(prof, getattr(args, "timed_steps", args.steps), args.dtype)
+        roofline, table = roofline_from_profile(prof, getattr(args, "timed_steps", args.steps), args.dtype, in_graph)
         if args.launch_log:
             os.makedirs(os.path.dirname(os.path.abspath(args.launch_log)), exist_ok=True)
             json.dump([[n, list(d)] for n, d in _lib.profile_sequence()], open(args.launch_log, "w"))

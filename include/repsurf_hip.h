@@ -422,9 +422,11 @@ int rs_smooth_cls_loss(int rows, int classes, float eps, const float *logp, cons
 /* nn.CrossEntropyLoss(ignore_index) of the segmentation train loop (segmentation/tool/train.py:110,296) on logits (rows, classes):
  * loss[0] = mean over rows with target != ignore_index of logsumexp(row) - row[target]; inv_count[0] = 1 / (number of such rows);
  * dlogits (rows, classes) = softmax(row) - onehot(target) (zero rows where ignored): d loss / d logits = dlogits * inv_count[0].
- * partial: 2 * ceil(rows / 256) doubles of scratch. */
+ * partial: 2 * ceil(rows / 256) doubles of scratch.  A label outside [0, classes) that is not ignore_index makes the row's loss and
+ * gradient NaN (torch traps it with a device assert) and adds 1 to *bad_labels (device int, never reset by the library; NULL:
+ * not counted) -- what a training loop polls, since a NaN inside a replayed graph raises nothing on the host. */
 int rs_cross_entropy_forward(long long rows, int classes, long long ignore_index, const float *logits, const long long *target,
-                             float *loss, float *inv_count, float *dlogits, double *partial, void *stream);
+                             float *loss, float *inv_count, float *dlogits, double *partial, int *bad_labels, void *stream);
 /* out[i] = x[i] * a[0] * (b ? b[0] : 1): a, b device scalars (the loss gradient times 1 / count and the incoming gradient) */
 int rs_scale_by_scalars(long long n, const float *x, const float *a, const float *b, float *out, void *stream);
 /* Column sums, stage 1: partial (nblk, n), row slab b of x (rows, n; rows ldx floats apart) summed per column and multiplied by

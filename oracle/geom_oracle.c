@@ -17,10 +17,11 @@
  *   t / np.pi, t / (2*np.pi) + .5  -> t / (float)pi, t / (float)(2 pi) + 0.5f
  * Compile with -ffp-contract=off (see Makefile) so that only the fmaf() calls fuse.
  *
- * Parity status: PINNED against the reference's executable classification CPU path for
- * FPS / ball query / kNN indices (bit-exact) and umbrella features (1e-6); the segmentation
- * functions (packed batches) restate CUDA kernels that cannot run here -> "parity unpinned"
- * for those.
+ * Parity status: PINNED for both sub-projects.  Classification: against the reference's executable CPU path for
+ * FPS / ball query / kNN indices (bit-exact) and umbrella features (1e-6).  Segmentation (packed batches): the functions
+ * restate CUDA kernels, and those kernels are EXECUTED here -- oracle/_ref compiles the reference's *_cuda_kernel.cu files
+ * unmodified as host code (oracle/Makefile.ref) and tests/test_oracle_ref.py / test_oracle_seg_golden.py compare every
+ * packed-batch function below with them, tie rules included.
  */
 #include <math.h>
 #include <stdint.h>

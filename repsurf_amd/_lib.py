@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -50,7 +50,7 @@ SIGNATURES = {
     "rs_pool_select": [c_ll, c_int, P, P, P, P, P, P, P, P, P],
     "rs_reduce_partials": [c_int, c_ll, P, P, P],
     "rs_backward_tail": [P, P],
-    "rs_cross_entropy_forward": [c_ll, c_int, c_ll, P, P, P, P, P, P, P],
+    "rs_cross_entropy_forward": [c_ll, c_int, c_ll, P, P, P, P, P, P, P, P],
     "rs_scale_by_scalars": [c_ll, P, P, P, P, P],
     "rs_col_sum_partials": [c_ll, c_int, P, c_ll, ctypes.c_float, P, c_int, P],
     "rs_bn_finalize_batch": [P, c_int, P],
@@ -176,9 +176,38 @@ def profile_sequence():
     return [(entry[0], _dims_of(entry)) for entry in _frozen]
 
 
+GEMM_FAMILY = ("rs_mlp_gemm_rows", "rs_mlp_gemm_rows_bf16", "rs_mlp_wgrad", "rs_mlp_wgrad_bf16")
+_recorded = None   # None = off; else [(name, args)] of the GEMM-family calls made while recording
+
+
+def record_calls(on):
+    """Keep (name, arguments) of every GEMM-family ABI call made from now on (bench.py replays them as ONE hipGraph to time the
+    matrix-pipe launches of a step the way a replayed step runs them: back to back, no host in between).  The argument tuples keep
+    their ctypes structs alive; the caller keeps the TENSORS alive (it holds the step's loss, hence the autograd nodes' saved state).
+    record_calls(False) -> the list."""
+    global _recorded
+    if on:
+        _recorded = []
+        return None
+    out, _recorded = _recorded, None
+    return out or []
+
+
+def replay_calls(calls, stream):
+    """Re-issue recorded calls on `stream` (a raw hipStream_t; the stream argument is the last one of every ABI function)."""
+    lib = load()
+    for name, args in calls:
+        rc = getattr(lib, name)(*args[:-1], stream)
+        if rc != 0:
+            msg = lib.rs_last_error()
+            raise RepSurfHipError(f"{name} (replayed) failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
 def call(name, *args):
     """Invoke an ABI function; non-zero return -> RepSurfHipError with the library's message."""
     lib = load()
+    if _recorded is not None and name in GEMM_FAMILY:
+        _recorded.append((name, args))
     if _profile is not None:
         import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -106,7 +106,7 @@ class UmbrellaClassifier(nn.Module):
         else:           # one serial branch next to another batch's network: full-chip kNN first (under the light
             feat = sc.features(center, flip)    # head of that forward), the 32-workgroup FPS chains afterwards (1.98 vs 2.00 ms)
             plan = GeometryPlan(xyz, self._sampling, fork=False, compact=self._compact())
-        moments = sc.moments(feat) if self.training else None
+        moments = sc.moments(feat) if (self.training and _mlp.umbrella_moments_wanted(3)) else None
         return GeoState(feat, [plan.stage(i) for i in range(len(self._sampling))], xyz, moments)
 
     def early_gradient_modules(self):
@@ -153,4 +153,6 @@ class UmbrellaClassifier(nn.Module):
         x = feature.reshape(-1, self.head_in)
         if _head.usable(self.classfier, x):            # training batches of <= 64 clouds: 3 fused launches
             return _head.classifier_logprobs(self.classfier, x)
-        return F.log_softmax(self.classfier(x), -1)
+        if _head.rows_usable(self.classfier, x):       # eval mode / more rows / SyncBatchNorm: row stacks of the shared-MLP kernels
+            return _head.classifier_logprobs_rows(self.classfier, x)
+        return F.log_softmax(self.classfier(x), -1)    # (a head that is not the reference's Sequential)

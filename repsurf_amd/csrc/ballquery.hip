@@ -473,7 +473,7 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
           float4 c4[4];
           bool hit[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) c4[i] = sp4[j + i];                 // j <= n: at most BC_SLACK entries past the cloud (never valid)
+          for (int i = 0; i < 4; ++i) c4[i] = sp4[j + i];                 // j <= jend <= n (finished lanes stand still below): at most BC_SLACK entries past the cloud, never valid
           bool any = false;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -489,7 +489,7 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
                 ++count;
               }
           }
-          j += 4;
+          j = j < jend ? j + 4 : j;      // a lane whose row is exhausted stays inside it while the wave finishes the longest row
         }
       }
       // (tried, round 3: reading a slot only where it holds a candidate -- exec-masked ds_read_b128, 27 of ~80 slots -- and

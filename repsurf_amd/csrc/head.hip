@@ -531,7 +531,7 @@ smooth_loss_kernel(int R, int classes, float eps, const float *__restrict__ logp
 // fixed-order tree per workgroup -> partial[block] = {sum, count}.
 __global__ void __launch_bounds__(256)
 ce_rows_kernel(long long rows, int classes, long long ignore_index, const float *__restrict__ logits,
-               const long long *__restrict__ target, float *__restrict__ dlogits, double *__restrict__ partial) {
+               const long long *__restrict__ target, float *__restrict__ dlogits, double *__restrict__ partial, int *__restrict__ bad_labels) {
   __shared__ double ps[256], pc[256];
   const int tid = threadIdx.x;
   const long long r = (long long)blockIdx.x * 256 + tid;
@@ -545,7 +545,10 @@ ce_rows_kernel(long long rows, int classes, long long ignore_index, const float 
     } else if (t < 0 || t >= classes) {
       // a label outside [0, classes) that is NOT the ignore label is a data bug (torch traps it with a device assert): it must
       // not train as a silently masked row -- the row's loss and gradient become NaN, which the mean carries to the caller
+      // (a NaN inside a replayed graph reaches Adam's moments with no host-visible error: the persistent counter is what a
+      //  training loop polls -- repsurf_amd.head.bad_label_count -- when it reads its loss)
       const float qnan = __builtin_nanf("");
+      if (bad_labels) atomicAdd(bad_labels, 1);
       for (int j = 0; j < classes; ++j) d[j] = qnan;
       loss = (double)qnan;
       cnt = 1.0;
@@ -641,12 +644,12 @@ col_sum_kernel(long long rows, int n, const float *__restrict__ x, long long ldx
 }  // namespace
 
 extern "C" int rs_cross_entropy_forward(long long rows, int classes, long long ignore_index, const float *logits, const long long *target,
-                                        float *loss, float *inv_count, float *dlogits, double *partial, void *stream) {
+                                        float *loss, float *inv_count, float *dlogits, double *partial, int *bad_labels, void *stream) {
   RS_REQUIRE(rows > 0 && classes > 0 && rows <= (1LL << 31) * 255, "rs_cross_entropy_forward: bad size");
   RS_REQUIRE(logits && target && loss && inv_count && dlogits && partial, "rs_cross_entropy_forward: null pointer");
   const int nblk = (int)((rows + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ce_rows_kernel, dim3(nblk), dim3(256), 0, st, rows, classes, ignore_index, logits, target, dlogits, partial);
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(nblk), dim3(256), 0, st, rows, classes, ignore_index, logits, target, dlogits, partial, bad_labels);
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, nblk, partial, loss, inv_count);
   RS_CHECK_LAUNCH("rs_cross_entropy_forward");
   return RS_OK;
@@ -704,7 +707,10 @@ extern "C" int rs_head_output_backward(int rows, int k, int classes, const float
   RS_REQUIRE(rows > 0 && rows <= HD_MAXR && k > 0 && classes > 0 && classes <= 256, "rs_head_output_backward: bad size");
   RS_REQUIRE(dlogp && logp && h && dlogits && dw && db, "rs_head_output_backward: null pointer");
   HeadOutBwd O{dlogp, logp, h, dlogits, dw, db, rows, k, classes};
-  hipLaunchKernelGGL(head_out_bwd_kernel, dim3(1), dim3(1024), 3 * sizeof(float) * (size_t)rows * classes, (hipStream_t)stream, O);
+  const size_t lds = 3 * sizeof(float) * (size_t)rows * classes;      // dlogits, dlogp, logp staged for all rows
+  RS_REQUIRE(lds <= 64 * 1024, "rs_head_output_backward: rows=%d x classes=%d needs %zu bytes of LDS staging (limit 65536): the fused head serves "
+             "rows * classes <= 5461 (the shipped 15 / 40-class heads at <= 64 rows)", rows, classes, lds);
+  hipLaunchKernelGGL(head_out_bwd_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, O);
   RS_CHECK_LAUNCH("rs_head_output_backward");
   return RS_OK;
 }

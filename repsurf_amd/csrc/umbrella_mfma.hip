@@ -25,7 +25,10 @@
 //   * the BatchNorm finalize launches between the passes are prologues of the consuming pass (every workgroup reduces the few
 //     partial rows itself, fixed order, identical in every workgroup; workgroup 0 publishes the vectors / running statistics).
 // Three-layer (classification): F1 (statistics of y1) -> F2 (output) | B1 -> B2 -> FIN: 5 launches against 6 passes + 4 finalizes
-// + reductions; two-layer (segmentation): F2 | B2 -> FIN.  Partial sums: fp32 inside a workgroup (<= a few thousand rows), fp64
+// + reductions; two-layer (segmentation): F2 | B2 -> FIN.  (Merging the passes of a direction into ONE launch whose workgroups meet
+// at a grid-wide barrier was built and measured in round 4 -- tools/probes/grid_meet.hip: 9.4 us per meeting with release /
+// acquire fences, 6.1 with write-through stores and relaxed polling, 4.3 with per-XCD arrival counters -- and LOST to the kernel
+// boundary it replaces: forward 30 us merged against 25 us as two launches, backward 80 against 59.  Not kept.)  Partial sums: fp32 inside a workgroup (<= a few thousand rows), fp64
 // across workgroups, fixed order everywhere (deterministic).
 #include "rs_common.h"
 
@@ -35,7 +38,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int C = RS_UMB_C;           // 10 channels
 constexpr int CP = 16;                // padded (one MFMA tile edge)
-constexpr int TH = 256;               // 4 waves per workgroup
+constexpr int TH = 512;               // 8 waves per workgroup: two per SIMD when a workgroup has a CU to itself
 constexpr int NW = TH / 64;
 constexpr int TILE = C * CP;          // rows m < 10 of a 16 x 16 accumulator tile
 constexpr int B1_ROW = RS_UMB_B1_ROW; // [dW2][S1 = sum dz1 a0^T][Sy = sum yhat1 a0^T][db1][dg1][sa0][db2]
@@ -46,24 +49,38 @@ static_assert(B1_ROW == 3 * TILE + 4 * CP && B2_ROW == 2 * TILE + 3 * CP && MOM_
 __device__ __forceinline__ f4 mfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 struct Frag { float s[4]; };
+// Weight fragments: unconditional loads from clamped addresses, zeroed by a select (a load under `if` is a branch per load, and the
+// 64-bit addresses the compiler keeps live across those branches spilled the tile's rows to scratch).  W == NULL (a layer the
+// variant does not have): any valid matrix stands in, the fragment is never used.
 // y = W v: lane (l, g), step s holds W[out = l][in = 4g + s]
 __device__ __forceinline__ Frag frag_w(const float *W, int l, int g) {
   Frag f;
+  const int lc = l < C ? l : C - 1;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int ch = 4 * g + s;
-    f.s[s] = (W && l < C && ch < C) ? W[l * C + ch] : 0.f;
+    const int ch = 4 * g + s, cc = ch < C ? ch : C - 1;
+    const float v = W[lc * C + cc];
+    f.s[s] = (l < C && ch < C) ? v : 0.f;
   }
   return f;
 }
 // da = W^T dy: step s holds W[out = 4g + s][in = l]
 __device__ __forceinline__ Frag frag_wt(const float *W, int l, int g) {
   Frag f;
+  const int lc = l < C ? l : C - 1;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int ch = 4 * g + s;
-    f.s[s] = (W && l < C && ch < C) ? W[ch * C + l] : 0.f;
+    const int ch = 4 * g + s, cc = ch < C ? ch : C - 1;
+    const float v = W[cc * C + lc];
+    f.s[s] = (l < C && ch < C) ? v : 0.f;
   }
+  return f;
+}
+// the identity as a weight fragment: mm_lc(v, I) re-lays an L-R tensor out as L-C (exact: one product per element, the rest zeros)
+__device__ __forceinline__ Frag frag_id(int l, int g) {
+  Frag f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) f.s[s] = (l == 4 * g + s && l < C) ? 1.f : 0.f;
   return f;
 }
 // rows as the N index: D[ch 4g+i][row l] = sum_k W[ch][k] v[row][k]   (v: L-R; result: L-R)
@@ -102,7 +119,7 @@ struct Sh {
   float sc1[CP], sh1[CP], mu1[CP], is1[CP];
   float b0[CP], c1[CP], c2[CP];
   float m1[CP], m2[CP];                 // db1 / rows, dg1 / rows
-  double slice[8][32];
+  double slice[16][32];
   double fin[64];
   float wred[NW][B1_ROW];
 };
@@ -143,25 +160,27 @@ __device__ __forceinline__ void publish_bn(int ch, double mean, double var, doub
 }
 
 // BatchNorm 0 of y0 = W0 x (+ b0) from the moments of x: mean = W0 Sx / n + b0, E[(y - b0)^2] = w^T Sxx w / n  (fp64).
+// Thread (c, k), c, k < 10, takes row k of the quadratic form (10 loads + 10 fused multiply-adds), thread c sums its ten rows.
 __device__ void bn0_from_moments(Sh &L, const rs_umbrella_mfma &m, bool publish) {
   const int t = threadIdx.x;
+  const double *S = m.moments;
+  if (t < C * C) {
+    const int c = t / C, k = t % C;
+    double r = 0.0;
+#pragma unroll
+    for (int k2 = 0; k2 < C; ++k2) r += (double)m.w0[c * C + k2] * S[k * CP + k2];
+    const double wk = (double)m.w0[c * C + k];
+    L.slice[c][k] = wk * r;                       // w_k (Sxx w)_k
+    L.slice[c][C + k] = wk * S[10 * CP + k];      // w_k Sx_k
+  }
+  __syncthreads();
   if (t < CP) {
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
     if (t < C) {
-      const double *S = m.moments;
       const double n = S[10 * CP + 10];
-      double w[C];
-#pragma unroll
-      for (int k = 0; k < C; ++k) w[k] = (double)m.w0[t * C + k];
       double lin = 0.0, quad = 0.0;
 #pragma unroll
-      for (int k = 0; k < C; ++k) {
-        lin += w[k] * S[10 * CP + k];
-        double r = 0.0;
-#pragma unroll
-        for (int k2 = 0; k2 < C; ++k2) r += w[k2] * S[k * CP + k2];
-        quad += w[k] * r;
-      }
+      for (int k = 0; k < C; ++k) { quad += L.slice[t][k]; lin += L.slice[t][C + k]; }
       const double ml = lin / n;
       double var = quad / n - ml * ml;
       if (var < 0.0) var = 0.0;
@@ -176,33 +195,28 @@ __device__ void bn0_from_moments(Sh &L, const rs_umbrella_mfma &m, bool publish)
     }
     L.sc0[t] = sc; L.sh0[t] = sh; L.mu0[t] = mu; L.is0[t] = is;
   }
+  __syncthreads();
 }
 
-// sum of 32 doubles per partial row over `nblk` rows (row pitch `pitch` doubles), fixed order: 8 slices, then the slices -> L.fin[0..32)
-__device__ void reduce32_f64(Sh &L, const double *part, int nblk, int pitch) {
+// sum of 32 values per partial row over `nblk` rows (row pitch `pitch` elements), fixed order: 16 slices of rows (each thread batches 8
+// independent loads per trip: the prologue is a couple of memory latencies deep, not nblk / 16), then the slices -> L.fin[0..32)
+template <typename T>
+__device__ void reduce32(Sh &L, const T *part, int nblk, int pitch) {
   const int t = threadIdx.x, v = t & 31, sl = t >> 5;
   double a = 0.0;
-  for (int b = sl; b < nblk; b += 8) a += part[(long long)b * pitch + v];
-  L.slice[sl][v] = a;
-  __syncthreads();
-  if (t < 32) {
-    double s = 0.0;
+  for (int b = sl; b < nblk; b += 16 * 8) {
+    double x[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += L.slice[k][t];
-    L.fin[t] = s;
+    for (int u = 0; u < 8; ++u) x[u] = b + 16 * u < nblk ? (double)part[(long long)(b + 16 * u) * pitch + v] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += x[u];
   }
-  __syncthreads();
-}
-__device__ void reduce32_f32(Sh &L, const float *part, int nblk, int pitch) {
-  const int t = threadIdx.x, v = t & 31, sl = t >> 5;
-  double a = 0.0;
-  for (int b = sl; b < nblk; b += 8) a += (double)part[(long long)b * pitch + v];
   L.slice[sl][v] = a;
   __syncthreads();
   if (t < 32) {
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += L.slice[k][t];
+    for (int k = 0; k < 16; ++k) s += L.slice[k][t];
     L.fin[t] = s;
   }
   __syncthreads();
@@ -210,7 +224,7 @@ __device__ void reduce32_f32(Sh &L, const float *part, int nblk, int pitch) {
 
 // BatchNorm 1 from the F1 partials {sum y1, sum y1^2} (nblk, 2, 16) fp64
 __device__ void bn1_from_partials(Sh &L, const rs_umbrella_mfma &m, bool publish) {
-  reduce32_f64(L, m.stat, m.nblk_f1, 32);
+  reduce32<double>(L, m.stat, m.nblk_f1, 32);
   const int t = threadIdx.x;
   if (t < CP) {
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
@@ -267,9 +281,8 @@ __device__ __forceinline__ f4 relu_affine(f4 y, float s, float t) {
 
 struct Walk {      // the tiles of one wave: 16 points each, interleaved over all waves of the grid
   long long points, tiles, tile, step;
-  int group, l, g, wave;
+  int l, g, wave;
   __device__ Walk(const rs_umbrella_mfma &m) {
-    group = m.group;
     points = m.rows / m.group;
     tiles = (points + 15) >> 4;
     wave = threadIdx.x >> 6;
@@ -281,23 +294,36 @@ struct Walk {      // the tiles of one wave: 16 points each, interleaved over al
   }
 };
 
+// The G fan rows of a tile's 16 points, L-R form, ALL requested before anything waits for them: a wave has one or two tiles, so
+// per-row prefetching left every sub-tile behind its own memory latency (the first version: 18 us per pass for 2-6 us of MFMAs).
+template <int G>
+__device__ __forceinline__ void ld_tile_lr(const float *x, long long pl, int g, f4 (&xr)[G]) {
+#pragma unroll
+  for (int k = 0; k < G; ++k) xr[k] = ld_lr(x, pl * G + k, g);
+}
+
 // ---------------------------------------------------------------------------------------------------- moments of x
+// 4 tiles (64 rows) per trip, their 16 loads in flight together
 __global__ void __launch_bounds__(TH)
 umb_moments_kernel(const float *__restrict__ x, long long rows, float *__restrict__ partial) {
   __shared__ float red[NW][MOM_ROW];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l = lane & 15, g = lane >> 4;
   const int lc = l < C ? l : C - 1;
+  const float one = l == C ? 1.f : 0.f;
   f4 acc = splat(0.f);
-  const long long tiles = (rows + 15) >> 4;
-  for (long long tile = (long long)blockIdx.x * NW + wave; tile < tiles; tile += (long long)gridDim.x * NW) {
-    f4 xa;
+  const long long quads = (rows + 63) >> 6;
+  for (long long q = (long long)blockIdx.x * NW + wave; q < quads; q += (long long)gridDim.x * NW) {
+    f4 xa[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long long r = tile * 16 + 4 * g + i;
-      const float v = x[(r < rows ? r : rows - 1) * C + lc];
-      xa[i] = r < rows ? (l < C ? v : (l == C ? 1.f : 0.f)) : 0.f;
-    }
-    acc = mm_rows(xa, xa, acc);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long r = q * 64 + u * 16 + 4 * g + i;
+        const float v = x[(r < rows ? r : rows - 1) * C + lc];
+        xa[u][i] = r < rows ? (l < C ? v : one) : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = mm_rows(xa[u], xa[u], acc);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -310,47 +336,74 @@ umb_moments_kernel(const float *__restrict__ x, long long rows, float *__restric
     partial[(long long)blockIdx.x * MOM_ROW + e] = s;
   }
 }
-__global__ void __launch_bounds__(TH)
+// (nblk, 176) fp32 -> (176) fp64: 5 slices of rows x 176 values (880 of 1024 threads), 8 loads per trip, then the slices in order
+__global__ void __launch_bounds__(1024)
 umb_moments_reduce_kernel(const float *__restrict__ partial, int nblk, double *__restrict__ out) {
-  const int t = threadIdx.x;
-  if (t >= MOM_ROW) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(long long)b * MOM_ROW + t];
-  out[t] = s;
+  __shared__ double sl[5][MOM_ROW];
+  const int t = threadIdx.x, v = t % MOM_ROW, s = t / MOM_ROW;
+  if (s < 5) {
+    double a = 0.0;
+    for (int b = s; b < nblk; b += 5 * 8) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = b + 5 * u < nblk ? (double)partial[(long long)(b + 5 * u) * MOM_ROW + v] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += x[u];
+    }
+    sl[s][v] = a;
+  }
+  __syncthreads();
+  if (t < MOM_ROW) out[t] = (((sl[0][t] + sl[1][t]) + sl[2][t]) + sl[3][t]) + sl[4][t];
 }
 
-// ---------------------------------------------------------------------------------------------------- F1: statistics of y1
-__global__ void __launch_bounds__(TH, 4)
-umb_f1_kernel(rs_umbrella_mfma m) {
-  __shared__ Sh L;
-  stage_vectors(L, m);
-  bn0_from_moments(L, m, blockIdx.x == 0);
-  __syncthreads();
-  Walk w(m);
+// ---------------------------------------------------------------------------------------------------- the four tile loops
+// Each loop walks the wave's tiles (first one: rows already in xr, requested by the kernel before its prologue); the next tile's
+// rows are requested under the current tile's tail.  `pl`: the wave's L-R point of the current tile (clamped).
+template <int G>
+__device__ __forceinline__ void reload_first(const rs_umbrella_mfma &m, const Walk &w, f4 (&xr)[G], long long &pl) {
+  const long long pn = w.tile * 16 + w.l;
+  pl = pn < w.points ? pn : w.points - 1;
+  if (w.tile < w.tiles) ld_tile_lr<G>(m.x, pl, w.g, xr);
+}
+template <int G>
+__device__ __forceinline__ void next_tile(const rs_umbrella_mfma &m, const Walk &w, long long tile, f4 (&xr)[G], long long &pl) {
+  if (tile + w.step < w.tiles) {
+    const long long pn = (tile + w.step) * 16 + w.l;
+    pl = pn < w.points ? pn : w.points - 1;
+    ld_tile_lr<G>(m.x, pl, w.g, xr);
+  }
+}
+
+// F1: per-lane sums of y1 and y1^2 (channel l, the lane's rows)
+template <int G>
+__device__ __forceinline__ void f1_loop(const rs_umbrella_mfma &m, const Sh &L, const Walk &w, f4 (&xr)[G], long long &pl,
+                                        const Frag &W0, const Frag &W1, float &sum, float &sq) {
   const int l = w.l, g = w.g;
-  const Frag W0 = frag_w(m.w0, l, g), W1 = frag_w(m.w1, l, g);
   const f4 s0r = vec_r(L.sc0, g), t0r = vec_r(L.sh0, g), b0r = vec_r(L.b0, g);
   const float c1c = L.c1[l];
-  float sum = 0.f, sq = 0.f;
   for (long long tile = w.tile; tile < w.tiles; tile += w.step) {
     const long long p0 = tile * 16;
-    const long long pl = p0 + l < w.points ? p0 + l : w.points - 1;
     const bool tail = p0 + 16 > w.points;
-    f4 xr = ld_lr(m.x, pl * w.group, g);
-    for (int k = 0; k < w.group; ++k) {
-      const f4 xn = ld_lr(m.x, pl * w.group + (k + 1 < w.group ? k + 1 : k), g);     // next fan row under this one's MFMAs
-      const f4 a0 = relu_affine(mm_lr(W0, xr, b0r), s0r, t0r);
-      f4 y1 = mm_lc(a0, W1, splat(c1c));
+    f4 y1[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const f4 a0 = relu_affine(mm_lr(W0, xr[k], b0r), s0r, t0r);
+      y1[k] = mm_lc(a0, W1, splat(c1c));
+    }
+    next_tile<G>(m, w, tile, xr, pl);
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
       if (tail)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y1[i] = p0 + 4 * g + i < w.points ? y1[i] : 0.f;
+        for (int i = 0; i < 4; ++i) y1[k][i] = p0 + 4 * g + i < w.points ? y1[k][i] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { sum += y1[i]; sq = fmaf(y1[i], y1[i], sq); }
-      xr = xn;
+      for (int i = 0; i < 4; ++i) { sum += y1[k][i]; sq = fmaf(y1[k][i], y1[k][i], sq); }
     }
   }
-  put_vec(&L.wred[w.wave][0], sum, l, g);
-  put_vec(&L.wred[w.wave][CP], sq, l, g);
+}
+__device__ __forceinline__ void f1_store(Sh &L, const rs_umbrella_mfma &m, const Walk &w, float sum, float sq) {
+  put_vec(&L.wred[w.wave][0], sum, w.l, w.g);
+  put_vec(&L.wred[w.wave][CP], sq, w.l, w.g);
   __syncthreads();
   if (threadIdx.x < 32) {
     double a = 0.0;
@@ -360,43 +413,28 @@ umb_f1_kernel(rs_umbrella_mfma m) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------- F2: output
-template <int LAYERS>
-__global__ void __launch_bounds__(TH, 4)
-umb_f2_kernel(rs_umbrella_mfma m) {
-  __shared__ Sh L;
-  stage_vectors(L, m);
-  if (LAYERS == 3) {
-    load_bn(L.sc0, L.sh0, L.mu0, L.is0, m.bn0);
-    bn1_from_partials(L, m, blockIdx.x == 0);
-  } else {
-    bn0_from_moments(L, m, blockIdx.x == 0);
-  }
-  __syncthreads();
-  Walk w(m);
+// F2: out = out_scale * sum over the fan of the last layer
+template <int LAYERS, int G>
+__device__ __forceinline__ void f2_loop(const rs_umbrella_mfma &m, const Sh &L, const Walk &w, f4 (&xr)[G], long long &pl,
+                                        const Frag &W0, const Frag &W1, const Frag &W2) {
   const int l = w.l, g = w.g;
-  const Frag W0 = frag_w(m.w0, l, g), W1 = frag_w(m.w1, l, g), W2 = frag_w(m.w2, l, g);
   const f4 s0r = vec_r(L.sc0, g), t0r = vec_r(L.sh0, g), b0r = vec_r(L.b0, g);
   const f4 s1r = vec_r(L.sc1, g), t1r = vec_r(L.sh1, g), c1r = vec_r(L.c1, g);
   const float c1c = L.c1[l], c2c = L.c2[l];
   for (long long tile = w.tile; tile < w.tiles; tile += w.step) {
     const long long p0 = tile * 16;
-    const long long pl = p0 + l < w.points ? p0 + l : w.points - 1;
     f4 acc = splat(0.f);
-    f4 xr = ld_lr(m.x, pl * w.group, g);
-    for (int k = 0; k < w.group; ++k) {
-      const f4 xn = ld_lr(m.x, pl * w.group + (k + 1 < w.group ? k + 1 : k), g);
-      const f4 a0 = relu_affine(mm_lr(W0, xr, b0r), s0r, t0r);
-      f4 yo;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const f4 a0 = relu_affine(mm_lr(W0, xr[k], b0r), s0r, t0r);
       if (LAYERS == 3) {
         const f4 a1 = relu_affine(mm_lr(W1, a0, c1r), s1r, t1r);
-        yo = mm_lc(a1, W2, splat(c2c));
+        acc += mm_lc(a1, W2, splat(c2c));
       } else {
-        yo = mm_lc(a0, W1, splat(c1c));
+        acc += mm_lc(a0, W1, splat(c1c));
       }
-      acc += yo;
-      xr = xn;
     }
+    next_tile<G>(m, w, tile, xr, pl);
     if (l < C)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -406,17 +444,10 @@ umb_f2_kernel(rs_umbrella_mfma m) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------- B1 (three layers)
-// dW2 = sum dy2^T a1, db2; BatchNorm-1 backward sums db1 = sum dz1, dg1 = sum dz1 yhat1; for dW1: S1 = sum dz1^T a0,
-// Sy = sum yhat1^T a0, sa0 = sum a0.
-__global__ void __launch_bounds__(TH, 4)
-umb_b1_kernel(rs_umbrella_mfma m) {
-  __shared__ Sh L;
-  stage_vectors(L, m);
-  load_bn(L.sc0, L.sh0, L.mu0, L.is0, m.bn0);
-  load_bn(L.sc1, L.sh1, L.mu1, L.is1, m.bn1);
-  __syncthreads();
-  Walk w(m);
+// B1 (three layers): dW2 = sum dy2^T a1, db2; BatchNorm-1 backward sums db1 = sum dz1, dg1 = sum dz1 yhat1; for dW1:
+// S1 = sum dz1^T a0, Sy = sum yhat1^T a0, sa0 = sum a0.  Leaves the wave's row in L.wred[wave].
+template <int G>
+__device__ __forceinline__ void b1_loop(const rs_umbrella_mfma &m, Sh &L, const Walk &w, f4 (&xr)[G], long long &pl) {
   const int l = w.l, g = w.g, lc = l < C ? l : C - 1;
   const Frag W0 = frag_w(m.w0, l, g), W1 = frag_w(m.w1, l, g), W2t = frag_wt(m.w2, l, g);
   const f4 s0r = vec_r(L.sc0, g), t0r = vec_r(L.sh0, g);
@@ -425,8 +456,6 @@ umb_b1_kernel(rs_umbrella_mfma m) {
   float db1 = 0.f, dg1 = 0.f, sa0 = 0.f, db2 = 0.f;
   for (long long tile = w.tile; tile < w.tiles; tile += w.step) {
     const long long p0 = tile * 16;
-    const long long pl = p0 + l < w.points ? p0 + l : w.points - 1;
-    const bool tail = p0 + 16 > w.points;
     const f4 dy2r = ld_lr(m.dout, pl, g);
     f4 dy2c, vm;
 #pragma unroll
@@ -436,13 +465,12 @@ umb_b1_kernel(rs_umbrella_mfma m) {
       const float v = m.dout[(pc < w.points ? pc : w.points - 1) * C + lc];
       dy2c[i] = (l < C && pc < w.points) ? v : 0.f;
     }
-    f4 xr = ld_lr(m.x, pl * w.group, g);
-    for (int k = 0; k < w.group; ++k) {
-      const f4 xn = ld_lr(m.x, pl * w.group + (k + 1 < w.group ? k + 1 : k), g);
-      const f4 z = splat(0.f);
-      const f4 y0r = mm_lr(W0, xr, z);
-      f4 a0c = relu_affine(mm_lc(xr, W0, z), s0c, t0c);
-      const f4 da1c = mm_lc(dy2r, W2t, z);
+    const f4 z = splat(0.f);
+    const f4 da1c = mm_lc(dy2r, W2t, z);                           // the same for every fan row of the point
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const f4 y0r = mm_lr(W0, xr[k], z);
+      f4 a0c = relu_affine(mm_lc(xr[k], W0, z), s0c, t0c);
       const f4 a0r = relu_affine(y0r, s0r, t0r);
       const f4 y1c = mm_lc(a0r, W1, splat(c1c));
       f4 a1c, yh1c, dz1c;
@@ -452,15 +480,15 @@ umb_b1_kernel(rs_umbrella_mfma m) {
         yh1c[i] = (y1c[i] - mu1c) * is1c;
         dz1c[i] = a1c[i] > 0.f ? da1c[i] : 0.f;
       }
-      if (tail) { a0c *= vm; yh1c *= vm; dz1c *= vm; }
+      a0c *= vm; yh1c *= vm; dz1c *= vm;          // (rows beyond the last point: zero; unconditional -- a branch per fan row splits the schedule)
       aW2 = mm_rows(dy2c, a1c, aW2);
       aS1 = mm_rows(dz1c, a0c, aS1);
       aSy = mm_rows(yh1c, a0c, aSy);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { db1 += dz1c[i]; dg1 = fmaf(dz1c[i], yh1c[i], dg1); sa0 += a0c[i]; }
-      xr = xn;
     }
-    db2 += (float)w.group * ((dy2c[0] + dy2c[1]) + (dy2c[2] + dy2c[3]));
+    db2 += (float)G * ((dy2c[0] + dy2c[1]) + (dy2c[2] + dy2c[3]));
+    next_tile<G>(m, w, tile, xr, pl);
   }
   float *row = L.wred[w.wave];
   put_tile(row, aW2, l, g);
@@ -470,80 +498,62 @@ umb_b1_kernel(rs_umbrella_mfma m) {
   put_vec(row + 3 * TILE + CP, dg1, l, g);
   put_vec(row + 3 * TILE + 2 * CP, sa0, l, g);
   put_vec(row + 3 * TILE + 3 * CP, db2, l, g);
-  store_partial_row(L, m.part_b1 + (long long)blockIdx.x * B1_ROW, B1_ROW);
 }
 
-// ---------------------------------------------------------------------------------------------------- B2: sums of the first layer
-// T1 = sum dz0^T x, db0 = sum dz0, dg0 = sum dz0 yhat0;  two layers: also dW1 = sum dy1^T a0, db1 = sum dy1 (dy1 = dout[point]).
-template <int LAYERS>
-__global__ void __launch_bounds__(TH, LAYERS == 3 ? 3 : 4)
-umb_b2_kernel(rs_umbrella_mfma m) {
-  __shared__ Sh L;
-  stage_vectors(L, m);
-  load_bn(L.sc0, L.sh0, L.mu0, L.is0, m.bn0);
-  if (LAYERS == 3) {
-    load_bn(L.sc1, L.sh1, L.mu1, L.is1, m.bn1);
-    reduce32_f32(L, m.part_b1 + 3 * TILE, m.nblk_b1, B1_ROW);     // db1 (16), dg1 (16) of B1
-    if (threadIdx.x < CP) {
-      const double n = (double)m.rows;
-      L.m1[threadIdx.x] = threadIdx.x < C ? (float)(L.fin[threadIdx.x] / n) : 0.f;
-      L.m2[threadIdx.x] = threadIdx.x < C ? (float)(L.fin[CP + threadIdx.x] / n) : 0.f;
-    }
-  }
-  __syncthreads();
-  Walk w(m);
+// B2: T1 = sum dz0^T x, db0 = sum dz0, dg0 = sum dz0 yhat0;  two layers: also dW1 = sum dy1^T a0, db1 = sum dy1 (dy1 = dout[point]).
+// Leaves the wave's row in L.wred[wave].  xr: the first tile's rows, already requested; x in L-C form (the B operand of T1) comes
+// out of the matrix pipe too (mm_lc with the identity: 4 MFMAs instead of 4 strided loads per fan row and 4 more registers per row).
+template <int LAYERS, int G>
+__device__ __forceinline__ void b2_loop(const rs_umbrella_mfma &m, Sh &L, const Walk &w, f4 (&xr)[G], long long &pl) {
   const int l = w.l, g = w.g, lc = l < C ? l : C - 1;
-  const Frag W0 = frag_w(m.w0, l, g), W1 = frag_w(m.w1, l, g), W1t = frag_wt(m.w1, l, g), W2t = frag_wt(m.w2, l, g);
+  const Frag W0 = frag_w(m.w0, l, g), W1 = frag_w(m.w1, l, g), W1t = frag_wt(m.w1, l, g), W2t = frag_wt(m.w2 ? m.w2 : m.w0, l, g), Id = frag_id(l, g);
   const f4 s0r = vec_r(L.sc0, g), t0r = vec_r(L.sh0, g);
-  const f4 s1r = vec_r(L.sc1, g), t1r = vec_r(L.sh1, g), mu1r = vec_r(L.mu1, g), is1r = vec_r(L.is1, g), c1r = vec_r(L.c1, g);
-  const f4 m1r = vec_r(L.m1, g), m2r = vec_r(L.m2, g);
+  const f4 s1r = vec_r(L.sc1, g), t1r = vec_r(L.sh1, g), c1r = vec_r(L.c1, g);
+  // BatchNorm-1 backward as dy1 = p dz1 + q y1 + r:  p = s1, q = -s1 is1 dg1/m, r = -s1 db1/m - q mu1  (three vectors in registers)
+  f4 q1r, r1r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    q1r[i] = -s1r[i] * L.is1[4 * g + i] * L.m2[4 * g + i];
+    r1r[i] = -s1r[i] * L.m1[4 * g + i] - q1r[i] * L.mu1[4 * g + i];
+  }
   const float s0c = L.sc0[l], t0c = L.sh0[l], mu0c = L.mu0[l], is0c = L.is0[l], b0c = L.b0[l];
   f4 aT1 = splat(0.f), aWl = splat(0.f);
   float db0 = 0.f, dg0 = 0.f, dbl = 0.f;
   for (long long tile = w.tile; tile < w.tiles; tile += w.step) {
     const long long p0 = tile * 16;
-    const long long pl = p0 + l < w.points ? p0 + l : w.points - 1;
-    const bool tail = p0 + 16 > w.points;
     const f4 dor = ld_lr(m.dout, pl, g);          // the incoming gradient of the point, L-R
     f4 doc = splat(0.f), vm;
-    long long rowc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long pc = p0 + 4 * g + i;
       vm[i] = pc < w.points ? 1.f : 0.f;
-      rowc[i] = (pc < w.points ? pc : w.points - 1) * w.group;
       if (LAYERS == 2) {
         const float v = m.dout[(pc < w.points ? pc : w.points - 1) * C + lc];
         doc[i] = (l < C && pc < w.points) ? v : 0.f;
       }
     }
-    f4 xr = ld_lr(m.x, pl * w.group, g);
-    for (int k = 0; k < w.group; ++k) {
-      const f4 xn = ld_lr(m.x, pl * w.group + (k + 1 < w.group ? k + 1 : k), g);
-      f4 xc;
+    const f4 z = splat(0.f);
+    f4 da1r = z, da0c2 = z;
+    if (LAYERS == 3) da1r = mm_lr(W2t, dor, z);                     // the same for every fan row of the point
+    else da0c2 = mm_lc(dor, W1t, z);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = m.x[(rowc[i] + k) * C + lc];
-        xc[i] = l < C ? v : 0.f;
-      }
-      const f4 z = splat(0.f);
-      const f4 y0c = mm_lc(xr, W0, splat(b0c));
+    for (int k = 0; k < G; ++k) {
+      const f4 y0c = mm_lc(xr[k], W0, splat(b0c));
       f4 da0c;
       if (LAYERS == 3) {
-        const f4 a0r = relu_affine(mm_lr(W0, xr, z), s0r, t0r);
-        const f4 da1r = mm_lr(W2t, dor, z);
+        const f4 a0r = relu_affine(mm_lr(W0, xr[k], z), s0r, t0r);
         const f4 y1r = mm_lr(W1, a0r, c1r);
         f4 dy1r;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float dz1 = fmaf(s1r[i], y1r[i], t1r[i]) > 0.f ? da1r[i] : 0.f;
-          const float yh1 = (y1r[i] - mu1r[i]) * is1r[i];
-          dy1r[i] = s1r[i] * ((dz1 - m1r[i]) - yh1 * m2r[i]);
+          dy1r[i] = fmaf(s1r[i], dz1, fmaf(q1r[i], y1r[i], r1r[i]));
         }
         da0c = mm_lc(dy1r, W1t, z);
       } else {
-        da0c = mm_lc(dor, W1t, z);
+        da0c = da0c2;
       }
+      const f4 xq = mm_lc(xr[k], Id, z);
       f4 a0c, yh0c, dz0c;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -551,14 +561,16 @@ umb_b2_kernel(rs_umbrella_mfma m) {
         yh0c[i] = (y0c[i] - mu0c) * is0c;
         dz0c[i] = a0c[i] > 0.f ? da0c[i] : 0.f;
       }
-      if (tail) dz0c *= vm;
-      aT1 = mm_rows(dz0c, xc, aT1);
+      dz0c *= vm;
+      aT1 = mm_rows(dz0c, xq, aT1);
       if (LAYERS == 2) aWl = mm_rows(doc, a0c, aWl);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { db0 += dz0c[i]; dg0 = fmaf(dz0c[i], yh0c[i], dg0); }
-      xr = xn;
+      // (no __builtin_amdgcn_sched_barrier between the fan rows: with one here the launch computed WRONG sums on gfx950 / ROCm 7.0 --
+      //  dW0, dgamma0, dbeta0 off by O(1), found by tools A/B builds in round 4 -- so the schedule is left to the compiler)
     }
-    if (LAYERS == 2) dbl += (float)w.group * ((doc[0] + doc[1]) + (doc[2] + doc[3]));
+    if (LAYERS == 2) dbl += (float)G * ((doc[0] + doc[1]) + (doc[2] + doc[3]));
+    next_tile<G>(m, w, tile, xr, pl);
   }
   float *row = L.wred[w.wave];
   put_tile(row, aT1, l, g);
@@ -566,6 +578,86 @@ umb_b2_kernel(rs_umbrella_mfma m) {
   put_vec(row + 2 * TILE, db0, l, g);
   put_vec(row + 2 * TILE + CP, dg0, l, g);
   put_vec(row + 2 * TILE + 2 * CP, dbl, l, g);
+}
+// db1 / rows, dg1 / rows out of the B1 partial rows (the BatchNorm-1 backward coefficients every lane needs)
+__device__ void b1_coefficients(Sh &L, const rs_umbrella_mfma &m) {
+  reduce32<float>(L, m.part_b1 + 3 * TILE, m.nblk_b1, B1_ROW);     // db1 (16), dg1 (16)
+  if (threadIdx.x < CP) {
+    const double n = (double)m.rows;
+    L.m1[threadIdx.x] = threadIdx.x < C ? (float)(L.fin[threadIdx.x] / n) : 0.f;
+    L.m2[threadIdx.x] = threadIdx.x < C ? (float)(L.fin[CP + threadIdx.x] / n) : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- one launch per pass
+template <int G>
+__global__ void __launch_bounds__(TH, 3)
+umb_f1_kernel(rs_umbrella_mfma m) {
+  __shared__ Sh L;
+  Walk w(m);
+  f4 xr[G];
+  long long pl;
+  reload_first<G>(m, w, xr, pl);                                   // in flight under the prologue
+  const Frag W0 = frag_w(m.w0, w.l, w.g), W1 = frag_w(m.w1, w.l, w.g);
+  stage_vectors(L, m);
+  bn0_from_moments(L, m, blockIdx.x == 0);
+  float sum = 0.f, sq = 0.f;
+  f1_loop<G>(m, L, w, xr, pl, W0, W1, sum, sq);
+  f1_store(L, m, w, sum, sq);
+}
+
+template <int LAYERS, int G>
+__global__ void __launch_bounds__(TH, 3)
+umb_f2_kernel(rs_umbrella_mfma m) {
+  __shared__ Sh L;
+  Walk w(m);
+  f4 xr[G];
+  long long pl;
+  reload_first<G>(m, w, xr, pl);
+  const Frag W0 = frag_w(m.w0, w.l, w.g), W1 = frag_w(m.w1, w.l, w.g), W2 = frag_w(m.w2 ? m.w2 : m.w0, w.l, w.g);
+  stage_vectors(L, m);
+  if (LAYERS == 3) {
+    load_bn(L.sc0, L.sh0, L.mu0, L.is0, m.bn0);
+    bn1_from_partials(L, m, blockIdx.x == 0);
+    __syncthreads();
+  } else {
+    bn0_from_moments(L, m, blockIdx.x == 0);
+  }
+  f2_loop<LAYERS, G>(m, L, w, xr, pl, W0, W1, W2);
+}
+
+template <int G>
+__global__ void __launch_bounds__(TH, 3)
+umb_b1_kernel(rs_umbrella_mfma m) {
+  __shared__ Sh L;
+  Walk w(m);
+  f4 xr[G];
+  long long pl;
+  reload_first<G>(m, w, xr, pl);
+  stage_vectors(L, m);
+  load_bn(L.sc0, L.sh0, L.mu0, L.is0, m.bn0);
+  load_bn(L.sc1, L.sh1, L.mu1, L.is1, m.bn1);
+  __syncthreads();
+  b1_loop<G>(m, L, w, xr, pl);
+  store_partial_row(L, m.part_b1 + (long long)blockIdx.x * B1_ROW, B1_ROW);
+}
+
+template <int LAYERS, int G>
+__global__ void __launch_bounds__(TH, 3)
+umb_b2_kernel(rs_umbrella_mfma m) {
+  __shared__ Sh L;
+  Walk w(m);
+  f4 xr[G];
+  long long pl;
+  reload_first<G>(m, w, xr, pl);
+  stage_vectors(L, m);
+  load_bn(L.sc0, L.sh0, L.mu0, L.is0, m.bn0);
+  if (LAYERS == 3) {
+    load_bn(L.sc1, L.sh1, L.mu1, L.is1, m.bn1);
+    b1_coefficients(L, m);
+  }
+  __syncthreads();
+  b2_loop<LAYERS, G>(m, L, w, xr, pl);
   store_partial_row(L, m.part_b2 + (long long)blockIdx.x * B2_ROW, B2_ROW);
 }
 
@@ -573,25 +665,37 @@ umb_b2_kernel(rs_umbrella_mfma m) {
 // workgroup j = output channel j of every layer.  grads: [dW0 100][dgamma0 10][dbeta0 10][dW1 100][dbias1 10][dgamma1 10]
 // [dbeta1 10][dW2 100][dbias2 10]  (two layers: W1 is the last conv, dbias1 = sum dy1; three layers: dbias1 is 0 -- a bias in
 // front of a BatchNorm -- and is left to the caller).
+// `count` (<= 64) values per partial row at offsets offs[v], summed over nblk rows: 8 slices of rows, 8 independent loads per trip
 __device__ void reduce64(Sh &L, const float *part, int nblk, int pitch, const int *offs, int count) {
-  __shared__ double sl4[4][64];
+  __shared__ double sl8[8][64];
   const int t = threadIdx.x, v = t & 63, s = t >> 6;
   double a = 0.0;
-  if (v < count)
-    for (int b = s; b < nblk; b += 4) a += (double)part[(long long)b * pitch + offs[v]];
-  sl4[s][v] = a;
+  if (v < count) {
+    const float *src = part + offs[v];
+    for (int b = s; b < nblk; b += 8 * 8) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = b + 8 * u < nblk ? (double)src[(long long)(b + 8 * u) * pitch] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += x[u];
+    }
+  }
+  sl8[s][v] = a;
   __syncthreads();
-  if (t < 64) L.fin[t] = (sl4[0][t] + sl4[1][t]) + (sl4[2][t] + sl4[3][t]);
+  if (t < 64) {
+    double r = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += sl8[k][t];
+    L.fin[t] = r;
+  }
   __syncthreads();
 }
 
 template <int LAYERS>
-__global__ void __launch_bounds__(TH)
-umb_fin_kernel(rs_umbrella_mfma m) {
-  __shared__ Sh L;
+__device__ void fin_body(const rs_umbrella_mfma &m, Sh &L, int j) {
   __shared__ int offs[64];
   __shared__ double keep[64];
-  const int j = blockIdx.x, t = threadIdx.x;
+  const int t = threadIdx.x;
   const double n = (double)m.rows;
   float *G = m.grads;
   if (LAYERS == 3) {
@@ -646,6 +750,14 @@ umb_fin_kernel(rs_umbrella_mfma m) {
   }
 }
 
+
+template <int LAYERS>
+__global__ void __launch_bounds__(TH)
+umb_fin_kernel(rs_umbrella_mfma m) {
+  __shared__ Sh L;
+  fin_body<LAYERS>(m, L, blockIdx.x);
+}
+
 }  // namespace
 
 extern "C" int rs_umbrella_moments(const float *x, long long rows, float *partial, int nblk, double *moments, void *stream) {
@@ -653,15 +765,21 @@ extern "C" int rs_umbrella_moments(const float *x, long long rows, float *partia
   RS_REQUIRE(rows < (1LL << 40), "rs_umbrella_moments: rows out of range");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(umb_moments_kernel, dim3(nblk), dim3(TH), 0, st, x, rows, partial);
-  hipLaunchKernelGGL(umb_moments_reduce_kernel, dim3(1), dim3(TH), 0, st, partial, nblk, moments);
+  hipLaunchKernelGGL(umb_moments_reduce_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, moments);
   RS_CHECK_LAUNCH("rs_umbrella_moments");
   return RS_OK;
 }
 
+// fans of 8 (classification, group_size 8) and 9 (segmentation: k = group_size + 1 triangles): the tile's rows are register arrays
+#define RS_UMB_G(KERNEL, ...) do { if (m->group == 8) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ 8>), grid, block, 0, st, *m); \
+                                   else hipLaunchKernelGGL((KERNEL<__VA_ARGS__ 9>), grid, block, 0, st, *m); } while (0)
+#define RS_COMMA ,
+
 extern "C" int rs_umbrella_mfma_pass(int pass, const rs_umbrella_mfma *m, int nblk, void *stream) {
   RS_REQUIRE(m && m->x && m->w0 && m->w1 && m->moments && m->bn0, "rs_umbrella_mfma_pass: null descriptor / input / weights / moments");
   RS_REQUIRE(m->layers == 2 || m->layers == 3, "rs_umbrella_mfma_pass: layers = %d (2 or 3)", m->layers);
-  RS_REQUIRE(m->group > 0 && m->rows > 0 && m->rows % m->group == 0 && nblk > 0, "rs_umbrella_mfma_pass: bad size");
+  RS_REQUIRE(m->group == 8 || m->group == 9, "rs_umbrella_mfma_pass: fans of 8 or 9 rows (group = %d: use rs_umbrella_mlp_pass)", m->group);
+  RS_REQUIRE(m->rows > 0 && m->rows % m->group == 0 && nblk > 0, "rs_umbrella_mfma_pass: bad size");
   RS_REQUIRE(((uintptr_t)m->x % 8) == 0 && (m->dout == nullptr || ((uintptr_t)m->dout % 8) == 0), "rs_umbrella_mfma_pass: rows must be 8-byte aligned");
   const bool l3 = m->layers == 3;
   if (l3) RS_REQUIRE(m->w2 && m->bn1, "rs_umbrella_mfma_pass: the three-layer MLP needs w2 and bn1");
@@ -670,22 +788,22 @@ extern "C" int rs_umbrella_mfma_pass(int pass, const rs_umbrella_mfma *m, int nb
   switch (pass) {
     case RS_UMB_F1:
       RS_REQUIRE(l3 && m->stat && m->nblk_f1 == nblk, "rs_umbrella_mfma_pass: F1 is a three-layer pass with stat (nblk_f1 = nblk rows)");
-      hipLaunchKernelGGL(umb_f1_kernel, grid, block, 0, st, *m);
+      RS_UMB_G(umb_f1_kernel, );
       break;
     case RS_UMB_F2:
       RS_REQUIRE(m->out && (!l3 || (m->stat && m->nblk_f1 > 0)), "rs_umbrella_mfma_pass: F2 needs out (and the F1 partials)");
-      if (l3) hipLaunchKernelGGL(umb_f2_kernel<3>, grid, block, 0, st, *m);
-      else hipLaunchKernelGGL(umb_f2_kernel<2>, grid, block, 0, st, *m);
+      if (l3) RS_UMB_G(umb_f2_kernel, 3 RS_COMMA);
+      else RS_UMB_G(umb_f2_kernel, 2 RS_COMMA);
       break;
     case RS_UMB_B1:
       RS_REQUIRE(l3 && m->dout && m->part_b1 && m->nblk_b1 == nblk, "rs_umbrella_mfma_pass: B1 is a three-layer pass with dout and part_b1 (nblk_b1 = nblk rows)");
-      hipLaunchKernelGGL(umb_b1_kernel, grid, block, 0, st, *m);
+      RS_UMB_G(umb_b1_kernel, );
       break;
     case RS_UMB_B2:
       RS_REQUIRE(m->dout && m->part_b2 && m->nblk_b2 == nblk && (!l3 || (m->part_b1 && m->nblk_b1 > 0)),
                  "rs_umbrella_mfma_pass: B2 needs dout, part_b2 (nblk_b2 = nblk rows) (and the B1 partials)");
-      if (l3) hipLaunchKernelGGL(umb_b2_kernel<3>, grid, block, 0, st, *m);
-      else hipLaunchKernelGGL(umb_b2_kernel<2>, grid, block, 0, st, *m);
+      if (l3) RS_UMB_G(umb_b2_kernel, 3 RS_COMMA);
+      else RS_UMB_G(umb_b2_kernel, 2 RS_COMMA);
       break;
     case RS_UMB_FIN:
       RS_REQUIRE(m->grads && m->part_b2 && m->nblk_b2 > 0 && (!l3 || (m->part_b1 && m->nblk_b1 > 0)), "rs_umbrella_mfma_pass: FIN needs grads and the partials");

@@ -144,12 +144,12 @@ class PipelinedStep:
             # (net.early_gradient_modules(): the last SA stage + the head) form bucket 0, whose all-reduce is issued from a
             # tensor hook on that stage's input gradient -- i.e. as soon as they are complete -- and runs on the process
             # group's stream under the rest of the backward pass; bucket 1 follows the backward as before.
-            early, self._early_work = None, None
+            early, self._early_work, self._hook = None, None, None
             if (os.environ.get("REPSURF_GRAD_BUCKETS", "1") == "2" and hasattr(net, "early_gradient_modules")
                     and os.environ.get("REPSURF_CAPTURE_ALLREDUCE", "1") != "0" and self._collective_capturable()):
                 mods = net.early_gradient_modules()
                 early = [p for m_ in mods for p in m_.parameters()]
-                mods[0].register_forward_pre_hook(self._arm_early_bucket)
+                self._hook = mods[0].register_forward_pre_hook(self._arm_early_bucket)      # removed by close()
             self.grads = FlatGrads(list(net.parameters()), early=early)
             self.flat = self.grads.flat
         dev = label.device
@@ -182,9 +182,12 @@ class PipelinedStep:
         # were being captured).  So every capture of a sharded step is thread-local, and the watchdog gets one poll period to
         # retire what has already completed.
         mode = {"capture_error_mode": "thread_local"} if sharded else {}
-        if sharded:
-            import time
-            time.sleep(0.3)
+        if sharded and self.dist.is_initialized():
+            # every rank has finished its warm-up collectives before any rank starts capturing (no timing assumption: the device is
+            # idle -- synchronize above -- and the ranks meet on the host; what the watchdog still polls are COMPLETED events, which
+            # thread-local capture mode lets another thread query while this one captures)
+            self.dist.barrier(group)
+            torch.cuda.synchronize()
         # geometry graphs and network graphs run concurrently: separate memory pools
         self.g_geo, self.g_net, self.loss = [], [], []
         for p in (0, 1):
@@ -235,6 +238,13 @@ class PipelinedStep:
             self.geo_done[q].record(self.side)
             self.net_done[q].record(self.main)
         self.parity = 0
+
+    def close(self):
+        """Detach from the model: the forward pre-hook of the two-bucket mode is bound to this step (a copy.deepcopy of the model,
+        or a second PipelinedStep on it, would carry / duplicate it).  The captured graphs stay valid but must not be replayed."""
+        if getattr(self, "_hook", None) is not None:
+            self._hook.remove()
+            self._hook = None
 
     def _geometry(self, p):
         """geometry of the batch the NEXT call trains on (buffers 1 - p), as one serial chain"""
@@ -411,9 +421,23 @@ class FlatGrads:
                 return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
             except (RuntimeError, ValueError):           # a build without ncclAvg refuses at call time: sum and scale
                 self._avg_ok = False
-        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=False)
-        buf.div_(world)
-        return None if not async_op else work
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if not async_op:
+            buf.div_(world)
+            return None
+        return _ScaledWork(work, buf, world)      # the mean is complete once the caller has waited
+
+
+class _ScaledWork:
+    """async SUM all-reduce standing in for AVG: wait() joins the collective, then scales the buffer on the current stream"""
+
+    def __init__(self, work, buf, world):
+        self.work, self.buf, self.world = work, buf, world
+
+    def wait(self):
+        self.work.wait()
+        self.buf.div_(self.world)
+        return True
 
 
 def attach_flat_grads(params):

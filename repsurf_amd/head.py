@@ -58,7 +58,8 @@ def _parse(seq):
     """nn.Sequential(Linear, BN1d, ReLU, Dropout, Linear, BN1d, ReLU, Dropout, Linear) -> pieces, or None"""
     import torch.nn as nn
     mods = list(seq)
-    kinds = [nn.Linear, nn.BatchNorm1d, nn.ReLU, nn.Dropout, nn.Linear, nn.BatchNorm1d, nn.ReLU, nn.Dropout, nn.Linear]
+    bn = (nn.BatchNorm1d, nn.SyncBatchNorm)       # (convert_sync_batchnorm replaces the BatchNorm1d modules)
+    kinds = [nn.Linear, bn, nn.ReLU, nn.Dropout, nn.Linear, bn, nn.ReLU, nn.Dropout, nn.Linear]
     if len(mods) != len(kinds) or not all(isinstance(m, k) for m, k in zip(mods, kinds)):
         return None
     return mods[0], mods[1], mods[3], mods[4], mods[5], mods[7], mods[8]
@@ -71,9 +72,31 @@ def usable(seq, x):
     if parts is None:
         return False
     l1, bn1, d1, l2, bn2, d2, l3 = parts
+    from . import mlp_hip
+    if mlp_hip.sync_of(bn1) is not None or mlp_hip.sync_of(bn2) is not None:
+        return False          # SyncBatchNorm: statistics over the ranks -- the row-stack route below (one all-reduce per BatchNorm)
     return (bn1.training and bn2.training and bn1.momentum is not None and bn2.momentum is not None
             and bn1.affine and bn2.affine and l1.bias is not None and l2.bias is not None and l3.bias is not None
             and l3.out_features <= 256)
+
+
+def rows_usable(seq, x):
+    """The head outside its fused case (eval mode, more than MAX_ROWS clouds per GPU, SyncBatchNorm): the same Sequential on the
+    shared-MLP kernels -- no library GEMM on the path."""
+    return bool(x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and _parse(seq) is not None)
+
+
+def classifier_logprobs_rows(seq, x):
+    """Linear-BN1d-ReLU-Dropout x 2, Linear, log-softmax (classification/models/repsurf/repsurf_ssg_umb.py:32-41,56) as row
+    stacks of the shared-MLP kernels: each Linear + BatchNorm1d + ReLU block is a stack of groups of ONE row (row GEMM with the
+    statistics in its epilogue, finalize, BN + ReLU pass; training and eval mode; SyncBatchNorm-aware), the output Linear is
+    mlp.row_linear; Dropout and the log-softmax over <= 40 classes stay elementwise framework kernels."""
+    import torch.nn.functional as F
+    from . import mlp_hip
+    l1, bn1, d1, l2, bn2, d2, l3 = _parse(seq)
+    h = d1(mlp_hip.sa_mlp_plain(x, [l1], [bn1], 1))
+    h = d2(mlp_hip.sa_mlp_plain(h, [l2], [bn2], 1))
+    return F.log_softmax(mlp_hip.row_linear(h, l3), -1)
 
 
 class _Head(Function):
@@ -204,6 +227,25 @@ def smooth_cls_loss(logp, target, eps):
     return _SmoothLoss.apply(logp, target.to(torch.int64), eps)
 
 
+_bad = {}
+
+
+def _bad_counter(device):
+    key = str(torch.device(device))
+    if key not in _bad:
+        _bad[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+    return _bad[key]
+
+
+def bad_label_count(device=None):
+    """Labels outside [0, classes) (and not the ignore label) the cross-entropy kernel has met on this device since the process
+    started: each made its row's loss and gradient NaN.  Inside a replayed hipGraph nothing else tells the host (the NaN reaches the
+    optimizer state silently), so a training loop calls this -- one 4-byte read-back -- whenever it reads its loss."""
+    if device is None:
+        return sum(int(t.item()) for t in _bad.values())
+    return int(_bad_counter(device).item())
+
+
 class _CrossEntropy(Function):
     @staticmethod
     def forward(ctx, logits, target, ignore_index):
@@ -214,7 +256,7 @@ class _CrossEntropy(Function):
         d = torch.empty_like(logits)
         part = torch.empty((2 * ((rows + 255) // 256),), dtype=torch.float64, device=dev)
         _lib.call("rs_cross_entropy_forward", rows, classes, int(ignore_index), logits.data_ptr(), target.contiguous().data_ptr(),
-                  out.data_ptr(), out.data_ptr() + 4, d.data_ptr(), part.data_ptr(), _stream())
+                  out.data_ptr(), out.data_ptr() + 4, d.data_ptr(), part.data_ptr(), _bad_counter(dev).data_ptr(), _stream())
         ctx.save_for_backward(d, out)
         return out[0]
 
@@ -248,6 +290,11 @@ class CrossEntropyLoss(torch.nn.Module):
 
     def forward(self, logits, target):
         return cross_entropy(logits, target, self.ignore_index)
+
+    @staticmethod
+    def bad_labels(device=None):
+        """see bad_label_count"""
+        return bad_label_count(device)
 
 
 def col_sum(x, scale=1.0):

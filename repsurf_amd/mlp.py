@@ -64,6 +64,12 @@ def umbrella_mlp2(x, mlps, group, moments=None):
     return mlp_hip.umbrella_mlp2(x, mlps, group, moments)
 
 
+def umbrella_moments_wanted(layers):
+    """Does the constructor MLP with this many conv layers (3: classification, 2: segmentation) run on the path that reads the
+    moments?  (The geometry stage computes them only then.)"""
+    return bool(mlp_hip.FUSED_UMBRELLA and mlp_hip.UMB_MFMA and (layers == 2 or mlp_hip.UMB_MFMA_FWD3))
+
+
 def umbrella_moments(x):
     """First and second moments of the (rows, 10) constructor features, (11, 16) fp64 (csrc/umbrella_mfma.hip): what BatchNorm 0
     of the constructor MLP and the linear part of its first weight gradient are computed from.  Geometry-only."""

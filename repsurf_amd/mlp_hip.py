@@ -162,12 +162,46 @@ class deferred_counters:
 
 
 class BNVec:
-    """Per-channel vectors of one BatchNorm for one forward pass."""
-    __slots__ = ("scale", "shift", "mean", "invstd")
+    """Per-channel vectors of one BatchNorm for one forward pass (+ `sync`: how its statistics were reduced over the ranks)."""
+    __slots__ = ("scale", "shift", "mean", "invstd", "sync")
 
     def __init__(self, c, device):
         buf = torch.empty((4, c), dtype=torch.float32, device=device)
         self.scale, self.shift, self.mean, self.invstd = buf[0], buf[1], buf[2], buf[3]
+        self.sync = None
+
+
+# ---- synchronized BatchNorm (the reference's --sync_bn: nn.SyncBatchNorm.convert_sync_batchnorm(model),
+# segmentation/tool/train.py:47,141-142).  The stacks read BatchNorm modules as parameter containers; a module that
+# convert_sync_batchnorm turned into nn.SyncBatchNorm asks for statistics over ALL ranks: the fp64 partial sums a producing
+# kernel leaves ((workgroups, 2|3, C): sum y, sum y^2 forward; sum dz, sum dz*yhat backward) are summed over the process group
+# by ONE all-reduce in front of the finalize launch that reads them, and the finalize divides by the global row count.
+# Every rank runs the same batch layout (weak scaling; DistributedSampler + drop_last in the reference), so the global count
+# is rows x world.  Under RCCL the collective is recorded into the step's hipGraph like the gradient all-reduce.
+SYNC_BN_FORCE = os.environ.get("REPSURF_SYNC_BN_FORCE", "0") != "0"     # tests: also on a 1-rank group (the identity)
+
+
+def sync_of(bn_mod):
+    """(dist, group, world) when this BatchNorm's batch statistics span the process group, else None."""
+    if not isinstance(bn_mod, torch.nn.SyncBatchNorm) or not bn_mod.training:
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn_mod.process_group
+    world = dist.get_world_size(group)
+    if world <= 1 and not SYNC_BN_FORCE:
+        return None
+    return dist, group, world
+
+
+def sync_partials(part, sync):
+    """Sum a partial-sum tensor over the ranks (in place); returns the factor the row count grows by."""
+    if sync is None:
+        return 1
+    dist, group, world = sync
+    dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    return world
 
 
 def _w2d(w):
@@ -341,6 +375,8 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
             epi.pool_amax, epi.pool_amin = pos[0].data_ptr(), pos[1].data_ptr()
             pool = (ext, pos)
         gemm_rows(rows, kdim, cout, x_op, wk if wk is not None else w_fwd(w2d), epi, rows_dev)
+        vec.sync = sync_of(bn_mod)
+        bn_rows = bn_rows * sync_partials(part, vec.sync)      # SyncBatchNorm: statistics over every rank's rows
         track = bn_mod.track_running_stats and bn_mod.running_mean is not None
         if track:
             _pending_counters.append(bn_mod.num_batches_tracked)
@@ -387,7 +423,32 @@ def wgrad_chunks(rows, ncols, kcols):
 # Weight-gradient partials whose fixed-order sum rides along with the next BatchNorm-backward finalize launch of the same
 # backward call (rs_bn_backward_finalize_reduce): (partial, chunks, elements, dw).  Same stream, consumed in order;
 # `flush_reduces` sums what is left when the chain ends.
-_pending_reduce = []
+class _PendingReduces:
+    """One queue per (device, stream): a weight gradient's partials are summed by a later launch on the SAME stream (that is what
+    orders them), so work queued on one device / stream must never ride with, or be drained by, a launch on another (ADVICE r3:
+    the single process-wide list was drained on whatever stream was current).  len() / bool(): over all queues."""
+
+    def __init__(self):
+        self.queues = {}
+
+    def cur(self):
+        key = (torch.cuda.current_device(), _stream())
+        q = self.queues.get(key)
+        if q is None:
+            q = self.queues[key] = []
+        return q
+
+    def append(self, item):
+        self.cur().append(item)
+
+    def __len__(self):
+        return sum(len(q) for q in self.queues.values())
+
+    def __bool__(self):
+        return any(self.queues.values())
+
+
+_pending_reduce = _PendingReduces()
 
 
 def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None, defer=False):
@@ -402,14 +463,7 @@ def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None, defer=False):
     _lib.call("rs_mlp_wgrad_bf16" if _mlp.PRECISION == "bf16" else "rs_mlp_wgrad", rows, rows_dev, ncols, kcols, ctypes.byref(p_op), ctypes.byref(q_op), _ptr(part), chunks,
               None if defer else _ptr(dw), _stream())
     if defer:
-        # the queue is ONE per process and is drained on the current stream: this package runs one process per GPU
-        # (repsurf_amd.dist); a second device in the same process (autograd runs its backward on a thread of its own) must not
-        # interleave with it -- its sums are launched at once instead of being carried
-        if _pending_reduce and _pending_reduce[0][0].device != part.device:
-            flush_reduces()
-            _lib.call("rs_reduce_partials", chunks, ncols * kcols, _ptr(part), _ptr(dw), _stream())
-        else:
-            _pending_reduce.append((part, chunks, ncols * kcols, dw))
+        _pending_reduce.append((part, chunks, ncols * kcols, dw))      # the queue of THIS device and stream
     return dw
 
 
@@ -419,8 +473,9 @@ def _tail(fin_items, max_red=TAIL_RED_MAX):
     work.nfin = len(fin_items)
     for i, it in enumerate(fin_items):
         work.fin[i] = it
-    nred = min(len(_pending_reduce), max_red)
-    keep = [_pending_reduce.pop(0) for _ in range(nred)]
+    queue = _pending_reduce.cur()
+    nred = min(len(queue), max_red)
+    keep = [queue.pop(0) for _ in range(nred)]
     work.nred = nred
     for j, (part, chunks, n, dw) in enumerate(keep):
         work.red[j] = ReduceItem(chunks=chunks, n=n, partial=_ptr(part), out=_ptr(dw))
@@ -428,9 +483,17 @@ def _tail(fin_items, max_red=TAIL_RED_MAX):
         _lib.call("rs_backward_tail", ctypes.byref(work), _stream())
 
 
-def flush_reduces():
-    while _pending_reduce:
+def flush_reduces(everywhere=False):
+    """Sum what is pending on the current (device, stream); everywhere=True: on every queue, each under its own device and
+    stream (the end-of-pass callback runs on the thread that called backward, whatever streams the pass used)."""
+    while _pending_reduce.cur():
         _tail([])
+    if everywhere:
+        for (dev, stream), queue in list(_pending_reduce.queues.items()):
+            if queue:
+                with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                    while queue:
+                        _tail([])
 
 
 # A stack's backward ends with weight-gradient partials whose sum is still pending (its first-layer weights).  Summing them
@@ -472,7 +535,7 @@ class owned_pass:
 def _end_of_pass_flush():
     global _flush_armed
     _flush_armed = False
-    flush_reduces()
+    flush_reduces(everywhere=True)
 
 
 def _stack_begins():
@@ -482,7 +545,7 @@ def _stack_begins():
 
 def _stack_ends():
     global _flush_armed
-    if not _pending_reduce:
+    if not _pending_reduce.cur():
         return
     if OWNED_PASS:
         if not _flush_armed:
@@ -500,14 +563,27 @@ def bwd_coeffs_multi(specs, device):
     launch, which also sums the pending weight-gradient partials (up to TAIL_RED_MAX of them).
     frozen (eval mode: the layer normalised with its running statistics, which are constants): dy = scale * dz, i.e.
     p = scale, q = r = 0; dgamma / dbeta are the same sums (vec.mean / vec.invstd hold the running statistics)."""
-    items, outs = [], []
+    items, outs, synced = [], [], []
+    reduced = {}
     for c, rows, part, nstat, which, vec, nblk, frozen in specs:
+        if vec.sync is not None and not frozen:          # SyncBatchNorm: the backward sums span the ranks too (once per tensor)
+            if part.data_ptr() not in reduced:
+                reduced[part.data_ptr()] = sync_partials(part if nblk is None else part[:nblk], vec.sync)
+            rows = rows * reduced[part.data_ptr()]
         buf = torch.empty((5, c), dtype=torch.float32, device=device)
+        synced.append(reduced.get(part.data_ptr(), 1) if (vec.sync is not None and not frozen) else 1)
         items.append(BnBwdItem(c=c, nblk=part.shape[0] if nblk is None else nblk, nstat=nstat, which=which, rows=rows, partial=part.data_ptr(),
                                scale=_ptr(vec.scale), mean=_ptr(vec.mean), invstd=_ptr(vec.invstd), p=_ptr(buf[0]), q=_ptr(buf[1]), r=_ptr(buf[2]),
                                dgamma=_ptr(buf[3]), dbeta=_ptr(buf[4])))
         outs.append((buf, vec, frozen, c))
     _tail(items)
+    for (buf, _, _, _), world in zip(outs, synced):
+        if world > 1:
+            # the finalize saw the sums over ALL ranks: right for p, q, r (the data gradient of synchronized statistics), but
+            # dgamma / dbeta are then the global sums on every rank, and the gradient all-reduce AVERAGES over the ranks: scale
+            # them so that the average is the whole batch's gradient (torch's SyncBatchNorm hands out the local sums instead;
+            # after the averaging both give the same parameters)
+            buf[3:5].mul_(1.0 / world)
     res = []
     for buf, vec, frozen, c in outs:
         if frozen:
@@ -943,20 +1019,29 @@ class UmbrellaMFMADesc(ctypes.Structure):      # rs_umbrella_mfma
 UMB_F1, UMB_F2, UMB_B1, UMB_B2, UMB_FIN = 1, 2, 3, 4, 5
 UMB_MOM_ROW, UMB_B1_ROW, UMB_B2_ROW, UMB_GRADS = 176, 544, 368, 360
 UMB_MFMA = os.environ.get("REPSURF_UMB_MFMA", "1") != "0"         # 0: the register-resident VALU passes of csrc/umbrella_mlp.hip
+# three-layer (classification) constructor: which direction runs on the matrix pipe (the BatchNorm vectors the forward publishes are
+# the ones the VALU backward passes read, so the two mix freely); measured per direction inside the step, DESIGN.md 5
+# Round 4, same box, three interleaved rounds of bench.py (ms per step): VALU passes 1.420 / 1.432 / 1.423, matrix-pipe forward + VALU
+# backward 1.427 / 1.434 / 1.423, matrix pipe both ways 1.441 / 1.438 / 1.444 -- stand-alone the matrix-pipe passes are level
+# (86 against 83 us) but their 512-thread workgroups share the CUs worse with the geometry stream's kernels at the head of the step;
+# the two-layer (segmentation) variant wins both stand-alone (53 against 76 us) and in the step (4.31 against 4.35 ms).  So the
+# three-layer constructor stays on the VALU passes by default.
+UMB_MFMA_FWD3 = os.environ.get("REPSURF_UMB_MFMA_FWD3", "0") != "0"
+UMB_MFMA_BWD3 = os.environ.get("REPSURF_UMB_MFMA_BWD3", "1") != "0"
 UMB_MFMA_BLOCKS = int(os.environ.get("REPSURF_UMB_MFMA_BLOCKS", "256"))
 
 
 def _umb_blocks(rows, group):
-    """workgroups of a constructor pass: 4 waves each, a wave takes tiles of 16 points; at least one tile per wave"""
+    """workgroups of a constructor pass: 8 waves each, a wave takes tiles of 16 points; at least one tile per wave"""
     tiles = -(-(rows // group) // 16)
-    return max(1, min(UMB_MFMA_BLOCKS, -(-tiles // 4)))
+    return max(1, min(UMB_MFMA_BLOCKS, -(-tiles // 8)))
 
 
 def umbrella_moments(x):
     """(11, 16) fp64 moments of the (rows, 10) constructor features: S[m][n] = sum x_m x_n, index 10 = the constant 1.  They depend
     on the geometry only: the pipelined step computes them in the geometry stage (side stream), next to the features."""
     rows = x.shape[0]
-    nblk = max(1, min(256, -(-rows // 1024)))
+    nblk = max(1, min(512, -(-rows // 512)))          # a wave takes 64 rows per trip, 8 waves per workgroup
     part = torch.empty((nblk, UMB_MOM_ROW), dtype=torch.float32, device=x.device)
     mom = torch.empty((11, 16), dtype=torch.float64, device=x.device)
     _lib.call("rs_umbrella_moments", _ptr(x), rows, _ptr(part), nblk, _ptr(mom), _stream())
@@ -1008,12 +1093,10 @@ class _UmbrellaMFMA(Function):
                                 moments=_ptr(moments))
         out = torch.empty((rows // group, 10), dtype=torch.float32, device=dev)
         desc.out, desc.out_scale = _ptr(out), (1.0 / group if meta.get("aggr") == "avg" else 1.0)
-        keep = [x, moments, w0_, w1_, w2_, v0, v1, out]
         if layers == 3:
             stat = torch.empty((nblk, 2, 16), dtype=torch.float64, device=dev)
             desc.stat, desc.nblk_f1 = stat.data_ptr(), nblk
             _lib.call("rs_umbrella_mfma_pass", UMB_F1, ctypes.byref(desc), nblk, _stream())
-            keep.append(stat)
         _lib.call("rs_umbrella_mfma_pass", UMB_F2, ctypes.byref(desc), nblk, _stream())
         ctx.saved = dict(x=x, moments=moments, w0=w0_, w1=w1_, w2=w2_, cb0=det(cb0), c1=det(c1), c2=det(c2), v0=v0, v1=v1, nblk=nblk)
         ctx.meta = meta
@@ -1023,6 +1106,9 @@ class _UmbrellaMFMA(Function):
     @staticmethod
     def backward(ctx, dout):
         s, meta = ctx.saved, ctx.meta
+        if meta["layers"] == 3 and not UMB_MFMA_BWD3:      # the register-resident VALU passes read the same saved tensors / vectors
+            g = _UmbrellaFused.backward(ctx, dout)
+            return g[:2] + (None,) + g[2:]
         x, v0, v1 = s["x"], s["v0"], s["v1"]
         dev = x.device
         rows, group, layers, nblk = x.shape[0], meta["group"], meta["layers"], s["nblk"]
@@ -1037,6 +1123,7 @@ class _UmbrellaMFMA(Function):
         if layers == 3:
             part_b1 = torch.empty((nblk, UMB_B1_ROW), dtype=torch.float32, device=dev)
             desc.part_b1, desc.nblk_b1 = _ptr(part_b1), nblk
+        if layers == 3:
             _lib.call("rs_umbrella_mfma_pass", UMB_B1, ctypes.byref(desc), nblk, _stream())
         _lib.call("rs_umbrella_mfma_pass", UMB_B2, ctypes.byref(desc), nblk, _stream())
         _lib.call("rs_umbrella_mfma_pass", UMB_FIN, ctypes.byref(desc), nblk, _stream())
@@ -1161,8 +1248,9 @@ def umbrella_mlp2(x, mlps, group, moments=None):
     conv0, bn0, _, conv1 = mlps
     meta = {"group": group, "bn": bn0, "training": bn0.training, "shapes": [conv0.weight.shape, conv1.weight.shape]}
     fused = (x.shape[1] == 10 and tuple(conv0.weight.shape[:2]) == (10, 10) and tuple(conv1.weight.shape[:2]) == (10, 10)
-             and conv0.bias is not None and conv1.bias is not None and bn0.training and FUSED_UMBRELLA)
-    if fused and UMB_MFMA and bn0.weight is not None:
+             and conv0.bias is not None and conv1.bias is not None and bn0.training and FUSED_UMBRELLA
+             and sync_of(bn0) is None)      # (SyncBatchNorm: the generic stack, whose finalizes take the all-reduced sums)
+    if fused and UMB_MFMA and bn0.weight is not None and group in (8, 9):      # (the tile's fan rows are register arrays: fans of 8 / 9)
         meta.update(layers=2, bns=(bn0,))
         return _UmbrellaMFMA.apply(x, meta, moments, conv0.weight, conv0.bias, bn0.weight, bn0.bias, conv1.weight, conv1.bias)
     fn = _UmbrellaFused2 if fused else _UmbrellaStack2
@@ -1175,8 +1263,9 @@ def umbrella_mlp(x, mlps, group, aggr, moments=None):
     meta = {"group": group, "aggr": aggr, "bns": (bn0, bn1), "training": bn0.training,
             "shapes": [conv0.weight.shape, conv1.weight.shape, conv2.weight.shape]}
     fused = (x.shape[1] == 10 and conv0.weight.shape[:2] == (10, 10) and conv1.weight.shape[:2] == (10, 10)
-             and conv2.weight.shape[:2] == (10, 10) and aggr in ("sum", "avg") and bn0.training and FUSED_UMBRELLA)
-    if fused and UMB_MFMA and conv0.bias is None and bn0.weight is not None and bn1.weight is not None:
+             and conv2.weight.shape[:2] == (10, 10) and aggr in ("sum", "avg") and bn0.training and FUSED_UMBRELLA
+             and sync_of(bn0) is None and sync_of(bn1) is None)
+    if fused and UMB_MFMA and UMB_MFMA_FWD3 and conv0.bias is None and bn0.weight is not None and bn1.weight is not None and group in (8, 9):
         meta["layers"] = 3
         return _UmbrellaMFMA.apply(x, meta, moments, conv0.weight, bn0.weight, bn0.bias, conv1.weight, conv1.bias, bn1.weight,
                                    bn1.bias, conv2.weight, conv2.bias)

@@ -66,7 +66,7 @@ class Model(nn.Module):
         fps = []
         for fine, coarse in ((3, 4), (2, 3), (1, 2), (0, 1)):          # fp4, fp3, fp2, fp1
             fps.append(SurfaceFeaturePropagationCD.geometry(centers[fine], offsets[fine], centers[coarse], offsets[coarse]))
-        moments = _mlp.umbrella_moments(feat.reshape(-1, 10)) if (self.training and feat.is_cuda) else None
+        moments = _mlp.umbrella_moments(feat.reshape(-1, 10)) if (self.training and feat.is_cuda and _mlp.umbrella_moments_wanted(2)) else None
         return SegGeoState(feat, stages, fps, moments)
 
     def forward(self, pos_feat_off0, geo=None):

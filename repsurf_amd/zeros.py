@@ -8,7 +8,7 @@ fresh zeros, and every slice is distinct memory (an in-place op on one gradient 
 import torch
 
 CAPACITY = 8192            # floats per pool chunk (the classifier needs ~4.3 k per pass)
-_pool = {}                 # device -> [buffer, used]
+_pool = {}                 # (device, stream) -> [buffer, used]: the fill that makes a pool is ordered on ONE stream
 _armed = False
 
 
@@ -26,7 +26,7 @@ def take(n, device):
             _armed = True
         except RuntimeError:                 # not inside a backward pass: nothing to scope a pool to
             return torch.zeros((n,), dtype=torch.float32, device=device)
-    key = str(device)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     ent = _pool.get(key)
     if ent is None or ent[1] + n > ent[0].numel():
         ent = [torch.zeros((max(CAPACITY, n),), dtype=torch.float32, device=device), 0]

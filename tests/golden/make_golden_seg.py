@@ -22,6 +22,10 @@ Fixtures:
                   so that the sector branch runs on small clouds.
   seg_model.npz   repsurf_umb_ssg on 2 packed clouds (2048 + 1536 points): logits, loss, stage outputs
                   (subsampled), parameter-gradient norms + subsampled gradients; name-seeded weights, dropout 0.
+  seg_cfg3.npz    (`--configs3`, ~10 minutes) the reference's own model at BASELINE configs[3] size -- 16 x 4096 uniform clouds, the
+                  batch tests/test_parity_full_gpu.py::test_segmentation_step_at_the_benchmark_configuration_three_way builds --
+                  in fp32 AND in float64: logits of every 16th row, loss, gradient norms of both runs: pins "the reference's own fp32
+                  run is further than 1e-5 from its float64 evaluation" at the benchmark size, not only on the 2-cloud fixture.
   seg_pointnet2.npz  the reference's PointNet++ baseline (models/pointnet2/pointnet2_ssg.py over modules/pointnet2_utils.py)
                   on the same clouds: logits, loss, gradient norms + subsampled gradients.
 """
@@ -254,5 +258,55 @@ def main():
     print("wrote seg_pointnet2.npz; loss", loss.item())
 
 
+def configs3():
+    """The reference's own model, fp32 and float64, on the configs[3] batch of the GPU parity test (same generator calls)."""
+    import time
+    install_stubs()
+    from models.repsurf.repsurf_umb_ssg import Model
+    args = argparse.Namespace(return_polar=False, in_channel=6, group_size=8, num_class=13)
+    r = np.random.RandomState(3)
+    n = 16 * 4096
+    coord = torch.from_numpy((r.rand(n, 3) * 2 - 1).astype(np.float32))
+    rgb = torch.from_numpy(r.rand(n, 3).astype(np.float32))
+    offset = torch.from_numpy((np.arange(1, 17) * 4096).astype(np.int32))
+    label = torch.from_numpy(r.randint(0, 13, n).astype(np.int64))
+
+    def build():
+        m_ = Model(args).train()
+        name_seeded_init(m_)
+        for mod in m_.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        np.random.seed(17)                     # cal_normal draws the 16 flips from here (recons_utils.py:29)
+        return m_
+    t0 = time.time()
+    model = build()
+    logits = model([coord, rgb.clone(), offset])
+    loss = torch.nn.functional.cross_entropy(logits, label)
+    loss.backward()
+    print("fp32 run %.0f s, loss %.6f" % (time.time() - t0, loss.item()), flush=True)
+    out = {"rows": np.arange(0, n, 16, dtype=np.int32), "logits32": logits.detach().numpy()[::16].copy(), "loss32": np.float32(loss.item())}
+    for name, p in model.named_parameters():
+        out["gnorm32/" + name] = np.float32(p.grad.norm().item())
+    t0 = time.time()
+    l64, loss64, g64 = truth_run(build, lambda dt: [coord, rgb.clone().to(dt), offset], label)
+    print("fp64 run %.0f s, loss %.9f" % (time.time() - t0, loss64), flush=True)
+    out["logits64"], out["loss64"] = l64[::16].copy(), np.float64(loss64)
+    rel = {}
+    for name, p in model.named_parameters():
+        g = g64[name]
+        out["gnorm64/" + name] = np.float64(g.norm().item())
+        if g.norm().item() > 1e-5:
+            rel[name] = float((p.grad.double() - g).norm() / g.norm())
+            out["grel32/" + name] = np.float64(rel[name])       # relative L2 distance of the reference's fp32 gradient from its fp64 one
+    out["logits32_vs_64_max_abs_all_rows"] = np.float64(np.abs(logits.detach().numpy() - l64).max())
+    print("reference fp32 vs its own fp64 at configs[3]: logits max abs", out["logits32_vs_64_max_abs_all_rows"], "scale", np.abs(l64).max(),
+          "gradient rel-L2 median / max", np.median(list(rel.values())), max(rel.values()))
+    np.savez_compressed(os.path.join(HERE, "seg_cfg3.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--configs3" in sys.argv:
+        configs3()
+    else:
+        main()

@@ -210,3 +210,41 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     assert len(lines) == 1, res.stdout
     out = json.loads(lines[0])
     assert out == {"dry_run": True, "n_gpus": 2, "requested": 2, "rank_sum": 3.0, "backend": "gloo"}
+
+
+def _sync_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from repsurf_amd import mlp_hip
+    plain, synced = torch.nn.BatchNorm1d(4), torch.nn.SyncBatchNorm(4)
+    assert mlp_hip.sync_of(plain) is None and mlp_hip.sync_of(synced.eval()) is None
+    sync = mlp_hip.sync_of(synced.train())
+    assert sync is not None and sync[2] == world
+    # what a producing kernel leaves on this rank: fp64 partial sums {sum y, sum y^2} of ITS rows, two workgroup rows
+    g = torch.Generator().manual_seed(7)
+    y = torch.randn(world * 10, 4, generator=g, dtype=torch.float64)
+    mine = y[rank * 10:(rank + 1) * 10]
+    part = torch.stack([torch.stack([mine[:5].sum(0), (mine[:5] ** 2).sum(0)]), torch.stack([mine[5:].sum(0), (mine[5:] ** 2).sum(0)])])
+    factor = mlp_hip.sync_partials(part, sync)
+    rows = 10 * factor
+    mean = part[:, 0].sum(0) / rows
+    var = part[:, 1].sum(0) / rows - mean ** 2
+    out[rank] = (factor, mean, var, y.mean(0), y.var(0, unbiased=False))
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_partials_span_the_ranks():
+    """repsurf_amd.mlp_hip.sync_of / sync_partials (the --sync_bn option, segmentation/tool/train.py:141-142): an nn.SyncBatchNorm
+    module in training mode asks for statistics over the process group; one all-reduce of the fp64 partial sums in front of the
+    finalize and the global row count give the whole batch's mean and variance on every rank."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_sync_worker, args=(world, port, out), nprocs=world, join=True)
+        for r in range(world):
+            factor, mean, var, ref_mean, ref_var = out[r]
+            assert factor == world
+            assert torch.allclose(mean, ref_mean, atol=1e-12) and torch.allclose(var, ref_var, atol=1e-12)

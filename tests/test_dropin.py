@@ -62,7 +62,9 @@ def test_reference_classifier_file_forward_backward_matches_its_cpu_fixture():
         worst = max(worst, abs(got - ref) / max(ref, 1e-2))
     parity_report("dropin_cls_reference_file", logits_max_abs=err, loss_abs=abs(loss.item() - float(g["loss"])),
                   grad_norm_rel=worst)
-    assert err <= 5e-5 and abs(loss.item() - float(g["loss"])) < 1e-5 and worst <= 2e-3
+    # the bound is stated of the tensor's scale (log-probabilities of magnitude ~4): measured 1.03e-5 absolute = 2.6e-6 of scale
+    scale = float(np.abs(g["logits"]).max())
+    assert err <= 5e-6 * scale and err <= 1.5e-5 and abs(loss.item() - float(g["loss"])) < 1e-5 and worst <= 2e-3, (err, scale, worst)
 
 
 @need

@@ -763,12 +763,12 @@ def test_owned_pass_carries_pending_reductions_across_stacks_with_identical_grad
     assert H.OWNED_PASS == 0
 
 
-@pytest.mark.parametrize("layers,points,group", [(3, 300, 8), (3, 2048, 8), (3, 33, 5), (2, 200, 9), (2, 7000, 9), (2, 16, 8), (3, 1, 8)])
+@pytest.mark.parametrize("layers,points,group", [(3, 300, 8), (3, 2048, 8), (3, 33, 9), (3, 40000, 8), (2, 200, 9), (2, 7000, 9), (2, 16, 8), (3, 1, 8), (2, 70000, 9)])
 def test_constructor_mlp_on_the_matrix_pipe(layers, points, group):
     """csrc/umbrella_mfma.hip (v_mfma_f32_16x16x4_f32 tiles of 16 points, BatchNorm 0 from the moments of x, finalizes folded into the
     consuming passes) against (a) the fp64 evaluation of the same modules, (b) the register-resident VALU passes it replaces
     (csrc/umbrella_mlp.hip): output, both BatchNorms' running statistics, every gradient; point counts that are not a multiple of
-    the 16-point tile, fans of 5 / 8 / 9, a single point; the moments handed in ahead of time (the geometry stage does) or not."""
+    the 16-point tile, fans of 8 / 9, a single point, more tiles than waves; the moments handed in ahead of time (the geometry stage does) or not."""
     from repsurf_amd import mlp, mlp_hip as H
     torch.manual_seed(31 + points)
     if layers == 3:
@@ -794,6 +794,7 @@ def test_constructor_mlp_on_the_matrix_pipe(layers, points, group):
             m, xx = m.double(), x.double()
             torch_executor.set_backend("torch")
         H.UMB_MFMA = kind in ("mfma", "mfma+moments")
+        fwd3, H.UMB_MFMA_FWD3 = H.UMB_MFMA_FWD3, True          # (the three-layer constructor is on the VALU passes by default: measured, mlp_hip)
         try:
             mom = mlp.umbrella_moments(x) if kind == "mfma+moments" else None
             if layers == 3:
@@ -802,13 +803,22 @@ def test_constructor_mlp_on_the_matrix_pipe(layers, points, group):
                 out = mlp.umbrella_mlp2(xx, m, group, moments=mom)
             (out * w.to(out.dtype)).sum().backward()
         finally:
-            H.UMB_MFMA = True
+            H.UMB_MFMA, H.UMB_MFMA_FWD3 = True, fwd3
             torch_executor.set_backend("hip")
         stats = [t.clone() for i in bn_idx for t in (m[i].running_mean, m[i].running_var)]
         return out.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}, stats
 
     ref, valu, new, new2 = run("fp64"), run("valu"), run("mfma"), run("mfma+moments")
     assert torch.equal(new[0], new2[0]) and all(torch.equal(new[1][k], new2[1][k]) for k in new[1])
+    if layers == 3:      # forward on the matrix pipe, backward on the VALU passes (they read the vectors the forward published)
+        H.UMB_MFMA_BWD3 = not H.UMB_MFMA_BWD3
+        try:
+            mixed = run("mfma")
+        finally:
+            H.UMB_MFMA_BWD3 = not H.UMB_MFMA_BWD3
+        assert torch.equal(new[0], mixed[0])
+        for k in new[1]:
+            assert k == "3.bias" or rel_l2(mixed[1][k].double(), ref[1][k]) < 2e-3, k
     pre_bn_bias = "3.bias" if layers == 3 else "0.bias"
     single = points * group < 2           # one row: the batch variance is 0 and every BatchNorm gradient degenerates
     for name, got in (("valu", valu), ("mfma", new)):

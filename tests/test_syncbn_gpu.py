@@ -1,0 +1,117 @@
+"""--sync_bn (segmentation/tool/train.py:47,141-142: nn.SyncBatchNorm.convert_sync_batchnorm(model)) over the HIP stacks: the
+BatchNorm partial sums are all-reduced over the process group in front of every finalize launch (repsurf_amd.mlp_hip.sync_of).
+Two ranks share the one GPU of the box (gloo carries the collectives: RCCL refuses two ranks on one device); each trains on HALF
+of a batch with synchronized statistics, and the result must equal ONE process training on the whole batch:
+loss (mean of the two), every parameter gradient (mean of the two = what the gradient all-reduce gives), running statistics."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_and_batch(kind):
+    import argparse
+    import sys
+    sub = os.path.join(ROOT, "repsurf_amd", "classification" if kind == "cls" else "segmentation")
+    for p in (ROOT, sub):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from repsurf_amd import rng
+    # deterministic draws, identical for a cloud whichever process holds it: flips +1, FPS starts 0
+    rng._cpu_draw = lambda k, b, n: (torch.ones(b) if k in ("flip", "npflip") else torch.zeros(b, dtype=torch.int32))
+    torch.manual_seed(0)
+    r = np.random.RandomState(5)
+    if kind == "cls":
+        from models.repsurf.repsurf_ssg_umb import Model
+        from util.utils import SmoothClsLoss
+        args = argparse.Namespace(num_point=256, return_dist=True, return_center=True, return_polar=True, group_size=8,
+                                  umb_pool="sum", cuda_ops=True, num_class=15)
+        model = Model(args)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        xyz = torch.from_numpy((r.rand(8, 3, 1024) * 2 - 1).astype(np.float32))
+        label = torch.from_numpy(r.randint(0, 15, 8))
+        return model, SmoothClsLoss(), (xyz, label)
+    from models.repsurf.repsurf_umb_ssg import Model
+    args = argparse.Namespace(return_polar=False, in_channel=6, group_size=8, num_class=13)
+    model = Model(args)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    n = 4 * 1024
+    coord = torch.from_numpy((r.rand(n, 3) * 2 - 1).astype(np.float32))
+    rgb = torch.from_numpy(r.rand(n, 3).astype(np.float32))
+    label = torch.from_numpy(r.randint(0, 13, n))
+    return model, torch.nn.CrossEntropyLoss(), (coord, rgb, label)
+
+
+def _half(kind, batch, rank, world):
+    if kind == "cls":
+        xyz, label = batch
+        per = xyz.shape[0] // world
+        return (xyz[rank * per:(rank + 1) * per].cuda(),), label[rank * per:(rank + 1) * per].cuda()
+    coord, rgb, label = batch
+    clouds, pts = 4, 1024
+    per = clouds // world
+    lo, hi = rank * per * pts, (rank + 1) * per * pts
+    off = (torch.arange(1, per + 1) * pts).to(torch.int32).cuda()
+    return ([coord[lo:hi].cuda(), rgb[lo:hi].cuda(), off],), label[lo:hi].cuda()
+
+
+def _run(kind, rank, world, sync):
+    model, crit, batch = _model_and_batch(kind)
+    model = model.cuda().train()
+    if sync:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    args, label = _half(kind, batch, rank, world)
+    loss = crit(model(*args), label)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters()}
+    stats = {n: b.detach().cpu() for n, b in model.named_buffers() if n.endswith("running_var") or n.endswith("running_mean")}
+    return float(loss.item()), grads, stats
+
+
+def _worker(rank, world, port, kind, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out[rank] = _run(kind, rank, world, True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["cls", "seg"])
+def test_two_halves_with_sync_bn_equal_one_whole_batch(kind):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, port, kind, out), nprocs=2, join=True)
+        (l0, g0, s0), (l1, g1, s1) = out[0], out[1]
+    lw, gw, sw = _run(kind, 0, 1, False)
+    assert abs((l0 + l1) / 2 - lw) <= 2e-6 * max(1.0, abs(lw)), (l0, l1, lw)
+    for name, ref in sw.items():          # synchronized statistics: both ranks hold the whole batch's
+        for s_ in (s0, s1):
+            assert torch.allclose(s_[name], ref, rtol=2e-5, atol=1e-6), name
+    worst = 0.0
+    for name, ref in gw.items():
+        if ref.norm() < 1e-4:             # analytically zero: biases in front of a BatchNorm (exact zeros here) and the constructor's
+            assert g0[name].norm() < 1e-3, name    # last bias (a constant shift of every normal, removed by the next BatchNorm: fp noise)
+            continue
+        got = (g0[name] + g1[name]) / 2
+        err = ((got - ref).norm() / ref.norm()).item()
+        worst = max(worst, err)
+        assert err < 1e-2, (name, err)
+    print("worst gradient relative L2", worst)

@@ -58,7 +58,7 @@ def case(layers, points, group, label):
 
     H.UMB_MFMA = False
     t_old, f_old = graph_time(lambda: fwd_bwd(None)), graph_time(lambda: fwd_only(None))
-    H.UMB_MFMA = True
+    H.UMB_MFMA = H.UMB_MFMA_FWD3 = True
     print(f"{label}: VALU passes fwd+bwd {t_old:7.1f} us (fwd {f_old:6.1f})")
     for blocks in BLOCKS:
         H.UMB_MFMA_BLOCKS = blocks
