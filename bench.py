@@ -140,6 +140,21 @@ def reference_cpu_baseline(args, threads):
         return None
 
 
+def reference_seg_cpu_baseline(points, threads):
+    """SURVEY 8(d) for configs[3]: the REFERENCE's own segmentation step timed on this host by oracle/ref_seg_cpu.py (its unmodified
+    Python over oracle/_ref, the host build of its own kernels), 2 clouds, 1 warm-up + 1 timed step, in a process of its own.
+    None when the files / the host build are not staged."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_seg_cpu.py"), "--clouds", "2", "--points", str(points), "--steps", "1",
+           "--threads", str(threads)]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**os.environ, "OMP_NUM_THREADS": str(threads)})
+        rec = json.loads(res.stdout.strip().splitlines()[-1])
+        return None if "error" in rec else rec
+    except (subprocess.SubprocessError, OSError, ValueError, IndexError):
+        return None
+
+
 def cpu_baseline(args, state):
     """The CPU path on the same workload: B x points clouds, zero_grad -> forward -> SmoothClsLoss -> backward, 1 warm-up +
     `--cpu-steps` timed iterations on this host.  /root/reference does not exist on the GPU box, so the
@@ -292,24 +307,23 @@ def algorithmic_bytes(name, dims):
     return None
 
 
-def gemm_family_in_graph(forward_loss, net, replays=20):
+def gemm_family_in_graph(net, criterion, points, label, replays=20):
     """The matrix-pipe launches of ONE step (every rs_mlp_gemm_rows / rs_mlp_wgrad call of forward + backward) as they run inside
-    a replayed step: recorded during one eager pass, captured into ONE hipGraph, replayed `replays` times between two HIP events.
-    Per-launch events of the eager pass include ~5-10 us of idle device in front of every launch (the host is slower than the
-    kernels); a replay has none, which is what the training step's graph sees (rocprofv3 of the replayed step agrees:
-    profiles/r04/).  The loss is held until the replays are done, so every tensor the calls read is alive; what they WRITE are
-    buffers of that same pass (free blocks of the caching allocator by then: nothing else allocates in between).
+    a replayed step: a forward + backward of `net` is captured as a hipGraph with the GEMM-family ABI calls recorded
+    (repsurf_amd.graph.GraphedStep(record_calls=True)); those calls are then captured on their own into ONE hipGraph and replayed
+    `replays` times between two HIP events.  Per-launch events of the eager pass include ~5-10 us of idle device in front of every
+    launch (the host is slower than the kernels); a replay has none, which is what the training step's graph sees (rocprofv3 of
+    the replayed step agrees: profiles/r04/).  Every pointer of the recorded calls lies in the first graph's private memory pool,
+    which lives until this function returns: the replays read and write nothing else.
     -> {"ms_per_step": all launches, "launches": n, "by_class_us": {class key: avg us per launch}}"""
     from repsurf_amd import _lib
-    for p in net.parameters():
-        p.grad = None
-    _lib.record_calls(True)
-    loss = forward_loss()
-    loss.backward()
-    calls = _lib.record_calls(False)
-    torch.cuda.synchronize()
+    from repsurf_amd.graph import GraphedStep
+    holder = GraphedStep(net, criterion, None, points, label, warmup=2, record_calls=True)
+    calls = holder.recorded_calls
     if not calls:
         return None
+    holder()                      # one replay of the whole step: a capture runs nothing, and the recorded launches read device-side row
+    torch.cuda.synchronize()      # counts (compacted groups), indices and activations that only the step's other kernels produce
 
     def timed_graph(subset):
         side = torch.cuda.Stream()
@@ -345,7 +359,7 @@ def gemm_family_in_graph(forward_loss, net, replays=20):
         ids = {id(c[1]) for c in v}
         rest = [c for c in calls if id(c[1]) not in ids]
         out["by_class_us"][k] = max(0.0, total - (timed_graph(rest) if rest else 0.0)) * 1e3 / len(v)
-    del loss
+    del holder
     return out
 
 
@@ -404,6 +418,8 @@ def roofline_from_profile(prof, timed_steps, dtype, in_graph=None):
             roofline["eager_avg_launch_us"] = round(row["eager_avg_us"], 2)
         roofline["launches_per_step"] = row["launches"] // max(1, timed_steps)
         roofline["traffic"] = traffic_from_profiles(row["kernel"], row["dims"])
+        roofline["traffic_source"] = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch class, committed "
+                                      "(tools/gpu_profile.sh, tools/traffic_from_pmc.py); NOT measured in this run") if roofline["traffic"] is not None else None
         ab = algorithmic_bytes(row["kernel"], row["dims"])
         roofline["algorithmic_bytes"] = ab
         if ab and row["unit"] == "flops":
@@ -606,12 +622,22 @@ def main_seg(args):
                 seg_ref.step(cpu_state, coord_h, rgb_h, off_h, label_h, None)
                 ts.append(time.perf_counter() - t1)
             cdt = float(np.mean(ts[1:]))
-            cpu = {"value": round(clouds / cdt, 3), "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
-                   "sample": f"{args.cpu_steps} timed steps (after 1 warm-up) of the same {clouds} x {pts}-point batch, fwd + "
-                             f"cross-entropy + bwd through oracle/seg_ref.py (torch {torch.__version__} CPU dense ops, C geometry, "
-                             f"{threads} threads).  The reference's segmentation path has no CPU implementation (pointops_cuda only), "
-                             f"so there is no reference timing to calibrate this port against.",
-                   "s_per_step": round(cdt, 4)}
+            port = {"value": round(clouds / cdt, 3), "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
+                    "sample": f"{args.cpu_steps} timed steps (after 1 warm-up) of the same {clouds} x {pts}-point batch, fwd + "
+                              f"cross-entropy + bwd through oracle/seg_ref.py (torch {torch.__version__} CPU dense ops, C/OpenMP geometry, "
+                              f"{threads} threads)",
+                    "s_per_step": round(cdt, 4)}
+            cpu = port
+            ref = reference_seg_cpu_baseline(pts, threads)
+            if ref is not None:
+                # the reference's own code is the baseline: its unmodified Python over ITS OWN kernels compiled as host code
+                # (oracle/_ref); a bounded sample -- 2 of the batch's clouds -- because those kernels run block after block on one core
+                cpu = {"value": ref["clouds_per_s"], "unit": "clouds/s", "cores": ref["threads"], "kind": "reference",
+                       "sample": f"the reference's own segmentation step ({ref['source']}: segmentation/models/repsurf/repsurf_umb_ssg.py over its modules/, "
+                                 f"`pointops_cuda` = the reference's *_cuda_kernel.cu files compiled unmodified as host code, oracle/Makefile.ref), "
+                                 f"1 timed step (after 1 warm-up) of {ref['clouds']} x {ref['points']}-point clouds (a bounded sample of the {clouds}-cloud batch: "
+                                 f"the host-compiled kernels run single-threaded), zero_grad+fwd+CE+bwd, torch {ref['torch']} CPU dense ops with {ref['threads']} threads",
+                       "s_per_step": ref["s_per_step"], "port": port}
         out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, 4096-pt clouds @ B=16 per GPU", "value": round(clouds * world * steps_timed / dt, 2),
                "unit": "clouds/s", "points_per_s": round(n * world * steps_timed / dt), "n_gpus": world, "steps": args.steps, "steps_timed": steps_timed,
                "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -791,7 +817,7 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         _lib.profile_enable(False)
-        in_graph = gemm_family_in_graph(lambda: criterion(twin(points), label), twin)
+        in_graph = gemm_family_in_graph(copy.deepcopy(model), criterion, points, label)      # (a copy no eager step has run on: see the capture note above)
     dt = rdist.max_over_ranks(dt, device)
     allreduce_us = rdist.time_allreduce(sum(p.numel() for p in model.parameters()), device) if world > 1 else None
     if "REPSURF_BENCH_DUMP" in os.environ:       # test hook: every rank's parameters after the timed loop

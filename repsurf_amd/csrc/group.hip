@@ -307,22 +307,90 @@ compact_features_kernel(const int *__restrict__ rows_dev, int cn, int cf, int cp
   }
 }
 
+// ---- the gather with four channels per thread, the scatter with four elements in flight (round 4) ------------------------------------------------------------------
+// One element per thread meant one integer division, one dependent index load and one 4-byte access per float: the 48 k x 144 rows of
+// the second stage took 13 grid-stride trips per thread, each a chain of two memory latencies -- 32 us for 28 MB (1 TB/s) forward,
+// 40 us backward.  Here a thread owns a 16-byte chunk of a row: the feature part is one float4 load + one float4 store (forward) or
+// one float4 load + four atomics (backward); the first four chunks (position, polar, normal channels) are assembled by the same
+// scalar expressions as before (identical values).  Needs 16-byte aligned rows: (cpos + cn) % 4 == 0 and cf % 4 == 0.
+__device__ __forceinline__ float head_channel(int ch, int cpos, int cn, long long sp, long long g, const float *__restrict__ center,
+                                              const float *__restrict__ new_center, const float *__restrict__ normal) {
+  if (ch >= cpos) return normal[sp * cn + (ch - cpos)];
+  const float dx = center[sp * 3 + 0] - new_center[g * 3 + 0];
+  const float dy = center[sp * 3 + 1] - new_center[g * 3 + 1];
+  const float dz = center[sp * 3 + 2] - new_center[g * 3 + 2];
+  if (ch < 3) return (ch == 0) ? dx : (ch == 1 ? dy : dz);
+  const float rho = sqrtf(rs_sqnorm(dx, dy, dz));
+  if (ch == 3) return rho;
+  if (ch == 4) return (rho == 0.f) ? 0.f : acosf(dz / rho) / RS_PI_F;
+  return atan2f(dy, dx) / RS_TWO_PI_F + 0.5f;
+}
+
+__global__ void __launch_bounds__(GR_THREADS)
+compact_features4_kernel(const int *__restrict__ rows_dev, int cn, int cf, int cpos, int ctot,
+                         const float *__restrict__ center, const float *__restrict__ new_center,
+                         const float *__restrict__ normal, const float *__restrict__ feature,
+                         const int *__restrict__ grp, const int *__restrict__ src, float *__restrict__ out,
+                         long long groups, int m, int n, const int *__restrict__ fps_idx, float *__restrict__ new_normal) {
+  const int q = ctot >> 2, qh = (cpos + cn) >> 2;                 // chunks per row, of which the head
+  const long long total = (long long)(*rows_dev) * q;
+  if (fps_idx) {
+    const long long extra = groups * cn;
+    for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < extra; e += (long long)gridDim.x * GR_THREADS) {
+      const long long g = e / cn;
+      const int ch = (int)(e - g * cn);
+      new_normal[e] = normal[((g / m) * n + fps_idx[g]) * cn + ch];
+    }
+  }
+  for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GR_THREADS) {
+    const long long u = e / q;
+    const int j = (int)(e - u * q);
+    const long long sp = src[u];
+    float4 v;
+    if (j >= qh) {
+      v = *reinterpret_cast<const float4 *>(feature + sp * cf + 4 * (j - qh));
+    } else {
+      const long long g = grp[u];
+      v.x = head_channel(4 * j + 0, cpos, cn, sp, g, center, new_center, normal);
+      v.y = head_channel(4 * j + 1, cpos, cn, sp, g, center, new_center, normal);
+      v.z = head_channel(4 * j + 2, cpos, cn, sp, g, center, new_center, normal);
+      v.w = head_channel(4 * j + 3, cpos, cn, sp, g, center, new_center, normal);
+    }
+    reinterpret_cast<float4 *>(out)[e] = v;
+  }
+}
+
 // grad_normal[src[u], :] += grad_out[u, cpos : cpos+cn], grad_feature[src[u], :] += grad_out[u, cpos+cn : ctot] -- one atomic per
 // distinct neighbour and channel, both tensors in ONE launch; fps_idx != NULL: also the backward of the centre-row gather
 // of compact_features_kernel, grad_normal[cloud(g) * n + fps_idx[g], :] += grad_new_normal[g * ldg + :]
+// Backward: still ONE float per lane and atomic instruction -- consecutive lanes add to consecutive addresses, a wave's atomic covers two
+// full cache lines (a float4 per lane put every line under four separate atomic instructions: measured 1.5x slower) -- but FOUR
+// independent (index, value) pairs per trip, so a thread's 13 grid-stride trips of two dependent memory latencies become 4.
 __global__ void __launch_bounds__(GR_THREADS)
-compact_scatter_kernel(const int *__restrict__ rows_dev, int cn, int cf, int cpos, int ctot, const float *__restrict__ grad_out,
-                       const int *__restrict__ src, float *__restrict__ grad_normal, float *__restrict__ grad_feature,
-                       long long groups, int m, int n, const int *__restrict__ fps_idx, const float *__restrict__ grad_new_normal,
-                       long long ldg) {
+compact_scatter4_kernel(const int *__restrict__ rows_dev, int cn, int cf, int cpos, int ctot, const float *__restrict__ grad_out,
+                        const int *__restrict__ src, float *__restrict__ grad_normal, float *__restrict__ grad_feature,
+                        long long groups, int m, int n, const int *__restrict__ fps_idx, const float *__restrict__ grad_new_normal,
+                        long long ldg) {
   const int c0 = grad_normal ? 0 : cn, cw = (grad_normal ? cn : 0) + (grad_feature ? cf : 0);     // channels [c0, c0 + cw) behind cpos
-  const long long total = (long long)(*rows_dev) * cw;
-  for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GR_THREADS) {
-    const long long u = e / cw;
-    const int ch = c0 + (int)(e - u * cw);
-    const float v = grad_out[u * ctot + cpos + ch];
-    if (ch < cn) atomicAdd(grad_normal + (long long)src[u] * cn + ch, v);
-    else atomicAdd(grad_feature + (long long)src[u] * cf + (ch - cn), v);
+  const long long total = (long long)(*rows_dev) * cw, step = (long long)gridDim.x * GR_THREADS;
+  for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total; e += 4 * step) {
+    long long sp[4];
+    int ch[4];
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long ei = e + i * step, ec = ei < total ? ei : e;
+      const long long u = ec / cw;
+      ch[i] = c0 + (int)(ec - u * cw);
+      v[i] = grad_out[u * ctot + cpos + ch[i]];
+      sp[i] = src[u];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (e + i * step >= total) continue;
+      if (ch[i] < cn) atomicAdd(grad_normal + sp[i] * cn + ch[i], v[i]);
+      else atomicAdd(grad_feature + sp[i] * cf + (ch[i] - cn), v[i]);
+    }
   }
   if (fps_idx) {
     const long long extra = groups * cn;
@@ -488,9 +556,15 @@ extern "C" int rs_group_features_compact(int b, int n, int m, int nsample, int c
   if (!have_index)
     hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(groups * nsample)), dim3(GR_THREADS), 0, st, groups, nsample, m, n,
                        idx, cnt, offsets, grp, slot, src, mult);
-  hipLaunchKernelGGL(compact_features_kernel, dim3(grid_for(groups * nsample * ctot / 4 + 1)), dim3(GR_THREADS), 0, st,
-                     offsets + groups, cn, cf, cpos, ctot, center, new_center, normal, feature, grp, src, out,
-                     groups, m, n, cn > 0 ? fps_idx : nullptr, new_normal);
+  const bool vec4 = ((cpos + cn) & 3) == 0 && (cf & 3) == 0 && (((uintptr_t)out | (uintptr_t)feature) & 15) == 0;
+  if (vec4)
+    hipLaunchKernelGGL(compact_features4_kernel, dim3(grid_for(groups * nsample * (ctot / 4) / 4 + 1)), dim3(GR_THREADS), 0, st,
+                       offsets + groups, cn, cf, cpos, ctot, center, new_center, normal, feature, grp, src, out,
+                       groups, m, n, cn > 0 ? fps_idx : nullptr, new_normal);
+  else
+    hipLaunchKernelGGL(compact_features_kernel, dim3(grid_for(groups * nsample * ctot / 4 + 1)), dim3(GR_THREADS), 0, st,
+                       offsets + groups, cn, cf, cpos, ctot, center, new_center, normal, feature, grp, src, out,
+                       groups, m, n, cn > 0 ? fps_idx : nullptr, new_normal);
   RS_CHECK_LAUNCH("rs_group_features_compact");
   return RS_OK;
 }
@@ -510,7 +584,7 @@ extern "C" int rs_group_features_compact_backward(long long capacity, const int 
   if (cf == 0) grad_feature = nullptr;
   if (!grad_normal && !grad_feature) return RS_OK;
   const int cw = (grad_normal ? cn : 0) + (grad_feature ? cf : 0);
-  hipLaunchKernelGGL(compact_scatter_kernel, dim3(grid_for(capacity * cw / 4 + 1)), dim3(GR_THREADS), 0, (hipStream_t)stream, rows_dev, cn, cf,
+  hipLaunchKernelGGL(compact_scatter4_kernel, dim3(grid_for(capacity * cw / 16 + 1)), dim3(GR_THREADS), 0, (hipStream_t)stream, rows_dev, cn, cf,
                      cpos, ctot, grad_out, src, grad_normal, grad_feature, (long long)b * m, m, n, fps_idx, grad_new_normal, ldg);
   RS_CHECK_LAUNCH("rs_group_features_compact_backward");
   return RS_OK;

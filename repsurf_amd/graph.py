@@ -17,8 +17,13 @@ from . import rng
 
 
 class GraphedStep:
-    def __init__(self, net, criterion, optimizer, points, label, warmup=3):
+    def __init__(self, net, criterion, optimizer, points, label, warmup=3, record_calls=False):
+        """record_calls=True: keep (name, arguments) of the GEMM-family ABI calls made while the step is CAPTURED in
+        `self.recorded_calls` (repsurf_amd._lib.record_calls).  Their pointers lie in this graph's private memory pool, which lives
+        as long as this object: replaying them on their own (bench.py times the matrix-pipe launches of a step that way) touches
+        nothing but that pool."""
         self.net, self.criterion, self.optimizer = net, criterion, optimizer
+        self.recorded_calls = None
         self.points, self.label = points, label
         self.draws = rng.StaticDraws(label.device)
         side = torch.cuda.Stream()
@@ -35,7 +40,14 @@ class GraphedStep:
             self.draws.begin_pass()
             self.draws.refill()
             with torch.cuda.graph(self.graph):
-                self.loss = self._body()
+                if record_calls:
+                    from . import _lib
+                    _lib.record_calls(True)
+                try:
+                    self.loss = self._body()
+                finally:
+                    if record_calls:
+                        self.recorded_calls = _lib.record_calls(False)
         torch.cuda.synchronize()
 
     def _body(self):
