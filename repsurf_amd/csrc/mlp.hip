@@ -354,6 +354,18 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   // ~20 extra live VGPRs cost more than the hidden latency brings.  Kept for experiments only.
   constexpr bool EARLY_PREFETCH = false;
 #endif
+  // 128-row tiles (four stacked waves, the 32 / 64-column layers of the segmentation step's 524 288-row stages): the same epilogue
+  // straight from the accumulators unless the max-pool is folded into this launch (that one walks whole groups through the C tile
+  // in LDS).  Round 4: the LDS epilogue of these tiles -- C tile through LDS, three barriers, one exposed mask-load round trip per
+  // 32 rows -- held the 524 288 x 32 launches at 0.30 of the HBM roof.  A run-time, wave-uniform choice: both forms live in the
+  // instance.  -DRS_NO_DIRECT128 restores the LDS epilogue for A/B runs.
+#ifdef RS_NO_DIRECT128
+  const bool direct = DIRECT;
+#else
+  constexpr bool D128 = BM == 128 && BN <= 64 && !WS;       // (128-column tiles: four accumulator tiles per wave, the two forms in one
+  const bool direct = DIRECT || (D128 && ep.pool_ns <= 0);  //  instance spill 0.5-2 KB per lane: they keep the LDS epilogue)
+#endif
+  constexpr int NSLOT = 2 * WR;                             // (row wave, lane half) pairs that hold sums of one column
   static_assert(CT >= 1, "tile too narrow for the wave layout");
   static_assert(!BF || V >= 2, "bf16 staging packs pairs of k");
   constexpr int PLANE_A = BF ? BM * 4 + 16 : AStage<BM>::PLANE;
@@ -589,8 +601,8 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       RS_T(4);
     }
     }
-    if constexpr (DIRECT) {
-      // ---- epilogue straight from the accumulators (64-row tiles).  D[i][j]: j = lane & 31 is the output column,
+    if (direct) {
+      // ---- epilogue straight from the accumulators (64-row tiles; 128-row tiles without fused pooling).  D[i][j]: j = lane & 31 is the output column,
       // i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) the row: one store instruction covers two 128-byte row
       // segments (full cache lines), a lane keeps ONE column per accumulator tile, so the BatchNorm column sums are
       // lane-local fp32 sums that stay in registers over all tiles of this workgroup (<= 3 x CT VGPRs) and meet in
@@ -888,26 +900,29 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   }
 #endif
 
-  if constexpr (DIRECT) {
+  if (direct) {
     if (ep.mode != EPI_STORE && (long long)blockIdx.x < tiles) {
-      // lane-local column sums -> this workgroup's fp64 partial row: 4 contributions per column (2 row waves x 2 lane halves)
-      double *red = reinterpret_cast<double *>(smem);         // [stat][4][BN] doubles <= 12 KB (staging is idle: barrier below)
+      // lane-local column sums -> this workgroup's fp64 partial row: NSLOT contributions per column (row waves x 2 lane halves)
+      double *red = reinterpret_cast<double *>(smem);         // [stat][NSLOT][BN] doubles <= 24 KB (staging is idle: barrier below)
       const int nstat = (ep.mode == EPI_MASK && ep.my2) ? 3 : 2;
       __syncthreads();
       if (!loader) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           const int cl = (wave_c * CT + c) * 32 + lrow, slot = wave_r * 2 + lk;
-          red[(0 * 4 + slot) * BN + cl] = (double)st0[c];
-          red[(1 * 4 + slot) * BN + cl] = (double)st1[c];
-          if (nstat == 3) red[(2 * 4 + slot) * BN + cl] = (double)st2[c];
+          red[(0 * NSLOT + slot) * BN + cl] = (double)st0[c];
+          red[(1 * NSLOT + slot) * BN + cl] = (double)st1[c];
+          if (nstat == 3) red[(2 * NSLOT + slot) * BN + cl] = (double)st2[c];
         }
       }
       __syncthreads();
       if (tid < BN && n0 + tid < cols)
         for (int sidx = 0; sidx < nstat; ++sidx) {
-          const double t = (red[(sidx * 4 + 0) * BN + tid] + red[(sidx * 4 + 1) * BN + tid]) +
-                           (red[(sidx * 4 + 2) * BN + tid] + red[(sidx * 4 + 3) * BN + tid]);
+          double t = (red[(sidx * NSLOT + 0) * BN + tid] + red[(sidx * NSLOT + 1) * BN + tid]) +
+                     (red[(sidx * NSLOT + 2) * BN + tid] + red[(sidx * NSLOT + 3) * BN + tid]);
+          if (NSLOT == 8)
+            t += (red[(sidx * NSLOT + 4) * BN + tid] + red[(sidx * NSLOT + 5) * BN + tid]) +
+                 (red[(sidx * NSLOT + 6) * BN + tid] + red[(sidx * NSLOT + 7) * BN + tid]);
           ep.partial[((long long)blockIdx.x * nstat + sidx) * cols + n0 + tid] = t;
         }
     }
@@ -1783,7 +1798,11 @@ __device__ __forceinline__ void reduce_partials_body4(int bid, int nb, int chunk
 }
 __device__ __forceinline__ void reduce_partials_any(int bid, int nb, int chunks, long long n, const float *__restrict__ partial,
                                                     float *__restrict__ out) {
-  if ((n & 3) == 0 && (((uintptr_t)partial | (uintptr_t)out) & 15) == 0) reduce_partials_body4(bid, nb, chunks, n, partial, out);
+  // the 16-byte form for the WIDE gradients (few row slabs, many outputs); a narrow first-layer gradient is the opposite -- 512 slabs
+  // of 512 outputs -- and wants its outputs spread over as many workgroups as possible: the 4-byte form gives it 4 x the workgroups
+  // and 128 slabs per trip (with the 16-byte form such a reduction ran on 4 workgroups for 138 us)
+  if (chunks <= 64 && n >= 4096 && (n & 3) == 0 && (((uintptr_t)partial | (uintptr_t)out) & 15) == 0)
+    reduce_partials_body4(bid, nb, chunks, n, partial, out);
   else reduce_partials_body(bid, nb, chunks, n, partial, out);
 }
 

@@ -184,3 +184,35 @@ def test_bf16_mode_classifier_step():
     err = np.abs(res["bf16"][0] - res["fp32"][0]).max()
     print("bf16 vs fp32, 16 clouds: gradient cosine %.4f, log-probability max-abs %.4f" % (cos, err))
     assert cos > 0.85 and err < 0.15, (cos, err)
+
+
+def test_mirror_pointops_wrappers_the_reference_exports():
+    """modules.pointops.functions.pointops of the classification mirror: grouping_int, knnquery_naive and QueryAndGroup
+    (reference :183-203, :252-291, :357-410) against torch gathers / the package's own kNN."""
+    import sys
+    from tests.util import ROOT
+    cls = os.path.join(ROOT, "repsurf_amd", "classification")
+    if cls not in sys.path:
+        sys.path.insert(0, cls)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mirror_cls_pointops", os.path.join(cls, "modules", "pointops", "functions", "pointops.py"))
+    P = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(P)
+    g = torch.Generator().manual_seed(3)
+    xyz = (torch.rand(2, 256, 3, generator=g) * 2 - 1).cuda()
+    new_xyz = xyz[:, :64].contiguous()
+    feats = torch.randn(2, 5, 256, generator=g).cuda()
+    idx = P.ballquery(0.4, 16, xyz, new_xyz)
+    lab = (torch.arange(2 * 3 * 256).view(2, 3, 256) * 11 + (1 << 41)).cuda()
+    gi = P.grouping_int(lab, idx)
+    want = torch.gather(lab, 2, idx.long().reshape(2, 1, -1).expand(-1, 3, -1)).view(2, 3, 64, 16)
+    assert gi.dtype == torch.int64 and torch.equal(gi, want)
+    assert torch.equal(P.knnquery_naive(9, xyz, new_xyz), P.knnquery(9, xyz, new_xyz))
+    for radius in (0.4, None):
+        q = P.QueryAndGroup(radius=radius, nsample=16, use_xyz=True, return_idx=True)
+        nf, gxyz, gidx = q(xyz, new_xyz, feats)
+        assert nf.shape == (2, 8, 64, 16) and gxyz.shape == (2, 3, 64, 16) and gidx.dtype == torch.int64
+        ref_xyz = torch.gather(xyz.transpose(1, 2), 2, gidx.reshape(2, 1, -1).expand(-1, 3, -1)).view(2, 3, 64, 16)
+        ref_f = torch.gather(feats, 2, gidx.reshape(2, 1, -1).expand(-1, 5, -1)).view(2, 5, 64, 16)
+        assert torch.equal(gxyz, ref_xyz) and torch.equal(nf[:, 3:], ref_f)
+        assert torch.equal(nf[:, :3], ref_xyz - new_xyz.transpose(1, 2).unsqueeze(-1))
