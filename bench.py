@@ -584,6 +584,7 @@ def main_seg(args):
     dt = time.perf_counter() - t0
     timing = not args.no_kernel_timing
     timed_steps = 0
+    in_graph = None
     if timing and rank == 0:
         import copy
         twin = copy.deepcopy(model)
@@ -603,11 +604,12 @@ def main_seg(args):
             eager_step()
         torch.cuda.synchronize()
         _lib.profile_enable(False)
+        in_graph = gemm_family_in_graph(copy.deepcopy(model), criterion, inputs, label)
     dt = rdist.max_over_ranks(dt, device)
     prof = _lib.profile_collect()
     if rank == 0:
         ms = dt / steps_timed * 1e3
-        roofline, table = roofline_from_profile(prof, timed_steps, args.dtype) if timing else (None, [])
+        roofline, table = roofline_from_profile(prof, timed_steps, args.dtype, in_graph) if timing else (None, [])
         if args.breakdown:
             os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
             json.dump({"ms_per_step": ms, "kernels": table}, open(args.breakdown, "w"), indent=1)

@@ -124,6 +124,15 @@ int rs_umbrella_fan_offset(int m, int k, int b, int rotate, const float *xyz, co
  * segmentation/modules/pointops/functions/pointops.py:262-265): dist2 (n, 3) squared distances of the
  * three nearest neighbours -> weight (n, 3) = r_i / ((r_0 + r_1) + r_2), r_i = 1 / (sqrt(dist2_i) + 1e-8). */
 int rs_interp_weights(long long n, const float *dist2, float *weight, void *stream);
+/* rs_three_interpolate with the feature-propagation stage's skip connection and activation folded in
+ * (segmentation/modules/repsurface_utils.py:266-270: interpolated + skip, ReLU): out = relu?(interpolated + add?) (add (b, n, c)
+ * or NULL; relu != 0: ReLU).  Backward: the incoming gradient counts where fwd_out > 0 (fwd_out NULL: everywhere); it is
+ * scattered into grad_points (b, m, c), which the caller zeroed, and -- grad_add != NULL -- also written out masked (b, n, c):
+ * the gradient of `add`. */
+int rs_three_interpolate_fused(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                               const float *add, int relu, float *out, void *stream);
+int rs_three_interpolate_fused_backward(int b, int c, int n, int m, const float *grad_out, const float *fwd_out,
+                                        const int *idx, const float *weight, float *grad_points, float *grad_add, void *stream);
 
 /* ---- umbrella surface constructor ---------------------------------------
  * Fuses group_by_umbrella + cal_normal + cal_center + xyz2sphere + cal_const +

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -38,6 +38,8 @@ SIGNATURES = {
     "rs_three_nn": [c_int, c_int, c_int, P, P, P, P, P],
     "rs_three_interpolate": [c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_three_interpolate_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "rs_three_interpolate_fused": [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P],
+    "rs_three_interpolate_fused_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
     "rs_mlp_gemm_rows": [c_ll, P, c_int, c_int, P, P, c_int, P, P],
     "rs_mlp_gemm_rows_bf16": [c_ll, P, c_int, c_int, P, P, c_int, P, P],
     "rs_mlp_wgrad": [c_ll, P, c_int, c_int, P, P, P, c_int, P, P],

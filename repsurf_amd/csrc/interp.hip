@@ -57,16 +57,20 @@ three_nn_kernel(int b, int n, int m, int blocks_per_cloud, const float *__restri
 // arithmetic while the element count allows (two 64-bit divisions per element otherwise).
 __global__ void __launch_bounds__(IT_THREADS)
 interp_fwd_kernel(long long rows, int n, int m, int c, const float *__restrict__ points,
-                  const int *__restrict__ idx, const float *__restrict__ weight, float *__restrict__ out) {
+                  const int *__restrict__ idx, const float *__restrict__ weight, float *__restrict__ out,
+                  const float *__restrict__ add, int relu) {
+  // add / relu (round 4): out = relu(interpolated + add) in the same launch -- the feature-propagation stage's skip connection and
+  // activation (segmentation/modules/repsurface_utils.py:266-270) were two framework kernels behind this one, 3 + 2 passes over the tensor
   const long long total = rows * c, stride = (long long)gridDim.x * IT_THREADS;
   if (total < (1LL << 31) && rows * 3 < (1LL << 31)) {
     const unsigned tot = (unsigned)total, st = (unsigned)stride, cu = (unsigned)c, nu = (unsigned)n;
     for (unsigned e0 = blockIdx.x * IT_THREADS + threadIdx.x; e0 < tot; e0 += 4 * st) {
-      unsigned ch[4], cloud[4]; int id[4][3]; float w[4][3];
+      unsigned ch[4], cloud[4]; int id[4][3]; float w[4][3], sk[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const unsigned e = e0 + k * st < tot ? e0 + k * st : e0, r = e / cu;
         ch[k] = e - r * cu; cloud[k] = r / nu;
+        sk[k] = add ? add[e] : 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t) { id[k][t] = idx[r * 3 + t]; w[k][t] = weight[r * 3 + t]; }
       }
@@ -79,7 +83,11 @@ interp_fwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (e0 + k * st < tot) out[e0 + k * st] = (w[k][0] * v[k][0] + w[k][1] * v[k][1]) + w[k][2] * v[k][2];
+        if (e0 + k * st < tot) {
+          float o = (w[k][0] * v[k][0] + w[k][1] * v[k][1]) + w[k][2] * v[k][2];
+          if (add) o += sk[k];
+          out[e0 + k * st] = relu ? fmaxf(o, 0.f) : o;
+        }
     }
     return;
   }
@@ -91,14 +99,18 @@ interp_fwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
     const float v0 = weight[r * 3 + 0] * base[(long long)idx[r * 3 + 0] * c];
     const float v1 = weight[r * 3 + 1] * base[(long long)idx[r * 3 + 1] * c];
     const float v2 = weight[r * 3 + 2] * base[(long long)idx[r * 3 + 2] * c];
-    out[e] = (v0 + v1) + v2;
+    float o = (v0 + v1) + v2;
+    if (add) o += add[e];
+    out[e] = relu ? fmaxf(o, 0.f) : o;
   }
 }
 
 __global__ void __launch_bounds__(IT_THREADS)
 interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__ grad_out,
                   const int *__restrict__ idx, const float *__restrict__ weight,
-                  float *__restrict__ grad_points) {
+                  float *__restrict__ grad_points, const float *__restrict__ fwd_out, float *__restrict__ grad_add) {
+  // fwd_out != NULL: the forward ended in a ReLU -- the incoming gradient counts where fwd_out > 0; grad_add != NULL: the masked
+  // gradient is also written out (the skip connection's gradient), one pass instead of threshold_backward + this kernel
   const long long total = rows * c, stride = (long long)gridDim.x * IT_THREADS;
   if (total < (1LL << 31) && rows * 3 < (1LL << 31)) {
     const unsigned tot = (unsigned)total, st = (unsigned)stride, cu = (unsigned)c, nu = (unsigned)n;
@@ -110,12 +122,14 @@ interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
         const unsigned e = ok[k] ? e0 + k * st : e0, r = e / cu;
         ch[k] = e - r * cu; cloud[k] = r / nu;
         g[k] = grad_out[e];
+        if (fwd_out) g[k] = fwd_out[e] > 0.f ? g[k] : 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t) { id[k][t] = idx[r * 3 + t]; w[k][t] = weight[r * 3 + t]; }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (!ok[k]) continue;
+        if (grad_add) grad_add[e0 + k * st] = g[k];
         float *base = grad_points + (long long)cloud[k] * m * c + ch[k];
 #pragma unroll
         for (int t = 0; t < 3; ++t) atomicAdd(base + (long long)id[k][t] * c, g[k] * w[k][t]);
@@ -128,7 +142,9 @@ interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
     const int ch = (int)(e - r * c);
     const long long cloud = r / n;
     float *base = grad_points + cloud * m * c + ch;
-    const float g = grad_out[e];
+    float g = grad_out[e];
+    if (fwd_out) g = fwd_out[e] > 0.f ? g : 0.f;
+    if (grad_add) grad_add[e] = g;
 #pragma unroll
     for (int t = 0; t < 3; ++t) atomicAdd(base + (long long)idx[r * 3 + t] * c, g * weight[r * 3 + t]);
   }
@@ -163,8 +179,33 @@ extern "C" int rs_three_interpolate(int b, int c, int m, int n, const float *poi
   if (rows == 0 || c == 0) return RS_OK;
   RS_REQUIRE(points && idx && weight && out, "rs_three_interpolate: null pointer");
   hipLaunchKernelGGL(interp_fwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
-                     rows, n, m, c, points, idx, weight, out);
+                     rows, n, m, c, points, idx, weight, out, (const float *)nullptr, 0);
   RS_CHECK_LAUNCH("rs_three_interpolate");
+  return RS_OK;
+}
+
+extern "C" int rs_three_interpolate_fused(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                          const float *add, int relu, float *out, void *stream) {
+  RS_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "rs_three_interpolate_fused: negative size");
+  const long long rows = (long long)b * n;
+  if (rows == 0 || c == 0) return RS_OK;
+  RS_REQUIRE(points && idx && weight && out, "rs_three_interpolate_fused: null pointer");
+  hipLaunchKernelGGL(interp_fwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
+                     rows, n, m, c, points, idx, weight, out, add, relu);
+  RS_CHECK_LAUNCH("rs_three_interpolate_fused");
+  return RS_OK;
+}
+
+extern "C" int rs_three_interpolate_fused_backward(int b, int c, int n, int m, const float *grad_out, const float *fwd_out,
+                                                   const int *idx, const float *weight, float *grad_points, float *grad_add,
+                                                   void *stream) {
+  RS_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "rs_three_interpolate_fused_backward: negative size");
+  const long long rows = (long long)b * n;
+  if (rows == 0 || c == 0) return RS_OK;
+  RS_REQUIRE(grad_out && idx && weight && grad_points, "rs_three_interpolate_fused_backward: null pointer");
+  hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
+                     rows, n, m, c, grad_out, idx, weight, grad_points, fwd_out, grad_add);
+  RS_CHECK_LAUNCH("rs_three_interpolate_fused_backward");
   return RS_OK;
 }
 
@@ -176,7 +217,7 @@ extern "C" int rs_three_interpolate_backward(int b, int c, int n, int m, const f
   if (rows == 0 || c == 0) return RS_OK;
   RS_REQUIRE(grad_out && idx && weight && grad_points, "rs_three_interpolate_backward: null pointer");
   hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
-                     rows, n, m, c, grad_out, idx, weight, grad_points);
+                     rows, n, m, c, grad_out, idx, weight, grad_points, (const float *)nullptr, (float *)nullptr);
   RS_CHECK_LAUNCH("rs_three_interpolate_backward");
   return RS_OK;
 }

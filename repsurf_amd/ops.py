@@ -588,3 +588,38 @@ class _ThreeInterpolate(Function):
 def three_interpolate(points, idx, weight):
     """points (B,m,C), idx/weight (B,n,3) -> (B,n,C); differentiable w.r.t. points."""
     return _ThreeInterpolate.apply(points, idx, weight)
+
+
+class _ThreeInterpolateAddRelu(Function):
+    """relu(three_interpolate(points, idx, weight) + add): one launch forward, one backward (the masked gradient is scattered to
+    `points` and written out once for `add`)."""
+
+    @staticmethod
+    def forward(ctx, points, idx, weight, add):
+        _need_gpu(points, idx, weight, add)
+        points, idx, weight = _f32c(points), _i32c(idx), _f32c(weight)
+        add = None if add is None else _f32c(add)
+        b, m, c = points.shape
+        n = idx.shape[1]
+        out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
+        _lib.call("rs_three_interpolate_fused", b, c, m, n, _p(points), _p(idx), _p(weight), _p(add), 1, _p(out), _stream())
+        ctx.save_for_backward(idx, weight, out)
+        ctx.dims = (b, c, n, m)
+        ctx.has_add = add is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight, out = ctx.saved_tensors
+        b, c, n, m = ctx.dims
+        grad_out = _f32c(grad_out)
+        grad = torch.zeros((b, m, c), dtype=torch.float32, device=grad_out.device)
+        gadd = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device) if (ctx.has_add and ctx.needs_input_grad[3]) else None
+        _lib.call("rs_three_interpolate_fused_backward", b, c, n, m, _p(grad_out), _p(out), _p(idx), _p(weight), _p(grad), _p(gadd), _stream())
+        return grad, None, None, gadd
+
+
+def three_interpolate_add_relu(points, idx, weight, add=None):
+    """relu(three_interpolate(points, idx, weight) [+ add]): points (B,m,C), idx / weight (B,n,3), add (B,n,C) | None -> (B,n,C);
+    differentiable w.r.t. points and add (segmentation/modules/repsurface_utils.py:266-270 in one launch each way)."""
+    return _ThreeInterpolateAddRelu.apply(points, idx, weight, add)

@@ -213,10 +213,9 @@ class SurfaceFeaturePropagationCD(nn.Module):
         xyz2, points2, offset2 = pos_feat_off2      # coarse: (M,3), (M,C), (B,)
         idx, weight = geometry if geometry is not None else self.geometry(xyz1, offset1, xyz2, offset2)
         points2 = row_mlp(points2, [self.mlp_f0], [self.norm_f0], relu_last=False)
-        new_points = ops.three_interpolate(points2.unsqueeze(0), idx.unsqueeze(0), weight.unsqueeze(0)).squeeze(0)
-        if self.skip:
-            new_points = new_points + row_mlp(points1, [self.mlp_s0], [self.norm_s0], relu_last=False)
-        new_points = F.relu(new_points)
+        skip = row_mlp(points1, [self.mlp_s0], [self.norm_s0], relu_last=False).unsqueeze(0) if self.skip else None
+        # interpolation + skip connection + ReLU (reference :266-270) in one launch forward, one backward
+        new_points = ops.three_interpolate_add_relu(points2.unsqueeze(0), idx.unsqueeze(0), weight.unsqueeze(0), skip).squeeze(0)
         return row_mlp(new_points, self.mlp_convs, self.mlp_bns)
 
 

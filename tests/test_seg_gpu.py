@@ -489,3 +489,32 @@ def test_col_sum_matches_torch(rows, n):
     got, ref = head.col_sum(x), x.double().sum(0)
     assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-3 * max(1.0, rows ** 0.5 / 30))
     assert torch.equal(got, head.col_sum(x.contiguous()))                    # fixed summation order, pitch-independent
+
+
+def test_interpolation_with_skip_and_relu_in_one_launch():
+    """ops.three_interpolate_add_relu (the feature-propagation stage's interpolation + skip connection + ReLU,
+    segmentation/modules/repsurface_utils.py:266-270) against the three separate steps it replaces: same values, same gradients
+    (the scatter of the masked gradient uses atomics on both sides: 2e-5), with and without the skip tensor."""
+    from repsurf_amd import ops
+    g = torch.Generator().manual_seed(5)
+    b, m, n, c = 1, 700, 2500, 24
+    pts = torch.randn(b, m, c, generator=g).cuda()
+    idx = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32).cuda()
+    w = torch.rand(b, n, 3, generator=g).cuda()
+    w = w / w.sum(-1, keepdim=True)
+    skip = torch.randn(b, n, c, generator=g).cuda()
+    go = torch.randn(b, n, c, generator=g).cuda()
+    for use_skip in (True, False):
+        p1, s1 = pts.clone().requires_grad_(), skip.clone().requires_grad_()
+        ref = ops.three_interpolate(p1, idx, w)
+        if use_skip:
+            ref = ref + s1
+        ref = torch.relu(ref)
+        ref.backward(go)
+        p2, s2 = pts.clone().requires_grad_(), skip.clone().requires_grad_()
+        out = ops.three_interpolate_add_relu(p2, idx, w, s2 if use_skip else None)
+        out.backward(go)
+        assert torch.equal(out, ref)
+        assert (p2.grad - p1.grad).abs().max().item() <= 2e-5 * max(1.0, p1.grad.abs().max().item())
+        if use_skip:
+            assert torch.equal(s2.grad, s1.grad)

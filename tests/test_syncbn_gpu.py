@@ -107,8 +107,9 @@ def test_two_halves_with_sync_bn_equal_one_whole_batch(kind):
             assert torch.allclose(s_[name], ref, rtol=2e-5, atol=1e-6), name
     worst = 0.0
     for name, ref in gw.items():
-        if ref.norm() < 1e-4:             # analytically zero: biases in front of a BatchNorm (exact zeros here) and the constructor's
-            assert g0[name].norm() < 1e-3, name    # last bias (a constant shift of every normal, removed by the next BatchNorm: fp noise)
+        if ref.norm() < 1e-4:             # analytically zero over the WHOLE batch: biases in front of a BatchNorm (exact zeros) and the
+            got = (g0[name] + g1[name]) / 2    # constructor's last bias (a constant shift of every normal, removed by the next
+            assert got.norm() < 1e-3 * max(1.0, g0[name].norm().item()), name      # synchronized BatchNorm: the ranks' halves cancel)
             continue
         got = (g0[name] + g1[name]) / 2
         err = ((got - ref).norm() / ref.norm()).item()
