@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the merged outputs of tools/r03_evidence.sh (gpurun_out/) into profiles/<round>/ under the names DESIGN.md cites
-R=${1:-r03}; P=profiles/$R; H=gpurun_out/${R}h
+R=${1:-r03}; P=profiles/$R; H=gpurun_out/${R}h; [ -d gpurun_out/${R}ev ] && H=gpurun_out/${R}ev
 mkdir -p $P
 for f in bench_cls bench_cls_real bench_cls_dense bench_cls_2x bench_cls_nopipe bench_cls_bf16_b64 bench_seg; do tail -1 $H/$f.json > $P/$f.json; done
 cp $H/parity_report.jsonl $P/parity_report.jsonl
@@ -12,7 +12,8 @@ cp gpurun_out/prof_${R}_cls/traffic.json $P/traffic.json
 cp gpurun_out/prof_${R}_seg/graph_kernel_stats.csv $P/seg_graph_kernel_stats.csv
 cp gpurun_out/prof_${R}_seg/graph_kernel_stats_by_grid.csv $P/seg_graph_kernel_stats_by_grid.csv
 cp gpurun_out/prof_${R}_seg/traffic.json $P/traffic_seg.json
-cp $H/ballquery_phases.txt $P/ballquery_cells_phase_costs_final.txt
+[ -f $H/ballquery_phases.txt ] && cp $H/ballquery_phases.txt $P/ballquery_cells_phase_costs_final.txt
+for f in umb_bench.txt grid_meet.txt sharded_time.txt bench_spawn_dry_run.json gpu_tests.log; do [ -f $H/$f ] && cp $H/$f $P/$f; done
 python3 - <<PY
 import csv,json
 rows=list(csv.DictReader(open('$P/cls_graph_kernel_stats_by_grid.csv')))
