@@ -678,8 +678,8 @@ def dry_run(args):
     """--dry-run: the ranks exist, found each other and can reduce; nothing else."""
     from repsurf_amd import dist as rdist
     rank, world, local = rdist.env()
-    cuda = torch.cuda.is_available()
-    device = torch.device("cuda", local % max(1, torch.cuda.device_count())) if cuda else torch.device("cpu")
+    cuda = torch.cuda.is_available() and torch.cuda.device_count() >= world      # (RCCL refuses two ranks on one device: gloo then)
+    device = torch.device("cuda", local) if cuda else torch.device("cpu")
     rdist.init(backend=os.environ.get("REPSURF_DIST_BACKEND", "nccl" if cuda else "gloo"), device=device)
     t = torch.tensor([float(rank + 1)], device=device)
     if world > 1:

@@ -19,10 +19,8 @@ pytestmark = pytest.mark.gpu
 def _model_and_batch(kind):
     import argparse
     import sys
-    sub = os.path.join(ROOT, "repsurf_amd", "classification" if kind == "cls" else "segmentation")
-    for p in (ROOT, sub):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
     from repsurf_amd import rng
     # deterministic draws, identical for a cloud whichever process holds it: flips +1, FPS starts 0
     rng._cpu_draw = lambda k, b, n: (torch.ones(b) if k in ("flip", "npflip") else torch.zeros(b, dtype=torch.int32))
@@ -67,14 +65,16 @@ def _half(kind, batch, rank, world):
 
 
 def _run(kind, rank, world, sync):
-    model, crit, batch = _model_and_batch(kind)
-    model = model.cuda().train()
-    if sync:
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-    args, label = _half(kind, batch, rank, world)
-    loss = crit(model(*args), label)
-    loss.backward()
-    torch.cuda.synchronize()
+    from tests.util import subproject
+    with subproject("classification" if kind == "cls" else "segmentation"):      # (both ship `modules` / `models`: one live at a time)
+        model, crit, batch = _model_and_batch(kind)
+        model = model.cuda().train()
+        if sync:
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        args, label = _half(kind, batch, rank, world)
+        loss = crit(model(*args), label)
+        loss.backward()
+        torch.cuda.synchronize()
     grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters()}
     stats = {n: b.detach().cpu() for n, b in model.named_buffers() if n.endswith("running_var") or n.endswith("running_mean")}
     return float(loss.item()), grads, stats

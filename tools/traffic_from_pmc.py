@@ -25,15 +25,15 @@ import re
 # "gemm_rows_kernel" only: calls that took the narrow streaming kernels (wgrad_small_kernel, gemm_small_kernel) had no
 # dispatch of their own, the 1:1 alignment slipped and several size classes showed the same bytes.
 FAMILY = {
-    "rs_mlp_gemm_rows": r"gemm_rows_kernel|gemm_small_kernel",
-    "rs_mlp_wgrad": r"wgrad_kernel|wgrad_small_kernel",
+    "rs_mlp_gemm_rows": r"gemm_rows_kernel|gemm_small_kernel|gemm_narrow_kernel",
+    "rs_mlp_wgrad": r"wgrad_kernel|wgrad_small_kernel|wgrad_narrow_kernel|wgrad_narrow4_kernel",
     "rs_ballquery": r"ballquery_kernel|ballquery_grid_kernel",
     "rs_furthestsampling": r"fps_reg_kernel|fps_global_kernel",
     "rs_umbrella_features": r"umbrella_kernel",
     "rs_pool_max": r"pool_max_kernel|pool_max_long_kernel",
     "rs_pool_max_backward": r"pool_max_bwd_kernel",
-    "rs_group_features_compact": r"compact_features_kernel",
-    "rs_group_features_compact_backward": r"compact_scatter_kernel",
+    "rs_group_features_compact": r"compact_features_kernel|compact_features4_kernel",
+    "rs_group_features_compact_backward": r"compact_scatter_kernel|compact_scatter4_kernel",
 }
 
 
