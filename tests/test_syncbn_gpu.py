@@ -114,5 +114,7 @@ def test_two_halves_with_sync_bn_equal_one_whole_batch(kind):
         got = (g0[name] + g1[name]) / 2
         err = ((got - ref).norm() / ref.norm()).item()
         worst = max(worst, err)
-        assert err < 1e-2, (name, err)
+        # (the tolerances of the parity tests, DESIGN.md 4: 1e-2 classification, 3e-2 segmentation -- two ranks sum in another order than
+        #  one, and a ReLU / max-pool decision within rounding of a tie re-routes a whole row; measured worst 1.7e-2 on sa1.mlp_bns.1.bias)
+        assert err < (1e-2 if kind == "cls" else 3e-2), (name, err)
     print("worst gradient relative L2", worst)
