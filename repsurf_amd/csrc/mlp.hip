@@ -1526,118 +1526,11 @@ wgrad_narrow_kernel(long long rows_arg, const int *__restrict__ rows_dev, int nc
   }
 }
 
-// ---- the same product with 16-byte loads and a wave-private LDS transpose (round 4) ------------------------------------------------
-// wgrad_narrow_kernel loads its operands IN MFMA layout: one float per lane and row, a wave-load covers two 128-byte row segments,
-// 12 load instructions per 8 rows.  On the segmentation step's dense 524 288-row first layers that is 97 us per launch against a
-// 21 us HBM floor (2 x 67 MB of P, 33 MB of Q).  Here a lane loads float4s -- 8 lanes per 32-column row of P, 4 per 16-column row of
-// Q: 10 load instructions per 32 rows --, applies the BatchNorm-backward affine to its four columns, and the wave re-lays the
-// 32 x 32 block out through its own LDS slot (ds_write_b128 by (row, 4 columns), ds_read_b32 by (column, row): conflict-free,
-// no workgroup barrier: a wave's LDS operations complete in order).  The next block's loads are in flight under the 16 MFMAs.
-// P: OPM_AFF2 (dense or compacted rows: `mult`), fp32 tensors, ncols <= 32; Q: OPM_ID | OPM_RELU1, kcols <= 16; 16-byte aligned rows.
-template <int QM>
-__global__ void __launch_bounds__(GM_THREADS, 3)
-wgrad_narrow4_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, int kcols, RowOperand P, RowOperand Q,
-                     float *__restrict__ partial) {
-  constexpr int PP = 36;                                   // LDS row pitch (floats): 16-byte aligned rows, columns 32..35 never read
-  const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
-  __shared__ __attribute__((aligned(16))) float stage[GM_THREADS / 64][2][32 * PP];      // per wave: P block, Q block
-  __shared__ float red[GM_THREADS / 64][32][33];
-  const int tid = threadIdx.x, lane = tid & 63, l = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float *Ps = stage[wave][0], *Qs = stage[wave][1];
-  // the Q block's columns 16..31 are read by the lanes l >= 16 of every MFMA step and must be zero: filled once
-  for (int e = lane; e < 32 * PP; e += 64) Qs[e] = 0.f;
-  // this lane's columns: 4 of P (8 lanes per row), 4 of Q (4 lanes per row)
-  const int pc4 = (lane & 7) * 4, pr = lane >> 3;          // P: rows pr + 8 j
-  const int qc4 = (lane & 3) * 4, qr = lane >> 2;          // Q: rows qr + 16 j
-  const bool pok = pc4 < ncols, qok = qc4 < kcols;          // (ncols % 4 == 0: a chunk is whole or absent; kcols: per element below)
-  ColCoef<4> pk, qk;
-  op_coef<4, OPM_AFF2>(P, pok ? pc4 : 0, pok, pk);
-  op_coef<4, QM>(Q, 0, false, qk);
-  if (QM == OPM_RELU1)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const bool ok = qc4 + i < kcols; qk.s1[i] = ok ? Q.s1[qc4 + i] : 0.f; qk.t1[i] = ok ? Q.t1[qc4 + i] : 0.f; }
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const long long nblk = (rows + 31) >> 5, bstep = (long long)gridDim.x * (GM_THREADS / 64);
-  struct Raw { float4 a[4], b[4], q[2]; float m[4]; };
-  auto request = [&](long long blk_, Raw &r) {
-    const long long r0 = blk_ * 32;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long long row = r0 + pr + 8 * j, rc = row < rows ? row : r0;       // (beyond the end: the block's first row, discarded)
-      r.a[j] = *reinterpret_cast<const float4 *>(P.a + rc * P.lda + (pok ? pc4 : 0));
-      r.b[j] = *reinterpret_cast<const float4 *>(P.b + rc * P.ldb + (pok ? pc4 : 0));
-      r.m[j] = P.mult ? P.mult[rc] : 1.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const long long row = r0 + qr + 16 * j, rc = row < rows ? row : r0;
-      r.q[j] = *reinterpret_cast<const float4 *>(Q.a + rc * Q.lda + (qok ? qc4 : 0));
-    }
-  };
-  Raw cur, nxt;
-  long long blk = (long long)blockIdx.x * (GM_THREADS / 64) + wave;
-  if (blk < nblk) request(blk, cur);
-  __builtin_amdgcn_wave_barrier();
-  for (; blk < nblk; blk += bstep) {
-    const long long r0 = blk * 32;
-    const bool more = blk + bstep < nblk;
-    if (more) request(blk + bstep, nxt);
-    // affine + commit to the wave's LDS slot
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool rok = r0 + pr + 8 * j < rows && pok;
-      const float av[4] = {cur.a[j].x, cur.a[j].y, cur.a[j].z, cur.a[j].w}, bv[4] = {cur.b[j].x, cur.b[j].y, cur.b[j].z, cur.b[j].w};
-      float4 o;
-      float *ov = reinterpret_cast<float *>(&o);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = fmaf(pk.s1[i], av[i], cur.m[j] * fmaf(pk.s2[i], bv[i], pk.t1[i]));      // = op_finish<OPM_AFF2>
-        ov[i] = rok ? v : 0.f;
-      }
-      *reinterpret_cast<float4 *>(Ps + (pr + 8 * j) * PP + pc4) = o;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const bool rok = r0 + qr + 16 * j < rows;
-      const float qv[4] = {cur.q[j].x, cur.q[j].y, cur.q[j].z, cur.q[j].w};
-      float4 o;
-      float *ov = reinterpret_cast<float *>(&o);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = qv[i];
-        if (QM == OPM_RELU1) v = fmaxf(fmaf(qk.s1[i], v, qk.t1[i]), 0.f);
-        ov[i] = (rok && qc4 + i < kcols) ? v : 0.f;
-      }
-      *reinterpret_cast<float4 *>(Qs + (qr + 16 * j) * PP + qc4) = o;
-    }
-    __builtin_amdgcn_wave_barrier();               // (compiler-only: LDS operations of a wave complete in order)
-    // 16 MFMA steps: step t, half h -> row 2 t + h; lane l = column of P (A) / of Q (B)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const float pv = Ps[(2 * t + h) * PP + l], qv = Qs[(2 * t + h) * PP + l];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, qv, acc, 0, 0, 0);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (more) cur = nxt;
-  }
-  // D[i][j]: j = lane & 31 is the k index, row (reg & 3) + 8 (reg >> 2) + 4 h the column n of P   (as wgrad_narrow_kernel)
-  float *dst = partial + (long long)blockIdx.x * ncols * kcols;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) red[wave][(i & 3) + 8 * (i >> 2) + 4 * h][l] = acc[i];
-  __syncthreads();
-  for (int e = tid; e < 32 * 32; e += GM_THREADS) {
-    const int nl = e >> 5, k = e & 31;
-    if (nl < ncols && k < kcols) {
-      float t = red[0][nl][k];
-#pragma unroll
-      for (int w2 = 1; w2 < GM_THREADS / 64; ++w2) t += red[w2][nl][k];
-      dst[(long long)nl * kcols + k] = t;
-    }
-  }
-}
+// (Round 4 built this product with 16-byte loads and a wave-private LDS transpose -- 8 lanes per 32-column row, ds_write_b128 by
+//  (row, 4 columns), ds_read_b32 by (column, row), 10 load instructions per 32 rows instead of 48 -- for the segmentation step's dense
+//  524 288-row first layers, as the round-3 review proposed.  tools/wgrad_narrow_bench.py, kernel + partial reduction, 167 MB: 44.8 us
+//  warm / 70.6 us cold against 45.0 / 68.9 us for the kernel above: the load width is not what bounds it (the workgroup count is at
+//  its optimum, 512: 256 -> 59 us, 1 024 -> 43 us, 2 048 -> 48 us).  Not kept.)
 
 // ---- narrow weight gradient: kcols <= 16 (first-layer branches: 3 / 6 / 10 / 16 input channels) ---------------------
 // dw[n][k] = sum_r P[r][n] * Q[r][k] is a pure streaming reduction here: 2 * 16 flop per byte of P.  No LDS, no
@@ -2460,16 +2353,6 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
   const int vp = pick_vec(P, ncols), vq = pick_vec(Q, kcols);
   static const int small_on = env_int("RS_WGRAD_SMALL", 1);
   static const int wnarrow_on = env_int("RS_WGRAD_NARROW", 1);
-  static const int wnarrow4_on = env_int("RS_WGRAD_NARROW4", 1);
-  auto al16 = [](const void *p_) { return ((uintptr_t)p_ & 15) == 0; };
-  if (wnarrow4_on && wnarrow_on && !RS_STORE_BF16 && !bf && kcols <= 16 && ncols <= 32 && (ncols & 3) == 0 && P.mode == OPM_AFF2 &&
-      (Q.mode == OPM_ID || Q.mode == OPM_RELU1) && al16(P.a) && al16(P.b) && al16(Q.a) && (P.lda & 3) == 0 && (P.ldb & 3) == 0 &&
-      (Q.lda & 3) == 0 && Q.lda >= ((kcols + 3) & ~3) && rows >= 2048) {
-    // first-layer weight gradients with 16-byte aligned rows: float4 loads + wave-private LDS transpose
-    const dim3 grid(chunks, 1);
-    if (Q.mode == OPM_ID) hipLaunchKernelGGL((wgrad_narrow4_kernel<OPM_ID>), grid, dim3(GM_THREADS), 0, st, rows, rows_dev, ncols, kcols, P, Q, partial);
-    else hipLaunchKernelGGL((wgrad_narrow4_kernel<OPM_RELU1>), grid, dim3(GM_THREADS), 0, st, rows, rows_dev, ncols, kcols, P, Q, partial);
-  } else
   if (wnarrow_on && !RS_STORE_BF16 && !bf && kcols <= WS_KP && (Q.mode == OPM_ID || Q.mode == OPM_RELU1) &&
       (P.mode == OPM_AFF2 || P.mode == OPM_POOLED || P.mode == OPM_BCAST || P.mode == OPM_ID)) {
     // narrow gradient on the matrix pipe (rows = MFMA k), 64 columns of P per workgroup

@@ -26,7 +26,7 @@ import re
 # dispatch of their own, the 1:1 alignment slipped and several size classes showed the same bytes.
 FAMILY = {
     "rs_mlp_gemm_rows": r"gemm_rows_kernel|gemm_small_kernel|gemm_narrow_kernel",
-    "rs_mlp_wgrad": r"wgrad_kernel|wgrad_small_kernel|wgrad_narrow_kernel|wgrad_narrow4_kernel",
+    "rs_mlp_wgrad": r"wgrad_kernel|wgrad_small_kernel|wgrad_narrow_kernel",
     "rs_ballquery": r"ballquery_kernel|ballquery_grid_kernel",
     "rs_furthestsampling": r"fps_reg_kernel|fps_global_kernel",
     "rs_umbrella_features": r"umbrella_kernel",
