@@ -8,7 +8,7 @@ LIBDIR := repsurf_amd/lib
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
             -fhip-fp32-correctly-rounded-divide-sqrt -munsafe-fp-atomics -Wall -Wno-unused-function
 SRCS := $(CSRC)/rs_lib.cpp $(CSRC)/fps.hip $(CSRC)/ballquery.hip $(CSRC)/knn_umbrella.hip $(CSRC)/knn_wide.hip \
-        $(CSRC)/group.hip $(CSRC)/interp.hip $(CSRC)/seg_geom.hip $(CSRC)/scene_knn.hip $(CSRC)/mlp.hip $(CSRC)/umbrella_mlp.hip $(CSRC)/umbrella_mfma.hip $(CSRC)/head.hip $(CSRC)/adam.hip
+        $(CSRC)/group.hip $(CSRC)/interp.hip $(CSRC)/seg_geom.hip $(CSRC)/scene_knn.hip $(CSRC)/grid_knn.hip $(CSRC)/mlp.hip $(CSRC)/umbrella_mlp.hip $(CSRC)/umbrella_mfma.hip $(CSRC)/head.hip $(CSRC)/adam.hip
 OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS)) build/mlp_bf16.hip.o build/mlp_sb.hip.o
 
 all: $(LIBDIR)/librepsurf_hip.so oracle

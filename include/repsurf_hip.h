@@ -108,6 +108,23 @@ int rs_knnquery_offset(int m, int nsample, const float *xyz, const float *new_xy
                        const int *offset, const int *new_offset, int b,
                        int *idx, float *dist2, void *stream);
 
+/* The same lists, bit for bit, through per-cloud uniform grids (round 4; csrc/grid_knn.hip): the scan above evaluates every
+ * row of the cloud per query, a query's nsample nearest rows sit in a fraction of a percent of it.
+ * rs_knn_grid_build: per cloud, bounding box -> cubic cells (about `per_cell` rows each, at most RS_KNN_GRID_CELLS) ->
+ *   rows in cell-sorted order.  Workspaces: sorted (ntot x 4 floats: x, y, z, row bits; 16-byte aligned),
+ *   starts (b x (RS_KNN_GRID_CELLS + 1) ints), grid (b x 16 floats; 16-byte aligned).
+ * rs_knn_grid_query: per query the cells around its own, ring by ring, until the nsample-th distance is below the
+ *   distance to every unvisited cell (or the whole grid was visited); nsample <= 64; dist2 may be NULL.
+ *   new_offset: running ends of the QUERY rows per cloud (the cloud of a query selects the grid).
+ *   max_queries / max_rows: the largest number of queries / searched rows any cloud holds when the HOST knows them (they size the
+ *   launch and the LDS staging of a cloud's rows), 0 = unknown (m workgroup slots per cloud; clouds above 4096 rows are read
+ *   from global memory either way). */
+#define RS_KNN_GRID_CELLS 4096
+int rs_knn_grid_build(int b, const float *xyz, const int *offset, float per_cell, float *sorted, int *starts, float *grid,
+                      void *stream);
+int rs_knn_grid_query(int m, int nsample, int b, int max_queries, int max_rows, const float *new_xyz, const int *new_offset,
+                      const float *sorted, const int *starts, const float *grid, int *idx, float *dist2, void *stream);
+
 /* Segmentation umbrella fan: everything UmbrellaSurfaceConstructor.forward computes between the kNN and
  * self.mlps (segmentation/modules/repsurface_utils.py:77-98 group_by_umbrella_v2 / :101-122 group_by_umbrella,
  * :305-321; segmentation/modules/recons_utils.py:10-45,48-57,84-100,128-151; polar_utils.py:10-31).

@@ -9,7 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 25
+ABI_VERSION = 26
+KNN_GRID_CELLS = 4096          # RS_KNN_GRID_CELLS of include/repsurf_hip.h
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 P = c_void_p  # device pointers and the stream travel as void*
@@ -68,6 +69,8 @@ SIGNATURES = {
     "rs_head_input_backward": [c_int, c_int, c_int, P, P, P, P],
     "rs_smooth_cls_loss": [c_int, c_int, c_float, P, P, P, P, P],
     "rs_adam_step": [P, P, P, P, c_int, P],
+    "rs_knn_grid_build": [c_int, P, P, ctypes.c_float, P, P, P, P],
+    "rs_knn_grid_query": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P],
     "rs_scene_cells": [c_int, P, P, P, ctypes.c_float, P, P, P, P],
     "rs_scene_scatter": [c_int, P, P, P, P, P],
     "rs_scene_knn": [c_int, c_int, P, P, P, ctypes.c_float, P, P, P, P, P, P, P],

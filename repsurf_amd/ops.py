@@ -7,6 +7,8 @@ repsurf_amd._lib.call().  All tensors must live on a HIP device — there is no 
 Layouts are channels-last (see include/repsurf_hip.h): xyz (B,N,3), features (B,N,C),
 indices int32.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -304,13 +306,51 @@ def knnquery(nsample, xyz, new_xyz=None, return_dist=False):
     return (idx, d2) if return_dist else idx
 
 
-def knnquery_offset(nsample, xyz, new_xyz, offset, new_offset):
-    """Packed batches: xyz (N,3), new_xyz (M,3) -> idx (M,nsample) int32, dist2 (M,nsample)."""
+KNN_GRID = os.environ.get("REPSURF_KNN_GRID", "1") != "0"
+# rows per cell = fill * nsample.  The ball of the nsample nearest rows has the volume of nsample / density; one wave per query
+# (lists of 17 .. 64 entries) wants cells about as large as that ball -- 64 candidates per trip, the 27 cells around the query are
+# enough for most queries (16 384 queries over 16 x 4096 rows: fill 0.45 / 1.0 / 2.0 -> 76 / 71 / 68 us) --, one thread per query
+# (short lists) wants small cells: every candidate costs the same whether it is near or far (umbrella fans, 65 536 queries: fill
+# 0.083 / 0.25 / 0.8 -> 122 / 128 / 145 us).
+KNN_GRID_FILL = tuple(float(v) for v in os.environ.get("REPSURF_KNN_GRID_FILL", "0.125,1.0").split(","))
+# average rows per cloud from which the grid is used, for lists of <= 3 / <= 16 / <= 64 entries (below, the scan is as fast and
+# needs no set-up launch)
+KNN_GRID_MIN_ROWS = tuple(int(v) for v in os.environ.get("REPSURF_KNN_GRID_MIN_ROWS", "512,512,128").split(","))
+
+
+def _largest_cloud(offset):
+    """rows of the largest cloud of a packed batch if the host already holds the offsets (no device read), else 0"""
+    cached = getattr(offset, "_rs_host", None)
+    if cached is None or cached[0] != (offset.data_ptr(), offset._version) or not cached[1]:
+        return 0
+    ends = cached[1]
+    return max(e - s for s, e in zip((0,) + ends[:-1], ends))
+
+
+def knnquery_offset(nsample, xyz, new_xyz, offset, new_offset, grid=None):
+    """Packed batches: xyz (N,3), new_xyz (M,3) -> idx (M,nsample) int32, dist2 (M,nsample).
+    nsample <= 64 goes through per-cloud uniform grids (rs_knn_grid_build / rs_knn_grid_query: the cells around the query, ring by
+    ring, until the list is provably complete) -- the same lists, bit for bit, as the scan of the whole cloud per query
+    (rs_knnquery_offset; grid=False or REPSURF_KNN_GRID=0 selects it)."""
     _need_gpu(xyz, new_xyz, offset, new_offset)
     xyz, new_xyz, offset, new_offset = _f32c(xyz), _f32c(new_xyz), _i32c(offset), _i32c(new_offset)
     m = new_xyz.shape[0]
-    idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
-    d2 = torch.empty((m, nsample), dtype=torch.float32, device=xyz.device)
+    dev = xyz.device
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=dev)
+    d2 = torch.empty((m, nsample), dtype=torch.float32, device=dev)
+    b = offset.numel()
+    if grid is None:      # by measurement (tools/knn_grid_bench.py): the grid pays above a cloud size that grows with the list length
+        grid = KNN_GRID and xyz.shape[0] >= b * (KNN_GRID_MIN_ROWS[0] if nsample <= 3 else KNN_GRID_MIN_ROWS[1] if nsample <= 16 else KNN_GRID_MIN_ROWS[2])
+    if grid and 0 < nsample <= 64 and m > 0 and xyz.shape[0] > 0:
+        # cloud sizes, when the host has them (offset tensors made by offsets_tensor / strided_offset, or read once by host_offsets):
+        # they size the launch and the LDS staging; unknown = the safe bounds
+        max_q, max_n = _largest_cloud(new_offset), _largest_cloud(offset)
+        rows = torch.empty((xyz.shape[0], 4), dtype=torch.float32, device=dev)
+        starts = torch.empty((b, _lib.KNN_GRID_CELLS + 1), dtype=torch.int32, device=dev)
+        cells = torch.empty((b, 16), dtype=torch.float32, device=dev)
+        _lib.call("rs_knn_grid_build", b, _p(xyz), _p(offset), max(1.5, KNN_GRID_FILL[0 if nsample <= 16 else 1] * nsample), _p(rows), _p(starts), _p(cells), _stream())
+        _lib.call("rs_knn_grid_query", m, nsample, b, max_q, max_n, _p(new_xyz), _p(new_offset), _p(rows), _p(starts), _p(cells), _p(idx), _p(d2), _stream())
+        return idx, d2
     _lib.call("rs_knnquery_offset", m, nsample, _p(xyz), _p(new_xyz), _p(offset), _p(new_offset),
               offset.numel(), _p(idx), _p(d2), _stream())
     return idx, d2

@@ -30,6 +30,12 @@ def packed_cloud(seed, sizes, kind="uniform"):
     elif kind == "dup":          # every point twice: zero distances, degenerate fan triangles
         half = (r.rand((n + 1) // 2, 3) * 2 - 1).astype(np.float32)
         xyz = np.concatenate([half, half])[:n][r.permutation(n)]
+    elif kind == "flat":         # a wall: one axis has no extent at all, another a hair
+        xyz = (r.rand(n, 3) * 2 - 1).astype(np.float32)
+        xyz[:, 2] = 0.25
+        xyz[:, 1] *= 1e-4
+    elif kind == "clusters":     # two tight clusters far apart: almost every cell of the bounding box is empty
+        xyz = (0.01 * r.randn(n, 3) + np.where(r.rand(n, 1) < 0.5, -5.0, 5.0)).astype(np.float32)
     else:
         raise ValueError(kind)
     return xyz, np.cumsum(sizes).astype(np.int32)
@@ -41,21 +47,44 @@ def ops():
     return _ops
 
 
+@pytest.mark.parametrize("path", ["grid", "scan"])              # per-cloud uniform grids (csrc/grid_knn.hip) / the scan of the whole cloud
 @pytest.mark.parametrize("k", [3, 9, 16, 32, 64, 65, 100])     # > 64: the reference operator's full width, csrc/knn_wide.hip
-@pytest.mark.parametrize("kind", ["uniform", "grid", "dup"])
-def test_knnquery_offset_matches_oracle(ops, k, kind):
-    sizes = [700, 40, 1300, 5, 257, 2100]                 # clouds smaller than k (padding) and > one LDS tile
+@pytest.mark.parametrize("kind", ["uniform", "grid", "dup", "flat", "clusters"])
+def test_knnquery_offset_matches_oracle(ops, k, kind, path):
+    if path == "grid" and k > 64:
+        pytest.skip("lists longer than 64 always take the scan")
+    sizes = [700, 40, 1300, 5, 257, 2100, 1]              # clouds smaller than k (padding), one point, and > one LDS tile
     xyz, offset = packed_cloud(3 + k, sizes, kind)
     new_offset = seg_ref.strided_offset(offset, 3)
     r = np.random.RandomState(0)
     starts = np.concatenate([[0], offset[:-1]])
     pick = np.concatenate([np.sort(r.choice(e - s, (ne - ns_), replace=False)) + s
                            for s, e, ns_, ne in zip(starts, offset, np.concatenate([[0], new_offset[:-1]]), new_offset)])
-    q = xyz[pick]
-    idx, d2 = ops.knnquery_offset(k, dev(xyz), dev(q), dev(offset), dev(new_offset))
+    q = xyz[pick].copy()
+    q[::7] += (0.5 * r.randn(*q[::7].shape)).astype(np.float32)      # every 7th query elsewhere (some outside the bounding box)
+    idx, d2 = ops.knnquery_offset(k, dev(xyz), dev(q), dev(offset), dev(new_offset), grid=(path == "grid"))
     ridx, rd2 = G.knn_offset(k, xyz, q, offset, new_offset)
     assert np.array_equal(d2.cpu().numpy(), rd2)
     assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+@pytest.mark.parametrize("k,stride", [(9, 1), (32, 4), (3, 1), (16, 16)])
+def test_grid_knn_equals_scan_at_config4_size(ops, k, stride):
+    """16 x 4096 points (BASELINE configs[3]): the grid search and the scan return the same lists and distances, bit for bit --
+    self queries (umbrella fans), the strided centres of a grouping stage, and fine queries over coarse rows (interpolation)."""
+    xyz, offset = packed_cloud(11 + k, [4096] * 16)
+    x, off = dev(xyz), dev(offset)
+    if k == 3:          # feature propagation: the queries are the fine rows, the searched rows every 4th of them
+        coarse = np.ascontiguousarray(xyz.reshape(16, 4096, 3)[:, ::4].reshape(-1, 3))
+        coff = dev(np.arange(1, 17, dtype=np.int32) * 1024)
+        a = ops.knnquery_offset(3, dev(coarse), x, coff, off, grid=True)
+        b = ops.knnquery_offset(3, dev(coarse), x, coff, off, grid=False)
+    else:
+        q = np.ascontiguousarray(xyz.reshape(16, 4096, 3)[:, ::stride].reshape(-1, 3))
+        qoff = dev(np.arange(1, 17, dtype=np.int32) * (4096 // stride))
+        a = ops.knnquery_offset(k, x, dev(q), off, qoff, grid=True)
+        b = ops.knnquery_offset(k, x, dev(q), off, qoff, grid=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 def test_knnquery_offset_self_query_config4_properties(ops):
@@ -427,13 +456,13 @@ def test_scene_grid_knn_equals_scan(ops, kind, n, k):
     x = dev(xyz)
     off = ops.offsets_tensor([xyz.shape[0]], x.device)
     idx, d2, stats = ops.knn_scene(k, x, return_stats=True)
-    ref_i, ref_d = ops.knnquery_offset(k, x, x, off, off)
+    ref_i, ref_d = ops.knnquery_offset(k, x, x, off, off, grid=False)
     assert stats["grid"] and stats["rescanned"] < 0.05 * xyz.shape[0], stats
     assert torch.equal(idx, ref_i) and torch.equal(d2, ref_d), stats
     qn = 5000
     qs = (r.rand(qn, 3) * np.array([9.0, 7.0, 3.5]) - 0.5).astype(np.float32)          # ~25 % outside the bounding box
     qi, qd, qstats = ops.knn_scene(k, x, dev(qs), return_stats=True)
-    ri, rd = ops.knnquery_offset(k, x, dev(qs), off, ops.offsets_tensor([qn], x.device))
+    ri, rd = ops.knnquery_offset(k, x, dev(qs), off, ops.offsets_tensor([qn], x.device), grid=False)
     assert torch.equal(qi, ri) and torch.equal(qd, rd), qstats
     print("scene kNN", kind, n, k, stats, "queries elsewhere:", qstats)
 
