@@ -318,8 +318,22 @@ int ref_block_size(int work_size) {
 }
 
 // n_max: the largest cloud a workgroup can meet; packed: the tie rule of the reference kernel launched for n_max rows
+#ifdef RS_EXP_FAKE_FPS      // measurement builds only (tools/build_exp.sh): every (n / m)-th row instead of the sampling, to time a step without the sampling's launches
+__global__ void fake_fps_kernel(int n, int m, const int *__restrict__ offset, const int *__restrict__ new_offset, int *__restrict__ idx) {
+  const int c = blockIdx.x;
+  const int s = offset ? (c ? offset[c - 1] : 0) : c * n, e = offset ? offset[c] : (c + 1) * n;
+  const int ns = new_offset ? (c ? new_offset[c - 1] : 0) : c * m, ne = new_offset ? new_offset[c] : (c + 1) * m;
+  const int cnt = ne - ns, rows = e - s;
+  for (int j = threadIdx.x; j < cnt; j += blockDim.x) idx[ns + j] = (offset ? s : 0) + (int)((long long)j * rows / (cnt > 0 ? cnt : 1));
+}
+#endif
+
 int fps_dispatch(int blocks, int n_max, int n, int m, const float *xyz, const int *start,
                  const int *offset, const int *new_offset, float *temp, int *idx, bool packed, const int *n_dev, hipStream_t st) {
+#ifdef RS_EXP_FAKE_FPS
+  hipLaunchKernelGGL(fake_fps_kernel, dim3(blocks), dim3(256), 0, st, n, m, offset, new_offset, idx);
+  return RS_OK;
+#endif
   FpsTie tie = {0, 1, 0, n_dev};
   int positions = n_max;              // priority positions a workgroup must hold
   if (packed) {

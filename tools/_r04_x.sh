@@ -1,0 +1,11 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04x; mkdir -p $O
+one() { local tag=$1; shift; timeout 600 python bench.py --no-cpu-baseline --no-kernel-timing "$@" 2>$O/err_$tag.txt | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'], d['value'])"; }
+for r in 1 2; do
+one seg_default --workload seg --steps 20 --warmup 5
+REPSURF_HIP_LIB=build_exp/librepsurf_fakefps.so one seg_fake_fps --workload seg --steps 20 --warmup 5
+one cls_default --steps 40 --warmup 10
+REPSURF_HIP_LIB=build_exp/librepsurf_fakefps.so one cls_fake_fps --steps 40 --warmup 10
+done | tee $O/ab.txt
+tail -2 $O/err_seg_fake_fps.txt
