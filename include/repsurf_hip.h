@@ -163,6 +163,11 @@ int rs_three_interpolate_fused_backward(int b, int c, int n, int m, const float 
  * optional (NULL to skip).  feat: (b, n, k-1, 10).  k in {5, 9, 13, 17} (group_size 4/8/12/16). */
 int rs_umbrella_features(int b, int n, int k, const float *xyz, const float *inv_sign,
                          int *knn_idx, float *feat, void *stream);
+/* The same through per-cloud uniform grids (round 4; csrc/grid_knn.hip): the search visits the cells around a point instead of its
+ * whole cloud; same lists and features, bit for bit.  offset: (b) int32 = n, 2n, ... (the packed form of the dense batch);
+ * workspaces as for rs_knn_grid_build (sorted: b*n x 4 floats, starts: b x (RS_KNN_GRID_CELLS + 1) ints, grid: b x 16 floats). */
+int rs_umbrella_features_grid(int b, int n, int k, const float *xyz, const int *offset, const float *inv_sign, int *knn_idx,
+                              float *feat, float *sorted, int *starts, float *grid, void *stream);
 
 /* ---- grouping ------------------------------------------------------------
  * Builds the grouped shared-MLP input of sample_and_group

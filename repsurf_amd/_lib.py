@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 26
+ABI_VERSION = 27
 KNN_GRID_CELLS = 4096          # RS_KNN_GRID_CELLS of include/repsurf_hip.h
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
@@ -27,6 +27,7 @@ SIGNATURES = {
     "rs_umbrella_fan_offset": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
     "rs_interp_weights": [c_ll, P, P, P],
     "rs_umbrella_features": [c_int, c_int, c_int, P, P, P, P, P],
+    "rs_umbrella_features_grid": [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P],
     "rs_group_features": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P],
     "rs_group_features_backward": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P],
     "rs_group_all_features": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],

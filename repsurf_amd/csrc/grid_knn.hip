@@ -24,6 +24,7 @@
 //                       round trips that the whole wave waits for whenever one lane inserts: 401 us against the scan's 453 us.)
 // No fallback launch and no host read-back: every query ends by one of the two conditions above.
 #include "rs_common.h"
+#include "umbrella_fan.h"
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -40,7 +41,9 @@ struct CloudGrid {          // 16 words per cloud in the `grid` workspace
   float edge;               // e * GK_MARGIN
   int g[3];
   int first, rows;          // the cloud's rows [first, first + rows)
-  int pad[6];
+  float slack;              // how far the EXPANDED distance formula of the classification path (rs_sqdist_expanded) can be from
+                            // the true squared distance inside this cloud's bounding box: 64 * 2^-24 * (largest norm)^2 (bound: 22)
+  int pad[5];
 };
 static_assert(sizeof(CloudGrid) == 64, "CloudGrid is 16 words");
 
@@ -98,7 +101,10 @@ grid_build_kernel(const float *__restrict__ xyz, const int *__restrict__ offset,
     G.inv = 1.0f / e;
     G.edge = e * GK_MARGIN;
     G.first = first; G.rows = n;
-    for (int k = 0; k < 6; ++k) G.pad[k] = 0;
+    float r2 = 0.f;
+    for (int a = 0; a < 3; ++a) { const float m = fmaxf(fabsf(lo[a]), fabsf(lo[a] + ext[a])); r2 += m * m; }
+    G.slack = 64.f * 5.9604645e-8f * r2;
+    for (int k = 0; k < 5; ++k) G.pad[k] = 0;
     grid[c] = G;
   }
   for (int i = tid; i < GK_CELLS; i += GK_BUILD_T) hist[i] = 0;
@@ -138,14 +144,17 @@ grid_build_kernel(const float *__restrict__ xyz, const int *__restrict__ offset,
   }
 }
 
-// (distance, row) as ONE signed 64-bit key: a squared distance is a non-negative float, whose bits order like the value, the row
-// is the low word; "an equal distance never displaces an earlier row" is then a plain integer '<'.  (Written as d < e || (d == e &&
-// p < q) every step of the insertion below was two branches over the exec mask: the 32-entry list took 2.5 us per insertion.)
-typedef long long key_t;
-__device__ __forceinline__ key_t make_key(float d, int row) { return ((key_t)__float_as_int(d) << 32) | (key_t)(unsigned)row; }
-__device__ __forceinline__ float key_dist(key_t k) { return __int_as_float((int)(k >> 32)); }
-__device__ __forceinline__ int key_row(key_t k) { return (int)(unsigned)(k & 0xffffffffLL); }
-constexpr key_t KEY_SENTINEL = (key_t)0x8000000000000000ULL;       // below every real key
+// (distance, row) as ONE unsigned 64-bit key: the order-preserving image of the distance's bits (ordered(): a float compares like
+// the unsigned value, negative zero and the slightly negative results of the expanded distance formula included) in the high word,
+// the row in the low one; "an equal distance never displaces an earlier row" is then a plain integer '<'.  (Written as d < e ||
+// (d == e && p < q) every step of the insertion below was two branches over the exec mask: a 32-entry list took 2.5 us per
+// insertion.)
+typedef unsigned long long key_t;
+__device__ __forceinline__ key_t make_key(float d, int row) { return ((key_t)ordered(d) << 32) | (key_t)(unsigned)row; }
+__device__ __forceinline__ float key_dist(key_t k) { return unordered((unsigned)(k >> 32)); }
+__device__ __forceinline__ int key_row(key_t k) { return (int)(unsigned)(k & 0xffffffffULL); }
+constexpr key_t KEY_SENTINEL = 0ULL;                               // below every real key
+constexpr key_t KEY_INF = ~0ULL;                                   // above every real key
 
 template <int K>
 __device__ __forceinline__ void list_insert(key_t (&ls)[K], key_t k) {
@@ -174,11 +183,18 @@ __device__ __forceinline__ void list_insert(key_t (&ls)[K], key_t k) {
 // candidates into buckets of d^2 / edge^2 to bound the nsample-th distance and then inserts only ~45 of them: 668-1035 us, the
 // walk itself is what costs -- ~180 VALU instructions per trip of four candidates issued by one wave per SIMD.  Lists longer
 // than 16 entries go to grid_wave_kernel below.)
-template <int K, int T, int P>
+//
+// UMB (classification): the fused umbrella-surface constructor of csrc/knn_umbrella.hip over the grid -- the queries are the cloud's
+// own rows, the distance is the EXPANDED formula of query_knn_point (rs_sqdist_expanded: what the scan kernel evaluates, so the
+// keys and with them the lists are the same, bit for bit), whose value can differ from the true squared distance by `slack`: a
+// list is complete when its last distance is below (r e)^2 - slack.  The epilogue is umbrella_kernel's: the K - 1 neighbours
+// after the nearest -> fan features (umbrella_fan.h), one 40 (K - 1)-byte row per point; idx = the lists (optional), dist2 unused.
+template <int K, int T, int P, bool UMB>
 __global__ void __launch_bounds__(T)
 grid_query_kernel(int nsample, const float *__restrict__ new_xyz, const int *__restrict__ new_offset,
                   const float4 *__restrict__ sorted, const int *__restrict__ starts, const CloudGrid *__restrict__ grid,
-                  int lds_rows, int *__restrict__ idx, float *__restrict__ dist2) {
+                  int lds_rows, int *__restrict__ idx, float *__restrict__ dist2, const float *__restrict__ inv_sign,
+                  float *__restrict__ feat) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   key_t *park = reinterpret_cast<key_t *>(smem);                                          // [P][T]
   float4 *lrows = reinterpret_cast<float4 *>(smem + (size_t)P * T * 8);                    // [lds_rows]
@@ -205,7 +221,8 @@ grid_query_kernel(int nsample, const float *__restrict__ new_xyz, const int *__r
   // K - 1 whatever nsample is (a run-time index into the list is a round trip through scratch memory)
   key_t ls[K];
   const int lead = K - nsample;
-  const key_t empty = make_key(1e10f, G.first);                      // knnquery_cuda_kernel.cu:86-87
+  const key_t empty = UMB ? make_key(INFINITY, 0x7fffffff) : make_key(1e10f, G.first);   // csrc/knn_umbrella.hip knn_scan4 / knnquery_cuda_kernel.cu:86-87
+  const float qq = rs_sqnorm(qx, qy, qz);
 #pragma unroll
   for (int j = 0; j < K; ++j) ls[j] = j < lead ? KEY_SENTINEL : empty;
   int np = 0;
@@ -228,8 +245,13 @@ grid_query_kernel(int nsample, const float *__restrict__ new_xyz, const int *__r
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float dx = qx - v[u].x, dy = qy - v[u].y, dz = qz - v[u].z;
-        const float d = (dx * dx + dy * dy) + dz * dz;               // knnquery_cuda_kernel.cu:93 (no contraction: -ffp-contract=off)
+        float d;
+        if constexpr (UMB) {
+          d = rs_sqdist_expanded(qx, qy, qz, qq, v[u].x, v[u].y, v[u].z, rs_sqnorm(v[u].x, v[u].y, v[u].z));
+        } else {
+          const float dx = qx - v[u].x, dy = qy - v[u].y, dz = qz - v[u].z;
+          d = (dx * dx + dy * dy) + dz * dz;                         // knnquery_cuda_kernel.cu:93 (no contraction: -ffp-contract=off)
+        }
         const key_t k = make_key(d, __float_as_int(v[u].w));
         if (j + u < j1 && k < ls[K - 1]) { park[np * T + tid] = k; ++np; }
       }
@@ -275,12 +297,27 @@ grid_query_kernel(int nsample, const float *__restrict__ new_xyz, const int *__r
       if (!done) {
         const bool covered = cx - r <= 0 && cx + r >= gx - 1 && cy - r <= 0 && cy + r >= gy - 1 && cz - r <= 0 && cz + r >= gz - 1;
         const float reach = (float)r * G.edge;
-        if (covered || key_dist(ls[K - 1]) < reach * reach) done = true;         // every cell visited / every unvisited row is farther than the nsample-th
+        if (covered || key_dist(ls[K - 1]) < reach * reach - (UMB ? G.slack : 0.f)) done = true;   // every cell visited / every unvisited row is farther than the nsample-th
       }
     }
   };
   if (staged) search(std::true_type{}); else search(std::false_type{});
-  if (mine) {
+  if (!mine) return;
+  if constexpr (UMB) {                                                // (nsample == K here)
+    constexpr int G1 = K - 1;
+    if (idx) {
+#pragma unroll
+      for (int l = 0; l < K; ++l) idx[(size_t)q * K + l] = key_row(ls[l]) - G.first;     // positions inside the cloud, like rs_umbrella_features
+    }
+    // offsets of the k-1 neighbours that follow the nearest (repsurface_utils.py:119-121)
+    float ox[G1], oy[G1], oz[G1];
+#pragma unroll
+    for (int j = 0; j < G1; ++j) {
+      const float *p = new_xyz + (size_t)key_row(ls[j + 1]) * 3;
+      ox[j] = p[0] - qx; oy[j] = p[1] - qy; oz[j] = p[2] - qz;
+    }
+    rs_fan_features<G1, false, false>(ox, oy, oz, inv_sign ? inv_sign[c] : 1.f, feat + (size_t)q * (G1 * 10));
+  } else {
     int *oi = idx + (size_t)q * nsample;
     float *od = dist2 ? dist2 + (size_t)q * nsample : nullptr;
 #pragma unroll
@@ -299,13 +336,12 @@ grid_query_kernel(int nsample, const float *__restrict__ new_xyz, const int *__r
 // lane shuffles), laid against the list in opposite order -- the elementwise minimum of an ascending and a descending sequence
 // is a bitonic sequence holding the 64 smallest of the 128 -- and merged by 6 more stages.  A workgroup of 16 waves stages its
 // cloud's rows once and each wave takes `qpw` queries; the result row leaves as one coalesced store per query.
-constexpr key_t KEY_INF = (key_t)0x7fffffffffffffffLL;
 constexpr int GW_T = 1024;               // 16 waves share one staged cloud: four per SIMD hide each other's shuffle / LDS latency
                                          // (4 waves per workgroup, one workgroup per CU by its LDS: 185-285 us for 16 384 queries)
 
 __device__ __forceinline__ key_t shfl_xor_key(key_t k, int m) {
-  const int lo = __shfl_xor((int)(k & 0xffffffffLL), m, 64), hi = __shfl_xor((int)(k >> 32), m, 64);
-  return ((key_t)hi << 32) | (key_t)(unsigned)lo;
+  const int lo = __shfl_xor((int)(unsigned)(k & 0xffffffffULL), m, 64), hi = __shfl_xor((int)(unsigned)(k >> 32), m, 64);
+  return ((key_t)(unsigned)hi << 32) | (key_t)(unsigned)lo;
 }
 // ascending sort of one key per lane
 __device__ __forceinline__ key_t wave_sort(key_t k, int lane) {
@@ -372,9 +408,9 @@ grid_wave_kernel(int nsample, int qpw, const float *__restrict__ new_xyz, const 
       key_t m = rev < mine ? rev : mine;                             // bitonic: the 64 smallest of list + batch
       m = wave_merge(m, lane);
       mine = lane < nsample ? m : KEY_INF;
-      const int lo = __builtin_amdgcn_readlane((int)(mine & 0xffffffffLL), nsample - 1);
-      const int hi = __builtin_amdgcn_readlane((int)(mine >> 32), nsample - 1);
-      kth = ((key_t)hi << 32) | (key_t)(unsigned)lo;
+      const int lo = __builtin_amdgcn_readlane((int)(unsigned)(mine & 0xffffffffULL), nsample - 1);
+      const int hi = __builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), nsample - 1);
+      kth = ((key_t)(unsigned)hi << 32) | (key_t)(unsigned)lo;
     };
     auto range = [&](int j, int j1, auto staged_) {                  // rows [j, j1): wave-uniform bounds, 64 candidates per trip
       constexpr bool LDS = decltype(staged_)::value;
@@ -470,12 +506,48 @@ extern "C" int rs_knn_grid_query(int m, int nsample, int b, int max_queries, int
 #define RS_GQ(K_, T_, P_) do {                                                                                              \
     const dim3 g(rs_cdiv(max_queries, T_), b), t(T_);                                                                         \
     const size_t lds = (size_t)P_ * T_ * 8 + (size_t)lds_rows * 16 + (size_t)(GK_CELLS + 1) * 4;                              \
-    hipLaunchKernelGGL((grid_query_kernel<K_, T_, P_>), g, t, lds, st, nsample, new_xyz, new_offset, s4, starts, cg, lds_rows, idx, dist2); \
+    hipLaunchKernelGGL((grid_query_kernel<K_, T_, P_, false>), g, t, lds, st, nsample, new_xyz, new_offset, s4, starts, cg, lds_rows, idx, dist2, \
+                       (const float *)nullptr, (float *)nullptr);                                                           \
   } while (0)
   if (nsample <= 3) RS_GQ(3, 256, 8);
   else if (nsample <= 9) RS_GQ(9, 256, 8);
   else RS_GQ(16, 256, 8);
 #undef RS_GQ
   RS_CHECK_LAUNCH("rs_knn_grid_query");
+  return RS_OK;
+}
+
+/* rs_umbrella_features through the grid: rs_knn_grid_build over the B clouds of n rows (offset = n, 2n, ...), then the fused
+ * search + fan kernel.  Same outputs, bit for bit (the lists are the scan's). */
+extern "C" int rs_umbrella_features_grid(int b, int n, int k, const float *xyz, const int *offset, const float *inv_sign, int *knn_idx,
+                                         float *feat, float *sorted, int *starts, float *grid, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0, "rs_umbrella_features_grid: negative size");
+  if (b == 0 || n == 0) return RS_OK;
+  RS_REQUIRE(k == 5 || k == 9 || k == 13 || k == 17,
+             "rs_umbrella_features_grid: k=%d not built (group_size+1 must be 5, 9, 13 or 17)", k);
+  RS_REQUIRE(n >= k, "rs_umbrella_features_grid: cloud of %d points cannot supply %d neighbours", n, k);
+  RS_REQUIRE(xyz && offset && feat && sorted && starts && grid, "rs_umbrella_features_grid: null pointer");
+  RS_REQUIRE((long long)b * n < 2147483647LL, "rs_umbrella_features_grid: more than 2^31 rows");
+  int rc = rs_knn_grid_build(b, xyz, offset, 1.5f, sorted, starts, grid, stream);
+  if (rc != RS_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const float4 *s4 = reinterpret_cast<const float4 *>(sorted);
+  const CloudGrid *cg = reinterpret_cast<const CloudGrid *>(grid);
+  const int lds_rows = n < GK_LDS_ROWS ? n : GK_LDS_ROWS;
+#define RS_GU(K_) do {                                                                                                       \
+    constexpr int T_ = 256, P_ = 8;                                                                                           \
+    const dim3 g(rs_cdiv(n, T_), b), t(T_);                                                                                   \
+    const size_t lds = (size_t)P_ * T_ * 8 + (size_t)lds_rows * 16 + (size_t)(GK_CELLS + 1) * 4;                              \
+    hipLaunchKernelGGL((grid_query_kernel<K_, T_, P_, true>), g, t, lds, st, K_, xyz, offset, s4, starts, cg, lds_rows, knn_idx, \
+                       (float *)nullptr, inv_sign, feat);                                                                     \
+  } while (0)
+  switch (k) {
+    case 5: RS_GU(5); break;
+    case 9: RS_GU(9); break;
+    case 13: RS_GU(13); break;
+    default: RS_GU(17); break;
+  }
+#undef RS_GU
+  RS_CHECK_LAUNCH("rs_umbrella_features_grid");
   return RS_OK;
 }

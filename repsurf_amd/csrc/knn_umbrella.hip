@@ -214,7 +214,12 @@ umbrella_kernel(int b, int n, int blocks_per_cloud, const float *__restrict__ xy
   {   // phase 1: kNN, 4 lanes per query (64 queries per workgroup)
     const int q4 = min(chunk * KNN_QPB + (threadIdx.x >> 2), n - 1);
     float bd[K];
+#ifdef RS_EXP_FAKE_UMB_KNN      // measurement builds only (tools/build_exp.sh): the next K rows instead of the search, to time a step without it
+#pragma unroll
+    for (int j = 0; j < K; ++j) { bd[j] = 0.f; bi[j] = (q4 + j) % n; }
+#else
     knn_scan4<K>(pts, n, tile, pts[q4 * 3 + 0], pts[q4 * 3 + 1], pts[q4 * 3 + 2], bd, bi);
+#endif
   }
   // phase 2: one lane per query.  The lists travel through LDS so that wave 0 works with all 64 lanes.
   __syncthreads();

@@ -307,6 +307,10 @@ def knnquery(nsample, xyz, new_xyz=None, return_dist=False):
 
 
 KNN_GRID = os.environ.get("REPSURF_KNN_GRID", "1") != "0"
+UMBRELLA_GRID = os.environ.get("REPSURF_UMBRELLA_GRID", "1") != "0"        # classification: rs_umbrella_features_grid ...
+# ... from this many points per cloud (k = 9, stand-alone: 32 x 1024: grid 126 us, scan 92; 64 x 2048: 145 / 383; 16 x 4096: 133 / 340;
+# 8 x 8192: 158 / 546 -- inside the 32 x 1024 step the two are level, 1.402 / 1.405 ms)
+UMBRELLA_GRID_MIN_ROWS = int(os.environ.get("REPSURF_UMBRELLA_GRID_MIN_ROWS", "2048"))
 # rows per cell = fill * nsample.  The ball of the nsample nearest rows has the volume of nsample / density; one wave per query
 # (lists of 17 .. 64 entries) wants cells about as large as that ball -- 64 candidates per trip, the 27 cells around the query are
 # enough for most queries (16 384 queries over 16 x 4096 rows: fill 0.45 / 1.0 / 2.0 -> 76 / 71 / 68 us) --, one thread per query
@@ -365,7 +369,16 @@ def umbrella_features(xyz, k=9, inv_sign=None, return_knn=False):
     feat = torch.empty((b, n, k - 1, 10), dtype=torch.float32, device=xyz.device)
     kidx = torch.empty((b, n, k), dtype=torch.int32, device=xyz.device) if return_knn else None
     sg = None if inv_sign is None else _f32c(inv_sign.reshape(-1))
-    _lib.call("rs_umbrella_features", b, n, k, _p(xyz), _p(sg), _p(kidx), _p(feat), _stream())
+    if UMBRELLA_GRID and n >= UMBRELLA_GRID_MIN_ROWS and b * n < 2 ** 31:
+        # the search through per-cloud uniform grids (csrc/grid_knn.hip): the cells around a point instead of its whole cloud
+        dev = xyz.device
+        off = offsets_tensor([(i + 1) * n for i in range(b)], dev)
+        rows = torch.empty((b * n, 4), dtype=torch.float32, device=dev)
+        starts = torch.empty((b, _lib.KNN_GRID_CELLS + 1), dtype=torch.int32, device=dev)
+        cells = torch.empty((b, 16), dtype=torch.float32, device=dev)
+        _lib.call("rs_umbrella_features_grid", b, n, k, _p(xyz), _p(off), _p(sg), _p(kidx), _p(feat), _p(rows), _p(starts), _p(cells), _stream())
+    else:
+        _lib.call("rs_umbrella_features", b, n, k, _p(xyz), _p(sg), _p(kidx), _p(feat), _stream())
     return (feat, kidx) if return_knn else feat
 
 

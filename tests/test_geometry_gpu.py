@@ -99,7 +99,10 @@ def test_knn_bit_exact(ops, kind, b, n, s, k):
 @pytest.mark.parametrize("kind,b,n", [("uniform", 2, 1024), ("dup", 2, 512), ("grid", 1, 729),
                                       ("clustered", 2, 1024), ("uniform", 1, 3000), ("uniform", 3, 77)])
 @pytest.mark.parametrize("k", [9, 5])
-def test_umbrella_features(ops, kind, b, n, k):
+@pytest.mark.parametrize("path", ["grid", "scan"])      # the search through per-cloud grids (csrc/grid_knn.hip; by default from 2 048 points per cloud) / over the whole cloud
+def test_umbrella_features(ops, kind, b, n, k, path, monkeypatch):
+    monkeypatch.setattr(ops, "UMBRELLA_GRID", path == "grid")
+    monkeypatch.setattr(ops, "UMBRELLA_GRID_MIN_ROWS", 0)
     xyz = cloud(21 + n, b, n, kind)
     n = xyz.shape[1]
     sign = np.where(np.random.RandomState(n).rand(b) < 0.5, -1.0, 1.0).astype(np.float32)
@@ -115,6 +118,23 @@ def test_umbrella_features(ops, kind, b, n, k):
     err = np.nan_to_num(np.abs(got - of))
     assert (err <= 1e-5 + 1e-5 * np.nan_to_num(np.abs(of))).all(), float(err.max())
     assert err.max() <= 2e-6 and np.median(err) < 1e-7
+
+
+@pytest.mark.parametrize("shift", [0.0, 3.0, 50.0])
+def test_umbrella_grid_equals_scan(ops, shift, monkeypatch):
+    """The constructor over per-cloud grids against the scan of the whole cloud at the benchmark's size (32 x 1024), bit for bit:
+    lists and features.  Away from the origin the expanded distance formula loses digits (its error grows with the squared norm):
+    the grid search widens its completeness bound by that error (`slack`), at +50 it ends up visiting whole clouds."""
+    xyz = cloud(77, 32, 1024) + np.float32(shift)
+    sign = np.where(np.random.RandomState(5).rand(32) < 0.5, -1.0, 1.0).astype(np.float32)
+    out = {}
+    monkeypatch.setattr(ops, "UMBRELLA_GRID_MIN_ROWS", 0)
+    for path in ("grid", "scan"):
+        monkeypatch.setattr(ops, "UMBRELLA_GRID", path == "grid")
+        out[path] = ops.umbrella_features(dev(xyz), 9, dev(sign), return_knn=True)
+    assert torch.equal(out["grid"][1], out["scan"][1])
+    a, b = out["grid"][0], out["scan"][0]
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
 
 
 @pytest.mark.parametrize("tag", ["seed0", "seed1", "seed2", "seed3", "real"])
