@@ -150,6 +150,18 @@ int rs_three_interpolate_fused(int b, int c, int m, int n, const float *points, 
                                const float *add, int relu, float *out, void *stream);
 int rs_three_interpolate_fused_backward(int b, int c, int n, int m, const float *grad_out, const float *fwd_out,
                                         const int *idx, const float *weight, float *grad_points, float *grad_add, void *stream);
+/* Feature propagation, first layers (segmentation/modules/repsurface_utils.py:256-270; round 4): out = relu(interpolate(BN_f(points))
+ * + BN_s(add)), both BatchNorms as per-channel (scale, shift) applied on the fly to the raw Linear outputs (z = fma(scale, y,
+ * shift): what the BatchNorm pass computes) -- and its backward: g = grad_out * (fwd_out > 0) to grad_add, scattered with the
+ * weights into grad_points (zeroed by the caller), BN_s's backward sums {sum g, sum g * (add - mean) * invstd} to
+ * partial (partial_blocks, 2, c) doubles (c <= 256). */
+int rs_three_interpolate_affine(int b, int c, int m, int n, const float *points, const float *pscale, const float *pshift,
+                                const int *idx, const float *weight, const float *add, const float *ascale, const float *ashift,
+                                int relu, float *out, void *stream);
+int rs_three_interpolate_affine_backward(int b, int c, int n, int m, const float *grad_out, const float *fwd_out, const int *idx,
+                                         const float *weight, float *grad_points, float *grad_add, const float *add,
+                                         const float *add_mean, const float *add_invstd, double *partial, int partial_blocks,
+                                         void *stream);
 
 /* ---- umbrella surface constructor ---------------------------------------
  * Fuses group_by_umbrella + cal_normal + cal_center + xyz2sphere + cal_const +
@@ -381,7 +393,7 @@ int rs_pool_select(long long groups, int c, const float *ymax, const float *ymin
                    const int *amin, const float *scale, const float *shift, float *out, int *arg, void *stream);
 /* v = dout * (out > 0) and the BatchNorm-backward sums of the pooled layer from (groups, c) data only:
  * partial (partial_blocks, 2, c) = {sum v, sum v * yhat[arg row]}.  out = NULL: the pooled layer ended without a
- * ReLU (rs_pool_max called with relu = 0), v = dout.  dout: (groups, c) rows `ldd` floats apart (0 = c): the pooled
+ * ReLU (rs_pool_max called with relu = 0), v = dout (v may then be NULL: only the sums).  dout: (groups, c) rows `ldd` floats apart (0 = c): the pooled
  * activations' gradient is often a column slice of a wider tensor. */
 int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout, long long ldd,
                          const float *out, const int *arg, const float *y, int y_bf16, const float *mean,

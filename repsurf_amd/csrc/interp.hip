@@ -58,7 +58,11 @@ three_nn_kernel(int b, int n, int m, int blocks_per_cloud, const float *__restri
 __global__ void __launch_bounds__(IT_THREADS)
 interp_fwd_kernel(long long rows, int n, int m, int c, const float *__restrict__ points,
                   const int *__restrict__ idx, const float *__restrict__ weight, float *__restrict__ out,
-                  const float *__restrict__ add, int relu) {
+                  const float *__restrict__ add, int relu, const float *__restrict__ ps, const float *__restrict__ pt,
+                  const float *__restrict__ as, const float *__restrict__ at) {
+  // ps / pt, as / at (round 4, optional): per-channel affine maps of the gathered rows and of `add` -- the BatchNorm of the two
+  // Linear layers in front of the interpolation (repsurface_utils.py:256-270) applied on the fly, z = fma(scale, y, shift) as the
+  // BatchNorm pass computes it, instead of two passes that materialise the normalised tensors
   // add / relu (round 4): out = relu(interpolated + add) in the same launch -- the feature-propagation stage's skip connection and
   // activation (segmentation/modules/repsurface_utils.py:266-270) were two framework kernels behind this one, 3 + 2 passes over the tensor
   const long long total = rows * c, stride = (long long)gridDim.x * IT_THREADS;
@@ -84,8 +88,13 @@ interp_fwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (e0 + k * st < tot) {
+          if (ps) {
+            const float s_ = ps[ch[k]], t_ = pt[ch[k]];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) v[k][t] = fmaf(s_, v[k][t], t_);
+          }
           float o = (w[k][0] * v[k][0] + w[k][1] * v[k][1]) + w[k][2] * v[k][2];
-          if (add) o += sk[k];
+          if (add) o += as ? fmaf(as[ch[k]], sk[k], at[ch[k]]) : sk[k];
           out[e0 + k * st] = relu ? fmaxf(o, 0.f) : o;
         }
     }
@@ -96,11 +105,11 @@ interp_fwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
     const int ch = (int)(e - r * c);
     const long long cloud = r / n;
     const float *base = points + cloud * m * c + ch;
-    const float v0 = weight[r * 3 + 0] * base[(long long)idx[r * 3 + 0] * c];
-    const float v1 = weight[r * 3 + 1] * base[(long long)idx[r * 3 + 1] * c];
-    const float v2 = weight[r * 3 + 2] * base[(long long)idx[r * 3 + 2] * c];
+    float z0 = base[(long long)idx[r * 3 + 0] * c], z1 = base[(long long)idx[r * 3 + 1] * c], z2 = base[(long long)idx[r * 3 + 2] * c];
+    if (ps) { z0 = fmaf(ps[ch], z0, pt[ch]); z1 = fmaf(ps[ch], z1, pt[ch]); z2 = fmaf(ps[ch], z2, pt[ch]); }
+    const float v0 = weight[r * 3 + 0] * z0, v1 = weight[r * 3 + 1] * z1, v2 = weight[r * 3 + 2] * z2;
     float o = (v0 + v1) + v2;
-    if (add) o += add[e];
+    if (add) o += as ? fmaf(as[ch], add[e], at[ch]) : add[e];
     out[e] = relu ? fmaxf(o, 0.f) : o;
   }
 }
@@ -108,7 +117,14 @@ interp_fwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
 __global__ void __launch_bounds__(IT_THREADS)
 interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__ grad_out,
                   const int *__restrict__ idx, const float *__restrict__ weight,
-                  float *__restrict__ grad_points, const float *__restrict__ fwd_out, float *__restrict__ grad_add) {
+                  float *__restrict__ grad_points, const float *__restrict__ fwd_out, float *__restrict__ grad_add,
+                  const float *__restrict__ sy, const float *__restrict__ smean, const float *__restrict__ sinvstd,
+                  double *__restrict__ partial, int partial_blocks) {
+  // partial != NULL (round 4): the BatchNorm-backward sums of the skip branch -- per channel {sum g, sum g * yhat}, yhat = (sy - mean)
+  // * invstd, g the masked gradient -- leave with this pass (partial (partial_blocks, 2, c); the launcher makes the grid stride a
+  // multiple of c, c <= 256: a thread meets one channel only), instead of a second pass over g and sy (rs_pool_max_backward)
+  __shared__ double red[IT_THREADS][2];
+  double acc0 = 0.0, acc1 = 0.0;
   // fwd_out != NULL: the forward ended in a ReLU -- the incoming gradient counts where fwd_out > 0; grad_add != NULL: the masked
   // gradient is also written out (the skip connection's gradient), one pass instead of threshold_backward + this kernel
   const long long total = rows * c, stride = (long long)gridDim.x * IT_THREADS;
@@ -126,13 +142,34 @@ interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
 #pragma unroll
         for (int t = 0; t < 3; ++t) { id[k][t] = idx[r * 3 + t]; w[k][t] = weight[r * 3 + t]; }
       }
+      float yh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (partial) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) yh[k] = sy[ok[k] ? e0 + k * st : e0];
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (!ok[k]) continue;
         if (grad_add) grad_add[e0 + k * st] = g[k];
+        if (partial) { acc0 += (double)g[k]; acc1 += (double)(g[k] * ((yh[k] - smean[ch[k]]) * sinvstd[ch[k]])); }
         float *base = grad_points + (long long)cloud[k] * m * c + ch[k];
 #pragma unroll
         for (int t = 0; t < 3; ++t) atomicAdd(base + (long long)id[k][t] * c, g[k] * w[k][t]);
+      }
+    }
+    if (partial) {      // threads of one channel meet in LDS (fixed order), one partial row per workgroup
+      red[threadIdx.x][0] = acc0; red[threadIdx.x][1] = acc1;
+      __syncthreads();
+      if ((int)threadIdx.x < c) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int k = threadIdx.x; k < IT_THREADS; k += c) { t0 += red[k][0]; t1 += red[k][1]; }
+        const int chn = (int)((blockIdx.x * (unsigned)IT_THREADS + threadIdx.x) % cu);
+        partial[((long long)blockIdx.x * 2 + 0) * c + chn] = t0;
+        partial[((long long)blockIdx.x * 2 + 1) * c + chn] = t1;
+        for (int pb = blockIdx.x + gridDim.x; pb < partial_blocks; pb += gridDim.x) {      // rows no workgroup owns read as zero
+          partial[((long long)pb * 2 + 0) * c + chn] = 0.0;
+          partial[((long long)pb * 2 + 1) * c + chn] = 0.0;
+        }
       }
     }
     return;
@@ -179,7 +216,7 @@ extern "C" int rs_three_interpolate(int b, int c, int m, int n, const float *poi
   if (rows == 0 || c == 0) return RS_OK;
   RS_REQUIRE(points && idx && weight && out, "rs_three_interpolate: null pointer");
   hipLaunchKernelGGL(interp_fwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
-                     rows, n, m, c, points, idx, weight, out, (const float *)nullptr, 0);
+                     rows, n, m, c, points, idx, weight, out, (const float *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr);
   RS_CHECK_LAUNCH("rs_three_interpolate");
   return RS_OK;
 }
@@ -191,7 +228,7 @@ extern "C" int rs_three_interpolate_fused(int b, int c, int m, int n, const floa
   if (rows == 0 || c == 0) return RS_OK;
   RS_REQUIRE(points && idx && weight && out, "rs_three_interpolate_fused: null pointer");
   hipLaunchKernelGGL(interp_fwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
-                     rows, n, m, c, points, idx, weight, out, add, relu);
+                     rows, n, m, c, points, idx, weight, out, add, relu, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr);
   RS_CHECK_LAUNCH("rs_three_interpolate_fused");
   return RS_OK;
 }
@@ -204,7 +241,7 @@ extern "C" int rs_three_interpolate_fused_backward(int b, int c, int n, int m, c
   if (rows == 0 || c == 0) return RS_OK;
   RS_REQUIRE(grad_out && idx && weight && grad_points, "rs_three_interpolate_fused_backward: null pointer");
   hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
-                     rows, n, m, c, grad_out, idx, weight, grad_points, fwd_out, grad_add);
+                     rows, n, m, c, grad_out, idx, weight, grad_points, fwd_out, grad_add, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (double *)nullptr, 0);
   RS_CHECK_LAUNCH("rs_three_interpolate_fused_backward");
   return RS_OK;
 }
@@ -217,8 +254,53 @@ extern "C" int rs_three_interpolate_backward(int b, int c, int n, int m, const f
   if (rows == 0 || c == 0) return RS_OK;
   RS_REQUIRE(grad_out && idx && weight && grad_points, "rs_three_interpolate_backward: null pointer");
   hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
-                     rows, n, m, c, grad_out, idx, weight, grad_points, (const float *)nullptr, (float *)nullptr);
+                     rows, n, m, c, grad_out, idx, weight, grad_points, (const float *)nullptr, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (double *)nullptr, 0);
   RS_CHECK_LAUNCH("rs_three_interpolate_backward");
   return RS_OK;
 }
 
+
+/* Feature propagation, first layers (segmentation/modules/repsurface_utils.py:256-270): out = relu(interpolate(BN_f(points)) +
+ * BN_s(add)) with both BatchNorms given as per-channel (scale, shift) and applied on the fly to the raw Linear outputs `points`
+ * (b, m, c) and `add` (b, n, c) -- z = fma(scale, y, shift), the arithmetic of the BatchNorm pass it replaces. */
+extern "C" int rs_three_interpolate_affine(int b, int c, int m, int n, const float *points, const float *pscale, const float *pshift,
+                                           const int *idx, const float *weight, const float *add, const float *ascale,
+                                           const float *ashift, int relu, float *out, void *stream) {
+  RS_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "rs_three_interpolate_affine: negative size");
+  const long long rows = (long long)b * n;
+  if (rows == 0 || c == 0) return RS_OK;
+  RS_REQUIRE(points && idx && weight && out, "rs_three_interpolate_affine: null pointer");
+  RS_REQUIRE((pscale == nullptr) == (pshift == nullptr) && (ascale == nullptr) == (ashift == nullptr), "rs_three_interpolate_affine: scale and shift come together");
+  RS_REQUIRE(!ascale || add, "rs_three_interpolate_affine: an affine map of `add` needs `add`");
+  hipLaunchKernelGGL(interp_fwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
+                     rows, n, m, c, points, idx, weight, out, add, relu, pscale, pshift, ascale, ashift);
+  RS_CHECK_LAUNCH("rs_three_interpolate_affine");
+  return RS_OK;
+}
+
+/* Its backward: g = grad_out * (fwd_out > 0) is written to grad_add (the gradient at BN_s's output = at the interpolation's sum),
+ * scattered with the weights into grad_points (zeroed by the caller: the gradient at BN_f's output), and BN_s's backward sums
+ * {sum g, sum g * (add - mean) * invstd} per channel leave as partial (partial_blocks, 2, c) doubles (c <= 256). */
+extern "C" int rs_three_interpolate_affine_backward(int b, int c, int n, int m, const float *grad_out, const float *fwd_out,
+                                                    const int *idx, const float *weight, float *grad_points, float *grad_add,
+                                                    const float *add, const float *add_mean, const float *add_invstd,
+                                                    double *partial, int partial_blocks, void *stream) {
+  RS_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "rs_three_interpolate_affine_backward: negative size");
+  const long long rows = (long long)b * n;
+  if (rows == 0 || c == 0) return RS_OK;
+  RS_REQUIRE(grad_out && idx && weight && grad_points && grad_add && add && add_mean && add_invstd && partial && partial_blocks > 0,
+             "rs_three_interpolate_affine_backward: null pointer");
+  RS_REQUIRE(c <= IT_THREADS && rows * c < (1LL << 31) && rows * 3 < (1LL << 31),
+             "rs_three_interpolate_affine_backward: c=%d / %lld elements outside the fused-sums form (c <= 256, < 2^31 elements)", c, rows * c);
+  int g = grid_for(rows * c);
+  if (g > partial_blocks) g = partial_blocks;
+  int a = c, bb = IT_THREADS;                      // grid * 256 must be a multiple of c: a thread then meets one channel only
+  while (bb) { const int t = a % bb; a = bb; bb = t; }
+  const int step = c / a;
+  g = g / step * step;
+  RS_REQUIRE(g >= step && g >= 1, "rs_three_interpolate_affine_backward: partial_blocks=%d below %d", partial_blocks, step);
+  hipLaunchKernelGGL(interp_bwd_kernel, dim3(g), dim3(IT_THREADS), 0, (hipStream_t)stream, rows, n, m, c, grad_out, idx, weight,
+                     grad_points, fwd_out, grad_add, add, add_mean, add_invstd, partial, partial_blocks);
+  RS_CHECK_LAUNCH("rs_three_interpolate_affine_backward");
+  return RS_OK;
+}

@@ -2026,12 +2026,12 @@ pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ off
       const long long b0 = offsets ? (long long)offsets[g] : g * ns, b1 = offsets ? (long long)offsets[ok1 ? g1 : g] : (ok1 ? g1 : g) * ns;
       const float y0 = ldy<BF>(y, (b0 + a0) * c + ch), y1 = ldy<BF>(y, (b1 + a1) * c + ch);
       const float v0 = o0 > 0.f ? d0 : 0.f;                        // out == NULL: the pooled layer ended without a ReLU
-      v[e0] = v0;
+      if (v) v[e0] = v0;                                           // (v == NULL: only the sums -- v would be dout itself)
       s0 += (double)v0;
       s1 += (double)(v0 * ((y0 - mu) * is));
       if (ok1) {                                                  // (same order of the sums as one group per trip)
         const float v1 = o1 > 0.f ? d1 : 0.f;
-        v[e1] = v1;
+        if (v) v[e1] = v1;
         s0 += (double)v1;
         s1 += (double)(v1 * ((y1 - mu) * is));
       }
@@ -2636,7 +2636,7 @@ extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const 
                                     const float *invstd, float *v, double *partial, int partial_blocks, void *stream) {
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0 && partial_blocks > 0, "rs_pool_max_backward: bad size");
   if (groups == 0 || c == 0) return RS_OK;
-  RS_REQUIRE(dout && (arg || (nsample == 1 && !offsets)) && y && mean && invstd && v && partial, "rs_pool_max_backward: null pointer (arg may be NULL for dense groups of one row only)");
+  RS_REQUIRE(dout && (arg || (nsample == 1 && !offsets)) && y && mean && invstd && (v || !out) && partial, "rs_pool_max_backward: null pointer (arg may be NULL for dense groups of one row only; v for a layer without ReLU: it would equal dout)");
   if (ldd <= 0) ldd = c;
   RS_REQUIRE(ldd >= c, "rs_pool_max_backward: row stride of dout %lld < %d channels", ldd, c);
   const long long want = (groups + 3) / 4;

@@ -76,6 +76,17 @@ def umbrella_moments(x):
     return mlp_hip.umbrella_moments(x)
 
 
+def fp_front_usable(lin_f, bn_f, lin_s, bn_s):
+    """Can `fp_front` serve these layers (training mode, batch statistics, fp32, <= 256 channels)?"""
+    return mlp_hip.fp_front_usable(lin_f, bn_f, lin_s, bn_s)
+
+
+def fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s):
+    """Feature propagation in front of its [Linear, BN, ReLU]* chain (segmentation/modules/repsurface_utils.py:256-270) as one
+    node: relu(interpolate(bn_f(lin_f(points2)), idx, weight) + bn_s(lin_s(points1)))."""
+    return mlp_hip.fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s)
+
+
 def row_linear(x, linear):
     """A plain nn.Linear on ungrouped rows (no BatchNorm): y = x . W^T + b, forward and backward on the row GEMM /
     weight-gradient kernels (the segmentation classifier's 13-class output layer)."""

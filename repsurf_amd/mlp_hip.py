@@ -1275,6 +1275,90 @@ def umbrella_mlp(x, mlps, group, aggr, moments=None):
 
 
 # ------------------------------------------------------------------------------------------- plain row linear
+class _FPFront(Function):
+    """Feature propagation, everything in front of the [Linear, BN, ReLU]* chain (segmentation/modules/repsurface_utils.py:256-270):
+        out = relu(interpolate(BN_f(Linear_f(points2)), idx, weight) + BN_s(Linear_s(points1)))
+    as ONE autograd node (round 4): two row GEMMs with BatchNorm sums, one finalize launch for both BatchNorms, one interpolation
+    launch that applies both affine maps on the fly -- no BatchNorm pass materialises the normalised tensors (two passes per
+    stage and direction, 65 536 x 128 floats each way at the finest level); backward: one launch scatters the masked gradient to
+    the coarse rows, writes it for the skip branch and leaves that branch's BatchNorm-backward sums, one pass over the 4 x smaller
+    coarse gradient makes the other branch's sums, one launch turns both into coefficients, then the usual weight / data
+    gradient GEMMs.  Training mode, batch statistics (eval / SyncBatchNorm take the layer-by-layer route)."""
+
+    @staticmethod
+    def forward(ctx, points2, points1, idx, weight, meta, wf, bf, gf, betaf, ws, bs, gs, betas):
+        dev = points2.device
+        points2, points1, weight = points2.contiguous(), points1.contiguous(), weight.contiguous()
+        idx = (idx if idx.dtype == torch.int32 else idx.to(torch.int32)).contiguous()
+        m, c2 = points2.shape
+        n, c1 = points1.shape
+        bn_f, bn_s = meta["bns"]
+        wf2, ws2 = _w2d(wf), _w2d(ws)
+        c = wf2.shape[0]
+        y2, v2, it2 = fwd_layer(m, operand(OP_ID, points2, c2), c2, wf2, bf, bn_f, True, dev, wk=w_fwd(wf2), finalize=False)
+        y1, v1, it1 = fwd_layer(n, operand(OP_ID, points1, c1), c1, ws2, bs, bn_s, True, dev, wk=w_fwd(ws2), finalize=False)
+        bn_finalize_batch([it2, it1])
+        out = torch.empty((n, c), dtype=torch.float32, device=dev)
+        _lib.call("rs_three_interpolate_affine", 1, c, m, n, _ptr(y2), _ptr(v2.scale), _ptr(v2.shift), idx.data_ptr(), _ptr(weight),
+                  _ptr(y1), _ptr(v1.scale), _ptr(v1.shift), 1, _ptr(out), _stream())
+        _flush_counters()
+        ctx.saved = dict(points2=points2, points1=points1, idx=idx, weight=weight, y2=y2, y1=y1, v2=v2, v1=v1, out=out, wf2=wf2, ws2=ws2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s = ctx.saved
+        points2, points1, y2, y1, v2, v1, wf2, ws2 = s["points2"], s["points1"], s["y2"], s["y1"], s["v2"], s["v1"], s["wf2"], s["ws2"]
+        dev = dout.device
+        m, c2 = points2.shape
+        n, c1 = points1.shape
+        c = wf2.shape[0]
+        dout = dout.contiguous()
+        _stack_begins()
+        g = torch.empty((n, c), dtype=torch.float32, device=dev)             # gradient at BN_s's output (= at the sum, masked)
+        d2 = torch.zeros((m, c), dtype=torch.float32, device=dev)            # gradient at BN_f's output (scatter target)
+        nb1 = max(1, min(2048, -(-(n * c) // 1024)))      # one partial row per workgroup of the interpolation backward (<= 2048: its usual grid)
+        part1 = torch.empty((nb1, 2, c), dtype=torch.float64, device=dev)
+        _lib.call("rs_three_interpolate_affine_backward", 1, c, n, m, _ptr(dout), _ptr(s["out"]), s["idx"].data_ptr(), _ptr(s["weight"]),
+                  _ptr(d2), _ptr(g), _ptr(y1), _ptr(v1.mean), _ptr(v1.invstd), part1.data_ptr(), nb1, _stream())
+        nb2 = partial_rows(m, 4)
+        part2 = torch.empty((nb2, 2, c), dtype=torch.float64, device=dev)
+        _lib.call("rs_pool_max_backward", m, 1, c, None, _ptr(d2), c, None, None, _ptr(y2), 0, _ptr(v2.mean), _ptr(v2.invstd), None,
+                  part2.data_ptr(), nb2, _stream())
+        (p1, q1, r1, dg1, db1), (p2, q2, r2, dg2, db2) = bwd_coeffs_multi(
+            [(c, n, part1, 2, 1, v1, None, False), (c, m, part2, 2, 1, v2, None, False)], dev)
+        op1 = operand(OP_AFF2, g, c, y1, c, s1=p1, t1=r1, s2=q1)
+        op2 = operand(OP_AFF2, d2, c, y2, c, s1=p2, t1=r2, s2=q2)
+        dws = wgrad(n, c, c1, op1, operand(OP_ID, points1, c1), dev, None, defer=True)
+        dwf = wgrad(m, c, c2, op2, operand(OP_ID, points2, c2), dev, None, defer=True)
+        dp1 = dp2 = None
+        if ctx.needs_input_grad[1]:
+            dp1 = torch.empty((n, c1), dtype=torch.float32, device=dev)
+            gemm_rows(n, c, c1, op1, w_bwd(ws2), Epilogue(bias=None, out=_ptr(dp1), ldo=c1, mode=EPI_STORE))
+        if ctx.needs_input_grad[0]:
+            dp2 = torch.empty((m, c2), dtype=torch.float32, device=dev)
+            gemm_rows(m, c, c2, op2, w_bwd(wf2), Epilogue(bias=None, out=_ptr(dp2), ldo=c2, mode=EPI_STORE))
+        _stack_ends()
+        zb = _zeros.take(2 * c, dev)           # biases in front of a BatchNorm with batch statistics: exactly zero
+        return (dp2, dp1, None, None, None, dwf.reshape(s["wf2"].shape), zb[:c], dg2, db2, dws.reshape(s["ws2"].shape), zb[c:], dg1, db1)
+
+
+def fp_front_usable(lin_f, bn_f, lin_s, bn_s):
+    """the fused node serves training-mode BatchNorm with batch statistics, fp32 arithmetic, at most 256 channels"""
+    from . import mlp as _mlp
+    return (bn_f.training and bn_s.training and _mlp.PRECISION == "fp32" and lin_f.out_features <= 256
+            and lin_f.bias is not None and lin_s.bias is not None and sync_of(bn_f) is None and sync_of(bn_s) is None
+            and os.environ.get("REPSURF_FP_FRONT", "1") != "0")
+
+
+def fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s):
+    """relu(interpolate(bn_f(lin_f(points2)), idx, weight) + bn_s(lin_s(points1))): points2 (M, C2) coarse rows, points1 (N, C1)
+    fine rows, idx / weight (N, 3) -> (N, C)."""
+    meta = {"bns": (bn_f, bn_s)}
+    return _FPFront.apply(points2, points1, idx, weight, meta, lin_f.weight, lin_f.bias, bn_f.weight, bn_f.bias,
+                          lin_s.weight, lin_s.bias, bn_s.weight, bn_s.bias)
+
+
 class _RowLinear(torch.autograd.Function):
     """y = x . W^T + b on ungrouped rows (the 13-class output layer of the segmentation classifier,
     segmentation/models/repsurf/repsurf_umb_ssg.py:36-41): the row GEMM with a plain store epilogue forward, the same

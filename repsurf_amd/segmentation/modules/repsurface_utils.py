@@ -212,6 +212,11 @@ class SurfaceFeaturePropagationCD(nn.Module):
         xyz1, points1, offset1 = pos_feat_off1      # fine:   (N,3), (N,C)|None, (B,)
         xyz2, points2, offset2 = pos_feat_off2      # coarse: (M,3), (M,C), (B,)
         idx, weight = geometry if geometry is not None else self.geometry(xyz1, offset1, xyz2, offset2)
+        if self.skip and _mlp.fp_front_usable(self.mlp_f0, self.norm_f0, self.mlp_s0, self.norm_s0):
+            # both Linear + BatchNorm pairs, the interpolation, the skip connection and the ReLU as one node: the BatchNorms are
+            # applied inside the interpolation launch (round 4)
+            new_points = _mlp.fp_front(points2, points1, idx, weight, self.mlp_f0, self.norm_f0, self.mlp_s0, self.norm_s0)
+            return row_mlp(new_points, self.mlp_convs, self.mlp_bns)
         points2 = row_mlp(points2, [self.mlp_f0], [self.norm_f0], relu_last=False)
         skip = row_mlp(points1, [self.mlp_s0], [self.norm_s0], relu_last=False).unsqueeze(0) if self.skip else None
         # interpolation + skip connection + ReLU (reference :266-270) in one launch forward, one backward

@@ -547,3 +547,36 @@ def test_interpolation_with_skip_and_relu_in_one_launch():
         assert (p2.grad - p1.grad).abs().max().item() <= 2e-5 * max(1.0, p1.grad.abs().max().item())
         if use_skip:
             assert torch.equal(s2.grad, s1.grad)
+
+
+@pytest.mark.parametrize("n,m,c1,c2,c", [(4096, 1024, 32, 64, 128), (1000, 333, 19, 70, 96), (65536, 16384, 64, 128, 256)])
+def test_feature_propagation_front_as_one_node(n, m, c1, c2, c, monkeypatch):
+    """SurfaceFeaturePropagationCD with the fused front node (mlp_hip._FPFront: both Linear + BatchNorm pairs, interpolation, skip,
+    ReLU -- the BatchNorms applied inside the interpolation launch) against the layer-by-layer route (REPSURF_FP_FRONT=0): the
+    forward is the same arithmetic (bit-identical), the gradients agree to the noise of the different summation orders of the
+    BatchNorm-backward sums; odd widths (19 / 70 / 96 channels) take the unaligned operand paths."""
+    with subproject("segmentation"):
+        import importlib
+        mod = importlib.import_module("modules.repsurface_utils")
+        torch.manual_seed(n + c)
+        fp = mod.SurfaceFeaturePropagationCD(c2, c1, [c, c]).cuda().train()
+        g = torch.Generator().manual_seed(1)
+        p1 = torch.randn(n, c1, generator=g).cuda().requires_grad_()
+        p2 = torch.randn(m, c2, generator=g).cuda().requires_grad_()
+        idx = torch.randint(0, m, (n, 3), generator=g, dtype=torch.int32).cuda()
+        w = torch.rand(n, 3, generator=g).cuda()
+        w = (w / w.sum(1, keepdim=True)).contiguous()
+        probe = torch.randn(n, c, generator=g).cuda()
+        res = {}
+        for tag, env in (("node", "1"), ("layers", "0")):
+            monkeypatch.setenv("REPSURF_FP_FRONT", env)
+            for p in list(fp.parameters()) + [p1, p2]:
+                p.grad = None
+            out = fp([None, p1, None], [None, p2, None], geometry=(idx, w))
+            (out * probe).sum().backward()
+            res[tag] = (out.detach().clone(), [p.grad.detach().clone() for p in list(fp.parameters()) + [p1, p2]])
+        assert torch.equal(res["node"][0], res["layers"][0])
+        for (name, _), a, b in zip(list(fp.named_parameters()) + [("points1", None), ("points2", None)], res["node"][1], res["layers"][1]):
+            scale = b.abs().max().item()
+            err = (a - b).abs().max().item()
+            assert err <= 2e-4 * scale + 1e-6, (name, err, scale)

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from repsurf_amd import mlp as _mlp
 
-_PRODUCT = {n: getattr(_mlp, n) for n in ("sa_mlp_cd", "sa_mlp_plain", "umbrella_mlp", "umbrella_mlp2", "prepack",
+_PRODUCT = {n: getattr(_mlp, n) for n in ("sa_mlp_cd", "sa_mlp_plain", "umbrella_mlp", "umbrella_mlp2", "fp_front", "fp_front_usable", "prepack",
                                           "deferred_counters")}
 _PRODUCT_COMPACT = _mlp.COMPACT_GROUPS
 BACKEND = "hip"
@@ -70,6 +70,16 @@ def umbrella_mlp2(x, mlps, group, moments=None):
     return F.linear(h, _w2d(conv1), conv1.bias).view(-1, group, conv1.weight.shape[0]).sum(dim=1)
 
 
+def fp_front_usable(lin_f, bn_f, lin_s, bn_s):
+    return True
+
+
+def fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s):
+    z2 = _bn(F.linear(points2, lin_f.weight, lin_f.bias), bn_f)
+    z1 = _bn(F.linear(points1, lin_s.weight, lin_s.bias), bn_s)
+    return F.relu((z2[idx.long()] * weight.unsqueeze(-1)).sum(1) + z1)
+
+
 def set_backend(name):
     global BACKEND
     if name not in ("hip", "torch"):
@@ -82,6 +92,7 @@ def set_backend(name):
     else:
         _mlp.sa_mlp_cd, _mlp.sa_mlp_plain = sa_mlp_cd, sa_mlp_plain
         _mlp.umbrella_mlp, _mlp.umbrella_mlp2 = umbrella_mlp, umbrella_mlp2
+        _mlp.fp_front, _mlp.fp_front_usable = fp_front, fp_front_usable
         _mlp.prepack = lambda convs: None
         _mlp.deferred_counters = contextlib.nullcontext
         _mlp.COMPACT_GROUPS = False
