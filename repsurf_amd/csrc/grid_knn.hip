@@ -493,7 +493,7 @@ extern "C" int rs_knn_grid_query(int m, int nsample, int b, int max_queries, int
   const CloudGrid *cg = reinterpret_cast<const CloudGrid *>(grid);
   // LDS: the rows of the largest cloud, at most GK_LDS_ROWS of them, + its cell starts (larger clouds are read in place)
   int lds_rows = max_rows > 0 && max_rows < GK_LDS_ROWS ? max_rows : GK_LDS_ROWS;
-  if (nsample > 16) {
+  if (nsample > 16) {      // (short lists through this kernel: 65 536 queries, 9 entries 190-290 us against 122; 3 entries 157-174 against 74)
     // one wave per query, `qpw` queries per wave: enough waves to fill the chip (16 per CU) before a wave takes a second query
     int qpw = (int)(((long long)max_queries * b + 4095) / 4096);
     qpw = qpw < 1 ? 1 : (qpw > 64 ? 64 : qpw);
