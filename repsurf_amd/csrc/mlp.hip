@@ -355,15 +355,15 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   constexpr bool EARLY_PREFETCH = false;
 #endif
   // 128-row tiles (four stacked waves, the 32 / 64-column layers of the segmentation step's 524 288-row stages): the same epilogue
-  // straight from the accumulators unless the max-pool is folded into this launch (that one walks whole groups through the C tile
-  // in LDS).  Round 4: the LDS epilogue of these tiles -- C tile through LDS, three barriers, one exposed mask-load round trip per
+  // straight from the accumulators unless a max-pool over groups of other than 32 rows is folded into this launch (that one walks whole
+  // groups through the C tile in LDS; groups of 32 rows are pooled in the accumulators, see the epilogue).  Round 4: the LDS epilogue of these tiles -- C tile through LDS, three barriers, one exposed mask-load round trip per
   // 32 rows -- held the 524 288 x 32 launches at 0.30 of the HBM roof.  A run-time, wave-uniform choice: both forms live in the
   // instance.  -DRS_NO_DIRECT128 restores the LDS epilogue for A/B runs.
 #ifdef RS_NO_DIRECT128
   const bool direct = DIRECT;
 #else
   constexpr bool D128 = BM == 128 && BN <= 64 && !WS;       // (128-column tiles: four accumulator tiles per wave, the two forms in one
-  const bool direct = DIRECT || (D128 && ep.pool_ns <= 0);  //  instance spill 0.5-2 KB per lane: they keep the LDS epilogue)
+  const bool direct = DIRECT || (D128 && (ep.pool_ns <= 0 || ep.pool_ns == 32));  //  instance spill 0.5-2 KB per lane: they keep the LDS epilogue)
 #endif
   constexpr int NSLOT = 2 * WR;                             // (row wave, lane half) pairs that hold sums of one column
   static_assert(CT >= 1, "tile too narrow for the wave layout");
@@ -749,6 +749,30 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
           }
         }
         st0[c] += t0; st1[c] += t1; st2[c] += t2;
+        if (CAN_STATS && ep.pool_ns == 32) {
+          // Max-pool over groups of 32 rows folded into THIS epilogue (round 4): a wave's 32 x 32 accumulator tile IS one group
+          // per column (tiles start on multiples of 32 rows), a lane holds 16 of its rows in ascending order, the other 16 sit in
+          // lane ^ 32: raw extremes of the stored values and their first positions, resolved by rs_pool_select once BatchNorm's
+          // scale is known.  (Through the LDS epilogue -- C tile in LDS, a thread walks a group's 32 rows -- the 524 288 x 32 -> 64
+          // layer of the segmentation step ran at 2.2 TB/s: 90 us for 201 MB.)
+          float mx = -INFINITY, mn = INFINITY;
+          int ax = 0, an = 0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int k = 4 * lk + (i & 3) + 8 * (i >> 2);
+            const float v = ykeep[i];
+            if (v > mx) { mx = v; ax = k; }
+            if (v < mn) { mn = v; an = k; }
+          }
+          const float pmx = __shfl_xor(mx, 32, 64), pmn = __shfl_xor(mn, 32, 64);
+          const int pax = __shfl_xor(ax, 32, 64), pan = __shfl_xor(an, 32, 64);
+          if (pmx > mx || (pmx == mx && pax < ax)) { mx = pmx; ax = pax; }
+          if (pmn < mn || (pmn == mn && pan < an)) { mn = pmn; an = pan; }
+          if (lk == 0 && cok && r0 + wave_r * 32 < rows) {
+            const long long o = ((r0 + wave_r * 32) >> 5) * cols + col;
+            ep.pool_max[o] = mx; ep.pool_min[o] = mn; ep.pool_amax[o] = ax; ep.pool_amin[o] = an;
+          }
+        }
       }
       if (!WS) __syncthreads();   // every wave is past its fragment reads: the next tile may overwrite the staging buffers
                                   // (WS: the stage parity runs across tiles and the chunk barrier orders the overwrite)
@@ -2216,11 +2240,14 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
   if (epi_mode == EPI_MASK) RS_REQUIRE(ep.my1 && ep.ms1 && ep.mt1 && ep.mean1 && ep.invstd1, "rs_mlp_gemm_rows: mask epilogue needs the producing layer's y/scale/shift/mean/invstd");
   if (epi_mode == EPI_MASK && ep.my2) RS_REQUIRE(ep.ms2 && ep.mt2 && ep.mean2 && ep.invstd2, "rs_mlp_gemm_rows: second mask branch incomplete");
   if (epi_mode != EPI_MASK) { ep.my1 = nullptr; ep.my2 = nullptr; }
+  // groups of 32 rows are pooled straight from the accumulators wherever the epilogue is the direct one (64-row tiles, 128-row tiles
+  // of <= 64 columns); other group sizes, and 128 x 128 tiles, through the C tile in LDS
+  const bool pool32 = ep.pool_ns == 32 && epi_mode == EPI_STATS;
   if (ep.pool_ns > 0) {
     RS_REQUIRE(!rows_dev, "rs_mlp_gemm_rows: fused pooling needs dense groups (not a compacted row set)");
     RS_REQUIRE(ep.pool_max && ep.pool_min && ep.pool_amax && ep.pool_amin, "rs_mlp_gemm_rows: fused pooling needs its four outputs");
     const int rpt = GM_BM / (GM_THREADS / (cols <= 32 ? 32 : (cols <= 64 ? 64 : 128)));   // (pooling keeps 128-wide tiles)
-    RS_REQUIRE(rows % ep.pool_ns == 0 && rpt % ep.pool_ns == 0,
+    RS_REQUIRE(rows % ep.pool_ns == 0 && (pool32 || rpt % ep.pool_ns == 0),
                "rs_mlp_gemm_rows: fused pooling needs nsample (%d) to divide %d rows per thread", ep.pool_ns, rpt);
   }
   if (RS_STORE_BF16) {       // unit 3: the call's flags must be the storage-role table (top of this file)
@@ -2272,7 +2299,7 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
   const int v = pick_vec(E, kdim);
   // tile height: 64-row tiles (2 x 2 waves) wherever the layout allows -- twice the workgroups, three per CU
   static const int bm64_on = env_int("RS_GEMM_BM64", 1);
-  int bm = (bm64_on && cols > 32 && v >= 2 && ep.pool_ns == 0) ? 64 : GM_BM;
+  int bm = (bm64_on && cols > 32 && v >= 2 && (ep.pool_ns == 0 || pool32)) ? 64 : GM_BM;
   long long tiles = (rows + bm - 1) / bm;
   int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
   static const int bn_small = env_int("RS_GEMM_BN64_BELOW", 256), bn_small64 = env_int("RS_GEMM_BN64_BELOW64", 512);

@@ -336,6 +336,8 @@ def gemm_rows(rows, kdim, cols, x_op, wk, epi, rows_dev=None):
 
 def fused_pool_ok(cout, nsample):
     """the row GEMM can fold the max over nsample into its epilogue when whole groups sit in one thread's rows"""
+    if nsample == 32 and os.environ.get("REPSURF_POOL32_DIRECT", "1") != "0":
+        return True          # groups of 32 rows: pooled in the accumulators of a wave's 32-row tile (any width)
     rows_per_thread = 128 // (256 // (32 if cout <= 32 else (64 if cout <= 64 else 128)))
     return rows_per_thread % nsample == 0
 
