@@ -2380,6 +2380,9 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
   const int vp = pick_vec(P, ncols), vq = pick_vec(Q, kcols);
   static const int small_on = env_int("RS_WGRAD_SMALL", 1);
   static const int wnarrow_on = env_int("RS_WGRAD_NARROW", 1);
+  // (kcols <= 32 with <= 64 columns of P through this kernel -- the 32 / 64-column layers of the segmentation step's 524 288-row
+  // stage, whose 32 x 32 / 64 x 32 products keep one or two of the tiled kernel's four waves on the matrix pipe -- was measured in
+  // round 4: 3.72 against 3.67 ms per step; its one-float-per-lane loads cost more than the idle waves.)
   if (wnarrow_on && !RS_STORE_BF16 && !bf && kcols <= WS_KP && (Q.mode == OPM_ID || Q.mode == OPM_RELU1) &&
       (P.mode == OPM_AFF2 || P.mode == OPM_POOLED || P.mode == OPM_BCAST || P.mode == OPM_ID)) {
     // narrow gradient on the matrix pipe (rows = MFMA k), 64 columns of P per workgroup
