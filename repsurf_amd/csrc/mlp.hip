@@ -2260,24 +2260,8 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
     RS_REQUIRE(!(E.a_bf16 || E.b_bf16 || ep.out_bf16 || ep.my1_bf16 || ep.my2_bf16), "rs_mlp_gemm_rows: bf16 tensors are taken by rs_mlp_gemm_rows_bf16 only");
   }
   hipStream_t st0 = (hipStream_t)stream;
-  static const int small_on = env_int("RS_GEMM_SMALL", 1);
-  // Only where the MFMA kernel would have to take its scalar-load generic instance (an odd kdim or an unaligned
-  // operand, e.g. the 3 position channels of a 19-channel row: 166 us against 29 us at 524288 rows); with float2 /
-  // float4 operands the MFMA kernel is the faster one even at kdim = 6 (14 us against 15-18 us at 66 584 rows).
-  if (small_on && kdim <= WS_KP && E.mode == OPM_ID && epi_mode != EPI_MASK && ep.pool_ns == 0 && pick_vec(E, kdim) == 1) {
-    const int nb = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
-    int gxs = (int)((rows + 63) / 64);
-    if (gxs > 512) gxs = 512;
-    if (epi_mode != EPI_STORE && gxs > ep.partial_blocks) gxs = ep.partial_blocks;
-    if (gxs < 1) gxs = 1;
-    const dim3 grid(gxs, rs_cdiv(cols, nb));
-    if (nb == 32) hipLaunchKernelGGL(gemm_small_kernel<32>, grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-    else if (nb == 64) hipLaunchKernelGGL(gemm_small_kernel<64>, grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-    else hipLaunchKernelGGL(gemm_small_kernel<128>, grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep);
-    RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
-    return RS_OK;
-  }
-  // kdim <= 16, plain operand, rows on 16- or 8-byte boundaries, fp32 output: the LDS-free wave-per-32-rows kernel
+  // kdim <= 16, plain operand, rows on 16- or 8-byte boundaries, fp32 output: the LDS-free wave-per-32-rows kernel -- odd kdim
+  // included (round 4: the 3 position channels of the segmentation rows went to the streaming kernel below first, 29.5 us for 67 MB)
   static const int narrow_on = env_int("RS_GEMM_NARROW", 1);
   if (narrow_on && !RS_STORE_BF16 && !bf && kdim <= 16 && cols <= 128 && E.mode == OPM_ID && epi_mode != EPI_MASK && ep.pool_ns == 0) {
     const int kl = kdim <= 8 ? 1 : 2;
@@ -2295,6 +2279,23 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
       RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
       return RS_OK;
     }
+  }
+  static const int small_on = env_int("RS_GEMM_SMALL", 1);
+  // Only where the MFMA kernel would have to take its scalar-load generic instance (an odd kdim or an unaligned
+  // operand, e.g. the 3 position channels of a 19-channel row: 166 us against 29 us at 524288 rows); with float2 /
+  // float4 operands the MFMA kernel is the faster one even at kdim = 6 (14 us against 15-18 us at 66 584 rows).
+  if (small_on && kdim <= WS_KP && E.mode == OPM_ID && epi_mode != EPI_MASK && ep.pool_ns == 0 && pick_vec(E, kdim) == 1) {
+    const int nb = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
+    int gxs = (int)((rows + 63) / 64);
+    if (gxs > 512) gxs = 512;
+    if (epi_mode != EPI_STORE && gxs > ep.partial_blocks) gxs = ep.partial_blocks;
+    if (gxs < 1) gxs = 1;
+    const dim3 grid(gxs, rs_cdiv(cols, nb));
+    if (nb == 32) hipLaunchKernelGGL(gemm_small_kernel<32>, grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+    else if (nb == 64) hipLaunchKernelGGL(gemm_small_kernel<64>, grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+    else hipLaunchKernelGGL(gemm_small_kernel<128>, grid, dim3(GM_THREADS), 0, st0, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+    RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
+    return RS_OK;
   }
   const int v = pick_vec(E, kdim);
   // tile height: 64-row tiles (2 x 2 waves) wherever the layout allows -- twice the workgroups, three per CU
