@@ -483,9 +483,12 @@ def seg_geometry_lines(coord, offset):
     for name, k, q, qo in (("umbrella_k9", 9, coord, offset), ("group_k32", 32, centres, new_offset)):
         t = timed(lambda: ops.knnquery_offset(k, coord, q, offset, qo))
         nbytes = 4.0 * (3 * n + 3 * q.shape[0] + 2 * k * q.shape[0])             # xyz + queries + (idx, dist2)
+        grid = bool(ops.KNN_GRID and n >= len(host) * ops.KNN_GRID_MIN_ROWS[1 if k <= 16 else 2])
         knn[name] = {"us": round(t * 1e6, 1), "algorithmic_bytes": nbytes, "achieved_GBs": round(nbytes / t / 1e9, 1),
                      "frac_of_hbm": round(nbytes / t / 1e9 / PEAK_HBM_GBS, 5),
-                     "pair_tests_per_s": round(float(q.shape[0]) * host[0] / t / 1e9, 1)}
+                     "method": "per-cloud uniform grid, build + query (rs_knn_grid_*)" if grid else "scan of the whole cloud per query (rs_knnquery_offset)",
+                     # what a scan of every row per query would have to sustain to be as fast (the grid evaluates a few hundred rows per query)
+                     "scan_equivalent_G_pair_tests_per_s": round(float(q.shape[0]) * host[0] / t / 1e9, 1)}
     return fps, knn
 
 

@@ -13,7 +13,7 @@ cp gpurun_out/prof_${R}_seg/graph_kernel_stats.csv $P/seg_graph_kernel_stats.csv
 cp gpurun_out/prof_${R}_seg/graph_kernel_stats_by_grid.csv $P/seg_graph_kernel_stats_by_grid.csv
 cp gpurun_out/prof_${R}_seg/traffic.json $P/traffic_seg.json
 [ -f $H/ballquery_phases.txt ] && cp $H/ballquery_phases.txt $P/ballquery_cells_phase_costs_final.txt
-for f in umb_bench.txt grid_meet.txt sharded_time.txt bench_spawn_dry_run.json gpu_tests.log; do [ -f $H/$f ] && cp $H/$f $P/$f; done
+for f in umb_bench.txt grid_meet.txt sharded_time.txt bench_spawn_dry_run.json gpu_tests.log knn_grid_bench.txt umbrella_grid_bench.txt; do [ -f $H/$f ] && cp $H/$f $P/$f; done
 python3 - <<PY
 import csv,json
 rows=list(csv.DictReader(open('$P/cls_graph_kernel_stats_by_grid.csv')))

@@ -27,6 +27,8 @@ PY
 done
 timeout 300 python tools/umb_bench.py 256 > $O/umb_bench.txt 2>&1; cat $O/umb_bench.txt
 timeout 120 tools/probes/grid_meet > $O/grid_meet.txt 2>&1; cat $O/grid_meet.txt
+timeout 300 python tools/knn_grid_bench.py 2>&1 | grep -v amdgpu.ids > $O/knn_grid_bench.txt; cat $O/knn_grid_bench.txt
+bash tools/_r04_ab.sh 2>&1 | grep umbrella_features > $O/umbrella_grid_bench.txt; cat $O/umbrella_grid_bench.txt
 echo "== sharded step, 1-rank RCCL group, collective forced"; REPSURF_FORCE_ALLREDUCE=1 timeout 300 python tools/sharded_time.py pipe pipe_sharded pipe_sharded > $O/sharded_time.txt 2>&1; echo rc=$?; grep "ms/step\|rror" $O/sharded_time.txt | cut -c 1-300
 bash tools/gpu_profile.sh r04 cls > $O/profile_cls.log 2>&1; tail -5 $O/profile_cls.log
 bash tools/gpu_profile.sh r04 seg > $O/profile_seg.log 2>&1; tail -3 $O/profile_seg.log
