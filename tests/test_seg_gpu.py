@@ -68,6 +68,23 @@ def test_knnquery_offset_matches_oracle(ops, k, kind, path):
     assert np.array_equal(idx.cpu().numpy(), ridx)
 
 
+@pytest.mark.parametrize("k", [3, 9, 16, 24, 32, 50, 64])
+@pytest.mark.parametrize("kind", ["uniform", "clusters", "dup"])
+def test_grid_knn_equals_scan_on_large_and_ragged_clouds(ops, k, kind):
+    """Clouds above the 4 096 rows a workgroup stages in LDS (their rows are read from global memory), tiny ones and an empty one in
+    the same batch, queries = every third row plus a few elsewhere: the grid search against the scan, bit for bit (both kernels:
+    one thread per query up to 16 entries, one wave per query above)."""
+    sizes = [6000, 3, 0, 4500, 130, 9000]
+    xyz, offset = packed_cloud(100 + k, sizes, kind)
+    starts = np.concatenate([[0], offset[:-1]])
+    q = np.concatenate([xyz[s:e:3] for s, e in zip(starts, offset)]).astype(np.float32)
+    qoff = np.cumsum([len(range(s, e, 3)) for s, e in zip(starts, offset)]).astype(np.int32)
+    q[::11] += np.float32(0.3)
+    a = ops.knnquery_offset(k, dev(xyz), dev(q), dev(offset), dev(qoff), grid=True)
+    b = ops.knnquery_offset(k, dev(xyz), dev(q), dev(offset), dev(qoff), grid=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("k,stride", [(9, 1), (32, 4), (3, 1), (16, 16)])
 def test_grid_knn_equals_scan_at_config4_size(ops, k, stride):
     """16 x 4096 points (BASELINE configs[3]): the grid search and the scan return the same lists and distances, bit for bit --
