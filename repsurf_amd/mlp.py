@@ -45,9 +45,15 @@ def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample,
                              feat_off=feat_off, feat_k=feat_k)
 
 
-def sa_mlp_plain(x, convs, bns, nsample, relu_last=True):
-    """SurfaceAbstraction body (repsurface_utils.py:178-181)."""
-    return mlp_hip.sa_mlp_plain(x, convs, bns, nsample, relu_last)
+def sa_mlp_plain(x, convs, bns, nsample, relu_last=True, lazy_out=False):
+    """SurfaceAbstraction body (repsurface_utils.py:178-181).  lazy_out / a LazyRows input (nsample = 1): the last BatchNorm +
+    ReLU is left to the consumer's operand prologue (mlp_hip.LazyRows)."""
+    return mlp_hip.sa_mlp_plain(x, convs, bns, nsample, relu_last, lazy_out=lazy_out)
+
+
+def lazy_rows_usable(bn_mods):
+    """May the row stacks over these BatchNorms hand their last activation over unmaterialised (training, batch statistics, fp32)?"""
+    return mlp_hip.lazy_rows_usable(bn_mods)
 
 
 def umbrella_mlp(x, mlps, group, aggr, moments=None):

@@ -699,7 +699,8 @@ class _SAStack(Function):
             prev_c = wl2.shape[0]
             pi, bi = 8, 2
         else:
-            prev_op = operand(OP_ID, x, cx)
+            lazy_in = meta.get("lazy_in")
+            prev_op = operand(OP_ID, x, cx) if lazy_in is None else operand(OP_RELU1, x, cx, s1=lazy_in.vec.scale, t1=lazy_in.vec.shift)
             prev_c = cx
             pi, bi = 0, 0
         pooled = None
@@ -715,7 +716,11 @@ class _SAStack(Function):
             prev_op = operand(OP_RELU1, y, y.shape[1], s1=vec.scale, t1=vec.shift)
             prev_c = w2.shape[0]
             pi += 4; bi += 1
-        if pooled is not None:
+        if meta.get("lazy_out") is not None:      # the consumer applies this layer's BatchNorm + ReLU in its operand prologue (LazyRows)
+            assert ys and ns == 1 and rs.dev is None
+            out, arg = ys[-1], None
+            meta["vec_last"] = vecs[-1]
+        elif pooled is not None:
             out, arg = pooled
         elif ys:
             y_last, v_last = ys[-1], vecs[-1]
@@ -752,13 +757,24 @@ class _SAStack(Function):
         first = 8 if pos > 0 else 0
         # ---- pooled layer: BN-backward sums from (groups, c) data only
         c_last = ys[-1].shape[1]
-        v = torch.empty(dout.shape, dtype=torch.float32, device=dev)
-        pool_blk = partial_rows(groups, 4)
-        part = torch.empty((pool_blk, 2, c_last), dtype=torch.float64, device=dev)
-        _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), dout.stride(0), _ptr(s["out"]) if meta.get("relu_last", True) else None,
-                  None if s["arg"] is None else s["arg"].data_ptr(), _ptr(ys[-1]), _bf(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
-                  pool_blk, _stream())
-        p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev, frozen=frozen)
+        lazy_out = meta.get("lazy_out")
+        if lazy_out is not None:
+            # the consumer's data-gradient GEMM already masked the gradient with this layer's ReLU and summed its BatchNorm-backward
+            # moments (LazyRows): no pass over (rows, C) here
+            if lazy_out.part is None:
+                raise RuntimeError("LazyRows: the consumer's backward did not run before the producer's (a lazy activation has exactly one consumer)")
+            v = dout.contiguous()
+            part, nstat_last = lazy_out.part
+            lazy_out.part = None
+            p, q, r, dg, db = bwd_coeffs(c_last, full, part, nstat_last, 1, vecs[-1], dev, frozen=frozen)
+        else:
+            v = torch.empty(dout.shape, dtype=torch.float32, device=dev)
+            pool_blk = partial_rows(groups, 4)
+            part = torch.empty((pool_blk, 2, c_last), dtype=torch.float64, device=dev)
+            _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), dout.stride(0), _ptr(s["out"]) if meta.get("relu_last", True) else None,
+                      None if s["arg"] is None else s["arg"].data_ptr(), _ptr(ys[-1]), _bf(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
+                      pool_blk, _stream())
+            p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev, frozen=frozen)
         if s["arg"] is None:      # one-row groups: the pooled-gradient operand IS the two-tensor BatchNorm-backward affine (no index compare)
             p_op = operand(OP_AFF2, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, rs=rs)
         else:
@@ -787,7 +803,8 @@ class _SAStack(Function):
                 q_op = operand(OP_RELU2, s["yl"], cin, s["yf"], cin, s["vl"].scale, s["vl"].shift,
                                s["vf"].scale, s["vf"].shift)
             else:
-                q_op = operand(OP_ID, x, cx)
+                lazy_in = meta.get("lazy_in")
+                q_op = operand(OP_ID, x, cx) if lazy_in is None else operand(OP_RELU1, x, cx, s1=lazy_in.vec.scale, t1=lazy_in.vec.shift)
             grads[pidx] = fork.run(lambda: wgrad(rows, cout, cin, p_op, q_op, dev, rdev, defer=True))
             if li > 0:      # data gradient, ReLU mask and BN-backward sums of layer li-1
                 dz, part, nstat = dgrad_masked(rows, cout, cin, p_op, w2ds[li], ys[li - 1], vecs[li - 1], device=dev,
@@ -821,9 +838,14 @@ class _SAStack(Function):
                     epi = Epilogue(bias=None, out=_ptr(dx, foff), ldo=cx, mode=EPI_STORE)
                     gemm_rows(rows, cin, fk, opf, wts[("f", 0)], epi, rdev)
             elif ctx.needs_input_grad[0]:
-                dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
-                epi = Epilogue(bias=None, out=_ptr(dx), ldo=cx, mode=EPI_STORE)
-                gemm_rows(rows, cout, cx, p_op, wts[("l", 0)], epi, rdev)
+                lazy_in = meta.get("lazy_in")
+                if lazy_in is not None:      # the gradient of the producer's raw output: masked by its ReLU, its BatchNorm-backward moments beside it
+                    dx, part_in, nstat_in = dgrad_masked(rows, cout, cx, p_op, w2ds[0], x, lazy_in.vec, device=dev, rows_dev=rdev, wt=wts[("l", 0)])
+                    lazy_in.part = (part_in, nstat_in)
+                else:
+                    dx = torch.empty((rows, cx), dtype=torch.float32, device=dev)
+                    epi = Epilogue(bias=None, out=_ptr(dx), ldo=cx, mode=EPI_STORE)
+                    gemm_rows(rows, cout, cx, p_op, wts[("l", 0)], epi, rdev)
         _stack_ends()
         fork.join()
         out_grads = [None if g is None else g.reshape(shape) for g, shape in zip(grads, meta["shapes"])]
@@ -852,11 +874,53 @@ def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample,
     return _SAStack.apply(x, meta, *params)
 
 
-def sa_mlp_plain(x, convs, bns, nsample, relu_last=True):
-    """relu_last=False: the last layer ends at its BatchNorm (segmentation feature propagation, first layers)."""
+class LazyRows:
+    """relu(BatchNorm(y)) of a row stack's last layer, NOT materialised (round 4): `y` is the layer's raw output (rows, C) -- the
+    autograd edge --, `vec` its BatchNorm's (scale, shift, mean, invstd).  The consumer must be a node that applies the affine map
+    and the ReLU in its operand prologue (_SAStack with lazy_in, _FPFront): forward, its first GEMM reads y through RS_OP_RELU1;
+    backward, its data-gradient GEMM masks with relu'(.) and sums the BatchNorm-backward moments in its epilogue -- what the layers
+    INSIDE a stack do for each other -- and leaves them here (`part`) for the producer's backward, which receives the masked
+    gradient through autograd.  Saves the BatchNorm + ReLU pass over (rows, C) each way.  One consumer only."""
+    __slots__ = ("y", "vec", "part")
+
+    def __init__(self):
+        self.y = self.vec = self.part = None
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+    def detach(self):
+        """The activated rows, for inspection (forward hooks, tests): relu(scale * y + shift), detached.  Not the product path."""
+        return torch.relu(torch.addcmul(self.vec.shift, self.y.detach(), self.vec.scale))
+
+
+LAZY_ROWS = os.environ.get("REPSURF_LAZY_ROWS", "1") != "0"
+
+
+def lazy_rows_usable(bn_mods):
+    """row stacks can hand their last activation over unmaterialised: training mode, batch statistics, fp32 arithmetic"""
+    from . import mlp as _mlp
+    return LAZY_ROWS and _mlp.PRECISION == "fp32" and all(b.training and sync_of(b) is None for b in bn_mods)
+
+
+def sa_mlp_plain(x, convs, bns, nsample, relu_last=True, lazy_out=False):
+    """relu_last=False: the last layer ends at its BatchNorm (segmentation feature propagation, first layers).
+    x: a tensor or a LazyRows (nsample = 1); lazy_out: return a LazyRows instead of the activated tensor (nsample = 1, training)."""
     params, mods = _flat_params([], convs, bns)
     meta = {"nsample": nsample, "pos": 0, "bns": mods, "training": mods[0].training,
             "shapes": [p.shape for p in params], "relu_last": relu_last}
+    if isinstance(x, LazyRows):
+        assert mods[0].training, "a LazyRows input needs training-mode consumers"
+        meta["lazy_in"] = x
+        x = x.y
+    if lazy_out:
+        assert nsample == 1 and relu_last and mods[0].training, "lazy_out: ungrouped rows ending in BatchNorm + ReLU, training mode"
+        lazy = LazyRows()
+        meta["lazy_out"] = lazy
+        lazy.y = _SAStack.apply(x, meta, *params)
+        lazy.vec = meta["vec_last"]
+        return lazy
     return _SAStack.apply(x, meta, *params)
 
 
@@ -1290,6 +1354,7 @@ class _FPFront(Function):
     @staticmethod
     def forward(ctx, points2, points1, idx, weight, meta, wf, bf, gf, betaf, ws, bs, gs, betas):
         dev = points2.device
+        lazy2 = meta.get("lazy_in")       # points2 = the raw last output of the previous stage's stack (LazyRows): BN + ReLU in the operand prologue
         points2, points1, weight = points2.contiguous(), points1.contiguous(), weight.contiguous()
         idx = (idx if idx.dtype == torch.int32 else idx.to(torch.int32)).contiguous()
         m, c2 = points2.shape
@@ -1297,14 +1362,15 @@ class _FPFront(Function):
         bn_f, bn_s = meta["bns"]
         wf2, ws2 = _w2d(wf), _w2d(ws)
         c = wf2.shape[0]
-        y2, v2, it2 = fwd_layer(m, operand(OP_ID, points2, c2), c2, wf2, bf, bn_f, True, dev, wk=w_fwd(wf2), finalize=False)
+        op_in = operand(OP_ID, points2, c2) if lazy2 is None else operand(OP_RELU1, points2, c2, s1=lazy2.vec.scale, t1=lazy2.vec.shift)
+        y2, v2, it2 = fwd_layer(m, op_in, c2, wf2, bf, bn_f, True, dev, wk=w_fwd(wf2), finalize=False)
         y1, v1, it1 = fwd_layer(n, operand(OP_ID, points1, c1), c1, ws2, bs, bn_s, True, dev, wk=w_fwd(ws2), finalize=False)
         bn_finalize_batch([it2, it1])
         out = torch.empty((n, c), dtype=torch.float32, device=dev)
         _lib.call("rs_three_interpolate_affine", 1, c, m, n, _ptr(y2), _ptr(v2.scale), _ptr(v2.shift), idx.data_ptr(), _ptr(weight),
                   _ptr(y1), _ptr(v1.scale), _ptr(v1.shift), 1, _ptr(out), _stream())
         _flush_counters()
-        ctx.saved = dict(points2=points2, points1=points1, idx=idx, weight=weight, y2=y2, y1=y1, v2=v2, v1=v1, out=out, wf2=wf2, ws2=ws2)
+        ctx.saved = dict(points2=points2, points1=points1, idx=idx, weight=weight, y2=y2, y1=y1, v2=v2, v1=v1, out=out, wf2=wf2, ws2=ws2, lazy2=lazy2)
         return out
 
     @staticmethod
@@ -1332,14 +1398,20 @@ class _FPFront(Function):
         op1 = operand(OP_AFF2, g, c, y1, c, s1=p1, t1=r1, s2=q1)
         op2 = operand(OP_AFF2, d2, c, y2, c, s1=p2, t1=r2, s2=q2)
         dws = wgrad(n, c, c1, op1, operand(OP_ID, points1, c1), dev, None, defer=True)
-        dwf = wgrad(m, c, c2, op2, operand(OP_ID, points2, c2), dev, None, defer=True)
+        lazy2 = s["lazy2"]
+        q2 = operand(OP_ID, points2, c2) if lazy2 is None else operand(OP_RELU1, points2, c2, s1=lazy2.vec.scale, t1=lazy2.vec.shift)
+        dwf = wgrad(m, c, c2, op2, q2, dev, None, defer=True)
         dp1 = dp2 = None
         if ctx.needs_input_grad[1]:
             dp1 = torch.empty((n, c1), dtype=torch.float32, device=dev)
             gemm_rows(n, c, c1, op1, w_bwd(ws2), Epilogue(bias=None, out=_ptr(dp1), ldo=c1, mode=EPI_STORE))
         if ctx.needs_input_grad[0]:
-            dp2 = torch.empty((m, c2), dtype=torch.float32, device=dev)
-            gemm_rows(m, c, c2, op2, w_bwd(wf2), Epilogue(bias=None, out=_ptr(dp2), ldo=c2, mode=EPI_STORE))
+            if lazy2 is not None:
+                dp2, part_in, nstat_in = dgrad_masked(m, c, c2, op2, wf2, points2, lazy2.vec, device=dev, wt=w_bwd(wf2))
+                lazy2.part = (part_in, nstat_in)
+            else:
+                dp2 = torch.empty((m, c2), dtype=torch.float32, device=dev)
+                gemm_rows(m, c, c2, op2, w_bwd(wf2), Epilogue(bias=None, out=_ptr(dp2), ldo=c2, mode=EPI_STORE))
         _stack_ends()
         zb = _zeros.take(2 * c, dev)           # biases in front of a BatchNorm with batch statistics: exactly zero
         return (dp2, dp1, None, None, None, dwf.reshape(s["wf2"].shape), zb[:c], dg2, db2, dws.reshape(s["ws2"].shape), zb[c:], dg1, db1)
@@ -1357,6 +1429,9 @@ def fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s):
     """relu(interpolate(bn_f(lin_f(points2)), idx, weight) + bn_s(lin_s(points1))): points2 (M, C2) coarse rows, points1 (N, C1)
     fine rows, idx / weight (N, 3) -> (N, C)."""
     meta = {"bns": (bn_f, bn_s)}
+    if isinstance(points2, LazyRows):
+        meta["lazy_in"] = points2
+        points2 = points2.y
     return _FPFront.apply(points2, points1, idx, weight, meta, lin_f.weight, lin_f.bias, bn_f.weight, bn_f.bias,
                           lin_s.weight, lin_s.bias, bn_s.weight, bn_s.bias)
 

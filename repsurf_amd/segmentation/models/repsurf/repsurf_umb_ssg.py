@@ -89,10 +89,16 @@ class Model(nn.Module):
 
         def pfo(level):                                # [center, normal, feature, offset] -> [center, feature, offset]
             return [level[0], level[2], level[3]]
-        f3 = self.fp4(pfo(level3), pfo(level4), geometry=fg[0])
-        f2 = self.fp3(pfo(level2), [level3[0], f3, level3[3]], geometry=fg[1])
-        f1 = self.fp2(pfo(level1), [level2[0], f2, level2[3]], geometry=fg[2])
-        f0 = self.fp1([coord, None, offset], [level1[0], f1, level1[3]], geometry=fg[3])
+        # The decoder is a chain of row stacks, each the only consumer of the one before: the last BatchNorm + ReLU of a stage is
+        # applied in the operand prologue of the next stage's first GEMM (mlp_hip.LazyRows) instead of a pass over (rows, C) each way
+        fps = (self.fp4, self.fp3, self.fp2, self.fp1)
+        lazy = (coord.is_cuda and self.training and torch.is_grad_enabled() and all(fp.skip for fp in fps[:3])
+                and all(_mlp.fp_front_usable(fp.mlp_f0, fp.norm_f0, fp.mlp_s0, fp.norm_s0) for fp in fps[:3])
+                and _mlp.lazy_rows_usable([m_ for fp in fps for m_ in [fp.norm_f0] + list(fp.mlp_bns)] + [self.classifier[1]]))
+        f3 = self.fp4(pfo(level3), pfo(level4), geometry=fg[0], lazy_out=lazy)
+        f2 = self.fp3(pfo(level2), [level3[0], f3, level3[3]], geometry=fg[1], lazy_out=lazy)
+        f1 = self.fp2(pfo(level1), [level2[0], f2, level2[3]], geometry=fg[2], lazy_out=lazy)
+        f0 = self.fp1([coord, None, offset], [level1[0], f1, level1[3]], geometry=fg[3], lazy_out=lazy)
         cls = self.classifier                          # Linear-BN-ReLU on the fused kernels, Dropout, then the output Linear on the row GEMM
         return _mlp.row_linear(cls[3](row_mlp(f0, [cls[0]], [cls[1]])), cls[4])
 

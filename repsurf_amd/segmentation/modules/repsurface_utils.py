@@ -166,7 +166,7 @@ class SurfaceAbstractionCD(nn.Module):
         return [new_center, new_normal, pooled, new_offset]
 
 
-def row_mlp(x, linears, bns, relu_last=True):
+def row_mlp(x, linears, bns, relu_last=True, lazy_out=False):
     """[Linear, BatchNorm1d, ReLU]* on ungrouped rows (reference :281-283; the classifier's first block,
     segmentation/models/repsurf/repsurf_umb_ssg.py:38-41).  The chain runs on the fused
     shared-MLP kernels as a stack of groups of ONE row (GEMM + BatchNorm sums, finalize, BN + ReLU pass; one
@@ -175,7 +175,7 @@ def row_mlp(x, linears, bns, relu_last=True):
     32 x 32-tile library GEMM over the 65 536-deep reduction (178 us against ~25 us here)."""
     if len(linears) == 0:
         return x
-    return _mlp.sa_mlp_plain(x, linears, bns, 1, relu_last)
+    return _mlp.sa_mlp_plain(x, linears, bns, 1, relu_last, lazy_out=lazy_out)
 
 
 class SurfaceFeaturePropagationCD(nn.Module):
@@ -208,20 +208,23 @@ class SurfaceFeaturePropagationCD(nn.Module):
         idx, d2 = ops.knnquery_offset(3, xyz2, xyz1, offset2, offset1)
         return idx, ops.interp_weights(d2)
 
-    def forward(self, pos_feat_off1, pos_feat_off2, geometry=None):
+    def forward(self, pos_feat_off1, pos_feat_off2, geometry=None, lazy_out=False):
+        """lazy_out (round 4): return the last layer's raw output + BatchNorm coefficients (mlp_hip.LazyRows) instead of the activated
+        rows -- for a consumer that applies them in its first GEMM's operand prologue (the next stage, the classifier); points2 may
+        be such an object."""
         xyz1, points1, offset1 = pos_feat_off1      # fine:   (N,3), (N,C)|None, (B,)
-        xyz2, points2, offset2 = pos_feat_off2      # coarse: (M,3), (M,C), (B,)
+        xyz2, points2, offset2 = pos_feat_off2      # coarse: (M,3), (M,C) | LazyRows, (B,)
         idx, weight = geometry if geometry is not None else self.geometry(xyz1, offset1, xyz2, offset2)
         if self.skip and _mlp.fp_front_usable(self.mlp_f0, self.norm_f0, self.mlp_s0, self.norm_s0):
             # both Linear + BatchNorm pairs, the interpolation, the skip connection and the ReLU as one node: the BatchNorms are
             # applied inside the interpolation launch (round 4)
             new_points = _mlp.fp_front(points2, points1, idx, weight, self.mlp_f0, self.norm_f0, self.mlp_s0, self.norm_s0)
-            return row_mlp(new_points, self.mlp_convs, self.mlp_bns)
+            return row_mlp(new_points, self.mlp_convs, self.mlp_bns, lazy_out=lazy_out)
         points2 = row_mlp(points2, [self.mlp_f0], [self.norm_f0], relu_last=False)
         skip = row_mlp(points1, [self.mlp_s0], [self.norm_s0], relu_last=False).unsqueeze(0) if self.skip else None
         # interpolation + skip connection + ReLU (reference :266-270) in one launch forward, one backward
         new_points = ops.three_interpolate_add_relu(points2.unsqueeze(0), idx.unsqueeze(0), weight.unsqueeze(0), skip).squeeze(0)
-        return row_mlp(new_points, self.mlp_convs, self.mlp_bns)
+        return row_mlp(new_points, self.mlp_convs, self.mlp_bns, lazy_out=lazy_out)
 
 
 class UmbrellaSurfaceConstructor(nn.Module):

@@ -292,6 +292,35 @@ def test_seg_model_config4_runs_and_is_finite():
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+def test_seg_model_lazy_decoder_rows_equal_materialised_ones(monkeypatch):
+    """The decoder with every stage's last BatchNorm + ReLU applied in the next stage's operand prologue (mlp_hip.LazyRows: no pass
+    over (rows, C) each way) against the same model with the passes (LAZY_ROWS off): the forward is the same arithmetic (logits
+    bit-identical: relu(fma(scale, y, shift)) either way), the gradients agree to the noise of the BatchNorm-backward sums'
+    summation order (fp32 per tile + fp64 across tiles in the GEMM epilogue, fp64 per element in the pass)."""
+    from repsurf_amd import mlp_hip
+    r = np.random.RandomState(5)
+    n = 4 * 4096
+    coord = dev((r.rand(n, 3) * 2 - 1).astype(np.float32))
+    rgb = dev(r.rand(n, 3).astype(np.float32))
+    offset = dev((np.arange(1, 5) * 4096).astype(np.int32))
+    label = dev(r.randint(0, 13, n).astype(np.int64))
+    res = {}
+    for tag, on in (("lazy", True), ("passes", False)):
+        monkeypatch.setattr(mlp_hip, "LAZY_ROWS", on)
+        model = _seg_model()
+        np.random.seed(3)
+        torch.manual_seed(3)                     # (the classifier's dropout mask)
+        with subproject("segmentation"):
+            logits = model([coord, rgb, offset])
+        torch.nn.functional.cross_entropy(logits, label).backward()
+        res[tag] = (logits.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    assert torch.equal(res["lazy"][0], res["passes"][0])
+    for k, g in res["passes"][1].items():
+        scale = g.abs().max().item()
+        err = (res["lazy"][1][k] - g).abs().max().item()
+        assert err <= 5e-4 * scale + 1e-7, (k, err, scale)
+
+
 @pytest.mark.parametrize("clouds", [16])        # the full configs[3] batch (round 2 ran half of it)
 def test_seg_model_bf16_mode_stays_close_to_fp32(clouds):
     """The segmentation network in bf16 mode (bf16 MFMA operands + bf16 storage of the SA / decoder / classifier conv outputs) at

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from repsurf_amd import mlp as _mlp
 
-_PRODUCT = {n: getattr(_mlp, n) for n in ("sa_mlp_cd", "sa_mlp_plain", "umbrella_mlp", "umbrella_mlp2", "fp_front", "fp_front_usable", "prepack",
+_PRODUCT = {n: getattr(_mlp, n) for n in ("sa_mlp_cd", "sa_mlp_plain", "umbrella_mlp", "umbrella_mlp2", "fp_front", "fp_front_usable", "lazy_rows_usable", "prepack",
                                           "deferred_counters")}
 _PRODUCT_COMPACT = _mlp.COMPACT_GROUPS
 BACKEND = "hip"
@@ -43,7 +43,7 @@ def sa_mlp_cd(x, pos_channel, mlp_l0, bn_l0, mlp_f0, bn_f0, convs, bns, nsample,
     return h.view(-1, nsample, h.shape[1]).max(dim=1)[0]
 
 
-def sa_mlp_plain(x, convs, bns, nsample, relu_last=True):
+def sa_mlp_plain(x, convs, bns, nsample, relu_last=True, lazy_out=False):
     h = x
     for i, (conv, bn) in enumerate(zip(convs, bns)):
         h = _bn(F.linear(h, _w2d(conv), conv.bias), bn)
@@ -93,6 +93,7 @@ def set_backend(name):
         _mlp.sa_mlp_cd, _mlp.sa_mlp_plain = sa_mlp_cd, sa_mlp_plain
         _mlp.umbrella_mlp, _mlp.umbrella_mlp2 = umbrella_mlp, umbrella_mlp2
         _mlp.fp_front, _mlp.fp_front_usable = fp_front, fp_front_usable
+        _mlp.lazy_rows_usable = lambda bn_mods: False
         _mlp.prepack = lambda convs: None
         _mlp.deferred_counters = contextlib.nullcontext
         _mlp.COMPACT_GROUPS = False
