@@ -10,6 +10,31 @@ from tests.util import cloud, disable_dropout, name_seeded_init, ref_args
 pytestmark = pytest.mark.gpu
 
 
+def _isolated(name, timeout=600):
+    """Run a test body of this file in a process of its own.  The bodies that bring up an RCCL process group do: one full-suite run in
+    three ended with the whole pytest process aborted inside destroy_process_group (communicator teardown, after every assertion had
+    passed) -- in a child, a teardown that dies takes nothing with it, and the verdict is the marker the body prints before it."""
+    import os
+    import subprocess
+    import sys
+    import warnings
+    from tests.conftest import ROOT
+    code = ("import sys; sys.path[:0] = [%r, %r]; import tests.test_graph_gpu as t; t.%s(); print('ISOLATED-BODY-OK', flush=True)"
+            % (ROOT, os.path.join(ROOT, "repsurf_amd", "classification"), name))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert "ISOLATED-BODY-OK" in r.stdout or "ISOLATED-ASSERTS-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        warnings.warn(f"{name}: the assertions passed, the child exited with {r.returncode} afterwards (process-group teardown)")
+
+
+def test_sharded_step_single_rank_process_group():
+    _isolated("_sharded_step_single_rank_process_group")
+
+
+def test_pipelined_sharded_step_single_rank_process_group():
+    _isolated("_pipelined_sharded_step_single_rank_process_group")
+
+
 def test_graphed_step_matches_eager():
     from models.repsurf.repsurf_ssg_umb import Model
     from repsurf_amd import mlp
@@ -51,7 +76,7 @@ def test_graphed_step_matches_eager():
     assert np.isfinite(l4)
 
 
-def test_sharded_step_single_rank_process_group():
+def _sharded_step_single_rank_process_group():
     """ShardedGraphedStep (graph A -> all-reduce -> graph B) with a 1-rank RCCL process group."""
     import os
     import torch.distributed as dist
@@ -78,6 +103,7 @@ def test_sharded_step_single_rank_process_group():
         assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1 + 0.5
         assert not torch.equal(w0, m.classfier[8].weight)          # the optimizer graph ran
         assert step.flat.abs().sum() > 0
+        print("ISOLATED-ASSERTS-OK", flush=True)
     finally:
         step = m = opt = None          # (see test_pipelined_sharded_step_single_rank_process_group: graphs with recorded collectives first)
         import gc
@@ -138,7 +164,7 @@ def test_pipelined_step_matches_eager_step_for_step(monkeypatch):
     assert (g_p - g_e).norm() / g_e.norm() < 1e-3
 
 
-def test_pipelined_sharded_step_single_rank_process_group():
+def _pipelined_sharded_step_single_rank_process_group():
     """PipelinedStep(sharded=True): graph[p] (geometry s+1 | forward/backward s into the flat gradient buffer) -> RCCL
     all-reduce -> Adam graph, with a 1-rank process group and this package's Adam; it must train like the unsharded
     pipelined step from the same initial state (same draws).  Both runs make 2 warm-up + 3 measured Adam updates with
@@ -181,6 +207,7 @@ def test_pipelined_sharded_step_single_rank_process_group():
         assert np.allclose(losses["buckets"], losses["single"], atol=2e-2), losses
         assert np.allclose(losses["captured"], losses["between"], atol=2e-2), losses
         assert losses["captured"][2] < losses["captured"][0] + 0.5
+        print("ISOLATED-ASSERTS-OK", flush=True)
     finally:
         os.environ.pop("REPSURF_FORCE_ALLREDUCE", None)
         os.environ.pop("REPSURF_CAPTURE_ALLREDUCE", None)
