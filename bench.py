@@ -658,6 +658,7 @@ def main_seg(args):
         if cpu:
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
         print(json.dumps(out), flush=True)
+    pstep = step = None          # (graphs with recorded collectives go before their communicator: repsurf_amd.dist.finish)
     rdist.finish()
 
 
@@ -869,6 +870,7 @@ def main():
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out), flush=True)
+    pstep = step = None          # (graphs with recorded collectives go before their communicator: repsurf_amd.dist.finish)
     rdist.finish()
 
 

@@ -88,5 +88,13 @@ def barrier():
 
 
 def finish():
+    """Tear the process group down.  The caller has dropped its step objects first: a hipGraph with recorded collectives that outlives
+    its communicator made destroy_process_group abort (seen once in three full test runs, with a 1-rank group); everything in
+    flight is drained and every rank has arrived before any rank starts."""
     if dist.is_initialized():
+        import gc
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dist.barrier()
         dist.destroy_process_group()
