@@ -231,6 +231,15 @@ int rs_group_features_compact_backward(long long capacity, const int *rows_dev, 
                                        const float *grad_out, const int *src, float *grad_normal,
                                        float *grad_feature, int b, int n, int m, const int *fps_idx,
                                        const float *grad_new_normal, long long ldg, void *stream);
+/* The same backward as a gather (round 4): rs_compact_csr (geometry stage) inverts `src` -- csr_off (b*n + 1), csr_rows (capacity):
+ * the compacted rows that name each source point, ascending; centre_of (b*n): the group whose centre the point is, or -1 --
+ * and rs_group_features_compact_backward_csr WRITES every element of grad_normal / grad_feature (no zero fill, no atomics, a fixed
+ * summation order). */
+int rs_compact_csr(int b, int n, int m, const int *src, const int *offsets, const int *fps_idx, int *csr_off, int *centre_of,
+                   int *csr_rows, void *stream);
+int rs_group_features_compact_backward_csr(int b, int n, int cn, int cf, int polar, const float *grad_out, const int *csr_off,
+                                           const int *csr_rows, const int *centre_of, float *grad_normal, float *grad_feature,
+                                           const float *grad_new_normal, long long ldg, void *stream);
 /* group_all variant (sample_and_group_all, repsurface_utils.py:62-88):
  * row (b, j) = [center (3), polar of center (3, if polar), normal (cn), feature (cf)]. */
 int rs_group_all_features(int b, int n, int cn, int cf, int polar, const float *center,

@@ -402,6 +402,93 @@ compact_scatter4_kernel(const int *__restrict__ rows_dev, int cn, int cf, int cp
   }
 }
 
+// ---- the compacted grouping's backward as a GATHER (round 4) ---------------------------------------------------------------------
+// The scatter above is one atomic per distinct neighbour and channel into zero-filled targets: 6.6 M atomics + a fill for the second
+// stage of the classification step, 20 us per launch.  Which compacted rows name which source point is geometry: compact_csr_kernel
+// (geometry stage, one workgroup per cloud: LDS histogram of src -> scan -> fill, lists sorted so that the sums below have a fixed
+// order) inverts `src` into csr_off (points + 1) / csr_rows (the compacted rows of point p: csr_rows[csr_off[p] .. csr_off[p + 1])),
+// and centre_of[p] = the group whose centre p is (or -1).  The backward then reads, per source point and channel, the rows that
+// name it and writes every element of the targets exactly once: no atomics, no fill, bit-reproducible gradients.
+constexpr int CSR_THREADS = 1024;
+
+__global__ void __launch_bounds__(CSR_THREADS)
+compact_csr_kernel(int n, int m, const int *__restrict__ src, const int *__restrict__ offsets, const int *__restrict__ fps_idx,
+                   int *__restrict__ csr_off, int *__restrict__ centre_of, int *__restrict__ csr_rows) {
+  extern __shared__ int cnt[];                       // n counters, then n cursors
+  __shared__ int wsum[CSR_THREADS / 64];
+  int *cur = cnt + n;
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = offsets[(long long)c * m], r1 = offsets[(long long)(c + 1) * m];       // the compacted rows of this cloud
+  const long long p0 = (long long)c * n;
+  for (int p = tid; p < n; p += CSR_THREADS) { cnt[p] = 0; centre_of[p0 + p] = -1; }
+  __syncthreads();
+  for (int u = r0 + tid; u < r1; u += CSR_THREADS) atomicAdd(&cnt[src[u] - (int)p0], 1);
+  __syncthreads();
+  // exclusive scan of the n counters: consecutive chunks per thread, wave scan, wave totals through LDS
+  const int per = (n + CSR_THREADS - 1) / CSR_THREADS;
+  int run = 0;
+  for (int k = 0; k < per; ++k) { const int p = tid * per + k; if (p < n) run += cnt[p]; }
+  int inc = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = inc - run;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  for (int k = 0; k < per; ++k) {
+    const int p = tid * per + k;
+    if (p < n) { const int v = cnt[p]; cur[p] = base; csr_off[p0 + p] = r0 + base; base += v; }
+  }
+  if (c == (int)gridDim.x - 1 && tid == 0) csr_off[p0 + n] = r1;
+  __syncthreads();
+  for (int u = r0 + tid; u < r1; u += CSR_THREADS) {
+    const int pos = atomicAdd(&cur[src[u] - (int)p0], 1);
+    csr_rows[r0 + pos] = u;
+  }
+  __syncthreads();      // (global writes of this workgroup, read back by this workgroup below)
+  // every list in ascending row order: the sums of the backward then have one order, whatever the atomics' order was
+  for (int p = tid; p < n; p += CSR_THREADS) {
+    const int lo = r0 + (cur[p] - cnt[p]), hi = r0 + cur[p];
+    for (int i = lo + 1; i < hi; ++i) {
+      const int v = csr_rows[i];
+      int j = i - 1;
+      while (j >= lo && csr_rows[j] > v) { csr_rows[j + 1] = csr_rows[j]; --j; }
+      csr_rows[j + 1] = v;
+    }
+  }
+  if (fps_idx)
+    for (int g = tid; g < m; g += CSR_THREADS) centre_of[p0 + fps_idx[(long long)c * m + g]] = c * m + g;
+}
+
+__global__ void __launch_bounds__(GR_THREADS)
+compact_gather_bwd_kernel(long long points, int cn, int cf, int cpos, int ctot, const float *__restrict__ grad_out,
+                          const int *__restrict__ csr_off, const int *__restrict__ csr_rows, const int *__restrict__ centre_of,
+                          float *__restrict__ grad_normal, float *__restrict__ grad_feature,
+                          const float *__restrict__ grad_new_normal, long long ldg) {
+  const int c0 = grad_normal ? 0 : cn, cw = (grad_normal ? cn : 0) + (grad_feature ? cf : 0);     // channels [c0, c0 + cw) behind cpos
+  const long long total = points * cw;
+  for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GR_THREADS) {
+    const long long p = e / cw;
+    const int ch = c0 + (int)(e - p * cw);
+    const int lo = csr_off[p], hi = csr_off[p + 1];
+    const float *col = grad_out + cpos + ch;
+    float acc = 0.f;
+    int j = lo;
+    for (; j + 4 <= hi; j += 4) {                    // four rows in flight; the sum keeps the list's order
+      const float v0 = col[(long long)csr_rows[j] * ctot], v1 = col[(long long)csr_rows[j + 1] * ctot];
+      const float v2 = col[(long long)csr_rows[j + 2] * ctot], v3 = col[(long long)csr_rows[j + 3] * ctot];
+      acc = (((acc + v0) + v1) + v2) + v3;
+    }
+    for (; j < hi; ++j) acc += col[(long long)csr_rows[j] * ctot];
+    if (ch < cn) {
+      if (grad_new_normal) { const int g = centre_of[p]; if (g >= 0) acc += grad_new_normal[(long long)g * ldg + ch]; }
+      grad_normal[p * cn + ch] = acc;
+    } else {
+      grad_feature[p * cf + (ch - cn)] = acc;
+    }
+  }
+}
+
 inline int grid_for(long long work_items) {
   long long blocks = (work_items + GR_THREADS - 1) / GR_THREADS;
   const long long cap = 256LL * 8;     // 8 workgroups per CU, grid-stride beyond that
@@ -587,5 +674,42 @@ extern "C" int rs_group_features_compact_backward(long long capacity, const int 
   hipLaunchKernelGGL(compact_scatter4_kernel, dim3(grid_for(capacity * cw / 16 + 1)), dim3(GR_THREADS), 0, (hipStream_t)stream, rows_dev, cn, cf,
                      cpos, ctot, grad_out, src, grad_normal, grad_feature, (long long)b * m, m, n, fps_idx, grad_new_normal, ldg);
   RS_CHECK_LAUNCH("rs_group_features_compact_backward");
+  return RS_OK;
+}
+
+/* The inverse of `src` (rs_compact_index), for the gather form of the backward: csr_off (b*n + 1), csr_rows (capacity),
+ * centre_of (b*n; the group whose centre a point is, -1 otherwise; fps_idx may be NULL: all -1).  Geometry only. */
+extern "C" int rs_compact_csr(int b, int n, int m, const int *src, const int *offsets, const int *fps_idx, int *csr_off,
+                              int *centre_of, int *csr_rows, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0 && m >= 0, "rs_compact_csr: negative size");
+  if (b == 0 || n == 0) return RS_OK;
+  RS_REQUIRE(src && offsets && csr_off && centre_of && csr_rows, "rs_compact_csr: null pointer");
+  RS_REQUIRE(n <= 16384, "rs_compact_csr: %d points per cloud exceed the 16 384 the workgroup's counters hold", n);
+  hipLaunchKernelGGL(compact_csr_kernel, dim3(b), dim3(CSR_THREADS), (size_t)2 * n * sizeof(int), (hipStream_t)stream, n, m, src,
+                     offsets, fps_idx, csr_off, centre_of, csr_rows);
+  RS_CHECK_LAUNCH("rs_compact_csr");
+  return RS_OK;
+}
+
+/* rs_group_features_compact_backward without atomics: every element of grad_normal (b*n, cn) / grad_feature (b*n, cf) is WRITTEN
+ * (no zero fill by the caller) as the sum over the compacted rows that name the point, in ascending row order, plus -- with
+ * grad_new_normal -- the centre row's gradient of the group the point is the centre of. */
+extern "C" int rs_group_features_compact_backward_csr(int b, int n, int cn, int cf, int polar, const float *grad_out,
+                                                      const int *csr_off, const int *csr_rows, const int *centre_of,
+                                                      float *grad_normal, float *grad_feature, const float *grad_new_normal,
+                                                      long long ldg, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0 && cn >= 0 && cf >= 0, "rs_group_features_compact_backward_csr: negative size");
+  if (b == 0 || n == 0) return RS_OK;
+  RS_REQUIRE(grad_out && csr_off && csr_rows && centre_of, "rs_group_features_compact_backward_csr: null pointer");
+  RS_REQUIRE(!grad_new_normal || (grad_normal && ldg >= cn), "rs_group_features_compact_backward_csr: the centre rows add into grad_normal");
+  const int cpos = polar ? 6 : 3, ctot = cpos + cn + cf;
+  if (cn == 0) grad_normal = nullptr;
+  if (cf == 0) grad_feature = nullptr;
+  if (!grad_normal && !grad_feature) return RS_OK;
+  const int cw = (grad_normal ? cn : 0) + (grad_feature ? cf : 0);
+  const long long points = (long long)b * n;
+  hipLaunchKernelGGL(compact_gather_bwd_kernel, dim3(grid_for(points * cw)), dim3(GR_THREADS), 0, (hipStream_t)stream, points, cn, cf,
+                     cpos, ctot, grad_out, csr_off, csr_rows, centre_of, grad_normal, grad_feature, grad_new_normal, ldg);
+  RS_CHECK_LAUNCH("rs_group_features_compact_backward_csr");
   return RS_OK;
 }

@@ -36,6 +36,8 @@ class StageGeometry:
             # (grp, slot, src are rows of one (3, capacity) allocation: copied as that one tensor)
             out += [self.index.offsets, self.index.mult]
             out += [self.index.meta] if self.index.meta is not None else [self.index.grp, self.index.slot, self.index.src]
+            if self.index.pts is not None:
+                out += [self.index.pts]
         if any(t is None for t in out):
             raise RuntimeError("StageGeometry.tensors: a stage without ball-query counts cannot be part of a pipelined state set")
         return out
@@ -46,7 +48,8 @@ class StageGeometry:
         if self.index is not None:
             i = self.index
             if i.meta is not None:
-                index = CompactIndex.from_meta(i.offsets.clone(), i.mult.clone(), i.meta.clone())
+                index = CompactIndex.from_meta(i.offsets.clone(), i.mult.clone(), i.meta.clone(), None if i.pts is None else i.pts.clone())
+                index.csr_ready = i.csr_ready
             else:
                 index = CompactIndex(i.offsets.clone(), i.mult.clone(), i.grp.clone(), i.slot.clone(), i.src.clone())
         return StageGeometry(self.fps_idx.clone(), self.new_center.clone(), self.idx.clone(), self.cnt.clone(), index)
@@ -60,6 +63,7 @@ class GeometryPlan:
         """fork=False: everything on the current stream (the caller already runs this off the critical path).
         compact=True: also build every stage's ops.CompactIndex (scan of the ball-query counts + row bookkeeping)."""
         from .ops import CompactIndex
+        from . import ops as ops_mod
         self.stages = []
         self.events = []
         self.main = torch.cuda.current_stream()
@@ -71,12 +75,12 @@ class GeometryPlan:
         starts = [rng.draw("fps", b, n, dev) for n in sizes]
         # Outputs are allocated on the MAIN stream (the allocator then orders their reuse against the
         # consumers); only the kernels run on the side stream, between a fork and a join event.
-        for (npoint, radius, nsample) in stages:
+        for (npoint, radius, nsample), n_src in zip(stages, sizes):
             self.stages.append(StageGeometry(torch.empty((b, npoint), dtype=torch.int32, device=dev),
                                              torch.empty((b, npoint, 3), dtype=torch.float32, device=dev),
                                              torch.empty((b, npoint, nsample), dtype=torch.int32, device=dev),
                                              torch.empty((b, npoint), dtype=torch.int32, device=dev),
-                                             CompactIndex.empty(b * npoint, nsample, dev) if compact else None))
+                                             CompactIndex.empty(b * npoint, nsample, dev, points=b * n_src) if compact else None))
         if fork:
             side.wait_stream(self.main)
         with torch.cuda.stream(side):
@@ -94,6 +98,10 @@ class GeometryPlan:
                     ci = g.index
                     _lib.call("rs_compact_index", b, n, npoint, nsample, g.idx.data_ptr(), g.cnt.data_ptr(), ci.offsets.data_ptr(),
                               ci.grp.data_ptr(), ci.slot.data_ptr(), ci.src.data_ptr(), ci.mult.data_ptr(), st_ptr)
+                    if ci.pts is not None and n <= 16384 and ops_mod.COMPACT_CSR:      # the inverse of `src`: the grouping's backward becomes a gather (ops.COMPACT_CSR)
+                        _lib.call("rs_compact_csr", b, n, npoint, ci.src.data_ptr(), ci.offsets.data_ptr(), g.fps_idx.data_ptr(),
+                                  ci.pts.data_ptr(), ci.pts.data_ptr() + 4 * (b * n + 1), ci.csr_rows.data_ptr(), st_ptr)
+                        ci.csr_ready = True
                 g.center = center
                 center, n = g.new_center, npoint
                 if fork:

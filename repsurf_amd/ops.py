@@ -452,34 +452,55 @@ class CompactGroups:
 
 class CompactIndex:
     """The bookkeeping of compacted groups (rs_compact_index): offsets (groups + 1), mult / grp / slot / src (capacity).  It
-    depends on the ball query's (idx, cnt) only, so the geometry stage of a pipelined step builds it ahead of time."""
-    __slots__ = ("offsets", "mult", "grp", "slot", "src", "meta")
+    depends on the ball query's (idx, cnt) only, so the geometry stage of a pipelined step builds it ahead of time.
+    csr (round 4, optional): the inverse of `src` for the gather form of the backward (rs_compact_csr): `pts` (2 P + 1 ints:
+    csr_off (P + 1) then centre_of (P), P = source points) and `csr_rows` (capacity; the fourth row of `meta`)."""
+    __slots__ = ("offsets", "mult", "grp", "slot", "src", "meta", "pts", "csr_rows", "csr_ready")
 
-    def __init__(self, offsets, mult, grp, slot, src, meta=None):
-        """meta: the (3, capacity) int32 allocation grp / slot / src are rows of, when they were allocated that way (copied and
-        cloned as ONE tensor by the pipelined step's state sets); None when they are three separate tensors."""
+    def __init__(self, offsets, mult, grp, slot, src, meta=None, pts=None, csr_rows=None):
+        """meta: the (3 | 4, capacity) int32 allocation grp / slot / src (/ csr_rows) are rows of, when they were allocated that way
+        (copied and cloned as ONE tensor by the pipelined step's state sets); None when they are separate tensors."""
         self.offsets, self.mult, self.grp, self.slot, self.src, self.meta = offsets, mult, grp, slot, src, meta
+        self.pts, self.csr_rows = pts, csr_rows
+        self.csr_ready = False          # set by whoever ran rs_compact_csr on these tensors
 
     @staticmethod
-    def from_meta(offsets, mult, meta):
-        return CompactIndex(offsets, mult, meta[0], meta[1], meta[2], meta)
+    def from_meta(offsets, mult, meta, pts=None):
+        return CompactIndex(offsets, mult, meta[0], meta[1], meta[2], meta, pts, meta[3] if (pts is not None and meta.shape[0] > 3) else None)
 
     @staticmethod
-    def empty(groups, nsample, dev):
+    def empty(groups, nsample, dev, points=0):
+        """points > 0: with room for the inverse of `src` over that many source points"""
         cap = groups * nsample
-        meta = torch.empty((3, cap), dtype=torch.int32, device=dev)
+        meta = torch.empty((4 if points else 3, cap), dtype=torch.int32, device=dev)
+        pts = torch.empty((2 * points + 1,), dtype=torch.int32, device=dev) if points else None
         return CompactIndex.from_meta(torch.empty((groups + 1,), dtype=torch.int32, device=dev),
-                                      torch.empty((cap,), dtype=torch.float32, device=dev), meta)
+                                      torch.empty((cap,), dtype=torch.float32, device=dev), meta, pts)
+
+    def csr(self, points):
+        """(csr_off, centre_of, csr_rows) views, or None"""
+        if self.pts is None or self.csr_rows is None or not self.csr_ready or self.pts.numel() != 2 * points + 1:
+            return None
+        return self.pts[:points + 1], self.pts[points + 1:], self.csr_rows
 
 
-def compact_index(idx, cnt, n, out=None, stream=None):
-    """idx (B, M, ns), cnt (B, M) of a ball query over clouds of n points -> CompactIndex."""
+COMPACT_CSR = os.environ.get("REPSURF_COMPACT_CSR", "1") != "0"        # the compacted grouping's backward as a gather (rs_compact_csr)
+
+
+def compact_index(idx, cnt, n, out=None, stream=None, csr=False, fps_idx=None):
+    """idx (B, M, ns), cnt (B, M) of a ball query over clouds of n points -> CompactIndex.
+    csr=True: also the inverse of `src` (rs_compact_csr; fps_idx (B, M): the centres' own rows) -- the grouping's backward then gathers."""
     _need_gpu(idx, cnt)
     idx, cnt = _i32c(idx), _i32c(cnt)
     b, m, ns = idx.shape
-    ci = out if out is not None else CompactIndex.empty(b * m, ns, idx.device)
-    _lib.call("rs_compact_index", b, n, m, ns, _p(idx), _p(cnt), _p(ci.offsets), _p(ci.grp), _p(ci.slot), _p(ci.src), _p(ci.mult),
-              _stream() if stream is None else stream)
+    ci = out if out is not None else CompactIndex.empty(b * m, ns, idx.device, points=b * n if csr else 0)
+    st = _stream() if stream is None else stream
+    _lib.call("rs_compact_index", b, n, m, ns, _p(idx), _p(cnt), _p(ci.offsets), _p(ci.grp), _p(ci.slot), _p(ci.src), _p(ci.mult), st)
+    if csr and ci.pts is not None:
+        fps = None if fps_idx is None else _i32c(fps_idx)
+        _lib.call("rs_compact_csr", b, n, m, _p(ci.src), _p(ci.offsets), _p(fps), ci.pts.data_ptr(), ci.pts.data_ptr() + 4 * (b * n + 1),
+                  _p(ci.csr_rows), st)
+        ci.csr_ready = True
     return ci
 
 
@@ -524,6 +545,7 @@ class _GroupFeaturesCompact(Function):
                   _p(normal), _p(feature), _p(idx), _p(cnt), _p(offsets), _p(out), _p(mult), _p(grp), _p(slot),
                   _p(src), int(have), _p(fps_idx), _p(new_normal), _stream())
         ctx.save_for_backward(src, offsets, fps_idx)
+        ctx.csr = index.csr(b * n) if (have and COMPACT_CSR) else None
         ctx.dims = (b, n, m, cn, cf, int(polar), cap, groups)
         ctx.need = (ctx.needs_input_grad[2], feature is not None and ctx.needs_input_grad[3])
         ctx.mark_non_differentiable(mult, grp, slot, src, offsets)
@@ -541,6 +563,25 @@ class _GroupFeaturesCompact(Function):
             return (None,) * 9
         dev = src.device
         centre = fps_idx is not None and grad_new_normal is not None and ctx.need[0]
+        if grad_out is not None and ctx.csr is not None and (not centre or fps_idx is not None):
+            # gather form: per source point, the sum over the compacted rows that name it (+ its own centre row's gradient): every
+            # element written once -- no zero fill, no atomics, a fixed order (rs_compact_csr ran in the geometry stage)
+            c0, c1 = (cn if ctx.need[0] else 0), (cf if ctx.need[1] else 0)
+            if c0 + c1 == 0:
+                return (None,) * 9
+            buf = torch.empty((b * n * (c0 + c1),), dtype=torch.float32, device=dev)
+            gn = buf[:b * n * c0].view(b, n, c0) if c0 else None
+            gf = buf[b * n * c0:].view(b, n, c1) if c1 else None
+            grad_out = _f32c(grad_out)
+            ldg = 0
+            if centre:
+                ldg = _row_stride(grad_new_normal, groups, cn)
+                if ldg is None:
+                    grad_new_normal, ldg = _f32c(grad_new_normal), cn
+            csr_off, centre_of, csr_rows = ctx.csr
+            _lib.call("rs_group_features_compact_backward_csr", b, n, cn, cf, polar, _p(grad_out), _p(csr_off), _p(csr_rows), _p(centre_of),
+                      _p(gn), _p(gf), _p(grad_new_normal) if centre else None, ldg, _stream())
+            return None, None, gn, gf, None, None, None, None, None
         gn, gf = _zero_pair(b * n, cn if ctx.need[0] else 0, cf if (ctx.need[1] and grad_out is not None) else 0, (b, n), dev)
         if grad_out is None:       # only the centres' own rows were used downstream
             if centre:

@@ -339,25 +339,27 @@ def test_compact_grouping_with_prebuilt_index_and_fused_centre_rows(radius, ns, 
     w_rows = torch.randn(b * s * ns, ctot, generator=g).cuda()
     wide = torch.randn(b * s, cn + 7, generator=g).cuda()                      # the centre rows' gradient: columns [3, 3 + cn) of this
     res = {}
-    for kind in ("separate", "fused", "fused_strided"):
+    for kind in ("separate", "fused", "fused_strided", "gather", "gather_again", "gather_strided"):
         normal = normal0.clone().requires_grad_()
         feature = None if feature0 is None else feature0.clone().requires_grad_()
         if kind == "separate":
             cg = ops.group_features_compact(xyz, centres, normal, feature, idx, cnt, polar=True)
             new_normal = ops.gather_rows(normal, fps)
         else:
-            index = ops.compact_index(idx, cnt, n)
+            # gather*: the index carries the inverse of `src` (rs_compact_csr) and the backward is a gather -- no atomics, no fill
+            index = ops.compact_index(idx, cnt, n, csr=kind.startswith("gather"), fps_idx=fps)
+            assert (index.csr(b * n) is not None) == kind.startswith("gather")
             cg, new_normal = ops.group_features_compact(xyz, centres, normal, feature, idx, cnt, polar=True, index=index, fps_idx=fps)
         rows = int(cg.offsets[-1])
         loss = (cg.x[:rows] * w_rows[:rows]).sum()
-        if kind == "fused_strided":        # autograd hands the Function a (b, s, cn) view with row pitch cn + 7
+        if kind.endswith("_strided"):        # autograd hands the Function a (b, s, cn) view with row pitch cn + 7
             new_normal.backward(wide[:, 3:3 + cn].view(b, s, cn), retain_graph=True)
             loss.backward()
         else:
             (loss + (new_normal.reshape(b * s, cn) * wide[:, 3:3 + cn]).sum()).backward()
         res[kind] = (cg, new_normal.detach(), rows, normal.grad.clone(), None if feature is None else feature.grad.clone())
     sep = res["separate"]
-    for kind in ("fused", "fused_strided"):
+    for kind in ("fused", "fused_strided", "gather", "gather_strided"):
         got = res[kind]
         assert got[2] == sep[2] == int(cnt.sum())
         r = got[2]
@@ -366,12 +368,17 @@ def test_compact_grouping_with_prebuilt_index_and_fused_centre_rows(radius, ns, 
             assert torch.equal(getattr(got[0], name), getattr(sep[0], name))
         for name in ("mult", "grp", "slot", "src"):
             assert torch.equal(getattr(got[0], name)[:r], getattr(sep[0], name)[:r]), name
-        if kind == "fused":
+        if kind in ("fused", "gather"):
             assert torch.allclose(got[3], sep[3], rtol=1e-5, atol=1e-5)
             if cf:
                 assert torch.allclose(got[4], sep[4], rtol=1e-5, atol=1e-5)
     # the strided run accumulates the two contributions in two backward calls: compare with the sum
     assert torch.allclose(res["fused_strided"][3], sep[3], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(res["gather_strided"][3], sep[3], rtol=1e-5, atol=1e-5)
+    # the gather sums in a fixed order (the lists of rs_compact_csr are sorted): bit-reproducible, unlike the atomics
+    assert torch.equal(res["gather"][3], res["gather_again"][3])
+    if cf:
+        assert torch.equal(res["gather"][4], res["gather_again"][4])
 
 
 @pytest.mark.gpu
