@@ -240,6 +240,16 @@ int rs_compact_csr(int b, int n, int m, const int *src, const int *offsets, cons
 int rs_group_features_compact_backward_csr(int b, int n, int cn, int cf, int polar, const float *grad_out, const int *csr_off,
                                            const int *csr_rows, const int *centre_of, float *grad_normal, float *grad_feature,
                                            const float *grad_new_normal, long long ldg, void *stream);
+/* The inverse of ANY gather index over a packed batch (round 4): src (E edges -> global source rows), edge_ends / point_ends (b):
+ * running ends of the query rows (x `per` = edges: nsample of a grouping, 3 of an interpolation) and of the source rows per cloud
+ * -> csr_off (P + 1), csr_edges (E): the edges reading each source row, ascending.  overflow (1 int, zeroed by the caller) counts the
+ * clouds with more than max_points (<= 16384) source rows: their lists are then undefined.  Geometry only.
+ * rs_group_features_backward_csr: rs_group_features_backward (b = 1 packed layout) as a gather over it -- every element of
+ * grad_normal / grad_feature written once, ascending sums, no atomics; c0 = first gathered column (cpos + pad), ldo = row pitch. */
+int rs_inverse_index(int b, int per, int max_points, const int *src, const int *edge_ends, const int *point_ends, int *csr_off,
+                     int *csr_edges, int *overflow, void *stream);
+int rs_group_features_backward_csr(long long points, int cn, int cf, int c0, int ldo, const float *grad_out, const int *csr_off,
+                                   const int *csr_edges, float *grad_normal, float *grad_feature, void *stream);
 /* group_all variant (sample_and_group_all, repsurface_utils.py:62-88):
  * row (b, j) = [center (3), polar of center (3, if polar), normal (cn), feature (cf)]. */
 int rs_group_all_features(int b, int n, int cn, int cf, int polar, const float *center,

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 29
+ABI_VERSION = 30
 KNN_GRID_CELLS = 4096          # RS_KNN_GRID_CELLS of include/repsurf_hip.h
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
@@ -36,6 +36,8 @@ SIGNATURES = {
     "rs_group_features_compact": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P],
     "rs_group_features_compact_backward": [c_ll, P, c_int, c_int, c_int, P, P, P, P, c_int, c_int, c_int, P, P, c_ll, P],
     "rs_compact_csr": [c_int, c_int, c_int, P, P, P, P, P, P, P],
+    "rs_inverse_index": [c_int, c_int, c_int, P, P, P, P, P, P, P],
+    "rs_group_features_backward_csr": [c_ll, c_int, c_int, c_int, c_int, P, P, P, P, P, P],
     "rs_group_features_compact_backward_csr": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_ll, P],
     "rs_group_rows": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "rs_group_rows_backward": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],

@@ -460,6 +460,58 @@ compact_csr_kernel(int n, int m, const int *__restrict__ src, const int *__restr
     for (int g = tid; g < m; g += CSR_THREADS) centre_of[p0 + fps_idx[(long long)c * m + g]] = c * m + g;
 }
 
+// The same inversion for ANY gather of packed batches (round 4): edge e reads source row src[e]; the edges of cloud c are
+// [per * edge_ends[c-1], per * edge_ends[c]) (`per` edges per query row: nsample of a grouping, 3 of an interpolation), its source
+// rows [point_ends[c-1], point_ends[c]).  csr_off (P + 1), csr_edges (E): the edges that read each source row, ascending.
+__global__ void __launch_bounds__(CSR_THREADS)
+inverse_index_kernel(int per, const int *__restrict__ src, const int *__restrict__ edge_ends, const int *__restrict__ point_ends,
+                     int lds_points, int *__restrict__ csr_off, int *__restrict__ csr_edges, int *__restrict__ overflow) {
+  extern __shared__ int cnt[];                       // lds_points counters, then lds_points cursors
+  __shared__ int wsum[CSR_THREADS / 64];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p0 = c ? point_ends[c - 1] : 0, n = point_ends[c] - p0;
+  const int e0 = (c ? edge_ends[c - 1] : 0) * per, e1 = edge_ends[c] * per;
+  if (n > lds_points) {                              // (workgroup-uniform) a cloud the counters cannot hold: the caller falls back
+    if (tid == 0) atomicAdd(overflow, 1);
+    return;
+  }
+  int *cur = cnt + lds_points;
+  for (int p = tid; p < n; p += CSR_THREADS) cnt[p] = 0;
+  __syncthreads();
+  for (int e = e0 + tid; e < e1; e += CSR_THREADS) atomicAdd(&cnt[src[e] - p0], 1);
+  __syncthreads();
+  const int chunk = (n + CSR_THREADS - 1) / CSR_THREADS;
+  int run = 0;
+  for (int k = 0; k < chunk; ++k) { const int p = tid * chunk + k; if (p < n) run += cnt[p]; }
+  int inc = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = inc - run;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  for (int k = 0; k < chunk; ++k) {
+    const int p = tid * chunk + k;
+    if (p < n) { const int v = cnt[p]; cur[p] = base; csr_off[p0 + p] = e0 + base; base += v; }
+  }
+  if (c == (int)gridDim.x - 1 && tid == 0) csr_off[p0 + n] = e1;
+  __syncthreads();
+  for (int e = e0 + tid; e < e1; e += CSR_THREADS) {
+    const int pos = atomicAdd(&cur[src[e] - p0], 1);
+    csr_edges[e0 + pos] = e;
+  }
+  __syncthreads();
+  for (int p = tid; p < n; p += CSR_THREADS) {       // ascending lists: one summation order, whatever the atomics' order was
+    const int lo = e0 + (cur[p] - cnt[p]), hi = e0 + cur[p];
+    for (int i = lo + 1; i < hi; ++i) {
+      const int v = csr_edges[i];
+      int j = i - 1;
+      while (j >= lo && csr_edges[j] > v) { csr_edges[j + 1] = csr_edges[j]; --j; }
+      csr_edges[j + 1] = v;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(GR_THREADS)
 compact_gather_bwd_kernel(long long points, int cn, int cf, int cpos, int ctot, const float *__restrict__ grad_out,
                           const int *__restrict__ csr_off, const int *__restrict__ csr_rows, const int *__restrict__ centre_of,
@@ -711,5 +763,40 @@ extern "C" int rs_group_features_compact_backward_csr(int b, int n, int cn, int 
   hipLaunchKernelGGL(compact_gather_bwd_kernel, dim3(grid_for(points * cw)), dim3(GR_THREADS), 0, (hipStream_t)stream, points, cn, cf,
                      cpos, ctot, grad_out, csr_off, csr_rows, centre_of, grad_normal, grad_feature, grad_new_normal, ldg);
   RS_CHECK_LAUNCH("rs_group_features_compact_backward_csr");
+  return RS_OK;
+}
+
+/* Inverse of a gather index over a packed batch (round 4): src (E = per * edge_ends[b-1] edges, global source rows), edge_ends /
+ * point_ends (b): running ends of the query rows (x per = edges) and of the source rows per cloud -> csr_off (P + 1), csr_edges (E):
+ * the edges reading each source row, ascending.  overflow (1 int, zeroed by the caller): the number of clouds with more source rows
+ * than `max_points` (the counters of one workgroup: <= 16384) -- their part of the output is then undefined: use the scatter. */
+extern "C" int rs_inverse_index(int b, int per, int max_points, const int *src, const int *edge_ends, const int *point_ends,
+                                int *csr_off, int *csr_edges, int *overflow, void *stream) {
+  RS_REQUIRE(b >= 0 && per > 0, "rs_inverse_index: bad size");
+  if (b == 0) return RS_OK;
+  RS_REQUIRE(src && edge_ends && point_ends && csr_off && csr_edges && overflow, "rs_inverse_index: null pointer");
+  RS_REQUIRE(max_points > 0 && max_points <= 16384, "rs_inverse_index: max_points=%d outside 1..16384", max_points);
+  hipLaunchKernelGGL(inverse_index_kernel, dim3(b), dim3(CSR_THREADS), (size_t)2 * max_points * sizeof(int), (hipStream_t)stream, per, src,
+                     edge_ends, point_ends, max_points, csr_off, csr_edges, overflow);
+  RS_CHECK_LAUNCH("rs_inverse_index");
+  return RS_OK;
+}
+
+/* rs_group_features_backward as a gather over rs_inverse_index of the grouping index (b = 1 packed layout: `points` source rows):
+ * grad_normal (points, cn) / grad_feature (points, cf) WRITTEN as the sums over the grouped rows that read each point, ascending --
+ * no zero fill, no atomics.  c0: first gathered column of a grouped row (cpos + pad), ldo: its row pitch. */
+extern "C" int rs_group_features_backward_csr(long long points, int cn, int cf, int c0, int ldo, const float *grad_out,
+                                              const int *csr_off, const int *csr_edges, float *grad_normal, float *grad_feature,
+                                              void *stream) {
+  RS_REQUIRE(points >= 0 && cn >= 0 && cf >= 0 && c0 >= 0 && ldo >= c0 + cn + cf, "rs_group_features_backward_csr: bad size");
+  if (points == 0) return RS_OK;
+  RS_REQUIRE(grad_out && csr_off && csr_edges, "rs_group_features_backward_csr: null pointer");
+  if (cn == 0) grad_normal = nullptr;
+  if (cf == 0) grad_feature = nullptr;
+  if (!grad_normal && !grad_feature) return RS_OK;
+  const int cw = (grad_normal ? cn : 0) + (grad_feature ? cf : 0);
+  hipLaunchKernelGGL(compact_gather_bwd_kernel, dim3(grid_for(points * cw)), dim3(GR_THREADS), 0, (hipStream_t)stream, points, cn, cf,
+                     c0, ldo, grad_out, csr_off, csr_edges, (const int *)nullptr, grad_normal, grad_feature, (const float *)nullptr, 0LL);
+  RS_CHECK_LAUNCH("rs_group_features_backward_csr");
   return RS_OK;
 }

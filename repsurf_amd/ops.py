@@ -382,10 +382,37 @@ def umbrella_features(xyz, k=9, inv_sign=None, return_knn=False):
     return (feat, kidx) if return_knn else feat
 
 
+# ----------------------------------------------------------------------------- inverse of a gather index
+GATHER_BACKWARD = os.environ.get("REPSURF_GATHER_BACKWARD", "1") != "0"
+
+
+def inverse_index(src, per, edge_ends, point_ends):
+    """The edges that read each source row of a packed batch (rs_inverse_index): src (rows, per) | (rows * per,) int32 global source
+    rows, edge_ends / point_ends (B,) running ends of the query rows / source rows per cloud -> (csr_off (P + 1), csr_edges (E)) or
+    None when the host does not hold the cloud sizes or a cloud has more than 16 384 source rows (the backward then scatters).
+    Geometry only: lets the backward of the gather WRITE every gradient element as a sum in ascending edge order (no atomics)."""
+    if not GATHER_BACKWARD:
+        return None
+    largest = _largest_cloud(point_ends)
+    if largest <= 0 or largest > 16384:
+        return None
+    _need_gpu(src, edge_ends, point_ends)
+    src, edge_ends, point_ends = _i32c(src), _i32c(edge_ends), _i32c(point_ends)
+    points = point_ends._rs_host[1][-1]
+    e = src.numel()
+    dev = src.device
+    csr_off = torch.empty((points + 1,), dtype=torch.int32, device=dev)
+    csr_edges = torch.empty((max(e, 1),), dtype=torch.int32, device=dev)
+    overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _lib.call("rs_inverse_index", edge_ends.numel(), per, largest, _p(src), _p(edge_ends), _p(point_ends), _p(csr_off), _p(csr_edges),
+              _p(overflow), _stream())
+    return csr_off, csr_edges
+
+
 # ----------------------------------------------------------------------------- grouping
 class _GroupFeatures(Function):
     @staticmethod
-    def forward(ctx, center, new_center, normal, feature, idx, polar, aligned):
+    def forward(ctx, center, new_center, normal, feature, idx, polar, aligned, csr=None):
         _need_gpu(center, new_center, normal, feature, idx)
         center, new_center, normal, idx = _f32c(center), _f32c(new_center), _f32c(normal), _i32c(idx)
         feature = None if feature is None else _f32c(feature)
@@ -401,6 +428,7 @@ class _GroupFeatures(Function):
         _lib.call("rs_group_features", b, n, m, ns, cn, cf, int(polar), _p(center), _p(new_center),
                   _p(normal), _p(feature), _p(idx), _p(out), pad, ldo, _stream())
         ctx.save_for_backward(idx)
+        ctx.csr = csr if (csr is not None and b == 1 and csr[0].numel() == n + 1 and csr[1].numel() >= m * ns) else None
         ctx.dims = (b, n, m, ns, cn, cf, int(polar), pad, ldo)
         ctx.need = (ctx.needs_input_grad[2], feature is not None and ctx.needs_input_grad[3])
         return out
@@ -411,20 +439,30 @@ class _GroupFeatures(Function):
         b, n, m, ns, cn, cf, polar, pad, ldo = ctx.dims
         grad_out = _f32c(grad_out)
         dev = grad_out.device
+        if ctx.csr is not None:      # gather form (ops.inverse_index of the grouping index, built with the geometry): no fill, no atomics
+            c0, c1 = (cn if ctx.need[0] else 0), (cf if ctx.need[1] else 0)
+            if c0 + c1 == 0:
+                return (None,) * 8
+            buf = torch.empty((n * (c0 + c1),), dtype=torch.float32, device=dev)
+            gn = buf[:n * c0].view(1, n, c0) if c0 else None
+            gf = buf[n * c0:].view(1, n, c1) if c1 else None
+            _lib.call("rs_group_features_backward_csr", n, cn, cf, (6 if polar else 3) + pad, ldo, _p(grad_out), _p(ctx.csr[0]), _p(ctx.csr[1]),
+                      _p(gn), _p(gf), _stream())
+            return None, None, gn, gf, None, None, None, None
         gn, gf = _zero_pair(b * n, cn if ctx.need[0] else 0, cf if ctx.need[1] else 0, (b, n), dev)
         if gn is not None or gf is not None:
             _lib.call("rs_group_features_backward", b, n, m, ns, cn, cf, polar, _p(grad_out), _p(idx),
                       _p(gn), _p(gf), pad, ldo, _stream())
-        return None, None, gn, gf, None, None, None
+        return None, None, gn, gf, None, None, None, None
 
 
-def group_features(center, new_center, normal, feature, idx, polar=True, aligned=False):
+def group_features(center, new_center, normal, feature, idx, polar=True, aligned=False, csr=None):
     """Grouped shared-MLP input of sample_and_group (repsurface_utils.py:36-57):
     -> (B*S*ns, 3+3*polar+Cn+Cf) rows [offset, polar(offset), normal[idx], feature[idx]];
     differentiable w.r.t. normal and feature.
     aligned=True: the position block is zero-padded to 4 channels and rows to a multiple of 4 floats --
     (rows, ld) with [offset(3|6), 0.., normal, feature, unused..]; `aligned_layout` gives the offsets."""
-    return _GroupFeatures.apply(center, new_center, normal, feature, idx, polar, aligned)
+    return _GroupFeatures.apply(center, new_center, normal, feature, idx, polar, aligned, csr)
 
 
 def aligned_layout(polar, cn, cf):

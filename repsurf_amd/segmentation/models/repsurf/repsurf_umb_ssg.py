@@ -116,6 +116,8 @@ class SegGeoState:
         out = [self.feat] + ([self.moments] if self.moments is not None else [])
         for g in self.stages:
             out += [t for t in (g.fps_idx, g.new_center, g.group_idx) if t is not None]
+            if g.csr is not None:
+                out += list(g.csr)
         for idx, w in self.fps:
             out += [idx, w]
         return out
@@ -124,7 +126,7 @@ class SegGeoState:
         from modules.repsurface_utils import StageGeometry
         return SegGeoState(self.feat.clone(),
                            [StageGeometry(None if g.fps_idx is None else g.fps_idx.clone(), g.new_center.clone(), g.new_offset,
-                                          g.group_idx.clone()) for g in self.stages],
+                                          g.group_idx.clone(), None if g.csr is None else tuple(t.clone() for t in g.csr)) for g in self.stages],
                            [(i.clone(), w.clone()) for i, w in self.fps], None if self.moments is None else self.moments.clone())
 
     def copy_(self, other):

@@ -24,10 +24,12 @@ class StageGeometry:
     """The coordinate-only part of one sample_and_group call: sampled rows, their coordinates, the running ends of the
     sampled clouds and the kNN lists.  `stage_geometry` computes it; a training loop that has its next batch in hand
     can do that while the previous batch is still training (repsurf_amd.graph.PipelinedStep)."""
-    __slots__ = ("fps_idx", "new_center", "new_offset", "group_idx")
+    __slots__ = ("fps_idx", "new_center", "new_offset", "group_idx", "csr")
 
-    def __init__(self, fps_idx, new_center, new_offset, group_idx):
-        self.fps_idx, self.new_center, self.new_offset, self.group_idx = fps_idx, new_center, new_offset, group_idx
+    def __init__(self, fps_idx, new_center, new_offset, group_idx, csr=None):
+        """csr (round 4, optional): ops.inverse_index of group_idx -- (csr_off, csr_edges), the grouped rows that read each source
+        row: the grouping's backward then gathers (no atomics, no fill)"""
+        self.fps_idx, self.new_center, self.new_offset, self.group_idx, self.csr = fps_idx, new_center, new_offset, group_idx, csr
 
 
 def stage_geometry(stride, nsample, center, offset, num_sector=1, training=True):
@@ -42,7 +44,8 @@ def stage_geometry(stride, nsample, center, offset, num_sector=1, training=True)
     else:
         fps_idx, new_center, new_offset = None, center, offset
     group_idx, _ = ops.knnquery_offset(nsample, center, new_center, offset, new_offset)
-    return StageGeometry(fps_idx, new_center, new_offset, group_idx)
+    csr = ops.inverse_index(group_idx, nsample, new_offset, offset) if (training and center.is_cuda) else None
+    return StageGeometry(fps_idx, new_center, new_offset, group_idx, csr)
 
 
 def sample_and_group(stride, nsample, center, normal, feature, offset, return_polar=False, num_sector=1,
@@ -57,7 +60,7 @@ def sample_and_group(stride, nsample, center, normal, feature, offset, return_po
     m = new_center.shape[0]
     rows = ops.group_features(center.unsqueeze(0), new_center.unsqueeze(0), normal.unsqueeze(0),
                               None if feature is None else feature.unsqueeze(0), group_idx.unsqueeze(0),
-                              polar=return_polar, aligned=aligned)
+                              polar=return_polar, aligned=aligned, csr=g.csr)
     return new_center, new_normal, rows.view(m, nsample, -1), new_offset
 
 

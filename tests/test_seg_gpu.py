@@ -626,3 +626,41 @@ def test_feature_propagation_front_as_one_node(n, m, c1, c2, c, monkeypatch):
             scale = b.abs().max().item()
             err = (a - b).abs().max().item()
             assert err <= 2e-4 * scale + 1e-6, (name, err, scale)
+
+
+@pytest.mark.parametrize("aligned,cf", [(True, 13), (False, 0), (True, 64)])
+def test_grouping_backward_as_a_gather(ops, aligned, cf):
+    """ops.group_features over ops.inverse_index of the kNN lists (the grouped rows that read each source row, ascending): the
+    backward WRITES every gradient element as a sum in one order -- equal to the atomic scatter within rounding, bit-equal between
+    two runs; ragged clouds, a cloud smaller than the list length."""
+    sizes = [700, 40, 1300, 257, 9]
+    xyz, offset = packed_cloud(41, sizes)
+    off = ops.offsets_tensor([int(v) for v in offset], torch.device("cuda"))
+    new_off = ops.strided_offset(off, 4)
+    starts = np.concatenate([[0], offset[:-1]])
+    centres = np.concatenate([xyz[s:s + (e - s) // 4] for s, e in zip(starts, offset)]).astype(np.float32)
+    x, c = dev(xyz), dev(centres)
+    idx, _ = ops.knnquery_offset(16, x, c, off, new_off)
+    csr = ops.inverse_index(idx, 16, new_off, off)
+    assert csr is not None and csr[0].numel() == xyz.shape[0] + 1 and int(csr[0][-1]) == idx.numel()
+    g = torch.Generator().manual_seed(2)
+    normal0 = torch.randn(xyz.shape[0], 10, generator=g).cuda()
+    feat0 = torch.randn(xyz.shape[0], cf, generator=g).cuda() if cf else None
+    probe = None
+    res = {}
+    for tag in ("scatter", "gather", "gather_again"):
+        normal = normal0.clone().requires_grad_()
+        feat = None if feat0 is None else feat0.clone().requires_grad_()
+        rows = ops.group_features(x.unsqueeze(0), c.unsqueeze(0), normal.unsqueeze(0), None if feat is None else feat.unsqueeze(0),
+                                  idx.unsqueeze(0), polar=True, aligned=aligned, csr=None if tag == "scatter" else csr)
+        if probe is None:
+            probe = torch.randn(rows.shape, generator=g).cuda()
+        (rows * probe).sum().backward()
+        res[tag] = (rows.detach().clone(), normal.grad.clone(), None if feat is None else feat.grad.clone())
+    used = 6 + (2 if aligned else 0) + 10 + cf           # (the aligned layout pads rows to a multiple of 4 floats: the tail is never written)
+    assert torch.equal(res["gather"][0][:, :used], res["scatter"][0][:, :used])
+    assert torch.allclose(res["gather"][1], res["scatter"][1], rtol=1e-5, atol=1e-5)
+    assert torch.equal(res["gather"][1], res["gather_again"][1])
+    if cf:
+        assert torch.allclose(res["gather"][2], res["scatter"][2], rtol=1e-5, atol=1e-5)
+        assert torch.equal(res["gather"][2], res["gather_again"][2])
