@@ -162,6 +162,14 @@ int rs_three_interpolate_affine_backward(int b, int c, int n, int m, const float
                                          const float *weight, float *grad_points, float *grad_add, const float *add,
                                          const float *add_mean, const float *add_invstd, double *partial, int partial_blocks,
                                          void *stream);
+/* The interpolation's backward towards the coarse rows as a gather (round 4) over rs_inverse_index of idx (per = 3, built with the
+ * geometry): grad_points (m_rows, c) WRITTEN, ascending sums, no atomics.  g: the masked gradient (rs_three_interpolate_affine_backward
+ * with grad_points = NULL makes it), or NULL: grad_out where fwd_out > 0.  partial (optional): BatchNorm-backward sums of the coarse
+ * rows' BatchNorm from y / mean / invstd (c <= 256). */
+int rs_three_interpolate_backward_csr(long long m_rows, int c, const float *g, const float *grad_out, const float *fwd_out,
+                                      const float *weight, const int *csr_off, const int *csr_edges, float *grad_points,
+                                      const float *y, const float *mean, const float *invstd, double *partial, int partial_blocks,
+                                      void *stream);
 
 /* ---- umbrella surface constructor ---------------------------------------
  * Fuses group_by_umbrella + cal_normal + cal_center + xyz2sphere + cal_const +

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 30
+ABI_VERSION = 31
 KNN_GRID_CELLS = 4096          # RS_KNN_GRID_CELLS of include/repsurf_hip.h
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
@@ -48,6 +48,7 @@ SIGNATURES = {
     "rs_three_interpolate_fused_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
     "rs_three_interpolate_affine": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P, P],
     "rs_three_interpolate_affine_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P],
+    "rs_three_interpolate_backward_csr": [c_ll, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P],
     "rs_mlp_gemm_rows": [c_ll, P, c_int, c_int, P, P, c_int, P, P],
     "rs_mlp_gemm_rows_bf16": [c_ll, P, c_int, c_int, P, P, c_int, P, P],
     "rs_mlp_wgrad": [c_ll, P, c_int, c_int, P, P, P, c_int, P, P],

@@ -152,9 +152,11 @@ interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
         if (!ok[k]) continue;
         if (grad_add) grad_add[e0 + k * st] = g[k];
         if (partial) { acc0 += (double)g[k]; acc1 += (double)(g[k] * ((yh[k] - smean[ch[k]]) * sinvstd[ch[k]])); }
-        float *base = grad_points + (long long)cloud[k] * m * c + ch[k];
+        if (grad_points) {      // (NULL: only the masked gradient and the sums -- the coarse rows' gradient is gathered, interp_gather_bwd_kernel)
+          float *base = grad_points + (long long)cloud[k] * m * c + ch[k];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) atomicAdd(base + (long long)id[k][t] * c, g[k] * w[k][t]);
+          for (int t = 0; t < 3; ++t) atomicAdd(base + (long long)id[k][t] * c, g[k] * w[k][t]);
+        }
       }
     }
     if (partial) {      // threads of one channel meet in LDS (fixed order), one partial row per workgroup
@@ -184,6 +186,58 @@ interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
     if (grad_add) grad_add[e] = g;
 #pragma unroll
     for (int t = 0; t < 3; ++t) atomicAdd(base + (long long)idx[r * 3 + t] * c, g * weight[r * 3 + t]);
+  }
+}
+
+// The interpolation's backward towards the coarse rows as a GATHER (round 4): csr_off / csr_edges = rs_inverse_index of idx (edge
+// e = 3 n + t reads coarse row idx[e]), built with the geometry.  Per coarse row and channel, the weighted sum over the edges that
+// read it, ascending -- every element written once: no atomics, no zero fill, one summation order.  g: the masked gradient (N, c)
+// when a pass already made it (skip branch), else it is taken as grad_out where fwd_out > 0.  partial != NULL: the BatchNorm-backward
+// sums of the coarse branch {sum d, sum d * yhat} leave with this pass (grid stride a multiple of c, c <= 256, as in interp_bwd_kernel).
+__global__ void __launch_bounds__(IT_THREADS)
+interp_gather_bwd_kernel(unsigned total, int c, const float *__restrict__ g, const float *__restrict__ grad_out,
+                         const float *__restrict__ fwd_out, const float *__restrict__ weight, const int *__restrict__ csr_off,
+                         const int *__restrict__ csr_edges, float *__restrict__ grad_points, const float *__restrict__ sy,
+                         const float *__restrict__ smean, const float *__restrict__ sinvstd, double *__restrict__ partial,
+                         int partial_blocks) {
+  __shared__ double red[IT_THREADS][2];
+  double acc0 = 0.0, acc1 = 0.0;
+  const unsigned st = gridDim.x * IT_THREADS, cu = (unsigned)c;
+  for (unsigned e0 = blockIdx.x * IT_THREADS + threadIdx.x; e0 < total; e0 += st) {
+    const unsigned row = e0 / cu, ch = e0 - row * cu;
+    const int lo = csr_off[row], hi = csr_off[row + 1];
+    float acc = 0.f;
+    int j = lo;
+    auto term = [&](int e) {
+      const unsigned n = (unsigned)e / 3u;
+      const float w = weight[e];
+      float v;
+      if (g) v = g[n * cu + ch];
+      else { v = grad_out[n * cu + ch]; if (fwd_out) v = fwd_out[n * cu + ch] > 0.f ? v : 0.f; }
+      return w * v;
+    };
+    for (; j + 4 <= hi; j += 4) {                    // four edges in flight, the sum keeps the list's order
+      const float t0 = term(csr_edges[j]), t1 = term(csr_edges[j + 1]), t2 = term(csr_edges[j + 2]), t3 = term(csr_edges[j + 3]);
+      acc = (((acc + t0) + t1) + t2) + t3;
+    }
+    for (; j < hi; ++j) acc += term(csr_edges[j]);
+    grad_points[e0] = acc;
+    if (partial) { acc0 += (double)acc; acc1 += (double)(acc * ((sy[e0] - smean[ch]) * sinvstd[ch])); }
+  }
+  if (partial) {
+    red[threadIdx.x][0] = acc0; red[threadIdx.x][1] = acc1;
+    __syncthreads();
+    if ((int)threadIdx.x < c) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int k = threadIdx.x; k < IT_THREADS; k += c) { t0 += red[k][0]; t1 += red[k][1]; }
+      const int chn = (int)((blockIdx.x * (unsigned)IT_THREADS + threadIdx.x) % cu);
+      partial[((long long)blockIdx.x * 2 + 0) * c + chn] = t0;
+      partial[((long long)blockIdx.x * 2 + 1) * c + chn] = t1;
+      for (int pb = blockIdx.x + gridDim.x; pb < partial_blocks; pb += gridDim.x) {
+        partial[((long long)pb * 2 + 0) * c + chn] = 0.0;
+        partial[((long long)pb * 2 + 1) * c + chn] = 0.0;
+      }
+    }
   }
 }
 
@@ -288,8 +342,8 @@ extern "C" int rs_three_interpolate_affine_backward(int b, int c, int n, int m, 
   RS_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "rs_three_interpolate_affine_backward: negative size");
   const long long rows = (long long)b * n;
   if (rows == 0 || c == 0) return RS_OK;
-  RS_REQUIRE(grad_out && idx && weight && grad_points && grad_add && add && add_mean && add_invstd && partial && partial_blocks > 0,
-             "rs_three_interpolate_affine_backward: null pointer");
+  RS_REQUIRE(grad_out && idx && weight && grad_add && add && add_mean && add_invstd && partial && partial_blocks > 0,
+             "rs_three_interpolate_affine_backward: null pointer (grad_points may be NULL: rs_three_interpolate_backward_csr gathers it)");
   RS_REQUIRE(c <= IT_THREADS && rows * c < (1LL << 31) && rows * 3 < (1LL << 31),
              "rs_three_interpolate_affine_backward: c=%d / %lld elements outside the fused-sums form (c <= 256, < 2^31 elements)", c, rows * c);
   int g = grid_for(rows * c);
@@ -302,5 +356,33 @@ extern "C" int rs_three_interpolate_affine_backward(int b, int c, int n, int m, 
   hipLaunchKernelGGL(interp_bwd_kernel, dim3(g), dim3(IT_THREADS), 0, (hipStream_t)stream, rows, n, m, c, grad_out, idx, weight,
                      grad_points, fwd_out, grad_add, add, add_mean, add_invstd, partial, partial_blocks);
   RS_CHECK_LAUNCH("rs_three_interpolate_affine_backward");
+  return RS_OK;
+}
+
+/* The gradient of the interpolated rows (m_rows, c) as a gather over rs_inverse_index of idx (per = 3): grad_points WRITTEN (no zero
+ * fill, no atomics, ascending sums).  g (n, c): the masked gradient if a pass made it (rs_three_interpolate_affine_backward with
+ * grad_points = NULL), else NULL: grad_out where fwd_out > 0 (fwd_out NULL: no ReLU).  partial (optional): the BatchNorm-backward sums
+ * of the rows' BatchNorm {sum d, sum d * (y - mean) * invstd} with y (m_rows, c) their raw Linear output (c <= 256). */
+extern "C" int rs_three_interpolate_backward_csr(long long m_rows, int c, const float *g, const float *grad_out, const float *fwd_out,
+                                                 const float *weight, const int *csr_off, const int *csr_edges, float *grad_points,
+                                                 const float *y, const float *mean, const float *invstd, double *partial,
+                                                 int partial_blocks, void *stream) {
+  RS_REQUIRE(m_rows >= 0 && c >= 0, "rs_three_interpolate_backward_csr: negative size");
+  if (m_rows == 0 || c == 0) return RS_OK;
+  RS_REQUIRE((g || grad_out) && weight && csr_off && csr_edges && grad_points, "rs_three_interpolate_backward_csr: null pointer");
+  RS_REQUIRE(m_rows * c < (1LL << 31), "rs_three_interpolate_backward_csr: more than 2^31 elements");
+  int gr = grid_for(m_rows * c);
+  if (partial) {
+    RS_REQUIRE(y && mean && invstd && partial_blocks > 0 && c <= IT_THREADS, "rs_three_interpolate_backward_csr: the sums need y, mean, invstd and c <= 256");
+    if (gr > partial_blocks) gr = partial_blocks;
+    int a = c, bb = IT_THREADS;
+    while (bb) { const int t = a % bb; a = bb; bb = t; }
+    const int step = c / a;
+    gr = gr / step * step;
+    RS_REQUIRE(gr >= step && gr >= 1, "rs_three_interpolate_backward_csr: partial_blocks=%d below %d", partial_blocks, step);
+  }
+  hipLaunchKernelGGL(interp_gather_bwd_kernel, dim3(gr), dim3(IT_THREADS), 0, (hipStream_t)stream, (unsigned)(m_rows * c), c, g, grad_out,
+                     fwd_out, weight, csr_off, csr_edges, grad_points, y, mean, invstd, partial, partial_blocks);
+  RS_CHECK_LAUNCH("rs_three_interpolate_backward_csr");
   return RS_OK;
 }

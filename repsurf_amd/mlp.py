@@ -87,10 +87,10 @@ def fp_front_usable(lin_f, bn_f, lin_s, bn_s):
     return mlp_hip.fp_front_usable(lin_f, bn_f, lin_s, bn_s)
 
 
-def fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s):
+def fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s, csr=None):
     """Feature propagation in front of its [Linear, BN, ReLU]* chain (segmentation/modules/repsurface_utils.py:256-270) as one
     node: relu(interpolate(bn_f(lin_f(points2)), idx, weight) + bn_s(lin_s(points1)))."""
-    return mlp_hip.fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s)
+    return mlp_hip.fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s, csr=csr)
 
 
 def row_linear(x, linear):

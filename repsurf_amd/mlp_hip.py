@@ -1370,7 +1370,8 @@ class _FPFront(Function):
         _lib.call("rs_three_interpolate_affine", 1, c, m, n, _ptr(y2), _ptr(v2.scale), _ptr(v2.shift), idx.data_ptr(), _ptr(weight),
                   _ptr(y1), _ptr(v1.scale), _ptr(v1.shift), 1, _ptr(out), _stream())
         _flush_counters()
-        ctx.saved = dict(points2=points2, points1=points1, idx=idx, weight=weight, y2=y2, y1=y1, v2=v2, v1=v1, out=out, wf2=wf2, ws2=ws2, lazy2=lazy2)
+        ctx.saved = dict(points2=points2, points1=points1, idx=idx, weight=weight, y2=y2, y1=y1, v2=v2, v1=v1, out=out, wf2=wf2, ws2=ws2, lazy2=lazy2,
+                         csr=meta.get("csr") if (meta.get("csr") is not None and meta["csr"][0].numel() == m + 1 and m * c < 2 ** 31) else None)
         return out
 
     @staticmethod
@@ -1384,15 +1385,27 @@ class _FPFront(Function):
         dout = dout.contiguous()
         _stack_begins()
         g = torch.empty((n, c), dtype=torch.float32, device=dev)             # gradient at BN_s's output (= at the sum, masked)
-        d2 = torch.zeros((m, c), dtype=torch.float32, device=dev)            # gradient at BN_f's output (scatter target)
         nb1 = max(1, min(2048, -(-(n * c) // 1024)))      # one partial row per workgroup of the interpolation backward (<= 2048: its usual grid)
         part1 = torch.empty((nb1, 2, c), dtype=torch.float64, device=dev)
-        _lib.call("rs_three_interpolate_affine_backward", 1, c, n, m, _ptr(dout), _ptr(s["out"]), s["idx"].data_ptr(), _ptr(s["weight"]),
-                  _ptr(d2), _ptr(g), _ptr(y1), _ptr(v1.mean), _ptr(v1.invstd), part1.data_ptr(), nb1, _stream())
-        nb2 = partial_rows(m, 4)
-        part2 = torch.empty((nb2, 2, c), dtype=torch.float64, device=dev)
-        _lib.call("rs_pool_max_backward", m, 1, c, None, _ptr(d2), c, None, None, _ptr(y2), 0, _ptr(v2.mean), _ptr(v2.invstd), None,
-                  part2.data_ptr(), nb2, _stream())
+        csr = s["csr"]
+        if csr is not None:
+            # gather form (ops.inverse_index of idx, built with the geometry): one pass masks the gradient and sums the skip branch's
+            # moments, one pass gathers the coarse rows' gradient in ascending edge order and sums THEIR moments -- no atomics, no fill
+            d2 = torch.empty((m, c), dtype=torch.float32, device=dev)
+            _lib.call("rs_three_interpolate_affine_backward", 1, c, n, m, _ptr(dout), _ptr(s["out"]), s["idx"].data_ptr(), _ptr(s["weight"]),
+                      None, _ptr(g), _ptr(y1), _ptr(v1.mean), _ptr(v1.invstd), part1.data_ptr(), nb1, _stream())
+            nb2 = max(1, min(2048, -(-(m * c) // 256)))
+            part2 = torch.empty((nb2, 2, c), dtype=torch.float64, device=dev)
+            _lib.call("rs_three_interpolate_backward_csr", m, c, _ptr(g), None, None, _ptr(s["weight"]), _ptr(csr[0]), _ptr(csr[1]), _ptr(d2),
+                      _ptr(y2), _ptr(v2.mean), _ptr(v2.invstd), part2.data_ptr(), nb2, _stream())
+        else:
+            d2 = torch.zeros((m, c), dtype=torch.float32, device=dev)            # gradient at BN_f's output (scatter target)
+            _lib.call("rs_three_interpolate_affine_backward", 1, c, n, m, _ptr(dout), _ptr(s["out"]), s["idx"].data_ptr(), _ptr(s["weight"]),
+                      _ptr(d2), _ptr(g), _ptr(y1), _ptr(v1.mean), _ptr(v1.invstd), part1.data_ptr(), nb1, _stream())
+            nb2 = partial_rows(m, 4)
+            part2 = torch.empty((nb2, 2, c), dtype=torch.float64, device=dev)
+            _lib.call("rs_pool_max_backward", m, 1, c, None, _ptr(d2), c, None, None, _ptr(y2), 0, _ptr(v2.mean), _ptr(v2.invstd), None,
+                      part2.data_ptr(), nb2, _stream())
         (p1, q1, r1, dg1, db1), (p2, q2, r2, dg2, db2) = bwd_coeffs_multi(
             [(c, n, part1, 2, 1, v1, None, False), (c, m, part2, 2, 1, v2, None, False)], dev)
         op1 = operand(OP_AFF2, g, c, y1, c, s1=p1, t1=r1, s2=q1)
@@ -1425,10 +1438,10 @@ def fp_front_usable(lin_f, bn_f, lin_s, bn_s):
             and os.environ.get("REPSURF_FP_FRONT", "1") != "0")
 
 
-def fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s):
+def fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s, csr=None):
     """relu(interpolate(bn_f(lin_f(points2)), idx, weight) + bn_s(lin_s(points1))): points2 (M, C2) coarse rows, points1 (N, C1)
-    fine rows, idx / weight (N, 3) -> (N, C)."""
-    meta = {"bns": (bn_f, bn_s)}
+    fine rows, idx / weight (N, 3) -> (N, C).  csr: ops.inverse_index(idx, 3, ...) -- the backward then gathers."""
+    meta = {"bns": (bn_f, bn_s), "csr": csr}
     if isinstance(points2, LazyRows):
         meta["lazy_in"] = points2
         points2 = points2.y

@@ -727,7 +727,7 @@ class _ThreeInterpolateAddRelu(Function):
     `points` and written out once for `add`)."""
 
     @staticmethod
-    def forward(ctx, points, idx, weight, add):
+    def forward(ctx, points, idx, weight, add, csr=None):
         _need_gpu(points, idx, weight, add)
         points, idx, weight = _f32c(points), _i32c(idx), _f32c(weight)
         add = None if add is None else _f32c(add)
@@ -738,6 +738,8 @@ class _ThreeInterpolateAddRelu(Function):
         ctx.save_for_backward(idx, weight, out)
         ctx.dims = (b, c, n, m)
         ctx.has_add = add is not None
+        # gather form of the backward (ops.inverse_index of idx, per = 3): packed layout (b = 1), no skip branch here
+        ctx.csr = csr if (csr is not None and b == 1 and add is None and csr[0].numel() == m + 1 and m * c < 2 ** 31) else None
         return out
 
     @staticmethod
@@ -745,13 +747,18 @@ class _ThreeInterpolateAddRelu(Function):
         idx, weight, out = ctx.saved_tensors
         b, c, n, m = ctx.dims
         grad_out = _f32c(grad_out)
+        if ctx.csr is not None:
+            grad = torch.empty((b, m, c), dtype=torch.float32, device=grad_out.device)
+            _lib.call("rs_three_interpolate_backward_csr", m, c, None, _p(grad_out), _p(out), _p(weight), _p(ctx.csr[0]), _p(ctx.csr[1]), _p(grad),
+                      None, None, None, None, 0, _stream())
+            return grad, None, None, None, None
         grad = torch.zeros((b, m, c), dtype=torch.float32, device=grad_out.device)
         gadd = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device) if (ctx.has_add and ctx.needs_input_grad[3]) else None
         _lib.call("rs_three_interpolate_fused_backward", b, c, n, m, _p(grad_out), _p(out), _p(idx), _p(weight), _p(grad), _p(gadd), _stream())
-        return grad, None, None, gadd
+        return grad, None, None, gadd, None
 
 
-def three_interpolate_add_relu(points, idx, weight, add=None):
+def three_interpolate_add_relu(points, idx, weight, add=None, csr=None):
     """relu(three_interpolate(points, idx, weight) [+ add]): points (B,m,C), idx / weight (B,n,3), add (B,n,C) | None -> (B,n,C);
     differentiable w.r.t. points and add (segmentation/modules/repsurface_utils.py:266-270 in one launch each way)."""
-    return _ThreeInterpolateAddRelu.apply(points, idx, weight, add)
+    return _ThreeInterpolateAddRelu.apply(points, idx, weight, add, csr)

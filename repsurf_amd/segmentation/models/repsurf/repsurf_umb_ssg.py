@@ -65,7 +65,7 @@ class Model(nn.Module):
             offsets.append(g.new_offset)
         fps = []
         for fine, coarse in ((3, 4), (2, 3), (1, 2), (0, 1)):          # fp4, fp3, fp2, fp1
-            fps.append(SurfaceFeaturePropagationCD.geometry(centers[fine], offsets[fine], centers[coarse], offsets[coarse]))
+            fps.append(SurfaceFeaturePropagationCD.geometry(centers[fine], offsets[fine], centers[coarse], offsets[coarse], self.training))
         moments = _mlp.umbrella_moments(feat.reshape(-1, 10)) if (self.training and feat.is_cuda and _mlp.umbrella_moments_wanted(2)) else None
         return SegGeoState(feat, stages, fps, moments)
 
@@ -118,8 +118,8 @@ class SegGeoState:
             out += [t for t in (g.fps_idx, g.new_center, g.group_idx) if t is not None]
             if g.csr is not None:
                 out += list(g.csr)
-        for idx, w in self.fps:
-            out += [idx, w]
+        for f in self.fps:
+            out += [f[0], f[1]] + (list(f[2]) if (len(f) > 2 and f[2] is not None) else [])
         return out
 
     def clone(self):
@@ -127,7 +127,8 @@ class SegGeoState:
         return SegGeoState(self.feat.clone(),
                            [StageGeometry(None if g.fps_idx is None else g.fps_idx.clone(), g.new_center.clone(), g.new_offset,
                                           g.group_idx.clone(), None if g.csr is None else tuple(t.clone() for t in g.csr)) for g in self.stages],
-                           [(i.clone(), w.clone()) for i, w in self.fps], None if self.moments is None else self.moments.clone())
+                           [(f[0].clone(), f[1].clone(), None if (len(f) < 3 or f[2] is None) else tuple(t.clone() for t in f[2])) for f in self.fps],
+                           None if self.moments is None else self.moments.clone())
 
     def copy_(self, other):
         for d, s_ in zip(self.tensors(), other.tensors()):

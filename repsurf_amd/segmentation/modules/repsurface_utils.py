@@ -14,10 +14,17 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from repsurf_amd import mlp as _mlp
 from repsurf_amd import ops, rng
 from modules.pointops.functions import pointops
 from modules.polar_utils import xyz2sphere
+
+
+# The interpolation's backward as a gather over ops.inverse_index (no atomics, bit-reproducible gradients): measured level with the
+# atomic scatter inside the step (3.515 against 3.510 ms: every masked-gradient row is read three times) -- an option, off by default
+INTERP_GATHER = os.environ.get("REPSURF_INTERP_GATHER", "0") != "0"
 
 
 class StageGeometry:
@@ -206,10 +213,13 @@ class SurfaceFeaturePropagationCD(nn.Module):
             last = width
 
     @staticmethod
-    def geometry(xyz1, offset1, xyz2, offset2):
-        """3 nearest coarse rows of every fine row + inverse-distance weights (reference :261-265): coordinates only."""
+    def geometry(xyz1, offset1, xyz2, offset2, training=False):
+        """3 nearest coarse rows of every fine row + inverse-distance weights (reference :261-265): coordinates only.
+        training: also the inverse of the index (ops.inverse_index: the fine rows that read each coarse row) -- the interpolation's
+        backward then gathers; third element of the result (None when it cannot be built)."""
         idx, d2 = ops.knnquery_offset(3, xyz2, xyz1, offset2, offset1)
-        return idx, ops.interp_weights(d2)
+        csr = ops.inverse_index(idx, 3, offset1, offset2) if (training and xyz1.is_cuda and INTERP_GATHER) else None
+        return idx, ops.interp_weights(d2), csr
 
     def forward(self, pos_feat_off1, pos_feat_off2, geometry=None, lazy_out=False):
         """lazy_out (round 4): return the last layer's raw output + BatchNorm coefficients (mlp_hip.LazyRows) instead of the activated
@@ -217,16 +227,18 @@ class SurfaceFeaturePropagationCD(nn.Module):
         be such an object."""
         xyz1, points1, offset1 = pos_feat_off1      # fine:   (N,3), (N,C)|None, (B,)
         xyz2, points2, offset2 = pos_feat_off2      # coarse: (M,3), (M,C) | LazyRows, (B,)
-        idx, weight = geometry if geometry is not None else self.geometry(xyz1, offset1, xyz2, offset2)
+        geometry = geometry if geometry is not None else self.geometry(xyz1, offset1, xyz2, offset2, self.training and torch.is_grad_enabled())
+        idx, weight = geometry[0], geometry[1]
+        csr = geometry[2] if len(geometry) > 2 else None
         if self.skip and _mlp.fp_front_usable(self.mlp_f0, self.norm_f0, self.mlp_s0, self.norm_s0):
             # both Linear + BatchNorm pairs, the interpolation, the skip connection and the ReLU as one node: the BatchNorms are
             # applied inside the interpolation launch (round 4)
-            new_points = _mlp.fp_front(points2, points1, idx, weight, self.mlp_f0, self.norm_f0, self.mlp_s0, self.norm_s0)
+            new_points = _mlp.fp_front(points2, points1, idx, weight, self.mlp_f0, self.norm_f0, self.mlp_s0, self.norm_s0, csr=csr)
             return row_mlp(new_points, self.mlp_convs, self.mlp_bns, lazy_out=lazy_out)
         points2 = row_mlp(points2, [self.mlp_f0], [self.norm_f0], relu_last=False)
         skip = row_mlp(points1, [self.mlp_s0], [self.norm_s0], relu_last=False).unsqueeze(0) if self.skip else None
         # interpolation + skip connection + ReLU (reference :266-270) in one launch forward, one backward
-        new_points = ops.three_interpolate_add_relu(points2.unsqueeze(0), idx.unsqueeze(0), weight.unsqueeze(0), skip).squeeze(0)
+        new_points = ops.three_interpolate_add_relu(points2.unsqueeze(0), idx.unsqueeze(0), weight.unsqueeze(0), skip, csr=csr).squeeze(0)
         return row_mlp(new_points, self.mlp_convs, self.mlp_bns, lazy_out=lazy_out)
 
 

@@ -596,7 +596,7 @@ def test_interpolation_with_skip_and_relu_in_one_launch():
 
 
 @pytest.mark.parametrize("n,m,c1,c2,c", [(4096, 1024, 32, 64, 128), (1000, 333, 19, 70, 96), (65536, 16384, 64, 128, 256)])
-def test_feature_propagation_front_as_one_node(n, m, c1, c2, c, monkeypatch):
+def test_feature_propagation_front_as_one_node(ops, n, m, c1, c2, c, monkeypatch):
     """SurfaceFeaturePropagationCD with the fused front node (mlp_hip._FPFront: both Linear + BatchNorm pairs, interpolation, skip,
     ReLU -- the BatchNorms applied inside the interpolation launch) against the layer-by-layer route (REPSURF_FP_FRONT=0): the
     forward is the same arithmetic (bit-identical), the gradients agree to the noise of the different summation orders of the
@@ -618,7 +618,10 @@ def test_feature_propagation_front_as_one_node(n, m, c1, c2, c, monkeypatch):
             monkeypatch.setenv("REPSURF_FP_FRONT", env)
             for p in list(fp.parameters()) + [p1, p2]:
                 p.grad = None
-            out = fp([None, p1, None], [None, p2, None], geometry=(idx, w))
+            # the fused node also gets the inverse of the interpolation index: its backward gathers (no atomics); the layers scatter
+            csr = ops.inverse_index(idx, 3, ops.offsets_tensor([n], idx.device), ops.offsets_tensor([m], idx.device)) if tag == "node" else None
+            assert (csr is not None) == (tag == "node")
+            out = fp([None, p1, None], [None, p2, None], geometry=(idx, w, csr))
             (out * probe).sum().backward()
             res[tag] = (out.detach().clone(), [p.grad.detach().clone() for p in list(fp.parameters()) + [p1, p2]])
         assert torch.equal(res["node"][0], res["layers"][0])
@@ -664,3 +667,26 @@ def test_grouping_backward_as_a_gather(ops, aligned, cf):
     if cf:
         assert torch.allclose(res["gather"][2], res["scatter"][2], rtol=1e-5, atol=1e-5)
         assert torch.equal(res["gather"][2], res["gather_again"][2])
+
+
+@pytest.mark.parametrize("n,m,c", [(5000, 1250, 128), (777, 100, 19)])
+def test_interpolation_backward_as_a_gather(ops, n, m, c):
+    """relu(three_interpolate(points)) with ops.inverse_index of the index: the gradient of the coarse rows is GATHERED (written once
+    per element, ascending edges) -- equal to the atomic scatter within rounding, bit-equal between two runs."""
+    g = torch.Generator().manual_seed(n)
+    pts0 = torch.randn(1, m, c, generator=g).cuda()
+    idx = torch.randint(0, m, (1, n, 3), generator=g, dtype=torch.int32).cuda()
+    w = torch.rand(1, n, 3, generator=g).cuda()
+    w = (w / w.sum(2, keepdim=True)).contiguous()
+    probe = torch.randn(1, n, c, generator=g).cuda()
+    csr = ops.inverse_index(idx, 3, ops.offsets_tensor([n], idx.device), ops.offsets_tensor([m], idx.device))
+    assert csr is not None
+    res = {}
+    for tag in ("scatter", "gather", "gather_again"):
+        pts = pts0.clone().requires_grad_()
+        out = ops.three_interpolate_add_relu(pts, idx, w, None, csr=None if tag == "scatter" else csr)
+        (out * probe).sum().backward()
+        res[tag] = (out.detach().clone(), pts.grad.clone())
+    assert torch.equal(res["gather"][0], res["scatter"][0])
+    assert torch.allclose(res["gather"][1], res["scatter"][1], rtol=1e-5, atol=1e-5)
+    assert torch.equal(res["gather"][1], res["gather_again"][1])

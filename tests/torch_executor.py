@@ -74,7 +74,7 @@ def fp_front_usable(lin_f, bn_f, lin_s, bn_s):
     return True
 
 
-def fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s):
+def fp_front(points2, points1, idx, weight, lin_f, bn_f, lin_s, bn_s, csr=None):
     z2 = _bn(F.linear(points2, lin_f.weight, lin_f.bias), bn_f)
     z1 = _bn(F.linear(points1, lin_s.weight, lin_s.bias), bn_s)
     return F.relu((z2[idx.long()] * weight.unsqueeze(-1)).sum(1) + z1)
