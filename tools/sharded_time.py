@@ -27,6 +27,8 @@ def run(kind):
     for _ in range(40): f()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 40
     print(f"{kind:14s} {dt*1e3:.3f} ms/step  {32/dt:.0f} clouds/s", flush=True)
+    s = f = None          # (the graphs with recorded collectives go before the communicator)
 for k in sys.argv[1:] or ["pipe", "pipe_sharded", "two_graph"]:
     run(k)
-dist.destroy_process_group()
+from repsurf_amd import dist as rdist
+rdist.finish()
