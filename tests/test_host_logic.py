@@ -1,0 +1,54 @@
+"""Host-side bookkeeping of the round-4 geometry / decoder paths: what needs no device (CPU tensors only)."""
+import pytest
+import torch
+
+from repsurf_amd import mlp_hip, ops
+from repsurf_amd.geometry import StageGeometry
+
+
+def test_largest_cloud_comes_from_the_host_copy_only():
+    cpu = torch.device("cpu")
+    off = ops.offsets_tensor([3, 10, 12], cpu)
+    assert ops._largest_cloud(off) == 7
+    assert ops.host_offsets(off) == (3, 10, 12)
+    bare = torch.tensor([3, 10, 12], dtype=torch.int32)          # no host copy travels with it: unknown, never a device read
+    assert ops._largest_cloud(bare) == 0
+    off2 = ops.offsets_tensor([5], cpu)
+    assert ops._largest_cloud(off2) == 5
+
+
+def test_inverse_index_declines_without_known_cloud_sizes():
+    """ops.inverse_index builds nothing when the host does not hold the cloud sizes, or a cloud exceeds the 16 384 rows one
+    workgroup's counters hold: the backward of the gather then takes the atomic scatter."""
+    src = torch.zeros((8, 3), dtype=torch.int32)
+    bare = torch.tensor([8], dtype=torch.int32)
+    assert ops.inverse_index(src, 3, bare, bare) is None
+    big = ops.offsets_tensor([20000], torch.device("cpu"))
+    assert ops.inverse_index(src, 3, ops.offsets_tensor([8], torch.device("cpu")), big) is None
+
+
+def test_compact_index_carries_the_inverse_through_clone():
+    cpu = torch.device("cpu")
+    plain = ops.CompactIndex.empty(4, 8, cpu)
+    assert plain.meta.shape == (3, 32) and plain.pts is None and plain.csr(10) is None
+    ci = ops.CompactIndex.empty(4, 8, cpu, points=10)
+    assert ci.meta.shape == (4, 32) and ci.pts.numel() == 21 and ci.csr_rows.data_ptr() == ci.meta[3].data_ptr()
+    assert ci.csr(10) is None                                     # nothing built yet
+    ci.csr_ready = True
+    off, centre, rows = ci.csr(10)
+    assert off.numel() == 11 and centre.numel() == 10 and rows.numel() == 32
+    assert ci.csr(11) is None                                     # another number of source points: not this inverse
+    g = StageGeometry(torch.zeros((1, 4), dtype=torch.int32), torch.zeros((1, 4, 3)), torch.zeros((1, 4, 8), dtype=torch.int32),
+                      torch.zeros((1, 4), dtype=torch.int32), ci)
+    c = g.clone()
+    assert c.index.csr_ready and c.index.csr(10) is not None and c.index.pts.data_ptr() != ci.pts.data_ptr()
+    assert len(g.tensors()) == len(c.tensors()) == 8              # fps_idx, new_center, idx, cnt, offsets, mult, meta, pts
+
+
+def test_lazy_rows_is_a_training_time_handover():
+    lazy = mlp_hip.LazyRows()
+    assert lazy.y is None and lazy.vec is None and lazy.part is None
+    bn = torch.nn.BatchNorm1d(4)
+    assert mlp_hip.lazy_rows_usable([bn]) == mlp_hip.LAZY_ROWS
+    bn.eval()
+    assert not mlp_hip.lazy_rows_usable([bn])                     # running statistics: the layer-by-layer route
