@@ -9,7 +9,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
             -fhip-fp32-correctly-rounded-divide-sqrt -munsafe-fp-atomics -Wall -Wno-unused-function
 SRCS := $(CSRC)/rs_lib.cpp $(CSRC)/fps.hip $(CSRC)/ballquery.hip $(CSRC)/knn_umbrella.hip $(CSRC)/knn_wide.hip \
         $(CSRC)/group.hip $(CSRC)/interp.hip $(CSRC)/seg_geom.hip $(CSRC)/scene_knn.hip $(CSRC)/grid_knn.hip $(CSRC)/mlp.hip $(CSRC)/umbrella_mlp.hip $(CSRC)/umbrella_mfma.hip $(CSRC)/head.hip $(CSRC)/adam.hip
-OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS)) build/mlp_bf16.hip.o build/mlp_sb.hip.o
+OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS)) build/mlp_bf16.hip.o build/mlp_sb.hip.o build/mlp_split.hip.o
 
 all: $(LIBDIR)/librepsurf_hip.so oracle
 
@@ -17,7 +17,7 @@ build/%.o: $(CSRC)/% $(CSRC)/rs_common.h $(CSRC)/umbrella_fan.h include/repsurf_
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
-# mlp.hip is three translation units (fp32 entry points / the two bf16 ones / their bf16-storage instances): they compile
+# mlp.hip is four translation units (fp32 entry points / the two bf16 ones / their bf16-storage instances / the split-product ones): they compile
 # side by side
 build/mlp.hip.o: HIPFLAGS += -DRS_MLP_TU=0
 build/mlp_bf16.hip.o: $(CSRC)/mlp.hip $(CSRC)/rs_common.h include/repsurf_hip.h
@@ -26,6 +26,10 @@ build/mlp_bf16.hip.o: $(CSRC)/mlp.hip $(CSRC)/rs_common.h include/repsurf_hip.h
 build/mlp_sb.hip.o: $(CSRC)/mlp.hip $(CSRC)/rs_common.h include/repsurf_hip.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -DRS_MLP_TU=3 -x hip -c $< -o $@
+# unit 4: the fp32 product as six bf16 MFMAs over three-part operands (the default of the tiled kernels; RS_GEMM_SPLIT3=0: fp32 MFMAs)
+build/mlp_split.hip.o: $(CSRC)/mlp.hip $(CSRC)/rs_common.h include/repsurf_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -DRS_MLP_TU=4 -x hip -c $< -o $@
 
 $(LIBDIR)/librepsurf_hip.so: $(OBJS)
 	@mkdir -p $(LIBDIR)

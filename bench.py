@@ -413,6 +413,14 @@ def roofline_from_profile(prof, timed_steps, dtype, in_graph=None):
             roofline = {"kernel": row["kernel"], "dims": row["dims"], "bound": "hbm", "achieved": round(ach, 2),
                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5)}
         roofline["avg_launch_us"] = round(row["avg_us"], 2)
+        if row["unit"] == "flops" and dtype == "fp32" and mlp_hip_split3():
+            # the product is fp32 (error against fp64 = the fp32 MFMA's, profiles/r04/gemm_split3_ab.txt) but EXECUTED as six bf16 MFMAs
+            # over three-part operands: `frac` prices the algorithmic fp32 flops against the fp32 matrix peak, this entry the
+            # executed instructions against the bf16 one
+            roofline["mfma_pipe"] = {"instructions": "6 x v_mfma_f32_32x32x16_bf16 per 16 k (operands as three bf16 parts, fp32 accumulation); "
+                                                     "RS_GEMM_SPLIT3=0: 8 x v_mfma_f32_32x32x2_f32",
+                                     "executed_tflops": round(6 * ach, 1), "bf16_peak": PEAK_BF16_MFMA_TF,
+                                     "frac_of_bf16_peak": round(6 * ach / PEAK_BF16_MFMA_TF, 4)}
         if "eager_avg_us" in row:
             roofline["timed"] = ("avg_launch_us: inside a replayed hipGraph -- this class's launches of one recorded step, ten copies per graph, back to "
                                  "back, 20 replays between two HIP events (gemm_family_in_graph; rocprofv3 of the replayed step: profiles/r04/); "
@@ -453,6 +461,16 @@ def roofline_from_profile(prof, timed_steps, dtype, in_graph=None):
                 "eager": {"achieved": eager["achieved"], "frac": eager["frac"], "ms_per_step": eager["ms_per_step"],
                           "timed": "sum of per-launch HIP events of the eager pass"}}
     return roofline, table
+
+
+def mlp_hip_split3():
+    from repsurf_amd import mlp_hip
+    return mlp_hip.gemm_split3()
+
+
+GEMM_PRODUCTS = {True: "fp32 products as six bf16 MFMAs over three-part operands (fp32 tensors / prologues / accumulation / BatchNorm sums; error against "
+                       "fp64 equal to the fp32 MFMA's: profiles/r04/gemm_split3_ab.txt; RS_GEMM_SPLIT3=0 runs the fp32 MFMAs)",
+                 False: "v_mfma_f32_32x32x2_f32 (RS_GEMM_SPLIT3=0)"}
 
 
 def seg_geometry_lines(coord, offset):
@@ -653,6 +671,7 @@ def main_seg(args):
                "config": {"workload": f"configs[3]: RepSurf-U S3DIS segmentation (repsurf_umb_ssg), B={clouds}x{pts}x6 per GPU, {args.dtype}, "
                                       f"encoder + FP decoder + classifier, fwd+CE+bwd" + ("" if args.no_optim else "+Adam step"),
                           "global_batch": clouds * world, "points": pts, "parallelism": f"dp{world}", "launch": mode,
+                          "gemm_products": GEMM_PRODUCTS[mlp_hip_split3()] if args.dtype == "fp32" else "bf16 operands",
                           "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5)},
                "roofline": roofline, "fps_us_per_pick": fps_line, "knn": knn_line, "cpu_baseline": cpu}
         if cpu:
@@ -860,6 +879,7 @@ def main():
                                       + ("" if args.no_optim else "+Adam step"),
                           "global_batch": args.batch * world, "points": args.points,
                           "parallelism": f"dp{world}", "mlp_backend": "hip", "launch": mode,
+                          "gemm_products": GEMM_PRODUCTS[mlp_hip_split3()] if args.dtype == "fp32" else "bf16 operands",
                           "grouped_rows": ("compacted: distinct ball-query slots only (exact; DESIGN 6)" if mlp.COMPACT_GROUPS else
                                            "dense: every ball-query slot (REPSURF_COMPACT=0)"),
                           "distinct_slot_fraction_sa1_sa2": distinct_slot_fraction(points),

@@ -347,6 +347,15 @@ typedef struct rs_mlp_epilogue {
  * host; `rows` is then the capacity of the buffers. */
 int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
                      const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream);
+/* How rs_mlp_gemm_rows / rs_mlp_wgrad form their fp32 products on the tiled MFMA kernels (round 4).  1 (default; environment
+ * RS_GEMM_SPLIT3=0 selects 0, read once per process): every operand value -- after its fp32 prologue -- is committed to LDS as
+ * three bf16 parts h + m + l (each the nearest-even bf16 of what the parts before it left: 24 significant bits together) and a
+ * product is six v_mfma_f32_32x32x16_bf16 (hh, hm, mh, hl, lh, mm) accumulated in fp32: 192 matrix-pipe cycles per 16 k against
+ * the 512 of eight v_mfma_f32_32x32x2_f32, error against an fp64 product equal to the fp32 MFMA's (profiles/r04/gemm_split3_ab.txt;
+ * the two-part / three-product form misses the 1e-5 bound: tools/probes/bf16_split_accuracy.py).  0: v_mfma_f32_32x32x2_f32.
+ * Tensors, prologues, epilogues, accumulation and BatchNorm sums are fp32 either way; the row GEMM uses it for every launch of the
+ * tiled kernel with vector operands, the weight gradient for products of up to 64 columns of Q (RS_WGRAD_SPLIT3_WIDE=1: all). */
+int rs_mlp_gemm_split3(void);
 
 /* Mixed precision (BASELINE configs[4]: "bf16 mixed precision on CDNA4 MFMA for shared MLPs"): the same contract
  * and the same fp32 tensors in HBM; the operand E (after its fp32 prologue) and the weights are rounded to bf16

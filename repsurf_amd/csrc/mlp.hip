@@ -33,12 +33,19 @@
 //                  call marks tensors as bf16).  Which tensor of a launch is bf16 is a function of the operand mode, fixed at
 //                  compile time (sb_a / sb_b below): run-time flags in the load path cost 10 % of the bf16 step time, the
 //                  halved bytes win back 15 %;
+//   RS_MLP_TU = 4  (round 4; RS_GEMM_SPLIT3=0 switches it off) the fp32 product on the bf16 matrix pipe: every
+//                  operand value is committed to LDS as THREE bf16 parts h + m + l (each the nearest-even bf16 of what the parts
+//                  before it left: 24 significant bits together) and a product is six v_mfma_f32_32x32x16_bf16 -- hh, hm, mh, hl,
+//                  lh, mm -- with fp32 accumulation: error below the fp32 MFMA's own (tools/probes/bf16_split_accuracy.py: 5.7e-7
+//                  max against 1.3e-6 on a K = 512 layer; the usual two-part / three-product form is at 1.7e-5, outside the 1e-5
+//                  bound), 192 matrix-pipe cycles per 16 k against 512.  rs_sp_* : reached through the fp32 entry points of unit 0
+//                  for the launches that would take the tiled MFMA kernels;
 //   RS_MLP_TU = 2  (default, experiment builds of tools/build_exp.sh) units 0 + 1 in one.
 #ifndef RS_MLP_TU
 #define RS_MLP_TU 2
 #endif
 #define RS_TU_HAS_BF16 (RS_MLP_TU != 0)                         /* BF = true instances */
-#define RS_TU_BF16_ONLY (RS_MLP_TU == 1 || RS_MLP_TU == 3)      /* no fp32 entry points, no pooling / packing / BatchNorm kernels */
+#define RS_TU_BF16_ONLY (RS_MLP_TU == 1 || RS_MLP_TU == 3 || RS_MLP_TU == 4)      /* no fp32 entry points, no pooling / packing / BatchNorm kernels */
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -49,6 +56,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float pack_bf16(float lo, float hi) {
   const f32x2 f = {lo, hi};
   return __builtin_bit_cast(float, __builtin_convertvector(f, bf16x2));
+}
+
+// unit 4: x0, x1 -> the three dwords (bf16 pairs) of their parts.  The subtractions are exact (a bf16 of x shares x's exponent range),
+// so h + m + l differs from x by at most the last rounding: 2^-8 of 2^-16 |x|.
+constexpr bool RS_SPLIT = RS_MLP_TU == 4;
+__device__ __forceinline__ void split_bf16(float x0, float x1, float (&d)[3]) {
+  d[0] = pack_bf16(x0, x1);
+  unsigned u = __float_as_uint(d[0]);
+  float r0 = x0 - __uint_as_float(u << 16), r1 = x1 - __uint_as_float(u & 0xffff0000u);
+  d[1] = pack_bf16(r0, r1);
+  u = __float_as_uint(d[1]);
+  r0 -= __uint_as_float(u << 16);
+  r1 -= __uint_as_float(u & 0xffff0000u);
+  d[2] = pack_bf16(r0, r1);
 }
 
 // ---- on-the-fly row operands -----------------------------------------------------------------
@@ -376,8 +397,11 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   constexpr int W_VECS = BN / 32;                           // float4 (4 k of one output column) per thread and chunk
   constexpr int PLANE_W = BF ? BN * 4 + 16 : WStage<BN>::PLANE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *As0 = smem, *As1 = smem + AStage<BM>::SIZE;
-  float *Ws0 = smem + 2 * AStage<BM>::SIZE, *Ws1 = Ws0 + WStage<BN>::SIZE;
+  constexpr int PARTS = (BF && RS_SPLIT) ? 3 : 1;         // unit 4: three bf16 parts per value, each a stage of 4 planes
+  constexpr int PART_A = 4 * PLANE_A, PART_W = 4 * PLANE_W;
+  constexpr int A_STAGE = PARTS == 3 ? 3 * PART_A : AStage<BM>::SIZE, W_STAGE = PARTS == 3 ? 3 * PART_W : WStage<BN>::SIZE;
+  float *As0 = smem, *As1 = smem + A_STAGE;
+  float *Ws0 = smem + 2 * A_STAGE, *Ws1 = Ws0 + W_STAGE;
   static_assert(!WS || BM == 64, "wave specialisation is built for the 64-row tiles (direct epilogue)");
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
 #ifdef RS_EXP_WS_LOADERS_LAST
@@ -444,6 +468,16 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       op_finish<V, MODE>(E, coef[S], araw[S][p], r, kok, v);
       if constexpr (BF) {                                     // k = a_kq .. a_kq + V - 1 -> plane k >> 3, dword (k & 7) >> 1
         float *b = As + (a_kq >> 3) * PLANE_A + rl * 4 + ((a_kq & 7) >> 1);
+        if constexpr (PARTS == 3) {
+          float d0[3], d1[3];
+          split_bf16(v[0], v[1], d0);
+          if constexpr (V == 4) split_bf16(v[2], v[3], d1);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            if constexpr (V == 4) *reinterpret_cast<float2 *>(b + q * PART_A) = make_float2(d0[q], d1[q]);
+            else b[q * PART_A] = d0[q];
+          }
+        } else
         if constexpr (V == 4) *reinterpret_cast<float2 *>(b) = make_float2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
         else *b = pack_bf16(v[0], v[1]);
       } else {
@@ -457,7 +491,14 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
     for (int p = 0; p < W_VECS; ++p) {
       const int nl = p * 32 + w_n;
       const float v[4] = {wraw[S][p].x, wraw[S][p].y, wraw[S][p].z, wraw[S][p].w};
-      if constexpr (BF)
+      if constexpr (PARTS == 3) {
+        float d0[3], d1[3];
+        split_bf16(v[0], v[1], d0);
+        split_bf16(v[2], v[3], d1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          *reinterpret_cast<float2 *>(Ws + q * PART_W + (w_kq >> 3) * PLANE_W + nl * 4 + ((w_kq & 7) >> 1)) = make_float2(d0[q], d1[q]);
+      } else if constexpr (BF)
         *reinterpret_cast<float2 *>(Ws + (w_kq >> 3) * PLANE_W + nl * 4 + ((w_kq & 7) >> 1)) =
             make_float2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
       else
@@ -476,7 +517,29 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
 
   // MFMAs of one 32-deep chunk staged at (As, Ws) into acc[]
   auto mma = [&](f32x16 (&acc)[CT], const float *As, const float *Ws, int ch) {
-      if constexpr (BF) {
+      if constexpr (PARTS == 3) {
+        // per step: the three parts of both operands (3 + 3 CT ds_read_b128), then 6 x CT MFMAs, smallest terms first, the column
+        // tiles alternating (independent accumulators back to back)
+        const float *ap = As + lk * PLANE_A + (wave_r * 32 + lrow) * 4;
+        const float *bp = Ws + lk * PLANE_W + (wave_c * CT * 32 + lrow) * 4;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          float4 a3[3], b3[3][CT];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            a3[q] = *reinterpret_cast<const float4 *>(ap + q * PART_A + 2 * st * PLANE_A);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) b3[q][c] = *reinterpret_cast<const float4 *>(bp + q * PART_W + 2 * st * PLANE_W + c * 128);
+          }
+          constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // lh, hl, mm, mh, hm, hh
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+              acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a3[TA[t]]),
+                                                               __builtin_bit_cast(bf16x8, b3[TB[t]][c]), acc[c], 0, 0, 0);
+        }
+      } else if constexpr (BF) {
         // both steps' fragments first (2 + 2 CT ds_read_b128), then 2 x CT MFMAs; k beyond kdim was committed as zero
         const float *ap = As + lk * PLANE_A + (wave_r * 32 + lrow) * 4;
         const float *bp = Ws + lk * PLANE_W + (wave_c * CT * 32 + lrow) * 4;
@@ -990,7 +1053,10 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
   constexpr int P_RPP = GM_THREADS / P_TPR;                   // rows per pass (P_TPR <= 256 always)
   constexpr int Q_RPP = (GM_THREADS / Q_TPR) > 0 ? (GM_THREADS / Q_TPR) : 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *Ps0 = smem, *Ps1 = smem + WG_BR * BNN, *Qs0 = smem + 2 * WG_BR * BNN, *Qs1 = Qs0 + WG_BR * BKK;
+  constexpr int PARTS = (BF && RS_SPLIT) ? 3 : 1;         // unit 4: a part = 16 row pairs x columns dwords
+  constexpr int PART_P = (WG_BR / 2) * BNN, PART_Q = (WG_BR / 2) * BKK;
+  constexpr int P_STAGE = PARTS == 3 ? 3 * PART_P : WG_BR * BNN, Q_STAGE = PARTS == 3 ? 3 * PART_Q : WG_BR * BKK;
+  float *Ps0 = smem, *Ps1 = smem + P_STAGE, *Qs0 = smem + 2 * P_STAGE, *Qs1 = Qs0 + Q_STAGE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WK, wk = wave % WK;
   const int n0 = blockIdx.y * BNN, k0 = blockIdx.z * BKK;
@@ -1047,6 +1113,19 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
         __attribute__((aligned(16))) float v0[VP], v1[VP], d[VP];
         op_finish<VP, PM>(P, pcoef, praw[2 * u], r0 + 2 * t, pc_ok && r0 + 2 * t < rend, v0);
         op_finish<VP, PM>(P, pcoef, praw[2 * u + 1], r0 + 2 * t + 1, pc_ok && r0 + 2 * t + 1 < rend, v1);
+        if constexpr (PARTS == 3) {
+          __attribute__((aligned(16))) float d3[3][VP];
+#pragma unroll
+          for (int i = 0; i < VP; ++i) {
+            float e[3];
+            split_bf16(v0[i], v1[i], e);
+            d3[0][i] = e[0]; d3[1][i] = e[1]; d3[2][i] = e[2];
+          }
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            *reinterpret_cast<typename VecT<VP>::F *>(Ps + q * PART_P + t * BNN + p_c) = *reinterpret_cast<typename VecT<VP>::F *>(d3[q]);
+          continue;
+        }
 #pragma unroll
         for (int i = 0; i < VP; ++i) d[i] = pack_bf16(v0[i], v1[i]);
         *reinterpret_cast<typename VecT<VP>::F *>(Ps + t * BNN + p_c) = *reinterpret_cast<typename VecT<VP>::F *>(d);
@@ -1058,6 +1137,19 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
           __attribute__((aligned(16))) float v0[VQ], v1[VQ], d[VQ];
           op_finish<VQ, QM>(Q, qcoef, qraw[2 * u], r0 + 2 * t, qc_ok && r0 + 2 * t < rend, v0);
           op_finish<VQ, QM>(Q, qcoef, qraw[2 * u + 1], r0 + 2 * t + 1, qc_ok && r0 + 2 * t + 1 < rend, v1);
+          if constexpr (PARTS == 3) {
+            __attribute__((aligned(16))) float d3[3][VQ];
+#pragma unroll
+            for (int i = 0; i < VQ; ++i) {
+              float e[3];
+              split_bf16(v0[i], v1[i], e);
+              d3[0][i] = e[0]; d3[1][i] = e[1]; d3[2][i] = e[2];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              *reinterpret_cast<typename VecT<VQ>::F *>(Qs + q * PART_Q + t * BKK + q_c) = *reinterpret_cast<typename VecT<VQ>::F *>(d3[q]);
+            continue;
+          }
 #pragma unroll
           for (int i = 0; i < VQ; ++i) d[i] = pack_bf16(v0[i], v1[i]);
           *reinterpret_cast<typename VecT<VQ>::F *>(Qs + t * BKK + q_c) = *reinterpret_cast<typename VecT<VQ>::F *>(d);
@@ -1102,7 +1194,37 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
     RS_T(2);
     if (r0 + rstep < rend) prefetch(r0 + rstep, -1);
     RS_T(3);
-    if constexpr (BF) {
+    if constexpr (PARTS == 3) {
+      // per step: the three parts of every P / Q tile column, then 6 x TN x TK MFMAs (smallest terms first)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const float *pp = Ps + (4 * (2 * st + lr)) * BNN + wn * TN * 32 + lcol;
+        const float *qp = Qs + (4 * (2 * st + lr)) * BKK + wk * TK * 32 + lcol;
+        float4 pa[3][TN], qb[3][TK];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int a = 0; a < TN; ++a) {
+            const float *x = pp + q * PART_P + a * 32;
+            pa[q][a] = make_float4(x[0], x[BNN], x[2 * BNN], x[3 * BNN]);
+          }
+#pragma unroll
+          for (int b = 0; b < TK; ++b) {
+            const float *x = qp + q * PART_Q + b * 32;
+            qb[q][b] = make_float4(x[0], x[BKK], x[2 * BKK], x[3 * BKK]);
+          }
+        }
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // lh, hl, mm, mh, hm, hh
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TK; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[TA[t]][a]),
+                                                                 __builtin_bit_cast(bf16x8, qb[TB[t]][b]), acc[a][b], 0, 0, 0);
+      }
+    } else if constexpr (BF) {
       // lane (col, g = lr), step st: dwords t = 4 (2 st + g) .. + 3 of its column; all reads first, then 2 x TN x TK MFMAs
       float4 pa[2][TN], qb[2][TK];
 #pragma unroll
@@ -2134,7 +2256,8 @@ int check_operand(const char *who, const RowOperand *o, long long rows) {
 template <int BM, int BN, int V, bool BF>
 void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                    const float *w, int ldw, const Epilogue &ep) {
-  const size_t lds = sizeof(float) * (2 * AStage<BM>::SIZE + 2 * WStage<BN>::SIZE);
+  const size_t lds = (BF && RS_SPLIT) ? sizeof(float) * 2 * 12 * ((BM * 4 + 16) + (BN * 4 + 16))      // unit 4: three parts of four planes per operand and stage
+                                      : sizeof(float) * (2 * AStage<BM>::SIZE + 2 * WStage<BN>::SIZE);
   // wave-specialised instances (8 waves: 4 MFMA + 4 loader, see the kernel): fp32, 64-row tiles, vector operands
   static const int ws_on = env_int("RS_GEMM_WS", 0);       // measured slower on the fused backward instances and equal on the forward ones: DESIGN.md 5
   if constexpr (BM == 64 && !BF && V >= 2) {
@@ -2182,7 +2305,7 @@ void launch_gemm(bool bf, int v, dim3 grid, hipStream_t st, long long rows, cons
 template <int WN, int WK, int TN, int TK, int VP, int VQ, bool BF>
 void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
                     const RowOperand &Q, float *partial) {
-  const size_t lds = sizeof(float) * 2 * WG_BR * (WN * TN * 32 + WK * TK * 32);
+  const size_t lds = sizeof(float) * 2 * ((BF && RS_SPLIT) ? 3 * (WG_BR / 2) : WG_BR) * (WN * TN * 32 + WK * TK * 32);
 #define RS_WG(PM_, QM_) hipLaunchKernelGGL((wgrad_kernel<WN, WK, TN, TK, VP, VQ, PM_, QM_, BF>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, ncols, kcols, P, Q, partial)
 #define RS_WGQ(PM_) do { if (Q.mode == OPM_ID) RS_WG(PM_, OPM_ID); else if (Q.mode == OPM_RELU1) RS_WG(PM_, OPM_RELU1); else if (Q.mode == OPM_RELU2) RS_WG(PM_, OPM_RELU2); else RS_WG(-1, -1); } while (0)
   if (VP == 1 || VQ == 1) { RS_WG(-1, -1); return; }
@@ -2220,6 +2343,16 @@ void launch_wgrad(bool bf, int vp, int vq, dim3 grid, hipStream_t st, long long 
 }
 
 }  // namespace
+
+#if RS_MLP_TU == 0
+extern "C" int rs_sp_gemm_rows(long long, const int *, int, int, const rs_row_operand *, const float *, int, const rs_mlp_epilogue *, void *);
+extern "C" int rs_sp_wgrad(long long, const int *, int, int, const rs_row_operand *, const rs_row_operand *, float *, int, float *, void *);
+static bool split3_on() { static const int on = env_int("RS_GEMM_SPLIT3", 1); return on != 0; }
+extern "C" int rs_mlp_gemm_split3(void) { return split3_on() ? 1 : 0; }
+static bool split3_wide_on() { static const int on = env_int("RS_WGRAD_SPLIT3_WIDE", 0); return on != 0; }
+#elif RS_MLP_TU == 2
+extern "C" int rs_mlp_gemm_split3(void) { return 0; }      // experiment builds carry no unit 4
+#endif
 
 static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
                           const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
@@ -2298,6 +2431,10 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
     return RS_OK;
   }
   const int v = pick_vec(E, kdim);
+#if RS_MLP_TU == 0
+  // the launches of the tiled kernel with vector operands run unit 4's split-product instances (RS_GEMM_SPLIT3=0: the fp32 MFMA ones below)
+  if (!bf && split3_on() && v >= 2) return rs_sp_gemm_rows(rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
+#endif
   // tile height: 64-row tiles (2 x 2 waves) wherever the layout allows -- twice the workgroups, three per CU
   static const int bm64_on = env_int("RS_GEMM_BM64", 1);
   int bm = (bm64_on && cols > 32 && v >= 2 && (ep.pool_ns == 0 || pool32)) ? 64 : GM_BM;
@@ -2331,7 +2468,13 @@ extern "C" int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, i
   return gemm_rows_impl(false, rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
 }
 #endif
-#if RS_MLP_TU == 3
+#if RS_MLP_TU == 4
+// the split-product instances behind the fp32 entry point of unit 0 (not part of the ABI)
+extern "C" __attribute__((visibility("hidden"))) int rs_sp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
+                                                                     const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
+  return gemm_rows_impl(true, rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
+}
+#elif RS_MLP_TU == 3
 // bf16 activation storage: the instances of this unit behind the public entry point of unit 1 (not part of the ABI)
 extern "C" __attribute__((visibility("hidden"))) int rs_sb_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, const rs_row_operand *x,
                                                                      const float *w, int ldw, const rs_mlp_epilogue *epi, void *stream) {
@@ -2413,10 +2556,18 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
 #undef RS_WSQ
 #undef RS_WS
   } else
-  if (kcols > 64) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
-    launch_wgrad<2, 2, 2, 2>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, rows_dev, ncols, kcols, P, Q, partial);
-  } else if (kcols > 32) {   // 128 x 64: waves 4 x 1, 1 x 2 tiles
-    launch_wgrad<4, 1, 1, 2>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, partial);
+#if RS_MLP_TU == 0
+  // (the 128 x 128 output block of unit 4 needs 96 KB of LDS -- one workgroup per CU: 83 -> 126 us at 4096 x 1024 x 512 -- so products
+  // wider than 64 columns of Q stay on the fp32 instances unless RS_WGRAD_SPLIT3_WIDE=1 sends them through unit 4's 128 x 64 blocks)
+  if (!bf && split3_on() && vp >= 2 && vq >= 2 && (kcols <= 64 || split3_wide_on())) {
+    return rs_sp_wgrad(rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
+  } else
+#endif
+  if (kcols > 64 && !RS_SPLIT) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
+    if constexpr (!RS_SPLIT)
+      launch_wgrad<2, 2, 2, 2>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, rows_dev, ncols, kcols, P, Q, partial);
+  } else if (kcols > 32) {   // 128 x 64: waves 4 x 1, 1 x 2 tiles (unit 4: also the wider products, 64 columns of Q per workgroup)
+    launch_wgrad<4, 1, 1, 2>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 64)), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   } else {                   // 128 x 32: waves 4 x 1, 1 x 1 tile
     launch_wgrad<4, 1, 1, 1>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), 1), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   }
@@ -2436,7 +2587,12 @@ extern "C" int rs_mlp_wgrad(long long rows, const int *rows_dev, int ncols, int 
   return wgrad_impl(false, rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
 }
 #endif
-#if RS_MLP_TU == 3
+#if RS_MLP_TU == 4
+extern "C" __attribute__((visibility("hidden"))) int rs_sp_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
+                                                                 const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
+  return wgrad_impl(true, rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
+}
+#elif RS_MLP_TU == 3
 extern "C" __attribute__((visibility("hidden"))) int rs_sb_wgrad(long long rows, const int *rows_dev, int ncols, int kcols, const rs_row_operand *p,
                                                                  const rs_row_operand *q, float *partial, int chunks, float *dw, void *stream) {
   return wgrad_impl(true, rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);

@@ -319,6 +319,12 @@ def fwd_weights(w2ds, device):
     return outs
 
 
+def gemm_split3():
+    """True when the tiled MFMA kernels form fp32 products as six bf16 MFMAs over three-part operands (include/repsurf_hip.h:
+    rs_mlp_gemm_split3; the library's default, RS_GEMM_SPLIT3=0 selects the fp32 MFMAs)."""
+    return bool(_lib.load().rs_mlp_gemm_split3())
+
+
 def w_fwd(w2d):
     return fwd_weights([w2d], w2d.device)[0]
 

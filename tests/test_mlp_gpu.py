@@ -837,3 +837,52 @@ def test_constructor_mlp_on_the_matrix_pipe(layers, points, group):
         for pname, gt in ref[1].items():
             if pname != pre_bn_bias:
                 assert rel_l2(new[1][pname].double(), gt) < 3 * rel_l2(valu[1][pname].double(), gt) + 1e-5, pname
+
+
+def _products_against_fp64():
+    """One row GEMM (BatchNorm + ReLU prologue) and one weight gradient against fp64 products: (forward max, forward rms,
+    gradient rms relative to the gradient's rms)."""
+    from repsurf_amd import mlp_hip as H
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    rows, k, n = 4096, 512, 1024
+    x = torch.randn(rows, k, generator=g).to(dev)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+    s = (torch.rand(k, generator=g) + 0.5).to(dev)
+    t = (torch.randn(k, generator=g) * 0.1).to(dev)
+    out = torch.empty(rows, n, device=dev)
+    H.gemm_rows(rows, k, n, H.operand(H.OP_RELU1, x, k, s1=s, t1=t), H.w_fwd(w), H.Epilogue(bias=None, out=H._ptr(out), ldo=n, mode=H.EPI_STORE))
+    ref = torch.relu(x * s + t).double() @ w.double().t()
+    err = (out.double() - ref).abs()
+    p = torch.randn(rows, 64, generator=g).to(dev)
+    dw = H.wgrad(rows, 64, k, H.operand(H.OP_ID, p, 64), H.operand(H.OP_ID, x, k), dev)
+    dw64 = H.wgrad(rows, n, 64, H.operand(H.OP_ID, out, n), H.operand(H.OP_ID, p, 64), dev)      # <= 64 columns of Q: the split-product block
+    refw, refw64 = p.double().t() @ x.double(), out.double().t() @ p.double()
+    gw = max(((dw.double() - refw).pow(2).mean().sqrt() / refw.pow(2).mean().sqrt()).item(),
+             ((dw64.double() - refw64).pow(2).mean().sqrt() / refw64.pow(2).mean().sqrt()).item())
+    return err.max().item(), err.pow(2).mean().sqrt().item(), gw
+
+
+def test_gemm_products_are_fp32_accurate():
+    """The tiled kernels form their products as six bf16 MFMAs over three-part operands (include/repsurf_hip.h: rs_mlp_gemm_split3):
+    the result must be as close to the fp64 product as the fp32 MFMA's -- measured 3.8e-6 max / 2.5e-7 rms on outputs of rms 0.75
+    (fp32 MFMA: 3.6e-6 / 2.2e-7; the usual two-part, three-product split: 1.7e-5 / 3.1e-6, tools/probes/bf16_split_accuracy.py)."""
+    from repsurf_amd import mlp_hip as H
+    assert H.gemm_split3() == (__import__("os").environ.get("RS_GEMM_SPLIT3", "1") != "0")
+    fmax, frms, gw = _products_against_fp64()
+    assert fmax < 8e-6 and frms < 5e-7, (fmax, frms)
+    assert gw < 2e-6, gw
+
+
+def test_fp32_mfma_instances_still_pass():
+    """RS_GEMM_SPLIT3=0 (the fp32 MFMA instances of the same kernels, read once per process): this file's tests in a child process."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    if os.environ.get("RS_GEMM_SPLIT3", "1") == "0":
+        pytest.skip("this process already runs the fp32 MFMA instances")
+    env = dict(os.environ, RS_GEMM_SPLIT3="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_mlp_gpu.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
