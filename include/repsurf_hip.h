@@ -354,7 +354,8 @@ int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, co
  * the 512 of eight v_mfma_f32_32x32x2_f32, error against an fp64 product equal to the fp32 MFMA's (profiles/r04/gemm_split3_ab.txt;
  * the two-part / three-product form misses the 1e-5 bound: tools/probes/bf16_split_accuracy.py).  0: v_mfma_f32_32x32x2_f32.
  * Tensors, prologues, epilogues, accumulation and BatchNorm sums are fp32 either way; the row GEMM uses it for every launch of the
- * tiled kernel with vector operands, the weight gradient for products of up to 64 columns of Q (RS_WGRAD_SPLIT3_WIDE=1: all). */
+ * tiled kernel with vector operands, the weight gradient for every product of its tiled kernel (RS_WGRAD_SPLIT3_WIDE=0: only those of up to
+ * 64 columns of Q). */
 int rs_mlp_gemm_split3(void);
 
 /* Mixed precision (BASELINE configs[4]: "bf16 mixed precision on CDNA4 MFMA for shared MLPs"): the same contract

@@ -519,7 +519,10 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   auto mma = [&](f32x16 (&acc)[CT], const float *As, const float *Ws, int ch) {
       if constexpr (PARTS == 3) {
         // per step: the three parts of both operands (3 + 3 CT ds_read_b128), then 6 x CT MFMAs, smallest terms first, the column
-        // tiles alternating (independent accumulators back to back)
+        // tiles alternating (independent accumulators back to back).  (A wave with ONE column tile runs a chunk's 12 MFMAs as one
+        // dependent chain; sending the three small terms to a second accumulator, folded in once per tile, was measured: the
+        // kernels alone unchanged, the classification step 1.350 -> 1.364 ms -- 16 more live VGPRs, and the other waves of the SIMD
+        // already fill the chain's gaps.)
         const float *ap = As + lk * PLANE_A + (wave_r * 32 + lrow) * 4;
         const float *bp = Ws + lk * PLANE_W + (wave_c * CT * 32 + lrow) * 4;
 #pragma unroll
@@ -1056,7 +1059,11 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
   constexpr int PARTS = (BF && RS_SPLIT) ? 3 : 1;         // unit 4: a part = 16 row pairs x columns dwords
   constexpr int PART_P = (WG_BR / 2) * BNN, PART_Q = (WG_BR / 2) * BKK;
   constexpr int P_STAGE = PARTS == 3 ? 3 * PART_P : WG_BR * BNN, Q_STAGE = PARTS == 3 ? 3 * PART_Q : WG_BR * BKK;
-  float *Ps0 = smem, *Ps1 = smem + P_STAGE, *Qs0 = smem + 2 * P_STAGE, *Qs1 = Qs0 + Q_STAGE;
+  // unit 4, 128 x 128 output block: two stages of three parts would be 96 KB -- one workgroup per CU -- so it runs on ONE stage and
+  // a second barrier per 32 rows
+  constexpr bool ONE_STAGE = PARTS == 3 && BNN + BKK > 192;
+  float *Ps0 = smem, *Ps1 = ONE_STAGE ? smem : smem + P_STAGE;
+  float *Qs0 = smem + (ONE_STAGE ? 1 : 2) * P_STAGE, *Qs1 = ONE_STAGE ? Qs0 : Qs0 + Q_STAGE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WK, wk = wave % WK;
   const int n0 = blockIdx.y * BNN, k0 = blockIdx.z * BKK;
@@ -1188,6 +1195,7 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
   for (long long r0 = rbeg; r0 < rend; r0 += rstep, ++it) {
     float *Ps = (it & 1) ? Ps1 : Ps0;
     float *Qs = (it & 1) ? Qs1 : Qs0;
+    if (ONE_STAGE && it > 0) __syncthreads();                 // every wave is done with the fragments of the previous 32 rows
     commit(Ps, Qs, r0);
     RS_T(1);
     __syncthreads();
@@ -2305,7 +2313,8 @@ void launch_gemm(bool bf, int v, dim3 grid, hipStream_t st, long long rows, cons
 template <int WN, int WK, int TN, int TK, int VP, int VQ, bool BF>
 void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int ncols, int kcols, const RowOperand &P,
                     const RowOperand &Q, float *partial) {
-  const size_t lds = sizeof(float) * 2 * ((BF && RS_SPLIT) ? 3 * (WG_BR / 2) : WG_BR) * (WN * TN * 32 + WK * TK * 32);
+  const size_t lds = sizeof(float) * ((BF && RS_SPLIT && (WN * TN + WK * TK) * 32 > 192) ? 1 : 2) * ((BF && RS_SPLIT) ? 3 * (WG_BR / 2) : WG_BR) *
+                     (WN * TN * 32 + WK * TK * 32);
 #define RS_WG(PM_, QM_) hipLaunchKernelGGL((wgrad_kernel<WN, WK, TN, TK, VP, VQ, PM_, QM_, BF>), grid, dim3(GM_THREADS), lds, st, rows, rows_dev, ncols, kcols, P, Q, partial)
 #define RS_WGQ(PM_) do { if (Q.mode == OPM_ID) RS_WG(PM_, OPM_ID); else if (Q.mode == OPM_RELU1) RS_WG(PM_, OPM_RELU1); else if (Q.mode == OPM_RELU2) RS_WG(PM_, OPM_RELU2); else RS_WG(-1, -1); } while (0)
   if (VP == 1 || VQ == 1) { RS_WG(-1, -1); return; }
@@ -2349,7 +2358,7 @@ extern "C" int rs_sp_gemm_rows(long long, const int *, int, int, const rs_row_op
 extern "C" int rs_sp_wgrad(long long, const int *, int, int, const rs_row_operand *, const rs_row_operand *, float *, int, float *, void *);
 static bool split3_on() { static const int on = env_int("RS_GEMM_SPLIT3", 1); return on != 0; }
 extern "C" int rs_mlp_gemm_split3(void) { return split3_on() ? 1 : 0; }
-static bool split3_wide_on() { static const int on = env_int("RS_WGRAD_SPLIT3_WIDE", 0); return on != 0; }
+static bool split3_wide_on() { static const int on = env_int("RS_WGRAD_SPLIT3_WIDE", 2); return on != 0; }
 #elif RS_MLP_TU == 2
 extern "C" int rs_mlp_gemm_split3(void) { return 0; }      // experiment builds carry no unit 4
 #endif
@@ -2524,6 +2533,7 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
   const int vp = pick_vec(P, ncols), vq = pick_vec(Q, kcols);
   static const int small_on = env_int("RS_WGRAD_SMALL", 1);
   static const int wnarrow_on = env_int("RS_WGRAD_NARROW", 1);
+  static const int wide_form = env_int("RS_WGRAD_SPLIT3_WIDE", 2);      // (unit 4) 2: the 128 x 128 block on one LDS stage; 1: 128 x 64 blocks
   // (kcols <= 32 with <= 64 columns of P through this kernel -- the 32 / 64-column layers of the segmentation step's 524 288-row
   // stage, whose 32 x 32 / 64 x 32 products keep one or two of the tiled kernel's four waves on the matrix pipe -- was measured in
   // round 4: 3.72 against 3.67 ms per step; its one-float-per-lane loads cost more than the idle waves.)
@@ -2557,14 +2567,14 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
 #undef RS_WS
   } else
 #if RS_MLP_TU == 0
-  // (the 128 x 128 output block of unit 4 needs 96 KB of LDS -- one workgroup per CU: 83 -> 126 us at 4096 x 1024 x 512 -- so products
-  // wider than 64 columns of Q stay on the fp32 instances unless RS_WGRAD_SPLIT3_WIDE=1 sends them through unit 4's 128 x 64 blocks)
+  // (products wider than 64 columns of Q, RS_WGRAD_SPLIT3_WIDE: 2 (default) unit 4's 128 x 128 output block on ONE LDS stage -- two stages
+  // of three parts are 96 KB, one workgroup per CU: 83 -> 126 us at 4096 x 1024 x 512; one stage and a second barrier per 32 rows: 76 us,
+  // classification step 1.342 -> 1.298 ms; 1: unit 4's 128 x 64 blocks, 89 us; 0: the fp32 instances)
   if (!bf && split3_on() && vp >= 2 && vq >= 2 && (kcols <= 64 || split3_wide_on())) {
     return rs_sp_wgrad(rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
   } else
 #endif
-  if (kcols > 64 && !RS_SPLIT) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
-    if constexpr (!RS_SPLIT)
+  if (kcols > 64 && (!RS_SPLIT || wide_form == 2)) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
       launch_wgrad<2, 2, 2, 2>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   } else if (kcols > 32) {   // 128 x 64: waves 4 x 1, 1 x 2 tiles (unit 4: also the wider products, 64 columns of Q per workgroup)
     launch_wgrad<4, 1, 1, 2>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 64)), st, rows, rows_dev, ncols, kcols, P, Q, partial);

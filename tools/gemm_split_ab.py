@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """fp32 product as six bf16 MFMAs over three-part operands (unit 4 of csrc/mlp.hip, RS_GEMM_SPLIT3=1) against the fp32 MFMA
 instances: error against an fp64 product and time per launch at the step's shapes.  The switch is read once per process:
-    python tools/gemm_split_ab.py            # fp32 MFMA
-    RS_GEMM_SPLIT3=1 python tools/gemm_split_ab.py
+    RS_GEMM_SPLIT3=0 python tools/gemm_split_ab.py      # fp32 MFMA
+    python tools/gemm_split_ab.py                       # the default: six bf16 MFMAs over three-part operands
 (GPU box; tools/_r04_bb.sh runs both and the step A/B -> profiles/r04/gemm_split3_ab.txt)"""
 import os
 import sys
@@ -13,7 +13,7 @@ from repsurf_amd import mlp_hip as H
 from tools.gemm_bench import timeit
 
 dev = torch.device("cuda")
-tag = "split3 (6 x bf16 MFMA)" if os.environ.get("RS_GEMM_SPLIT3", "0") == "1" else "fp32 MFMA"
+tag = "split3 (6 x bf16 MFMA)" if H.gemm_split3() else "fp32 MFMA"
 
 
 def accuracy(rows, k, n):
