@@ -52,3 +52,40 @@ def test_lazy_rows_is_a_training_time_handover():
     assert mlp_hip.lazy_rows_usable([bn]) == mlp_hip.LAZY_ROWS
     bn.eval()
     assert not mlp_hip.lazy_rows_usable([bn])                     # running statistics: the layer-by-layer route
+
+
+def test_three_bf16_parts_carry_an_fp32_product():
+    """The arithmetic behind the split-product GEMMs (csrc/mlp.hip unit 4; include/repsurf_hip.h: rs_mlp_gemm_split3), restated in
+    numpy: x = h + m + l with every part the nearest-even bf16 of what the parts before it left.  Three parts reproduce x to fp32's
+    last bit or better, and the six kept products (hh, hm, mh, hl, lh, mm) give a K = 512 dot product that is as close to the
+    float64 one as a plain fp32 product; two parts / three products -- the usual bf16x3 -- miss the 1e-5 the north star allows."""
+    import importlib.util
+    import os
+    import numpy as np
+    from tests.conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bf16_split_accuracy", os.path.join(ROOT, "tools", "probes", "bf16_split_accuracy.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(4096) * np.exp(rng.uniform(-20, 20, 4096))).astype(np.float32)
+    h, m, l = probe.split(x, 3)
+    for part in (h, m, l):                                   # every part IS a bf16: the low 16 bits of its fp32 pattern are zero
+        assert not (part.view(np.uint32) & 0xFFFF).any()
+    back = (h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64))
+    assert np.all(np.abs(back - x.astype(np.float64)) <= np.abs(x.astype(np.float64)) * 2.0 ** -24)
+    a = np.maximum(rng.standard_normal((64, 512)).astype(np.float32), 0)
+    w = (rng.standard_normal((512, 48)) / np.sqrt(512)).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64)
+
+    def product(parts, terms):
+        pa, pw = probe.split(a, parts), probe.split(w, parts)
+        acc = np.zeros(ref.shape, np.float32)
+        for i, j in reversed(terms):
+            acc = acc + (pa[i] @ pw[j]).astype(np.float32)
+        return np.abs(acc - ref).max()
+
+    six = product(3, [(0, 0), (0, 1), (1, 0), (0, 2), (2, 0), (1, 1)])
+    three = product(2, [(0, 0), (0, 1), (1, 0)])
+    plain = np.abs(a @ w - ref).max()
+    assert six <= 2 * plain and six < 2e-6, (six, plain)
+    assert three > 5e-6, three                               # what the third part buys
