@@ -472,8 +472,14 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
           float d0[3], d1[3];
           split_bf16(v[0], v[1], d0);
           if constexpr (V == 4) split_bf16(v[2], v[3], d1);
+#ifdef RS_EXP_SP_ONE_STORE     // what-if build (timing only, wrong results): a third of the LDS writes, the split still computed
+          d0[0] += d0[1] + d0[2]; if constexpr (V == 4) d1[0] += d1[1] + d1[2];
+#endif
 #pragma unroll
           for (int q = 0; q < 3; ++q) {
+#ifdef RS_EXP_SP_ONE_STORE
+            if (q > 0) continue;
+#endif
             if constexpr (V == 4) *reinterpret_cast<float2 *>(b + q * PART_A) = make_float2(d0[q], d1[q]);
             else b[q * PART_A] = d0[q];
           }
@@ -495,9 +501,16 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         float d0[3], d1[3];
         split_bf16(v[0], v[1], d0);
         split_bf16(v[2], v[3], d1);
+#ifdef RS_EXP_SP_ONE_STORE
+        d0[0] += d0[1] + d0[2]; d1[0] += d1[1] + d1[2];
+#endif
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 3; ++q) {
+#ifdef RS_EXP_SP_ONE_STORE
+          if (q > 0) continue;
+#endif
           *reinterpret_cast<float2 *>(Ws + q * PART_W + (w_kq >> 3) * PLANE_W + nl * 4 + ((w_kq & 7) >> 1)) = make_float2(d0[q], d1[q]);
+        }
       } else if constexpr (BF)
         *reinterpret_cast<float2 *>(Ws + (w_kq >> 3) * PLANE_W + nl * 4 + ((w_kq & 7) >> 1)) =
             make_float2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
@@ -530,17 +543,30 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
           float4 a3[3], b3[3][CT];
 #pragma unroll
           for (int q = 0; q < 3; ++q) {
+#ifdef RS_EXP_SP_ONE_FRAG      // what-if build (timing only, wrong results): a third of the fragment reads
+            if (q > 0) { a3[q] = a3[0]; for (int c = 0; c < CT; ++c) b3[q][c] = b3[0][c]; continue; }
+#endif
             a3[q] = *reinterpret_cast<const float4 *>(ap + q * PART_A + 2 * st * PLANE_A);
 #pragma unroll
             for (int c = 0; c < CT; ++c) b3[q][c] = *reinterpret_cast<const float4 *>(bp + q * PART_W + 2 * st * PLANE_W + c * 128);
           }
           constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // lh, hl, mm, mh, hm, hh
 #pragma unroll
+#ifdef RS_EXP_SP_ONE_MFMA      // what-if build (timing only, wrong results): a sixth of the MFMAs, every fragment still read and consumed
+          for (int t = 5; t < 6; ++t)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+              float4 aa = a3[0], bb = b3[0][c];
+              aa.x += a3[1].x + a3[2].x; bb.x += b3[1][c].x + b3[2][c].x;
+              acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa), __builtin_bit_cast(bf16x8, bb), acc[c], 0, 0, 0);
+            }
+#else
           for (int t = 0; t < 6; ++t)
 #pragma unroll
             for (int c = 0; c < CT; ++c)
               acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a3[TA[t]]),
                                                                __builtin_bit_cast(bf16x8, b3[TB[t]][c]), acc[c], 0, 0, 0);
+#endif
         }
       } else if constexpr (BF) {
         // both steps' fragments first (2 + 2 CT ds_read_b128), then 2 x CT MFMAs; k beyond kdim was committed as zero
