@@ -677,8 +677,9 @@ def main_seg(args):
         if cpu:
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
         print(json.dumps(out), flush=True)
-    pstep = step = None          # (graphs with recorded collectives go before their communicator: repsurf_amd.dist.finish)
-    rdist.finish()
+    held = locals().get("pstep")
+    pstep = step = None
+    rdist.finish(held)           # close() the pipelined step (graphs with recorded collectives go before their communicator), then tear down
 
 
 def spawn_ranks(args):
@@ -706,7 +707,7 @@ def dry_run(args):
     rdist.init(backend=os.environ.get("REPSURF_DIST_BACKEND", "nccl" if cuda else "gloo"), device=device)
     t = torch.tensor([float(rank + 1)], device=device)
     if world > 1:
-        dist.all_reduce(t)
+        rdist.all_reduce(t)
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "requested": args.gpus, "rank_sum": float(t.item()),
                           "backend": dist.get_backend() if dist.is_initialized() else None}), flush=True)
@@ -890,8 +891,9 @@ def main():
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out), flush=True)
-    pstep = step = None          # (graphs with recorded collectives go before their communicator: repsurf_amd.dist.finish)
-    rdist.finish()
+    held = locals().get("pstep")
+    pstep = step = None
+    rdist.finish(held)           # close() the pipelined step (graphs with recorded collectives go before their communicator), then tear down
 
 
 def timed_step_count(args, step, fence, world, device, rdist):

@@ -45,6 +45,40 @@ def wrap(model, device=None):
         find_unused_parameters=False)
 
 
+def all_reduce(buf, op=None, group=None, async_op=False):
+    """The one way this package issues a collective on device memory.
+
+    HIP keeps, per event, the stream it was last recorded in, and hipEventQuery on an event whose stream is CAPTURING -- now,
+    not when the event was recorded -- fails with hipErrorCapturedEvent and invalidates the capture.  The RCCL process group's
+    watchdog thread polls the end event of every eager collective until a poll (every ~100 ms) finds it complete, and c10d runs a
+    synchronous collective on the caller's current stream: a warm-up all-reduce on the stream a step is captured on a few
+    milliseconds later made the watchdog throw in about one process in four (profiles/r05/sharded_abort_root_cause.txt; rounds 3-4
+    saw it as SIGABRT of the sharded-step tests and of destroy_process_group).  Hence:
+      * eager (the stream is not capturing): async_op=True -- the collective and its events live on c10d's internal stream,
+        which this package never captures -- and the caller's stream joins it through work.wait();
+      * capturing: a synchronous collective on the capturing stream; c10d does not hand captured work to the watchdog.
+    async_op=True returns something with wait(); eager sync calls have waited already and return None."""
+    if op is None:
+        op = dist.ReduceOp.SUM
+    cuda = buf.is_cuda and dist.get_backend(group) == "nccl"
+    if not cuda:                              # gloo: host-driven, nothing to capture and no device events
+        work = dist.all_reduce(buf, op=op, group=group, async_op=async_op)
+        return work if async_op else None
+    if torch.cuda.is_current_stream_capturing():
+        dist.all_reduce(buf, op=op, group=group, async_op=False)
+        return _Done() if async_op else None
+    work = dist.all_reduce(buf, op=op, group=group, async_op=True)
+    if async_op:
+        return work
+    work.wait()                               # stream-side join: the host does not block
+    return None
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
 def rank_seed(base, rank):
     """Distinct synthetic data / CPU-generator streams per rank (config 3: rank r uses seed base*8+r)."""
     return base * 8 + rank
@@ -56,7 +90,7 @@ def max_over_ranks(seconds, device=None):
     if world == 1:
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
@@ -68,7 +102,7 @@ def time_allreduce(numel, device, reps=10):
         return None
     buf = torch.zeros(numel, dtype=torch.float32, device=device)
     for _ in range(2):
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        all_reduce(buf)
     cuda = torch.device(device).type == "cuda"
     if cuda:
         torch.cuda.synchronize()
@@ -76,25 +110,35 @@ def time_allreduce(numel, device, reps=10):
     import time
     t0 = time.perf_counter()
     for _ in range(reps):
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        all_reduce(buf)
     if cuda:
         torch.cuda.synchronize()
     return max_over_ranks((time.perf_counter() - t0) / reps, device) * 1e6
 
 
-def barrier():
-    if dist.is_initialized():
-        dist.barrier()
+def barrier(group=None):
+    """Every rank has arrived AND this rank's device is idle.  Under RCCL: a 1-element all-reduce through `all_reduce` above (never
+    dist.barrier(): its collective would sit on the caller's stream) followed by a device synchronize."""
+    if not dist.is_initialized():
+        return
+    if dist.get_backend(group) == "nccl" and torch.cuda.is_available():
+        all_reduce(torch.zeros(1, device="cuda"), group=group)
+        torch.cuda.synchronize()
+    else:
+        dist.barrier(group)
 
 
-def finish():
-    """Tear the process group down.  The caller has dropped its step objects first: a hipGraph with recorded collectives that outlives
-    its communicator made destroy_process_group abort (seen once in three full test runs, with a 1-rank group); everything in
-    flight is drained and every rank has arrived before any rank starts."""
+def finish(*steps):
+    """Tear the process group down: graphs -> synchronize -> barrier -> destroy_process_group, in that order, for every caller
+    (tests and bench.py alike).  `steps`: the graphed steps still alive -- their close() releases the hipGraphs that hold recorded
+    collectives of this communicator before it goes."""
+    for s in steps:
+        if s is not None and hasattr(s, "close"):
+            s.close()
     if dist.is_initialized():
         import gc
         gc.collect()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()

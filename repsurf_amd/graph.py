@@ -11,6 +11,7 @@ import os
 
 import torch
 
+from . import dist as _rdist
 from . import head as _head
 from . import mlp_hip
 from . import rng
@@ -39,7 +40,7 @@ class GraphedStep:
         with self.draws:
             self.draws.begin_pass()
             self.draws.refill()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **_capture_mode()):
                 if record_calls:
                     from . import _lib
                     _lib.record_calls(True)
@@ -63,6 +64,11 @@ class GraphedStep:
         if self.optimizer is not None:
             self.optimizer.step()
         return loss
+
+    def close(self):
+        torch.cuda.synchronize()
+        self.graph = self.loss = None
+        torch.cuda.synchronize()
 
     def __call__(self):
         self.draws.refill()        # fresh FPS starts / normal flips, same CPU-generator order as eager
@@ -170,6 +176,7 @@ class PipelinedStep:
         self.draws = rng.StaticDraws(dev)
         self.main = torch.cuda.Stream()          # M
         self.side = torch.cuda.Stream()          # S
+        self.comm = torch.cuda.Stream() if sharded else None     # the early bucket's branch of the captured network graph
         self.main.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.main), self.draws:
             self.draws.begin_pass()
@@ -188,18 +195,13 @@ class PipelinedStep:
         self.side.wait_stream(self.main)
         torch.cuda.current_stream().wait_stream(self.main)
         torch.cuda.synchronize()
-        # With a process group alive, its watchdog thread polls the events of the collectives issued so far (the warm-up's
-        # all-reduces, the parameter broadcast): a poll that lands inside a capture in the default (global) error mode aborts
-        # the process (seen: a second PipelinedStep of one process crashed in the watchdog thread while the geometry graphs
-        # were being captured).  So every capture of a sharded step is thread-local, and the watchdog gets one poll period to
-        # retire what has already completed.
-        mode = {"capture_error_mode": "thread_local"} if sharded else {}
+        # With a process group alive, its watchdog thread polls the end events of the eager collectives issued so far while this
+        # thread captures.  Two rules keep that safe (root cause of the round-3/4 aborts: repsurf_amd.dist.all_reduce): no eager
+        # collective of this package ever runs on a stream that is captured later (they live on c10d's internal stream), and
+        # every capture made while a process group exists is thread-local, so what another thread does is not this capture's error.
+        mode = _capture_mode()
         if sharded and self.dist.is_initialized():
-            # every rank has finished its warm-up collectives before any rank starts capturing (no timing assumption: the device is
-            # idle -- synchronize above -- and the ranks meet on the host; what the watchdog still polls are COMPLETED events, which
-            # thread-local capture mode lets another thread query while this one captures)
-            self.dist.barrier(group)
-            torch.cuda.synchronize()
+            _rdist.barrier(group)      # every rank has finished its warm-up collectives before any rank starts capturing
         # geometry graphs and network graphs run concurrently: separate memory pools
         self.g_geo, self.g_net, self.loss = [], [], []
         for p in (0, 1):
@@ -252,11 +254,18 @@ class PipelinedStep:
         self.parity = 0
 
     def close(self):
-        """Detach from the model: the forward pre-hook of the two-bucket mode is bound to this step (a copy.deepcopy of the model,
-        or a second PipelinedStep on it, would carry / duplicate it).  The captured graphs stay valid but must not be replayed."""
+        """Detach from the model and release the captured graphs.  The forward pre-hook of the two-bucket mode is bound to this step
+        (a copy.deepcopy of the model, or a second PipelinedStep on it, would carry / duplicate it); the graphs of a sharded step
+        hold recorded collectives of the process group's communicator and must be gone, with the device idle, before another step
+        is built on that communicator or the communicator is destroyed (repsurf_amd.dist.finish calls this)."""
         if getattr(self, "_hook", None) is not None:
             self._hook.remove()
             self._hook = None
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self.g_net, self.g_geo, self.graph_opt, self.loss = [], [], None, []
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
     def _geometry(self, p):
         """geometry of the batch the NEXT call trains on (buffers 1 - p), as one serial chain"""
@@ -304,7 +313,16 @@ class PipelinedStep:
         mlp_hip.flush_reduces()                      # weight-gradient sums still riding with a later launch (owned_pass)
         self.grads.pack(0)
         if self.dist.is_initialized():
-            self._early_work = self.grads.all_reduce_mean(self.dist, self.group, bucket=0, async_op=True)
+            if torch.cuda.is_current_stream_capturing():
+                # a forked branch of the capture on this step's own stream: c10d's internal stream stays out of every capture
+                # (eager collectives keep their events there -- repsurf_amd.dist.all_reduce)
+                cur = torch.cuda.current_stream()
+                self.comm.wait_stream(cur)
+                with torch.cuda.stream(self.comm):
+                    self.grads.all_reduce_mean(self.dist, self.group, bucket=0)
+                self._early_work = _StreamJoin(self.comm)
+            else:
+                self._early_work = self.grads.all_reduce_mean(self.dist, self.group, bucket=0, async_op=True)
         return None
 
     def _collective_capturable(self):
@@ -430,14 +448,32 @@ class FlatGrads:
         buf = self.flat if bucket is None or len(self.buckets) == 1 else self.buckets[bucket]
         if dist.get_backend(group) == "nccl" and getattr(self, "_avg_ok", True):    # RCCL averages in the collective
             try:
-                return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+                return _rdist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
             except (RuntimeError, ValueError):           # a build without ncclAvg refuses at call time: sum and scale
                 self._avg_ok = False
-        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        work = _rdist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if not async_op:
             buf.div_(world)
             return None
         return _ScaledWork(work, buf, world)      # the mean is complete once the caller has waited
+
+
+class _StreamJoin:
+    """wait() orders the current stream after everything enqueued on `stream` so far (a captured branch rejoining its graph)"""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return True
+
+
+def _capture_mode():
+    """keyword arguments of every torch.cuda.graph(...) of this module: thread-local error mode whenever a process group (and
+    with it a watchdog thread that talks to the HIP runtime) exists"""
+    import torch.distributed as dist
+    return {"capture_error_mode": "thread_local"} if (dist.is_available() and dist.is_initialized()) else {}
 
 
 class _ScaledWork:
@@ -502,12 +538,12 @@ class ShardedGraphedStep:
         with self.draws:
             self.draws.begin_pass()
             self.draws.refill()
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, **_capture_mode()):
                 self.loss = self._fwd_bwd()
         self.graph_b = None
         if optimizer is not None:
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), **_capture_mode()):
                 optimizer.step()
         torch.cuda.synchronize()
 
@@ -523,6 +559,12 @@ class ShardedGraphedStep:
     def _reduce(self):
         if self.dist.is_initialized():
             self.grads.all_reduce_mean(self.dist, self.group)
+
+    def close(self):
+        """release the captured graphs with the device idle (before another step is built, or the process group destroyed)"""
+        torch.cuda.synchronize()
+        self.graph_a = self.graph_b = self.loss = None
+        torch.cuda.synchronize()
 
     def __call__(self):
         self.draws.refill()

@@ -233,6 +233,11 @@ _bad = {}
 def _bad_counter(device):
     key = str(torch.device(device))
     if key not in _bad:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # created inside a capture, the counter would live in the graph's pool and its zero fill would be replayed: every
+            # replay would reset it.  The graphed steps of this package warm up eagerly first.
+            raise RuntimeError("repsurf_amd.head: the first cross-entropy call on a device must run eagerly (one warm-up pass) "
+                               "before the step is captured into a hipGraph")
         _bad[key] = torch.zeros((1,), dtype=torch.int32, device=device)
     return _bad[key]
 

@@ -195,12 +195,46 @@ def sync_of(bn_mod):
     return dist, group, world
 
 
-def sync_partials(part, sync):
-    """Sum a partial-sum tensor over the ranks (in place); returns the factor the row count grows by."""
+_sync_mismatch = {}      # device -> int32 counter: SyncBatchNorm reductions whose ranks held DIFFERENT row counts
+
+
+def sync_row_mismatch_count(device=None):
+    """SyncBatchNorm reductions (since the process started) in which the ranks did not all hold the same number of rows.  The global
+    row count handed to the finalize kernels is rows x world -- exact for the equal shards of weak scaling (DistributedSampler +
+    drop_last), wrong for ragged ones -- so a non-zero count means the statistics of those layers were mis-normalised.  The check
+    rides in the reduction itself (sum rows, sum rows^2) and costs no host synchronisation; read this where the loss is read."""
+    if device is None:
+        return sum(int(t.item()) for t in _sync_mismatch.values())
+    t = _sync_mismatch.get(str(torch.device(device)))
+    return 0 if t is None else int(t.item())
+
+
+def sync_partials(part, sync, rows=None):
+    """Sum a partial-sum tensor (nblk, nstat, C) over the ranks, in place: row 0 ends up holding the sum over every rank's rows
+    and the other rows zero, so the finalize that adds the nblk rows sees the global sums.  Returns the factor the row count
+    grows by (world).  The collective's shape, (nstat * C + 2,), does not depend on nblk: ranks with different row counts (ragged
+    packed batches) have different nblk and an all-reduce of `part` itself would hang or corrupt; `rows` (this rank's
+    count) travels with the sums as (rows, rows^2), and world * sum rows^2 != (sum rows)^2 counts a mismatch
+    (sync_row_mismatch_count)."""
     if sync is None:
         return 1
     dist, group, world = sync
-    dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    from . import dist as _rdist
+    flat = part.sum(0).reshape(-1)
+    n = float(part.shape[0] if rows is None else rows)
+    buf = torch.cat([flat, torch.full((1,), n, dtype=part.dtype, device=part.device),
+                     torch.full((1,), n * n, dtype=part.dtype, device=part.device)])
+    _rdist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)      # (eager: c10d's own stream; captured: this stream)
+    part[1:].zero_()
+    part[0].copy_(buf[:-2].view_as(part[0]))
+    if rows is not None:
+        key = str(part.device)
+        if key not in _sync_mismatch:
+            if part.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("SyncBatchNorm: the first synchronized pass on a device must run eagerly (warm-up) before capture")
+            _sync_mismatch[key] = torch.zeros((1,), dtype=torch.int32, device=part.device)
+        bad = (buf[-1] * world - buf[-2] * buf[-2]).abs() > 0.5
+        _sync_mismatch[key].add_(bad.to(torch.int32))
     return world
 
 
@@ -384,7 +418,7 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
             pool = (ext, pos)
         gemm_rows(rows, kdim, cout, x_op, wk if wk is not None else w_fwd(w2d), epi, rows_dev)
         vec.sync = sync_of(bn_mod)
-        bn_rows = bn_rows * sync_partials(part, vec.sync)      # SyncBatchNorm: statistics over every rank's rows
+        bn_rows = bn_rows * sync_partials(part, vec.sync, bn_rows)      # SyncBatchNorm: statistics over every rank's rows
         track = bn_mod.track_running_stats and bn_mod.running_mean is not None
         if track:
             _pending_counters.append(bn_mod.num_batches_tracked)
@@ -576,7 +610,7 @@ def bwd_coeffs_multi(specs, device):
     for c, rows, part, nstat, which, vec, nblk, frozen in specs:
         if vec.sync is not None and not frozen:          # SyncBatchNorm: the backward sums span the ranks too (once per tensor)
             if part.data_ptr() not in reduced:
-                reduced[part.data_ptr()] = sync_partials(part if nblk is None else part[:nblk], vec.sync)
+                reduced[part.data_ptr()] = sync_partials(part if nblk is None else part[:nblk], vec.sync, rows)
             rows = rows * reduced[part.data_ptr()]
         buf = torch.empty((5, c), dtype=torch.float32, device=device)
         synced.append(reduced.get(part.data_ptr(), 1) if (vec.sync is not None and not frozen) else 1)

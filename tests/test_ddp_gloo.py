@@ -228,10 +228,18 @@ def _sync_worker(rank, world, port, out):
     y = torch.randn(world * 10, 4, generator=g, dtype=torch.float64)
     mine = y[rank * 10:(rank + 1) * 10]
     part = torch.stack([torch.stack([mine[:5].sum(0), (mine[:5] ** 2).sum(0)]), torch.stack([mine[5:].sum(0), (mine[5:] ** 2).sum(0)])])
-    factor = mlp_hip.sync_partials(part, sync)
+    factor = mlp_hip.sync_partials(part, sync, 10)
     rows = 10 * factor
     mean = part[:, 0].sum(0) / rows
     var = part[:, 1].sum(0) / rows - mean ** 2
+    assert mlp_hip.sync_row_mismatch_count() == 0
+    # ragged shards: rank r holds 3 + r partial rows of 4 + r data rows each -- the collective's shape must not depend
+    # on the partial-row count (no hang), the sums are still the global sums, and the mismatch is counted
+    ragged = torch.ones((3 + rank, 2, 4), dtype=torch.float64)
+    mlp_hip.sync_partials(ragged, sync, (3 + rank) * (4 + rank))
+    assert torch.equal(ragged[0], torch.full((2, 4), float(sum(3 + r for r in range(world))), dtype=torch.float64))
+    assert ragged[1:].abs().sum() == 0
+    assert mlp_hip.sync_row_mismatch_count() == 1
     out[rank] = (factor, mean, var, y.mean(0), y.var(0, unbiased=False))
     dist.destroy_process_group()
 
