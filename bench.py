@@ -60,6 +60,8 @@ def parse():
                          "batch's network (repsurf_amd.graph.PipelinedStep)")
     ap.add_argument("--no-optim", action="store_true", help="stop the step at backward (BASELINE.md definition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-arithmetic", action="store_true",
+                    help="skip the second leg: the same step under the other fp32 product arithmetic (fp32 MFMA), 30 steps in a child process")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-batch", type=int, default=32, help="clouds in the CPU-baseline sample (default: the GPU batch)")
@@ -463,6 +465,31 @@ def roofline_from_profile(prof, timed_steps, dtype, in_graph=None):
     return roofline, table
 
 
+ARITHMETIC = {True: "fp32 via 3xbf16 split, 6 MFMA", False: "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
+
+
+def alt_arithmetic_ms(args):
+    """The same workload and step under the fp32-MFMA product instances (RS_GEMM_SPLIT3=0 is read once per process: a child
+    process), 30 timed steps, no CPU baseline and no per-launch timing: its ms_per_step, reported next to the headline as
+    `fp32_mfma_ms_per_step`.  None when it could not run."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "30", "--warmup", str(max(2, args.warmup)),
+           "--batch", str(args.batch), "--points", str(args.points), "--model", args.model, "--workload", args.workload,
+           "--dtype", args.dtype, "--data", args.data, "--no-cpu-baseline", "--no-kernel-timing", "--no-alt-arithmetic"]
+    for flag, on in (("--no-pipeline", args.no_pipeline), ("--no-optim", args.no_optim), ("--no-graph", args.no_graph)):
+        if on:
+            cmd.append(flag)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RS_GEMM_SPLIT3"] = "0"
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        return float(json.loads(line)["ms_per_step"])
+    except Exception as e:  # noqa: BLE001 - a reported extra, never a reason to lose the headline line
+        print(f"[bench] fp32-MFMA leg failed: {e!r}", file=sys.stderr)
+        return None
+
+
 def mlp_hip_split3():
     from repsurf_amd import mlp_hip
     return mlp_hip.gemm_split3()
@@ -676,6 +703,9 @@ def main_seg(args):
                "roofline": roofline, "fps_us_per_pick": fps_line, "knn": knn_line, "cpu_baseline": cpu}
         if cpu:
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
+        out["arithmetic"] = ARITHMETIC[mlp_hip_split3()] if args.dtype == "fp32" else "bf16 MFMA operands, fp32 accumulate"
+        if world == 1 and args.dtype == "fp32" and mlp_hip_split3() and not args.no_alt_arithmetic:
+            out["fp32_mfma_ms_per_step"] = alt_arithmetic_ms(args)
         print(json.dumps(out), flush=True)
     held = locals().get("pstep")
     pstep = step = None
@@ -873,6 +903,7 @@ def main():
                "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "steps_timed": steps_timed, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.dtype == "fp32" else "bf16 MFMA operands + bf16 conv-output storage, f32 accumulate / BatchNorm sums / gradients / parameters",
+               "arithmetic": ARITHMETIC[mlp_hip_split3()] if args.dtype == "fp32" else "bf16 MFMA operands, fp32 accumulate",
                "data": ("synthetic uniform [-1,1]^3 clouds" if args.data == "uniform" else
                         "the reference's 4 scanned objects (tests/golden/geom_real.npz) tiled to the batch, rotated + jittered per copy") + ", random-init weights",
                "config": {"workload": f"configs[{1 if args.dtype == 'fp32' else 4}]: RepSurf-U ({args.model}) classifier, B={args.batch}x{args.points} pts "
@@ -890,6 +921,8 @@ def main():
                "roofline": roofline, "roofline_ballquery": ball_line, "fps_us_per_pick": fps_line, "cpu_baseline": cpu}
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        if world == 1 and args.dtype == "fp32" and mlp_hip_split3() and not args.no_alt_arithmetic:
+            out["fp32_mfma_ms_per_step"] = alt_arithmetic_ms(args)      # the same step under RS_GEMM_SPLIT3=0, 30 steps, child process
         print(json.dumps(out), flush=True)
     held = locals().get("pstep")
     pstep = step = None

@@ -355,7 +355,11 @@ int rs_mlp_gemm_rows(long long rows, const int *rows_dev, int kdim, int cols, co
  * the two-part / three-product form misses the 1e-5 bound: tools/probes/bf16_split_accuracy.py).  0: v_mfma_f32_32x32x2_f32.
  * Tensors, prologues, epilogues, accumulation and BatchNorm sums are fp32 either way; the row GEMM uses it for every launch of the
  * tiled kernel with vector operands, the weight gradient for every product of its tiled kernel (RS_WGRAD_SPLIT3_WIDE=0: only those of up to
- * 64 columns of Q). */
+ * 64 columns of Q).
+ * Non-finite operands: a NaN poisons its output row in both forms; an infinity (or a finite |x| >= 2^127 (2 - 2^-8), whose bf16
+ * rounds to infinity) gives +-inf under the fp32 MFMA and NaN under the split (the residual of an infinity is inf - inf) -- the
+ * row is non-finite either way and no other row is touched.  Denormal operands contribute as zeros would (below 1e-30).
+ * tests/test_mlp_gpu.py::test_gemm_products_with_non_finite_and_denormal_operands. */
 int rs_mlp_gemm_split3(void);
 
 /* Mixed precision (BASELINE configs[4]: "bf16 mixed precision on CDNA4 MFMA for shared MLPs"): the same contract

@@ -19,8 +19,13 @@ from . import mlp_hip
 COMPACT_GROUPS = os.environ.get("REPSURF_COMPACT", "1") != "0"
 
 
-# Arithmetic of the MFMA row GEMMs (forward and data gradient):
-#   "fp32"  v_mfma_f32_32x32x2_f32 -- the parity path (1e-5 against the reference), the default and what bench.py reports;
+# Arithmetic of the MFMA row GEMMs (forward and data gradient) and weight gradients:
+#   "fp32"  fp32 operands, fp32 results within 1e-5 of the reference -- the parity path, the default and what bench.py reports.
+#           HOW the fp32 products are formed is a property of the library, read once per process (RS_GEMM_SPLIT3,
+#           include/repsurf_hip.h: rs_mlp_gemm_split3): 1 (default) = each operand split into three bf16 parts, six
+#           v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation -- as close to the fp64 product as the fp32 MFMA
+#           (tests/test_mlp_gpu.py::test_gemm_products_are_fp32_accurate); 0 = v_mfma_f32_32x32x2_f32.  bench.py names the
+#           one that ran in its `arithmetic` key.
 #   "bf16"  BASELINE configs[4]: operands rounded to bf16 at the LDS commit, v_mfma_f32_32x32x16_bf16, fp32 accumulation
 #           (rs_mlp_gemm_rows_bf16, rs_mlp_wgrad_bf16; weight-gradient slabs are summed in fp32).
 #           BatchNorm, pooling, the narrow first-layer kernels, the constructor MLP and the classifier head stay fp32.  Tolerance: tests/test_mlp_gpu.py (bf16 section).

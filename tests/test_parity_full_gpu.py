@@ -171,6 +171,23 @@ def test_segmentation_step_at_the_benchmark_configuration_three_way():
         assert e_hip <= 1.5 * e_ref, (e_hip, e_ref)
 
 
+def test_benchmark_configurations_under_the_fp32_mfma_instances_too():
+    """The two BASELINE-config parity tests above ran under this process's GEMM arithmetic (default: fp32 products formed as six bf16
+    MFMAs over three-part operands, RS_GEMM_SPLIT3=1).  Here the same two tests run in a child process under RS_GEMM_SPLIT3=0 (the
+    fp32 MFMA instances; the switch is read once per process), appending to the same parity report: every line carries
+    `gemm_products`, so the two arithmetics sit side by side (committed copy: profiles/r05/parity_report.jsonl)."""
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    if os.environ.get("RS_GEMM_SPLIT3", "1") == "0":
+        pytest.skip("this process already runs the fp32 MFMA instances")
+    env = dict(os.environ, RS_GEMM_SPLIT3="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_parity_full_gpu.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "classifier_step_at_the_benchmark_configuration or segmentation_step_at_the_benchmark_configuration"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "2 passed" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
 def test_segmentation_fixture_three_way():
     """The 2-cloud fixture of the reference's own run (tests/golden/seg_model.npz): additionally the REFERENCE's fp32 logits
     against the float64 truth -- the distance the reference itself keeps from the exact network."""

@@ -176,7 +176,8 @@ def parity_report(test, **numbers):
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "a") as f:
-            f.write(json.dumps({"test": test, **{k: _num(v) for k, v in numbers.items()}}) + "\n")
+            f.write(json.dumps({"test": test, "gemm_products": "fp32_mfma" if os.environ.get("RS_GEMM_SPLIT3", "1") == "0" else "bf16x3_split",
+                                **{k: _num(v) for k, v in numbers.items()}}) + "\n")
     except OSError:
         pass
     print("parity", test, {k: (float("%.3g" % v) if isinstance(_num(v), float) else v) for k, v in numbers.items()})
