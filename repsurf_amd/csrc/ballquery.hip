@@ -24,6 +24,7 @@
 #include "rs_common.h"
 #include <stdlib.h>
 #include <math.h>
+#include <type_traits>
 
 namespace {
 
@@ -616,6 +617,368 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
   }
 }
 
+
+// ---- cell list, third design (round 5) ----------------------------------------------------------------------------
+// What bounds the candidate walk (tools/probes/lds_gather.hip, profiles/r05/lds_gather.txt): 64 lanes gathering 16 random bytes
+// each cost the LDS pipe 13.1 clocks per ds_read_b128 (4.8 when the addresses are consecutive), the same bytes as four
+// ds_read2_b32 of a struct-of-arrays layout 57, and a ds_write_b16 per lane 7 -- a walk is 72 candidate slots per centre, so the
+// gathers alone are ~940 LDS clocks per wave and 25 us per launch of 2 048 clouds, next to a VALU stream of the same order.
+// ballquery_cells_kernel (rounds 2-3) pays ~11 VALU instructions per slot in a `while (ballot)` loop per row of cells and a
+// branchy hit path; this kernel keeps its data structure (cloud counting-sorted by cell into one float4 array, one thread per
+// centre, <= 9 contiguous candidate ranges per centre) and rebuilds the instruction stream around those costs:
+//   * the walk is STRAIGHT-LINE: every row takes eight candidate slots unconditionally (a wave's longest row holds 7.7 candidates
+//     on average, so the loop never ran fewer trips anyway), each ONE ds_read_b128 at an immediate offset from the row's address,
+//     five VALU for the reference's distance, and TWO for the outcome: v_cmp_nlt_f32 into VCC and v_addc_co_u32 acc, acc, acc --
+//     the hit bit is shifted into a per-lane word (three words of 3 rows x 8 slots); no LDS write, no branch, no exec juggling,
+//     the validity of a slot (inside the row's range) is ONE mask per row applied after the walk;
+//   * the 24 % of wave-rows with more than eight candidates continue in a ballot loop that appends hits directly;
+//   * the hits (4.9 per centre) are decoded from the words afterwards -- find-first-bit, position, point index -- into the
+//     thread's LDS row, sorted by an 8 / 12 / 16-input network chosen per wave (12 inputs: 39 compare-exchanges) and leave
+//     through the coalesced write-out, which reads a row as two dwords;
+//   * the build ranks a point inside its cell with the histogram's own atomic (ds_add_rtn), so the scatter needs no second
+//     atomic pass; bounding-box reductions are DPP / permlane-swap butterflies instead of ds_bpermute chains; the first
+//     centre of every thread is fetched before the build starts.
+// Same distance arithmetic, threshold and tie rules as the scan kernel: bit-identical rows (tests/test_geometry_gpu.py).
+constexpr int B3_THREADS = 512;
+constexpr int B3_HCAP = 16;                               // hits a thread keeps; rows with more are redone by their wave
+constexpr int B3_RSTRIDE = B3_HCAP + 2;                   // u16 per row: HCAP hits, one overflow slot, the count (36 B = 9 dwords: odd)
+constexpr int B3_COUNT = B3_RSTRIDE - 1;
+constexpr int B3_SLACK = 8;                               // float4 entries behind the sorted cloud the unconditional slots may read
+constexpr int B3_MAXG = 11;                               // cells per axis (LDS: three workgroups per CU at n = 1024)
+constexpr int B3_MAXCELLS = B3_MAXG * B3_MAXG * B3_MAXG;
+
+__device__ __forceinline__ float bq_wave_fmin(float x) {
+  unsigned v = __float_as_uint(x);
+#define BQ_STEP(EXPR) v = __float_as_uint(fminf(__uint_as_float(v), __uint_as_float(EXPR)))
+  BQ_STEP(rs_dpp<RS_DPP_QUAD_XOR1>(v)); BQ_STEP(rs_dpp<RS_DPP_QUAD_XOR2>(v));
+  BQ_STEP(rs_dpp<RS_DPP_ROW_HALF_MIRROR>(v)); BQ_STEP(rs_dpp<RS_DPP_ROW_MIRROR>(v));
+#undef BQ_STEP
+  auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = __float_as_uint(fminf(__uint_as_float((unsigned)r[0]), __uint_as_float((unsigned)r[1])));
+  auto s = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return fminf(__uint_as_float((unsigned)s[0]), __uint_as_float((unsigned)s[1]));
+}
+__device__ __forceinline__ float bq_wave_fmax(float x) { return -bq_wave_fmin(-x); }
+
+__device__ __forceinline__ void b3_sort12(int (&v)[16]) {
+  constexpr unsigned char P12[39][2] = {{0,8},{1,7},{2,6},{3,11},{4,10},{5,9},{0,1},{2,5},{3,4},{6,9},{7,8},{10,11},{0,2},{1,6},{5,10},{9,11},
+    {0,3},{1,2},{4,6},{5,7},{8,11},{9,10},{1,4},{3,5},{6,8},{7,10},{1,3},{2,5},{6,9},{8,10},{2,3},{4,5},{6,7},{8,9},{4,6},{5,7},{3,4},{5,6},{7,8}};
+#pragma unroll
+  for (int i = 0; i < 39; ++i) bc_cx(v[P12[i][0]], v[P12[i][1]]);
+}
+
+// acc = 2 * acc + (not (d > r2)): the outcome of one candidate slot, two VALU instructions
+__device__ __forceinline__ void b3_record(unsigned &acc, float d, float r2) {
+  asm("v_cmp_nlt_f32_e64 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(d), "s"(r2) : "vcc");
+}
+
+template <int PP>
+__global__ void __launch_bounds__(B3_THREADS, 6)
+ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
+                        const float *__restrict__ xyz, int *__restrict__ idx, int *__restrict__ cnt_out, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float4 *sp4 = reinterpret_cast<float4 *>(lds);                       // (x, y, z, |p|^2) sorted by cell (+ B3_SLACK entries)
+  unsigned short *sid = reinterpret_cast<unsigned short *>(lds + 4 * (n + B3_SLACK));
+  int *cstart = reinterpret_cast<int *>(sid + ((n + 1) & ~1));          // counts, then running starts (ncell + 1)
+  int *arena = cstart + B3_MAXCELLS + 1;                                // B3_THREADS / 64 rows of 64: a wave's cooperative overflow row
+  unsigned short *rows = reinterpret_cast<unsigned short *>(arena + B3_THREADS);     // one row of B3_RSTRIDE u16 per thread
+  __shared__ float red[6][B3_THREADS / 64];
+  __shared__ int wsum[B3_THREADS / 64];
+
+  const int cloud = blockIdx.x;
+  const float *pts = xyz + (size_t)cloud * n * 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float r2u = rs_uniform(radius2);
+
+  // the first centre of this thread: in flight while the grid is built
+  float cq0 = 0.f, cq1 = 0.f, cq2 = 0.f;
+  if (tid < m) { const float *c = new_xyz + ((size_t)cloud * m + tid) * 3; cq0 = c[0]; cq1 = c[1]; cq2 = c[2]; }
+
+  // A. this thread's points (registers), bounding box; counts zeroed
+  float px[PP], py[PP], pz[PP];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int k = 0; k < PP; ++k) {
+    const int p = tid + k * B3_THREADS;
+    if (p < n) {
+      px[k] = pts[p * 3 + 0]; py[k] = pts[p * 3 + 1]; pz[k] = pts[p * 3 + 2];
+      lo[0] = fminf(lo[0], px[k]); lo[1] = fminf(lo[1], py[k]); lo[2] = fminf(lo[2], pz[k]);
+      hi[0] = fmaxf(hi[0], px[k]); hi[1] = fmaxf(hi[1], py[k]); hi[2] = fmaxf(hi[2], pz[k]);
+    } else { px[k] = py[k] = pz[k] = 0.f; }
+  }
+  for (int c = tid; c <= B3_MAXCELLS; c += B3_THREADS) cstart[c] = 0;
+  if (tid < B3_SLACK) sp4[n + tid] = make_float4(0.f, 0.f, 0.f, INFINITY);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float l = bq_wave_fmin(lo[a]), h = bq_wave_fmax(hi[a]);
+    if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+  }
+  __syncthreads();
+  float ext = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float l = red[a][0], h = red[3 + a][0];
+#pragma unroll
+    for (int w = 1; w < B3_THREADS / 64; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+    lo[a] = l; hi[a] = h;
+    ext = fmaxf(ext, h - l);
+  }
+  // B. grid geometry (cell edge >= 1.001 r: a point inside the computed radius lies in the 27 cells around the centre's)
+  const float cell = fmaxf(sqrtf(radius2) * 1.001f, ext * (1.0001f / B3_MAXG));
+  const float inv = 1.0f / cell;
+  int g[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) g[a] = min(B3_MAXG, (int)((hi[a] - lo[a]) * inv) + 1);
+  const int ncell = g[0] * g[1] * g[2];
+
+  // C. histogram; the atomic's return value is the point's rank inside its cell
+  int pc[PP], rk[PP];
+#pragma unroll
+  for (int k = 0; k < PP; ++k)
+    if (tid + k * B3_THREADS < n) {
+      const int cx = min(g[0] - 1, (int)((px[k] - lo[0]) * inv));
+      const int cy = min(g[1] - 1, (int)((py[k] - lo[1]) * inv));
+      const int cz = min(g[2] - 1, (int)((pz[k] - lo[2]) * inv));
+      pc[k] = (cz * g[1] + cy) * g[0] + cx;
+      rk[k] = atomicAdd(&cstart[pc[k]], 1);
+    }
+  __syncthreads();
+  // D. exclusive scan of the counts: a run of consecutive cells per thread, wave scan, one LDS hop
+  const int per = (ncell + B3_THREADS - 1) / B3_THREADS;
+  int run = 0;
+  for (int k = 0; k < per; ++k) { const int c = tid * per + k; if (c < ncell) run += cstart[c]; }
+  int incl = run;
+  for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - run;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  for (int k = 0; k < per; ++k) {
+    const int c = tid * per + k;
+    if (c < ncell) { const int v = cstart[c]; cstart[c] = base; base += v; }
+  }
+  if (tid == 0) cstart[ncell] = n;
+  __syncthreads();
+  // E. place the points (order inside a cell is arbitrary: hits are sorted by index afterwards)
+#pragma unroll
+  for (int k = 0; k < PP; ++k) {
+    const int p = tid + k * B3_THREADS;
+    if (p < n) {
+      const int pos = cstart[pc[k]] + rk[k];
+      sp4[pos] = make_float4(px[k], py[k], pz[k], rs_sqnorm(px[k], py[k], pz[k]));
+      sid[pos] = (unsigned short)p;
+    }
+  }
+  __syncthreads();
+  if (dbg == 1) return;                                         // (experiment: cost of the build alone)
+
+  // F. centres, B3_THREADS at a time
+  unsigned short *row = rows + tid * B3_RSTRIDE;
+  for (int qb = 0; qb < m; qb += B3_THREADS) {
+    const int q = qb + tid;
+    const bool qv = q < m;
+    float qx = cq0, qy = cq1, qz = cq2;
+    if (qb > 0 && qv) { const float *c = new_xyz + ((size_t)cloud * m + q) * 3; qx = c[0]; qy = c[1]; qz = c[2]; }
+    const float qq = rs_sqnorm(qx, qy, qz);
+    int x0 = 1, x1 = 0, y0 = 0, z0 = 0, ny = 0, nrows = 0;
+    if (qv) {
+      const float fx = fminf(fmaxf((qx - lo[0]) * inv, -2.f), (float)B3_MAXG + 2.f);
+      const float fy = fminf(fmaxf((qy - lo[1]) * inv, -2.f), (float)B3_MAXG + 2.f);
+      const float fz = fminf(fmaxf((qz - lo[2]) * inv, -2.f), (float)B3_MAXG + 2.f);
+      const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+      x0 = max(cx - 1, 0); x1 = min(cx + 1, g[0] - 1);
+      y0 = max(cy - 1, 0); const int y1 = min(cy + 1, g[1] - 1);
+      z0 = max(cz - 1, 0); const int z1 = min(cz + 1, g[2] - 1);
+      ny = y1 - y0 + 1;
+      nrows = (x0 <= x1 && ny > 0 && z1 >= z0) ? ny * (z1 - z0 + 1) : 0;
+    }
+    unsigned jl[9];                                             // a row's range: first position | length << 16 (one register per row)
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int rz = r / 3, ry = r - rz * 3;                     // (ry, rz) enumerate a 3 x 3 block; clipped rows are empty
+      const bool on = ry < ny && rz * ny + ry < nrows && ry + y0 < g[1] && rz + z0 < g[2];
+      const int cb = ((z0 + (on ? rz : 0)) * g[1] + (y0 + (on ? ry : 0))) * g[0];
+      const int j0 = on ? cstart[cb + x0] : 0;
+      const int j1 = on ? cstart[cb + x1 + 1] : 0;
+      jl[r] = (unsigned)j0 | ((unsigned)(j1 - j0) << 16);
+    }
+    // The walk: row r = 3 w + k puts its eight slots into word w; after the walk slot s of that row sits at bit 23 - (8 k + s).
+    int cnt = 0;                                                // hits appended so far (the true count; the row keeps <= HCAP + 1)
+    unsigned acc[3] = {0u, 0u, 0u}, valid[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int jbr = (int)(jl[r] & 0xffffu), lnr = (int)(jl[r] >> 16);
+      const float4 *P = sp4 + jbr;
+#pragma unroll
+      for (int h = 0; h < 8; h += 4) {                            // four gathers in flight together (eight would spill)
+        float4 c4[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) c4[s] = P[h + s];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          b3_record(acc[r / 3], rs_sqdist_expanded(qx, qy, qz, qq, c4[s].x, c4[s].y, c4[s].z, c4[s].w), r2u);
+      }
+      valid[r / 3] |= ((0xff00u >> min(lnr, 8)) & 0xffu) << (8 * (2 - r % 3));      // the first min(len, 8) slots: the top bits of the row's byte
+      if (__ballot(lnr > 8)) {                                    // ~ a quarter of the wave-rows: the longest row of 64 lanes holds 7.7
+        for (int s = 8; __ballot(s < lnr); ++s) {
+          const int j = min(jbr + s, n);
+          const float4 c4 = sp4[j];
+          const float d = rs_sqdist_expanded(qx, qy, qz, qq, c4.x, c4.y, c4.z, c4.w);
+          if (s < lnr && !(d > radius2)) {
+            if (cnt <= B3_HCAP) row[cnt] = sid[j];
+            ++cnt;
+          }
+        }
+      }
+    }
+    if (dbg == 2) { if ((acc[0] ^ acc[1] ^ acc[2]) == 0x12345u) idx[0] = cnt; continue; }      // (experiment: build + walk)
+    // Hits out of the words, the three words side by side (independent find-first-bit / lookup chains in one loop): highest bit
+    // first = ascending slot; position -> point index -> the thread's row.
+    {
+      unsigned a0 = acc[0] & valid[0], a1 = acc[1] & valid[1], a2 = acc[2] & valid[2];
+      auto take = [&](unsigned &a, unsigned ra, unsigned rb, unsigned rc) {      // (the three rows of the word, by value: no indexed array)
+        if (a != 0u) {
+          const int bit = 31 - __clz((int)a);
+          a &= ~(1u << bit);
+          const unsigned jr = bit >= 16 ? ra : (bit >= 8 ? rb : rc);
+          const int j = (int)(jr & 0xffffu) + ((23 - bit) & 7);       // slot s of row k sits at bit 23 - (8 k + s)
+          const int sv = sid[j];
+          if (cnt <= B3_HCAP) row[cnt] = (unsigned short)sv;
+          ++cnt;
+        }
+      };
+      const unsigned r0 = jl[0], r1 = jl[1], r2_ = jl[2], r3 = jl[3], r4 = jl[4], r5 = jl[5], r6 = jl[6], r7 = jl[7], r8 = jl[8];
+      while (__ballot((a0 | a1 | a2) != 0u)) { take(a0, r0, r1, r2_); take(a1, r3, r4, r5); take(a2, r6, r7, r8); }
+    }
+    const bool over = cnt > B3_HCAP;
+    if (qv && cnt_out && !over) cnt_out[(size_t)cloud * m + q] = cnt > 0 ? min(cnt, nsample) : 1;
+    // sorted in registers (wave-uniform choice of the network: 8, 12 or 16 inputs)
+    {
+      const int kept = over ? 0 : cnt;
+      const int wmax = __builtin_amdgcn_readfirstlane((int)rs_wave_max_u32((unsigned)kept));
+      auto sorted = [&](auto width) {
+        constexpr int W = decltype(width)::value;
+        int v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < W; ++i) { const int e = row[i]; v[i] = i < kept ? e : 0x7fffffff; }
+        if constexpr (W == 8) bc_sort<8>(v); else if constexpr (W == 12) b3_sort12(v); else bc_sort<16>(v);
+        unsigned *row32 = reinterpret_cast<unsigned *>(row);
+#pragma unroll
+        for (int i = 0; i < W; i += 2) row32[i >> 1] = ((unsigned)v[i] & 0xffffu) | ((unsigned)v[i + 1] << 16);
+      };
+      if (wmax > 12) sorted(std::integral_constant<int, 16>{});
+      else if (wmax > 8) sorted(std::integral_constant<int, 12>{});
+      else if (wmax > 1) sorted(std::integral_constant<int, 8>{});
+    }
+    row[B3_COUNT] = over ? (unsigned short)0xffffu : (unsigned short)cnt;
+    __syncthreads();
+    if (dbg == 3) { __syncthreads(); continue; }                  // (experiment: build + walk + sort)
+    // coalesced write-out of the rows with <= B3_HCAP hits; padding = the lowest hit (an empty ball yields zeros)
+    const int nq = min(B3_THREADS, m - qb);
+    int *dst = idx + ((size_t)cloud * m + qb) * nsample;
+    if ((nsample & 3) == 0) {
+      const int gpr = nsample >> 2;                               // a row is nsample / 4 groups of four slots
+      const bool pow2 = (gpr & (gpr - 1)) == 0;
+      const int sh = 31 - __clz(gpr);
+      int4 *dst4 = reinterpret_cast<int4 *>(dst);
+      for (int e = tid; e < nq * gpr; e += B3_THREADS) {
+        const int ql = pow2 ? (e >> sh) : e / gpr, g4 = (e - ql * gpr) << 2;
+        const unsigned short *h = rows + ql * B3_RSTRIDE;
+        const int c = h[B3_COUNT];
+        if (c != 0xffff) {
+          const int take = min(c, nsample);
+          const int first = c > 0 ? h[0] : 0;
+          int4 v = make_int4(first, first, first, first);
+          if (g4 < take) {                                        // (then g4 + 3 < B3_HCAP: inside the row)
+            const unsigned *h32 = reinterpret_cast<const unsigned *>(h);
+            const unsigned a = h32[g4 >> 1], bb = h32[(g4 >> 1) + 1];
+            v.x = (int)(a & 0xffffu);
+            v.y = g4 + 1 < take ? (int)(a >> 16) : first;
+            v.z = g4 + 2 < take ? (int)(bb & 0xffffu) : first;
+            v.w = g4 + 3 < take ? (int)(bb >> 16) : first;
+          }
+          dst4[e] = v;
+        }
+      }
+    } else {
+      int ql = tid / nsample, sl = tid - ql * nsample;
+      const int dq = B3_THREADS / nsample, ds = B3_THREADS - dq * nsample;
+      for (int e = tid; e < nq * nsample; e += B3_THREADS) {
+        const unsigned short *h = rows + ql * B3_RSTRIDE;
+        const int c = h[B3_COUNT];
+        if (c != 0xffff) {
+          const int take = min(c, nsample);
+          dst[e] = c > 0 ? h[sl < take ? sl : 0] : 0;
+        }
+        ql += dq; sl += ds;
+        if (sl >= nsample) { sl -= nsample; ++ql; }
+      }
+    }
+    // Rows with more than B3_HCAP hits (dense clusters): the WAVE redoes them together, one row at a time -- 64 lanes over the
+    // row's candidates, hits through a ballot into the wave's arena, ranks by counting (<= 64 hits) or the nsample lowest
+    // indices by repeated minimum (more).
+    {
+      unsigned long long todo = __ballot(qv && over);
+      int *mine = arena + wave * 64;
+      while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const float cqx = __shfl(qx, src, 64), cqy = __shfl(qy, src, 64), cqz = __shfl(qz, src, 64), cqq = __shfl(qq, src, 64);
+        const int cx0 = __shfl(x0, src, 64), cx1 = __shfl(x1, src, 64), cy0 = __shfl(y0, src, 64), cz0 = __shfl(z0, src, 64);
+        const int cny = __shfl(ny, src, 64), cnrows = __shfl(nrows, src, 64);
+        const size_t qrow = (size_t)cloud * m + (qb + (wave << 6) + src);
+        int *out = idx + qrow * nsample;
+        auto sweep_rows = [&](auto &&visit) {
+          for (int r = 0; r < cnrows; ++r) {
+            const int rz = r / cny, ry = r - rz * cny;
+            const int cb = ((cz0 + rz) * g[1] + (cy0 + ry)) * g[0];
+            const int b0 = cstart[cb + cx0], e0 = cstart[cb + cx1 + 1];
+            for (int j0 = b0; j0 < e0; j0 += 64) visit(min(j0 + lane, n - 1), j0 + lane < e0);
+          }
+        };
+        int total = 0;
+        sweep_rows([&](int j, bool valid_) {
+          const float4 c4 = sp4[j];
+          const float d = rs_sqdist_expanded(cqx, cqy, cqz, cqq, c4.x, c4.y, c4.z, c4.w);
+          const bool hit = valid_ && !(d > radius2);
+          const unsigned long long mask = __ballot(hit);
+          const int slot = total + rs_mbcnt(mask);
+          if (hit && slot < 64) mine[slot] = sid[j];
+          total += __popcll(mask);
+        });
+        if (cnt_out && lane == 0) cnt_out[qrow] = min(total, nsample);
+        if (total <= 64) {
+          const int v = lane < total ? mine[lane] : 0x7fffffff;
+          int rank = 0;
+          for (int k = 0; k < total; ++k) rank += mine[k] < v ? 1 : 0;       // (broadcast reads; indices are distinct)
+          if (lane < total && rank < nsample) out[rank] = v;
+          const int first = (int)rs_wave_min_u32((unsigned)v);
+          for (int s2 = total + lane; s2 < nsample; s2 += 64) out[s2] = first;
+        } else {
+          int last = -1;
+          for (int s2 = 0; s2 < nsample; ++s2) {
+            int best = 0x7fffffff;
+            sweep_rows([&](int j, bool valid_) {
+              const int p = sid[j];
+              if (valid_ && p > last && p < best) {
+                const float4 c4 = sp4[j];
+                const float d = rs_sqdist_expanded(cqx, cqy, cqz, cqq, c4.x, c4.y, c4.z, c4.w);
+                if (!(d > radius2)) best = p;
+              }
+            });
+            best = (int)rs_wave_min_u32((unsigned)best);
+            if (lane == 0) out[s2] = best;
+            last = best;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int rs_ballquery(int b, int n, int m, float radius2, int nsample, const float *new_xyz,
@@ -631,8 +994,23 @@ extern "C" int rs_ballquery(int b, int n, int m, float radius2, int nsample, con
   static const int grid_mode = getenv("RS_BALLQUERY_GRID") ? atoi(getenv("RS_BALLQUERY_GRID")) : -1;
   const bool grid_ok = n <= BG_MAXN && n >= 64 && nsample <= 64;
   const bool use_grid = grid_mode > 0 || (grid_mode < 0 && (long long)b * m >= 65536 && n >= 1024 && nsample <= 32);
-  // 2 (default where the grid applies): the register-carried, cell-sorted variant; 1: the first cell-list kernel
-  static const int cells_on = getenv("RS_BALLQUERY_CELLS") ? atoi(getenv("RS_BALLQUERY_CELLS")) : 1;
+  // 2 (default where the grid applies): the straight-line pair walk (round 5); 1: the register-carried, cell-sorted variant with
+  // the ballot loop (rounds 2-3); 0: the first cell-list kernel
+  static const int cells_on = getenv("RS_BALLQUERY_CELLS") ? atoi(getenv("RS_BALLQUERY_CELLS")) : 2;
+  if (use_grid && grid_ok && cells_on >= 2 && nsample >= 1 && nsample <= 256 && n <= 8 * B3_THREADS) {
+    // round 5: the straight-line pair walk (ballquery_cells3_kernel); points a thread carries through the build: 2 / 4 / 8
+    static const int dbg = getenv("RS_BALLQUERY_DBG") ? atoi(getenv("RS_BALLQUERY_DBG")) : 0;
+    const size_t lds = (size_t)(n + B3_SLACK) * 16 + (size_t)((n + 1) & ~1) * 2 + sizeof(int) * (B3_MAXCELLS + 1 + B3_THREADS) +
+                       (size_t)B3_THREADS * B3_RSTRIDE * 2;
+    if (n <= 2 * B3_THREADS)
+      hipLaunchKernelGGL((ballquery_cells3_kernel<2>), dim3(b), dim3(B3_THREADS), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
+    else if (n <= 4 * B3_THREADS)
+      hipLaunchKernelGGL((ballquery_cells3_kernel<4>), dim3(b), dim3(B3_THREADS), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
+    else
+      hipLaunchKernelGGL((ballquery_cells3_kernel<8>), dim3(b), dim3(B3_THREADS), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
+    RS_CHECK_LAUNCH("rs_ballquery");
+    return RS_OK;
+  }
   if (use_grid && grid_ok && cells_on && nsample >= 1 && nsample <= 256) {
     static const int dbg = getenv("RS_BALLQUERY_DBG") ? atoi(getenv("RS_BALLQUERY_DBG")) : 0;
     // threads per cloud: 512 (256 = two passes over the centres with half the waves: 154 against 114 us, profiles/r03/)

@@ -268,10 +268,11 @@ def test_full_size_properties(ops):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells", ["1", "0"])
+@pytest.mark.parametrize("cells", ["2", "1", "0"])
 def test_ballquery_grid_variant_bit_exact(cells):
-    """The cell-list variants of rs_ballquery (forced with RS_BALLQUERY_GRID=1; RS_BALLQUERY_CELLS=1: the cell-sorted,
-    register-carried kernel, 0: the first cell-list kernel; the selection is read once per process,
+    """The cell-list variants of rs_ballquery (forced with RS_BALLQUERY_GRID=1; RS_BALLQUERY_CELLS=2: the straight-line pair walk of
+    round 5 (the default where the grid applies), 1: the cell-sorted, register-carried kernel with the ballot loop, 0: the first
+    cell-list kernel; the selection is read once per process,
     hence the subprocess) return the brute-force rows bit for bit: uniform, clustered (rows overflow nsample),
     lattice (exact distance ties at the radius) and duplicated points, both radii of the shipped model."""
     import subprocess
@@ -283,7 +284,8 @@ from repsurf_amd import ops
 from oracle import geom_oracle as G
 from tests.util import cloud
 for kind in ("uniform", "clustered", "grid", "dup"):
-    for (n, s, r, ns) in ((1024, 512, 0.2, 32), (512, 128, 0.4, 64), (1024, 512, 0.1, 24), (2048, 300, 0.15, 16)):
+    for (n, s, r, ns) in ((1024, 512, 0.2, 32), (512, 128, 0.4, 64), (1024, 512, 0.1, 24), (2048, 300, 0.15, 16), (1024, 700, 0.2, 30),
+                          (4096, 1100, 0.12, 8), (1000, 64, 0.05, 4), (200, 200, 0.6, 16)):
         xyz = cloud(7, 3, n, kind)
         pick = np.stack([np.random.RandomState(i).choice(xyz.shape[1], s, replace=False) for i in range(3)])
         centres = np.take_along_axis(xyz, pick[..., None].repeat(3, -1), 1)
