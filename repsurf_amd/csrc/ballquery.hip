@@ -640,9 +640,9 @@ ballquery_cells_kernel(int b, int n, int m, float radius2, int nsample, const fl
 //     centre of every thread is fetched before the build starts.
 // Same distance arithmetic, threshold and tie rules as the scan kernel: bit-identical rows (tests/test_geometry_gpu.py).
 constexpr int B3_THREADS = 512;
-constexpr int B3_HCAP = 16;                               // hits a thread keeps; rows with more are redone by their wave
-constexpr int B3_RSTRIDE = B3_HCAP + 2;                   // u16 per row: HCAP hits, one overflow slot, the count (36 B = 9 dwords: odd)
-constexpr int B3_COUNT = B3_RSTRIDE - 1;
+// HCAP: hits a thread keeps; rows with more are redone by their wave.  16 (three workgroups per CU, 80 VGPRs) or 12 (0.2 % of the
+// rows of a uniform cloud overflow; 38 KB of LDS at n = 1024 and 64 VGPRs: FOUR workgroups per CU, so that 2 048 clouds are two
+// full rounds of the chip instead of 2.67).  A row: HCAP hits, one overflow slot, the count = HCAP + 2 u16 (36 / 28 B: 9 / 7 dwords, odd).
 constexpr int B3_SLACK = 8;                               // float4 entries behind the sorted cloud the unconditional slots may read
 constexpr int B3_MAXG = 11;                               // cells per axis (LDS: three workgroups per CU at n = 1024)
 constexpr int B3_MAXCELLS = B3_MAXG * B3_MAXG * B3_MAXG;
@@ -672,16 +672,16 @@ __device__ __forceinline__ void b3_record(unsigned &acc, float d, float r2) {
   asm("v_cmp_nlt_f32_e64 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(d), "s"(r2) : "vcc");
 }
 
-template <int PP>
-__global__ void __launch_bounds__(B3_THREADS, 6)
+template <int PP, int B3_HCAP, int B3_WAVES>
+__global__ void __launch_bounds__(B3_THREADS, B3_WAVES)
 ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
                         const float *__restrict__ xyz, int *__restrict__ idx, int *__restrict__ cnt_out, int dbg) {
+  constexpr int B3_RSTRIDE = B3_HCAP + 2, B3_COUNT = B3_RSTRIDE - 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float4 *sp4 = reinterpret_cast<float4 *>(lds);                       // (x, y, z, |p|^2) sorted by cell (+ B3_SLACK entries)
   unsigned short *sid = reinterpret_cast<unsigned short *>(lds + 4 * (n + B3_SLACK));
   int *cstart = reinterpret_cast<int *>(sid + ((n + 1) & ~1));          // counts, then running starts (ncell + 1)
-  int *arena = cstart + B3_MAXCELLS + 1;                                // B3_THREADS / 64 rows of 64: a wave's cooperative overflow row
-  unsigned short *rows = reinterpret_cast<unsigned short *>(arena + B3_THREADS);     // one row of B3_RSTRIDE u16 per thread
+  unsigned short *rows = reinterpret_cast<unsigned short *>(cstart + B3_MAXCELLS + 1);     // one row of B3_RSTRIDE u16 per thread
   __shared__ float red[6][B3_THREADS / 64];
   __shared__ int wsum[B3_THREADS / 64];
 
@@ -780,7 +780,7 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
     float qx = cq0, qy = cq1, qz = cq2;
     if (qb > 0 && qv) { const float *c = new_xyz + ((size_t)cloud * m + q) * 3; qx = c[0]; qy = c[1]; qz = c[2]; }
     const float qq = rs_sqnorm(qx, qy, qz);
-    int x0 = 1, x1 = 0, y0 = 0, z0 = 0, ny = 0, nrows = 0;
+    int x0 = 1, x1 = 0, y0 = 0, z0 = 0, ny = 0, nz = 0, nrows = 0;
     if (qv) {
       const float fx = fminf(fmaxf((qx - lo[0]) * inv, -2.f), (float)B3_MAXG + 2.f);
       const float fy = fminf(fmaxf((qy - lo[1]) * inv, -2.f), (float)B3_MAXG + 2.f);
@@ -789,18 +789,21 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
       x0 = max(cx - 1, 0); x1 = min(cx + 1, g[0] - 1);
       y0 = max(cy - 1, 0); const int y1 = min(cy + 1, g[1] - 1);
       z0 = max(cz - 1, 0); const int z1 = min(cz + 1, g[2] - 1);
-      ny = y1 - y0 + 1;
-      nrows = (x0 <= x1 && ny > 0 && z1 >= z0) ? ny * (z1 - z0 + 1) : 0;
+      ny = max(y1 - y0 + 1, 0); nz = max(z1 - z0 + 1, 0);
+      if (x0 > x1) ny = 0;                                        // (a centre more than a cell outside the box: no row)
+      nrows = ny * nz;
     }
     unsigned jl[9];                                             // a row's range: first position | length << 16 (one register per row)
+    {
+      const int cb0 = (z0 * g[1] + y0) * g[0], xa = x0, xb = x1 + 1;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int rz = r / 3, ry = r - rz * 3;                     // (ry, rz) enumerate a 3 x 3 block; clipped rows are empty
-      const bool on = ry < ny && rz * ny + ry < nrows && ry + y0 < g[1] && rz + z0 < g[2];
-      const int cb = ((z0 + (on ? rz : 0)) * g[1] + (y0 + (on ? ry : 0))) * g[0];
-      const int j0 = on ? cstart[cb + x0] : 0;
-      const int j1 = on ? cstart[cb + x1 + 1] : 0;
-      jl[r] = (unsigned)j0 | ((unsigned)(j1 - j0) << 16);
+      for (int r = 0; r < 9; ++r) {
+        const int rz = r / 3, ry = r - rz * 3;                   // (ry, rz) enumerate a 3 x 3 block; clipped rows are empty
+        const bool on = ry < ny && rz < nz;
+        const int cb = cb0 + (rz * g[1] + ry) * g[0];
+        const int j0 = cstart[on ? cb + xa : 0], j1 = cstart[on ? cb + xb : 0];       // (off: twice the same entry, length 0)
+        jl[r] = (unsigned)j0 | ((unsigned)(j1 - j0) << 16);
+      }
     }
     // The walk: row r = 3 w + k puts its eight slots into word w; after the walk slot s of that row sits at bit 23 - (8 k + s).
     int cnt = 0;                                                // hits appended so far (the true count; the row keeps <= HCAP + 1)
@@ -868,9 +871,9 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
 #pragma unroll
         for (int i = 0; i < W; i += 2) row32[i >> 1] = ((unsigned)v[i] & 0xffffu) | ((unsigned)v[i + 1] << 16);
       };
-      if (wmax > 12) sorted(std::integral_constant<int, 16>{});
-      else if (wmax > 8) sorted(std::integral_constant<int, 12>{});
-      else if (wmax > 1) sorted(std::integral_constant<int, 8>{});
+      if constexpr (B3_HCAP > 12) { if (wmax > 12) sorted(std::integral_constant<int, 16>{}); }
+      if (wmax > 8 && wmax <= 12) sorted(std::integral_constant<int, 12>{});
+      else if (wmax > 1 && wmax <= 8) sorted(std::integral_constant<int, 8>{});
     }
     row[B3_COUNT] = over ? (unsigned short)0xffffu : (unsigned short)cnt;
     __syncthreads();
@@ -879,19 +882,21 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
     const int nq = min(B3_THREADS, m - qb);
     int *dst = idx + ((size_t)cloud * m + qb) * nsample;
     if ((nsample & 3) == 0) {
-      const int gpr = nsample >> 2;                               // a row is nsample / 4 groups of four slots
-      const bool pow2 = (gpr & (gpr - 1)) == 0;
-      const int sh = 31 - __clz(gpr);
+      // a row is gpr = nsample / 4 groups of four slots, one 16-byte store each.  The group a thread writes and the distance between
+      // its rows are the same in every trip (B3_THREADS is a multiple of gpr for the usual nsample = 8 .. 128; otherwise they advance
+      // by a fixed step): nothing but the row's count / lowest hit / two dwords of hits is fetched inside the loop.
+      const int gpr = nsample >> 2;
+      int ql = tid / gpr, g4 = (tid - ql * gpr) << 2;
+      const int dq = B3_THREADS / gpr, dg = (B3_THREADS - dq * gpr) << 2;
       int4 *dst4 = reinterpret_cast<int4 *>(dst);
       for (int e = tid; e < nq * gpr; e += B3_THREADS) {
-        const int ql = pow2 ? (e >> sh) : e / gpr, g4 = (e - ql * gpr) << 2;
         const unsigned short *h = rows + ql * B3_RSTRIDE;
         const int c = h[B3_COUNT];
         if (c != 0xffff) {
           const int take = min(c, nsample);
           const int first = c > 0 ? h[0] : 0;
           int4 v = make_int4(first, first, first, first);
-          if (g4 < take) {                                        // (then g4 + 3 < B3_HCAP: inside the row)
+          if (g4 < take) {                                        // (then g4 + 3 < B3_HCAP + 2: inside the row)
             const unsigned *h32 = reinterpret_cast<const unsigned *>(h);
             const unsigned a = h32[g4 >> 1], bb = h32[(g4 >> 1) + 1];
             v.x = (int)(a & 0xffffu);
@@ -901,6 +906,8 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
           }
           dst4[e] = v;
         }
+        ql += dq; g4 += dg;
+        if (g4 >= nsample) { g4 -= nsample; ++ql; }
       }
     } else {
       int ql = tid / nsample, sl = tid - ql * nsample;
@@ -919,9 +926,10 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
     // Rows with more than B3_HCAP hits (dense clusters): the WAVE redoes them together, one row at a time -- 64 lanes over the
     // row's candidates, hits through a ballot into the wave's arena, ranks by counting (<= 64 hits) or the nsample lowest
     // indices by repeated minimum (more).
+    __syncthreads();                                              // (the write-out has read every row: a wave's own rows now serve as its arena)
     {
       unsigned long long todo = __ballot(qv && over);
-      int *mine = arena + wave * 64;
+      int *mine = reinterpret_cast<int *>(rows + (wave * 64) * B3_RSTRIDE);      // 64 ints inside 64 rows of >= 28 B
       while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -1000,14 +1008,19 @@ extern "C" int rs_ballquery(int b, int n, int m, float radius2, int nsample, con
   if (use_grid && grid_ok && cells_on >= 2 && nsample >= 1 && nsample <= 256 && n <= 8 * B3_THREADS) {
     // round 5: the straight-line pair walk (ballquery_cells3_kernel); points a thread carries through the build: 2 / 4 / 8
     static const int dbg = getenv("RS_BALLQUERY_DBG") ? atoi(getenv("RS_BALLQUERY_DBG")) : 0;
-    const size_t lds = (size_t)(n + B3_SLACK) * 16 + (size_t)((n + 1) & ~1) * 2 + sizeof(int) * (B3_MAXCELLS + 1 + B3_THREADS) +
-                       (size_t)B3_THREADS * B3_RSTRIDE * 2;
-    if (n <= 2 * B3_THREADS)
-      hipLaunchKernelGGL((ballquery_cells3_kernel<2>), dim3(b), dim3(B3_THREADS), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
-    else if (n <= 4 * B3_THREADS)
-      hipLaunchKernelGGL((ballquery_cells3_kernel<4>), dim3(b), dim3(B3_THREADS), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
-    else
-      hipLaunchKernelGGL((ballquery_cells3_kernel<8>), dim3(b), dim3(B3_THREADS), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg);
+    // RS_BALLQUERY_OCC: 6 (default) = 16 kept hits, 80 VGPRs, three workgroups per CU at n = 1024; 8 = 12 kept hits, 64 VGPRs, four -- measured
+    // SLOWER (85.9 against 71.7 us at 2 048 clouds: 76 B of scratch per lane outside the walk, profiles/r05/ballquery_occupancy_ab.txt)
+    static const int occ = getenv("RS_BALLQUERY_OCC") ? atoi(getenv("RS_BALLQUERY_OCC")) : 6;
+    const int hcap = occ >= 8 ? 12 : 16;
+    const size_t lds = (size_t)(n + B3_SLACK) * 16 + (size_t)((n + 1) & ~1) * 2 + sizeof(int) * (B3_MAXCELLS + 1) +
+                       (size_t)B3_THREADS * (hcap + 2) * 2;
+#define RS_B3_LAUNCH(PP, HC, WV) hipLaunchKernelGGL((ballquery_cells3_kernel<PP, HC, WV>), dim3(b), dim3(B3_THREADS), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg)
+    if (hcap == 12) {
+      if (n <= 2 * B3_THREADS) RS_B3_LAUNCH(2, 12, 8); else if (n <= 4 * B3_THREADS) RS_B3_LAUNCH(4, 12, 8); else RS_B3_LAUNCH(8, 12, 8);
+    } else {
+      if (n <= 2 * B3_THREADS) RS_B3_LAUNCH(2, 16, 6); else if (n <= 4 * B3_THREADS) RS_B3_LAUNCH(4, 16, 6); else RS_B3_LAUNCH(8, 16, 6);
+    }
+#undef RS_B3_LAUNCH
     RS_CHECK_LAUNCH("rs_ballquery");
     return RS_OK;
   }

@@ -440,8 +440,14 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   constexpr bool PIPE = false;
 #endif
   constexpr int NSET = (WS || PIPE) ? 2 : 1;                // WS: the loaders keep two chunks of raw operands in flight
+  // Pre-split weights (round 5, ep.w3): a chunk's weight tile is 3 parts x BN columns x 4 planes of 16 bytes (8 bf16 of one column),
+  // 12 BN units for 256 threads -- loaded as they will lie in LDS, no split and no 8-byte stores in the loop
+  constexpr int W3_UNITS = 12 * BN, W3_VECS = PARTS == 3 ? (W3_UNITS + GM_THREADS - 1) / GM_THREADS : 0;
+  constexpr int WR_VECS = PARTS == 3 ? W3_VECS : W_VECS;    // (the split-product instances run ONLY on pre-split weights: the entry point sends launches without an image to the fp32 MFMA instances)
+  typedef const char __attribute__((address_space(1))) *gptr_t;      // (a global pointer: the generic one made the compiler test for the LDS aperture)
+  const gptr_t w3g = (gptr_t)(uintptr_t)ep.w3;
   RawVec<V> araw[NSET][A_VECS];
-  float4 wraw[NSET][W_VECS];
+  float4 wraw[NSET][WR_VECS];
   ColCoef<V> coef[NSET];
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, NSET - 1>;
@@ -459,13 +465,30 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
 #pragma unroll
     for (int p = 0; p < A_VECS; ++p)
       if (part < 0 || (p * 4) / A_VECS == part) op_load<V, MODE>(E, r0, min(p * A_RPP + a_r, rlast), k, true, araw[S][p]);
-    const int kw = min(k0 + w_kq, ldw - 4);
+    if constexpr (PARTS == 3) {
+      {
 #pragma unroll
-    for (int p = 0; p < W_VECS; ++p)
-      if (part < 0 || (p * 4) / W_VECS == part) {
-        const int n = min(n0 + p * 32 + w_n, cols - 1);
-        wraw[S][p] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(w) + 4u * ((unsigned)n * (unsigned)ldw + (unsigned)kw));   // SGPR base + 32-bit offset
+        for (int p = 0; p < W3_VECS; ++p) {
+          const int u = ltid + p * GM_THREADS;                // unit: part q, column nl of the tile, plane pl (k = 8 pl .. 8 pl + 7)
+          if (W3_UNITS % GM_THREADS == 0 || u < W3_UNITS) {
+            const int q = u / (BN * 4), nl = (u / 4) % BN, pl = u & 3;
+            const int n = min(n0 + nl, cols - 1);
+            const unsigned off = (unsigned)q * (unsigned)ep.w3_part + (unsigned)n * (unsigned)ep.ldw3 + (unsigned)(k0 + pl * 8);      // elements; k0 + 32 <= ldw3 (a multiple of 32 >= kdim); an image is < 2^31 bytes
+            typedef float v4f_t __attribute__((ext_vector_type(4)));
+            const v4f_t t4 = *reinterpret_cast<const v4f_t __attribute__((address_space(1))) *>(w3g + 2u * off);      // SGPR base + 32-bit offset
+            wraw[S][p] = make_float4(t4.x, t4.y, t4.z, t4.w);
+          }
+        }
       }
+    } else {
+      const int kw = min(k0 + w_kq, ldw - 4);
+#pragma unroll
+      for (int p = 0; p < W_VECS; ++p)
+        if (part < 0 || (p * 4) / W_VECS == part) {
+          const int n = min(n0 + p * 32 + w_n, cols - 1);
+          wraw[S][p] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(w) + 4u * ((unsigned)n * (unsigned)ldw + (unsigned)kw));   // SGPR base + 32-bit offset
+        }
+    }
   };
   auto commit = [&](auto set_, float *As, float *Ws, long long r0, int k0) {
     constexpr int S = decltype(set_)::value;
@@ -505,6 +528,18 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
     // The weights go to LDS as loaded: k in [kdim, ldw) is zero in memory, k beyond ldw (clamped to the row's last vector) meets
     // operand values that were committed as zero, and a column beyond `cols` (clamped to the last one: finite) feeds only its own
     // column of D, which no epilogue stores or sums.  (16 selects per chunk, 7 % of the loop, until round 3.)
+    if constexpr (PARTS == 3) {
+      {                                                       // the parts as loaded: one 16-byte store per unit, conflict-free (4 planes x 16 columns per 16 lanes)
+#pragma unroll
+        for (int p = 0; p < W3_VECS; ++p) {
+          const int u = ltid + p * GM_THREADS;
+          if (W3_UNITS % GM_THREADS == 0 || u < W3_UNITS) {
+            const int q = u / (BN * 4), nl = (u / 4) % BN, pl = u & 3;
+            *reinterpret_cast<float4 *>(smem + (2 * A_STAGE + (Ws == Ws1 ? W_STAGE : 0)) + q * PART_W + pl * PLANE_W + nl * 4) = wraw[S][p];      // (indexed off the LDS symbol itself)
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int p = 0; p < W_VECS; ++p) {
       const int nl = p * 32 + w_n;
@@ -528,6 +563,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
             make_float2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
       else
         frag_store<4>(Ws, PLANE_W, w_kq, nl, v);
+    }
     }
   };
 
@@ -2515,7 +2551,8 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
   const int v = pick_vec(E, kdim);
 #if RS_MLP_TU == 0
   // the launches of the tiled kernel with vector operands run unit 4's split-product instances (RS_GEMM_SPLIT3=0: the fp32 MFMA ones below)
-  if (!bf && split3_on() && v >= 2) return rs_sp_gemm_rows(rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
+  // ... when the caller handed the weights' three-part image along (rs_mlp_epilogue.w3, written by rs_pack_weights); without one: fp32 MFMAs
+  if (!bf && split3_on() && v >= 2 && epi->w3 && epi->ldw3 >= ((kdim + 31) & ~31) && epi->ldw3 % 32 == 0) return rs_sp_gemm_rows(rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
 #endif
   // tile height: 64-row tiles (2 x 2 waves) wherever the layout allows -- twice the workgroups, three per CU
   static const int bm64_on = env_int("RS_GEMM_BM64", 1);
@@ -2704,19 +2741,33 @@ extern "C" int rs_mlp_wgrad_bf16(long long rows, const int *rows_dev, int ncols,
 // transpose = 0:  dst[j*ld + k] = src[j*cin + k]  (k < cin, else 0), ld >= cin    -- forward operand of rs_mlp_gemm_rows
 //                 when cin is not a multiple of 4 (otherwise the conv weight is used in place);
 // transpose = 1:  dst[k*ld + j] = src[j*cin + k]  (j < cout, else 0), ld >= cout  -- data-gradient operand (dY . W).
+// one value -> its three bf16 parts (the scalar form of split_bf16: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); bits in the low half)
+__device__ __forceinline__ void split_bf16_1(float x, unsigned short (&d)[3]) {
+  unsigned u = __float_as_uint(pack_bf16(x, 0.f)) & 0xffffu;
+  d[0] = (unsigned short)u;
+  float r = x - __uint_as_float(u << 16);
+  u = __float_as_uint(pack_bf16(r, 0.f)) & 0xffffu;
+  d[1] = (unsigned short)u;
+  r -= __uint_as_float(u << 16);
+  d[2] = (unsigned short)(__float_as_uint(pack_bf16(r, 0.f)) & 0xffffu);
+}
+
 __global__ void __launch_bounds__(GM_THREADS)
 pack_weights_kernel(rs_pack_weights_args a) {
   const int e = blockIdx.y;
-  const int cout = a.cout[e], cin = a.cin[e], ld = a.ld[e];
+  const int cout = a.cout[e], cin = a.cin[e], ld = a.ld[e], ld3 = a.ld3[e];
   const float *__restrict__ src = a.src[e];
   float *__restrict__ dst = a.dst[e];
+  unsigned short *__restrict__ dst3 = reinterpret_cast<unsigned short *>(a.dst3[e]);
   if (a.transpose[e]) {
     // 32 x 32 tiles through LDS: rows of src are read along k, rows of dst written along j -- both coalesced.  (Element-wise,
     // consecutive lanes read src[j * cin + k] for consecutive j: one 4-byte word from each of 64 cache lines per load, the
     // 512 x 1 024 weight as 32 x its bytes; the launch took 13 us.)
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int tk = (cin + 31) >> 5, tj = (ld + 31) >> 5;
+    const int wide = dst3 ? max(ld, ld3) : ld;                   // (ld3 = round32(cout) >= ld = round4(cout))
+    const int tk = (cin + 31) >> 5, tj = (wide + 31) >> 5;
+    const long long part = (long long)cin * ld3;
     for (int t = blockIdx.x; t < tk * tj; t += gridDim.x) {
       const int k0 = (t / tj) << 5, j0 = (t % tj) << 5;
 #pragma unroll
@@ -2728,15 +2779,31 @@ pack_weights_kernel(rs_pack_weights_args a) {
 #pragma unroll
       for (int p2 = 0; p2 < 4; ++p2) {
         const int k = k0 + ty + 8 * p2, j = j0 + tx;
-        if (k < cin && j < ld) dst[k * ld + j] = tile[tx][ty + 8 * p2];
+        const float v = tile[tx][ty + 8 * p2];
+        if (dst && k < cin && j < ld) dst[k * ld + j] = v;
+        if (dst3 && k < cin && j < ld3) {
+          unsigned short d[3];
+          split_bf16_1(v, d);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) dst3[q * part + (long long)k * ld3 + j] = d[q];
+        }
       }
       __syncthreads();
     }
   } else {
-    const int total = cout * ld;
+    const int wide = dst3 ? max(ld, ld3) : ld;
+    const int total = cout * wide;
+    const long long part = (long long)cout * ld3;
     for (int i = blockIdx.x * GM_THREADS + threadIdx.x; i < total; i += gridDim.x * GM_THREADS) {
-      const int j = i / ld, k = i - j * ld;
-      dst[i] = k < cin ? src[j * cin + k] : 0.f;
+      const int j = i / wide, k = i - j * wide;
+      const float v = k < cin ? src[j * cin + k] : 0.f;
+      if (dst && k < ld) dst[j * ld + k] = v;
+      if (dst3 && k < ld3) {
+        unsigned short d[3];
+        split_bf16_1(v, d);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dst3[q * part + (long long)j * ld3 + k] = d[q];
+      }
     }
   }
 }
@@ -2748,10 +2815,13 @@ extern "C" int rs_pack_weights(const rs_pack_weights_args *args, void *stream) {
   for (int e = 0; e < args->n; ++e) {
     const int inner = args->transpose[e] ? args->cout[e] : args->cin[e];
     const int outer = args->transpose[e] ? args->cin[e] : args->cout[e];
-    RS_REQUIRE(args->src[e] && args->dst[e] && args->ld[e] >= inner && args->ld[e] % 4 == 0,
+    RS_REQUIRE(args->src[e] && (args->dst[e] || args->dst3[e]) && args->ld[e] >= inner && args->ld[e] % 4 == 0,
                "rs_pack_weights: entry %d invalid (ld=%d cout=%d cin=%d transpose=%d)", e, args->ld[e], args->cout[e],
                args->cin[e], args->transpose[e]);
-    biggest = max(biggest, args->transpose[e] ? 8 * GM_THREADS * (rs_cdiv(args->cin[e], 32) * rs_cdiv(args->ld[e], 32)) / 32 : outer * args->ld[e]);
+    RS_REQUIRE(!args->dst3[e] || (args->ld3[e] >= args->ld[e] && args->ld3[e] % 32 == 0),
+               "rs_pack_weights: entry %d: the split image needs ld3 (%d) >= ld (%d) and ld3 %% 32 == 0", e, args->ld3[e], args->ld[e]);
+    const int wide = args->dst3[e] ? max(args->ld[e], args->ld3[e]) : args->ld[e];
+    biggest = max(biggest, args->transpose[e] ? 8 * GM_THREADS * (rs_cdiv(args->cin[e], 32) * rs_cdiv(wide, 32)) / 32 : outer * wide);
   }
   int gx = rs_cdiv(biggest, GM_THREADS);        // (a transposed entry: ~a workgroup per four of its 32 x 32 tiles)
   if (gx > 128) gx = 128;

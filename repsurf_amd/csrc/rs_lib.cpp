@@ -13,7 +13,7 @@ void rs_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *rs_last_error(void) { return g_err; }
-extern "C" int rs_abi_version(void) { return 32; }
+extern "C" int rs_abi_version(void) { return 33; }
 
 extern "C" int rs_device_info(int *cu_count, int *wave_size, int *lds_bytes, char *arch, int arch_len) {
   int dev = 0;

@@ -56,7 +56,8 @@ class Epilogue(ctypes.Structure):            # rs_mlp_epilogue
                 ("my2", P), ("ldm2", c_ll), ("ms2", P), ("mt2", P), ("mean2", P), ("invstd2", P),
                 ("partial", P), ("partial_blocks", c_int),
                 ("pool_ns", c_int), ("pool_max", P), ("pool_min", P), ("pool_amax", P), ("pool_amin", P),
-                ("row_mult", P), ("out_bf16", c_int), ("my1_bf16", c_int), ("my2_bf16", c_int)]
+                ("row_mult", P), ("out_bf16", c_int), ("my1_bf16", c_int), ("my2_bf16", c_int),
+                ("w3", P), ("ldw3", c_int), ("w3_part", c_ll)]
 
 
 class BnItem(ctypes.Structure):              # rs_bn_item
@@ -253,29 +254,68 @@ PACK_MAX = 32
 
 class PackArgs(ctypes.Structure):            # rs_pack_weights_args
     _fields_ = [("src", P * PACK_MAX), ("dst", P * PACK_MAX), ("cout", c_int * PACK_MAX), ("cin", c_int * PACK_MAX),
-                ("ld", c_int * PACK_MAX), ("transpose", c_int * PACK_MAX), ("n", c_int)]
+                ("ld", c_int * PACK_MAX), ("transpose", c_int * PACK_MAX), ("n", c_int), ("dst3", P * PACK_MAX), ("ld3", c_int * PACK_MAX)]
+
+
+# Round 5: weights are constant during a step, yet the split-product row GEMM (rs_mlp_gemm_split3) split its weight tile into
+# three bf16 parts again in every row tile of every launch -- half of the loop's split arithmetic and all of its weight LDS
+# stores.  The pack launch at the top of a step now also writes every weight operand as three bf16 parts (the `w3` operand of
+# rs_mlp_epilogue), and the split-product instances run ONLY on such an image: `gemm_rows` finds it by the address of the fp32
+# operand it is handed, or makes it on the spot (one small launch: operands nobody prepacked -- unit tests, eval forwards).
+_split3 = {}      # address of the fp32 operand (n-major) -> (image (3, outer, ld3) bf16, ld3, weights epoch, source version, source, fp32 operand)
+
+
+def _presplit_on():
+    return gemm_split3()
+
+
+def _split3_of(wk):
+    hit = _split3.get(wk.data_ptr())
+    if hit is None or hit[2] != _weights_epoch or hit[3] != hit[4]._version or hit[5].shape != wk.shape:
+        return None
+    return hit
 
 
 def _pack_items(items, device):
     """items = [(w2d (cout, cin), transpose)] -> zero-padded n-major copies, ONE launch per 32 of them:
-    transpose=False -> (cout, pad4(cin)) for the forward GEMM, transpose=True -> (cin, pad4(cout)) for dY . W."""
+    transpose=False -> (cout, pad4(cin)) for the forward GEMM (the weight itself when it needs no copy), transpose=True ->
+    (cin, pad4(cout)) for dY . W.  With the split products on, every operand's three-part bf16 image is written by the same launch."""
     inner = [w.shape[0] if tr else w.shape[1] for w, tr in items]
     outer = [w.shape[1] if tr else w.shape[0] for w, tr in items]
+    inplace = [(not tr) and not _needs_copy(w) for w, tr in items]      # forward weights used in place: only the split image
     lds = [(-(-n // 4)) * 4 for n in inner]
-    sizes = [o * ld for o, ld in zip(outer, lds)]
-    flat = torch.empty((sum(-(-sz // 4) * 4 for sz in sizes),), dtype=torch.float32, device=device)
+    sizes = [0 if ip else o * ld for o, ld, ip in zip(outer, lds, inplace)]
+    flat = torch.empty((max(1, sum(-(-sz // 4) * 4 for sz in sizes)),), dtype=torch.float32, device=device)
     outs, off = [], 0
-    for o, ld, sz in zip(outer, lds, sizes):
-        outs.append(flat[off:off + sz].view(o, ld))
+    for (w, _), o, ld, sz, ip in zip(items, outer, lds, sizes, inplace):
+        outs.append(w if ip else flat[off:off + sz].view(o, ld))
         off += -(-sz // 4) * 4                      # keep every copy 16-byte aligned
+    split = _presplit_on()
+    ld3s = [(-(-n // 32)) * 32 for n in inner]
+    if split:
+        sz3 = [3 * o * l3 for o, l3 in zip(outer, ld3s)]
+        flat3 = torch.empty((sum(-(-sz // 8) * 8 for sz in sz3),), dtype=torch.bfloat16, device=device)
+        imgs, off = [], 0
+        for o, l3, sz in zip(outer, ld3s, sz3):
+            imgs.append(flat3[off:off + sz].view(3, o, l3))
+            off += -(-sz // 8) * 8                  # 16-byte aligned images
     for i in range(0, len(items), PACK_MAX):
         a = PackArgs()
-        chunk = list(zip(items[i:i + PACK_MAX], outs[i:i + PACK_MAX], lds[i:i + PACK_MAX]))
-        for j, ((w, tr), o, ld) in enumerate(chunk):
-            a.src[j], a.dst[j] = w.data_ptr(), o.data_ptr()
-            a.cout[j], a.cin[j], a.ld[j], a.transpose[j] = w.shape[0], w.shape[1], ld, int(bool(tr))
-        a.n = len(chunk)
-        _lib.call("rs_pack_weights", ctypes.byref(a), _stream())
+        n = 0
+        for j in range(i, min(i + PACK_MAX, len(items))):
+            w, tr = items[j]
+            if inplace[j] and not split:
+                continue                            # nothing to write for this one
+            a.src[n], a.dst[n] = w.data_ptr(), (None if inplace[j] else outs[j].data_ptr())
+            a.cout[n], a.cin[n], a.ld[n], a.transpose[n] = w.shape[0], w.shape[1], lds[j], int(bool(tr))
+            a.dst3[n], a.ld3[n] = (imgs[j].data_ptr(), ld3s[j]) if split else (None, 0)
+            n += 1
+        a.n = n
+        if n:
+            _lib.call("rs_pack_weights", ctypes.byref(a), _stream())
+    if split:
+        for (w, _), o, img, l3 in zip(items, outs, imgs, ld3s):
+            _split3[o.data_ptr()] = (img, l3, _weights_epoch, w._version, w, o)
     return outs
 
 
@@ -298,6 +338,7 @@ def weights_changed():
     global _weights_epoch
     _weights_epoch += 1
     _prepacked.clear()
+    _split3.clear()
 
 PREPACK = os.environ.get("REPSURF_PREPACK", "1") != "0"
 
@@ -311,17 +352,19 @@ def prepack(convs):
     forward copy of the weights whose cin is not a multiple of 4, and the transposed copy of every weight."""
     items = []
     _prepacked.clear()
+    _split3.clear()
     if not PREPACK:
         return
     for conv in convs:
         w = _w2d(conv.weight)
-        if _needs_copy(w):
+        if _needs_copy(w) or _presplit_on():        # (a weight used in place still gets its split image)
             items.append((w, False))
         items.append((w, True))
     if not items:
         return
     for (w, tr), out in zip(items, _pack_items(items, items[0][0].device)):
-        _prepacked[(w.data_ptr(), bool(tr))] = (w._version, out, w, _weights_epoch)
+        if out.data_ptr() != w.data_ptr():
+            _prepacked[(w.data_ptr(), bool(tr))] = (w._version, out, w, _weights_epoch)
 
 
 def pack_weights(w2ds, transpose, device):
@@ -370,6 +413,13 @@ def w_bwd(w2d):
 def gemm_rows(rows, kdim, cols, x_op, wk, epi, rows_dev=None):
     """out[rows, cols] = E[rows, kdim] . wk[:cols, :kdim]^T   (wk n-major (cols, ld), ld % 4 == 0, zero beyond kdim)"""
     from . import mlp as _mlp      # late: mlp imports this module on first use
+    epi.w3, epi.ldw3, epi.w3_part = None, 0, 0
+    if _mlp.PRECISION != "bf16" and _presplit_on():
+        hit = _split3_of(wk)
+        if hit is None:            # nobody packed this operand in this step: its image now (n-major fp32 -> three bf16 parts)
+            _pack_items([(wk, False)], wk.device)
+            hit = _split3_of(wk)
+        epi.w3, epi.ldw3, epi.w3_part = hit[0].data_ptr(), hit[1], hit[0].shape[1] * hit[1]
     _lib.call("rs_mlp_gemm_rows_bf16" if _mlp.PRECISION == "bf16" else "rs_mlp_gemm_rows", rows, rows_dev, kdim, cols, ctypes.byref(x_op), _ptr(wk), wk.shape[1],
               ctypes.byref(epi), _stream())
 

@@ -8,8 +8,11 @@ import torch
 from repsurf_amd import ops
 
 dev = torch.device("cuda")
-for (n, m, r, ns) in [(1024, 512, 0.2, 32), (1024, 32, 0.2, 32), (1024, 512, 0.05, 32), (512, 128, 0.4, 64)]:
-    for b in (32, 2048):
+SHAPES = [(1024, 512, 0.2, 32), (1024, 32, 0.2, 32), (1024, 512, 0.05, 32), (512, 128, 0.4, 64)]
+if os.environ.get("RS_BQ_ONLY"):            # one shape, 2 048 clouds only (PMC passes: a counter average must not mix shapes)
+    SHAPES = [SHAPES[int(os.environ["RS_BQ_ONLY"])]]
+for (n, m, r, ns) in SHAPES:
+    for b in ((2048,) if os.environ.get("RS_BQ_ONLY") else (32, 2048)):
         g = torch.Generator().manual_seed(b)
         xyz = (torch.rand(b, n, 3, generator=g) * 2 - 1).to(dev)
         centres = xyz[:, torch.randperm(n, generator=g)[:m]].contiguous()
