@@ -427,18 +427,10 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   const bool ep_vec = (((uintptr_t)ep.out | (uintptr_t)ep.my1 | (uintptr_t)ep.my2) % 16 == 0) && (ep.ldo % 4 == 0) &&
                       (ep.ldm1 % 4 == 0) && (ep.ldm2 % 4 == 0) && (cols % 4 == 0);
 
-#ifdef RS_EXP_SP_PIPE
-  // EXPERIMENT BUILD ONLY (-DRS_EXP_SP_PIPE, unit 4; written at the end of round 4 from the what-if measurements, NOT yet run on a GPU):
-  // the software-pipelined loop.  Chunk g of this workgroup's (tile, chunk) sequence lives in register set g & 1 and LDS stage g & 1;
-  // one trip = barrier -> request chunk g + 2 into the set chunk g came from -> the MFMAs of chunk g AND, in the same scheduling
-  // region, the commit (prologue + split + LDS writes) of chunk g + 1 into the other stage: the scheduler then places that VALU / LDS
-  // work in the issue slots behind the MFMAs (it does so by itself once both sit in one basic block: tools/probes/mfma_valu_overlap.hip).
-  // Instances whose two register sets do not spill (see the DEEP measurements in profiles/r04/gemm_split3_ab.txt).
-  constexpr bool PIPE = PARTS == 3 && BM == 64 && !WS &&
-                        (MODE == OPM_ID || MODE == OPM_RELU1 || MODE == OPM_BCAST || (BN == 64 && (MODE == OPM_RELU2 || MODE == OPM_AFF2)));
-#else
+  // (A software-pipelined form of this loop -- the MFMAs of chunk g and the commit of chunk g + 1 in one scheduling region, two register
+  //  sets -- was written at the end of round 4 and measured in round 5: slower in every class and in both steps, 1.283 -> 1.391 ms
+  //  classification, 3.378 -> 3.628 ms segmentation, profiles/r05/sp_pipe_ab.txt.  Removed.)
   constexpr bool PIPE = false;
-#endif
   constexpr int NSET = (WS || PIPE) ? 2 : 1;                // WS: the loaders keep two chunks of raw operands in flight
   // Pre-split weights (round 5, ep.w3): a chunk's weight tile is 3 parts x BN columns x 4 planes of 16 bytes (8 bf16 of one column),
   // 12 BN units for 256 threads -- loaded as they will lie in LDS, no split and no 8-byte stores in the loop
@@ -706,15 +698,6 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       RS_T(3);
     }
   } else {
-  int pipe_par = 0;                                         // PIPE: register set / LDS stage of the next tile's first chunk
-  if constexpr (PIPE) {
-    if ((long long)blockIdx.x < tiles) {                    // the first two chunks of this workgroup's sequence; chunk 0 into stage 0
-      prefetch(S0{}, (long long)blockIdx.x * BM, 0, -1);
-      const long long t1 = nchunks > 1 ? (long long)blockIdx.x : (long long)blockIdx.x + gridDim.x;
-      prefetch(S1{}, (t1 < tiles ? t1 : tiles - 1) * BM, nchunks > 1 ? GM_BK : 0, -1);
-      commit(S0{}, As0, Ws0, (long long)blockIdx.x * BM, 0);
-    }
-  }
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long r0 = tile * BM;
     f32x16 acc[CT];
@@ -733,31 +716,6 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         RS_T(4);
         ++gchunk;
       }
-    } else if constexpr (PIPE) {
-      // (every prefetch and every commit is unconditional -- past the end: the last tile again, into a free set / stage, unused -- so that
-      // the wait-count pass sees one straight-line pattern and mma + commit stay one basic block)
-      auto half = [&](auto set_, auto other_, int ch) __attribute__((always_inline)) {
-        constexpr int P = decltype(set_)::value;
-        __syncthreads();                                        // chunk g is visible in stage P; the readers of stage 1 - P (chunk g - 1) are done
-        RS_T(2);
-        long long t2 = tile;
-        int c2 = ch + 2;
-        while (c2 >= nchunks) { c2 -= nchunks; t2 += gridDim.x; }
-        prefetch(set_, (t2 < tiles ? t2 : tiles - 1) * BM, c2 * GM_BK, -1);       // chunk g + 2 -> the set chunk g came from
-        RS_T(3);
-        const bool last = ch + 1 == nchunks;                    // chunk g + 1: the next of this tile, or the first of the next tile
-        const long long tn = last ? tile + gridDim.x : tile;
-        mma(acc, P ? As1 : As0, P ? Ws1 : Ws0, ch);
-        commit(other_, P ? As0 : As1, P ? Ws0 : Ws1, (tn < tiles ? tn : tiles - 1) * BM, last ? 0 : (ch + 1) * GM_BK);
-        RS_T(4);
-      };
-      auto body = [&](auto first_, auto second_) __attribute__((always_inline)) {
-        int ch = 0;
-        for (; ch + 1 < nchunks; ch += 2) { half(first_, second_, ch); half(second_, first_, ch + 1); }
-        if (ch < nchunks) half(first_, second_, ch);
-      };
-      if (pipe_par == 0) body(S0{}, S1{}); else body(S1{}, S0{});
-      pipe_par = (pipe_par + nchunks) & 1;
     } else {
     // DIRECT: the first chunk of this tile was requested in front of the previous tile's epilogue (below)
     if (!EARLY_PREFETCH || tile == (long long)blockIdx.x) prefetch(S0{}, r0, 0, -1);

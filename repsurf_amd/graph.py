@@ -181,17 +181,19 @@ class PipelinedStep:
         with torch.cuda.stream(self.main), self.draws:
             self.draws.begin_pass()
             self.draws.refill()
+            # state[q]: the geometry the network of parity q reads.  It is whatever the geometry pass that runs BESIDE the network of
+            # parity 1 - q returns -- no staging copy (round 4 copied every geometry tensor into a second buffer set: two
+            # multi-tensor torch launches, 54 us of each step): under capture those tensors live in the geometry graph's pool, stay
+            # referenced from here, and every replay rewrites them in place.
             first = net.geometry(self.points[0], fork=False)
-            self.state = [first.clone(), first.clone()]
+            self._copy_state = os.environ.get("REPSURF_PIPE_COPY_STATE", "0") != "0"      # (=1: the round-4 form, a staging copy per replay: A/B and debugging)
+            self.state = [first.clone(), first.clone()] if self._copy_state else [first, first]
             for _ in range(warmup):                       # eager warm-up of the whole step on one stream
                 self.draws.begin_pass()
                 self.draws.refill()
                 self._geometry(0)
                 self._network(0)
                 self._finish()
-            self.draws.begin_pass()                        # the geometry the first call's network consumes (batch 0)
-            self.draws.refill()
-            self.state[0].copy_(net.geometry(self.points[0], fork=False))
         self.side.wait_stream(self.main)
         torch.cuda.current_stream().wait_stream(self.main)
         torch.cuda.synchronize()
@@ -202,13 +204,17 @@ class PipelinedStep:
         mode = _capture_mode()
         if sharded and self.dist.is_initialized():
             _rdist.barrier(group)      # every rank has finished its warm-up collectives before any rank starts capturing
-        # geometry graphs and network graphs run concurrently: separate memory pools
+        # Geometry graphs and network graphs run concurrently: separate memory pools.  The two geometry graphs have a pool EACH:
+        # state[1 - p] lives in the pool of geometry graph p and is read by the network that runs beside geometry graph 1 - p --
+        # in a shared pool the temporaries the first capture freed would be handed to the second capture's OUTPUTS, and a replay
+        # of the first graph would scribble over the state the network beside it is reading (seen: memory faults in the
+        # segmentation step; with the round-4 staging copy the aliasing was harmless, the two geometry graphs never overlap).
         self.g_geo, self.g_net, self.loss = [], [], []
         for p in (0, 1):
             g = torch.cuda.CUDAGraph()
             with self.draws:
                 self.draws.begin_pass()
-                with torch.cuda.graph(g, pool=self.g_geo[0].pool() if self.g_geo else None, stream=self.side, **mode):
+                with torch.cuda.graph(g, pool=(self.g_geo[0].pool() if (self.g_geo and self._copy_state) else None), stream=self.side, **mode):
                     self._geometry(p)
             self.g_geo.append(g)
         # Sharded: ONE replay per rank-step when RCCL accepts stream capture -- network + gradient pack + all-reduce + Adam in the
@@ -246,6 +252,13 @@ class PipelinedStep:
                 with torch.cuda.graph(self.graph_opt, pool=self.g_net[0].pool(), stream=self.main, **mode):
                     optimizer.step()
         torch.cuda.synchronize()
+        # the geometry the first call's network consumes (batch 0 sits in both input buffers): one replay of the graph that writes state[0]
+        with torch.cuda.stream(self.side), self.draws:
+            self.draws.begin_pass()
+            self.draws.refill()
+            if os.environ.get("REPSURF_PIPE_SKIP_GEO", "0") == "0":
+                self.g_geo[1].replay()
+        torch.cuda.synchronize()
         self.geo_done = [torch.cuda.Event(), torch.cuda.Event()]    # geo_done[q]: state[q] / points[q] are ready
         self.net_done = [torch.cuda.Event(), torch.cuda.Event()]    # net_done[q]: the network finished reading them
         for q in (0, 1):
@@ -270,7 +283,11 @@ class PipelinedStep:
     def _geometry(self, p):
         """geometry of the batch the NEXT call trains on (buffers 1 - p), as one serial chain"""
         if os.environ.get("REPSURF_PIPE_SKIP_GEO", "0") == "0":     # (=1: measurement only -- the network alone)
-            self.state[1 - p].copy_(self.net.geometry(self.points[1 - p], fork=False))
+            fresh = self.net.geometry(self.points[1 - p], fork=False)
+            if self._copy_state:
+                self.state[1 - p].copy_(fresh)
+            else:
+                self.state[1 - p] = fresh
 
     def _network(self, p):
         if self.sharded:

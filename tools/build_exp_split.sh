@@ -2,7 +2,7 @@
 # Experiment variants of UNIT 4 of mlp.hip (the split-product GEMMs: -DRS_EXP_<NAME> -DRS_MLP_TU=4) linked against the CURRENT objects of the
 # product build.  Run HERE after `make`; the .so files travel to the GPU box under build_exp/ (git-ignored; ~21 MB each: a push of
 # several takes tens of seconds) and are selected with REPSURF_HIP_LIB=build_exp/librepsurf_<NAME>.so.
-#   tools/build_exp_split.sh SP_PIPE                      the software-pipelined loop (DESIGN.md 5 "Round 4, last change"; tools/sp_pipe_ab.sh)
+#   (SP_PIPE, the software-pipelined loop, was measured in round 5 and removed: profiles/r05/sp_pipe_ab.txt)
 #   tools/build_exp_split.sh SP_ONE_MFMA SP_ONE_FRAG SP_ONE_STORE SP_ONE_MFMA+SP_ONE_FRAG+SP_ONE_STORE      the what-if builds (tools/_r04_bo.sh)
 set -e
 cd "$(dirname "$0")/.."
