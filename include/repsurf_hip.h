@@ -240,14 +240,17 @@ int rs_group_features_compact_backward(long long capacity, const int *rows_dev, 
                                        float *grad_feature, int b, int n, int m, const int *fps_idx,
                                        const float *grad_new_normal, long long ldg, void *stream);
 /* The same backward as a gather (round 4): rs_compact_csr (geometry stage) inverts `src` -- csr_off (b*n + 1), csr_rows (capacity):
- * the compacted rows that name each source point, ascending; centre_of (b*n): the group whose centre the point is, or -1 --
+ * the compacted rows that name each source point, ascending; centre_of (b*n): the group whose centre the point is, or -1 (see below) --
  * and rs_group_features_compact_backward_csr WRITES every element of grad_normal / grad_feature (no zero fill, no atomics, a fixed
  * summation order). */
 int rs_compact_csr(int b, int n, int m, const int *src, const int *offsets, const int *fps_idx, int *csr_off, int *centre_of,
                    int *csr_rows, void *stream);
 int rs_group_features_compact_backward_csr(int b, int n, int cn, int cf, int polar, const float *grad_out, const int *csr_off,
                                            const int *csr_rows, const int *centre_of, float *grad_normal, float *grad_feature,
-                                           const float *grad_new_normal, long long ldg, void *stream);
+                                           const float *grad_new_normal, long long ldg, const int *fps_idx, int m, void *stream);
+/* (round 5) centre_of[p] >= 0: the one group whose centre p is; -1: none; -2 - g: p is the centre of SEVERAL groups, g the lowest --
+ * FPS repeats a row when a cloud holds fewer distinct points than picks -- and the backward adds the centre-row gradient of every group
+ * of that cloud with fps_idx == p, ascending (fps_idx (b, m): required next to grad_new_normal). */
 /* The inverse of ANY gather index over a packed batch (round 4): src (E edges -> global source rows), edge_ends / point_ends (b):
  * running ends of the query rows (x `per` = edges: nsample of a grouping, 3 of an interpolation) and of the source rows per cloud
  * -> csr_off (P + 1), csr_edges (E): the edges reading each source row, ascending.  overflow (1 int, zeroed by the caller) counts the

@@ -38,7 +38,7 @@ SIGNATURES = {
     "rs_compact_csr": [c_int, c_int, c_int, P, P, P, P, P, P, P],
     "rs_inverse_index": [c_int, c_int, c_int, P, P, P, P, P, P, P],
     "rs_group_features_backward_csr": [c_ll, c_int, c_int, c_int, c_int, P, P, P, P, P, P],
-    "rs_group_features_compact_backward_csr": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_ll, P],
+    "rs_group_features_compact_backward_csr": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_ll, P, c_int, P],
     "rs_group_rows": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "rs_group_rows_backward": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "rs_three_nn": [c_int, c_int, c_int, P, P, P, P, P],

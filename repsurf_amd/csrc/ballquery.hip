@@ -1014,6 +1014,7 @@ extern "C" int rs_ballquery(int b, int n, int m, float radius2, int nsample, con
     const int hcap = occ >= 8 ? 12 : 16;
     const size_t lds = (size_t)(n + B3_SLACK) * 16 + (size_t)((n + 1) & ~1) * 2 + sizeof(int) * (B3_MAXCELLS + 1) +
                        (size_t)B3_THREADS * (hcap + 2) * 2;
+    RS_REQUIRE_LDS(lds, "rs_ballquery");
 #define RS_B3_LAUNCH(PP, HC, WV) hipLaunchKernelGGL((ballquery_cells3_kernel<PP, HC, WV>), dim3(b), dim3(B3_THREADS), lds, st, b, n, m, radius2, nsample, new_xyz, xyz, idx, cnt, dbg)
     if (hcap == 12) {
       if (n <= 2 * B3_THREADS) RS_B3_LAUNCH(2, 12, 8); else if (n <= 4 * B3_THREADS) RS_B3_LAUNCH(4, 12, 8); else RS_B3_LAUNCH(8, 12, 8);

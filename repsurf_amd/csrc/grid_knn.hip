@@ -493,6 +493,8 @@ extern "C" int rs_knn_grid_query(int m, int nsample, int b, int max_queries, int
   const CloudGrid *cg = reinterpret_cast<const CloudGrid *>(grid);
   // LDS: the rows of the largest cloud, at most GK_LDS_ROWS of them, + its cell starts (larger clouds are read in place)
   int lds_rows = max_rows > 0 && max_rows < GK_LDS_ROWS ? max_rows : GK_LDS_ROWS;
+  // (a device with less LDS than the staged cloud + lists need: no staging, the rows are read in place -- ADVICE r4)
+  if ((size_t)8 * 256 * 8 + (size_t)lds_rows * 16 + (size_t)(GK_CELLS + 1) * 4 > (size_t)rs_lds_limit()) lds_rows = 0;
   if (nsample > 16) {      // (short lists through this kernel: 65 536 queries, 9 entries 190-290 us against 122; 3 entries 157-174 against 74)
     // one wave per query, `qpw` queries per wave: enough waves to fill the chip (16 per CU) before a wave takes a second query
     int qpw = (int)(((long long)max_queries * b + 4095) / 4096);
@@ -533,7 +535,8 @@ extern "C" int rs_umbrella_features_grid(int b, int n, int k, const float *xyz, 
   hipStream_t st = (hipStream_t)stream;
   const float4 *s4 = reinterpret_cast<const float4 *>(sorted);
   const CloudGrid *cg = reinterpret_cast<const CloudGrid *>(grid);
-  const int lds_rows = n < GK_LDS_ROWS ? n : GK_LDS_ROWS;
+  int lds_rows = n < GK_LDS_ROWS ? n : GK_LDS_ROWS;
+  if ((size_t)8 * 256 * 8 + (size_t)lds_rows * 16 + (size_t)(GK_CELLS + 1) * 4 > (size_t)rs_lds_limit()) lds_rows = 0;      // (read the rows in place)
 #define RS_GU(K_) do {                                                                                                       \
     constexpr int T_ = 256, P_ = 8;                                                                                           \
     const dim3 g(rs_cdiv(n, T_), b), t(T_);                                                                                   \

@@ -456,8 +456,21 @@ compact_csr_kernel(int n, int m, const int *__restrict__ src, const int *__restr
       csr_rows[j + 1] = v;
     }
   }
-  if (fps_idx)
-    for (int g = tid; g < m; g += CSR_THREADS) centre_of[p0 + fps_idx[(long long)c * m + g]] = c * m + g;
+  // centre_of[p]: the group whose centre p is, -1 for none.  FPS repeats a row when a cloud holds fewer distinct points than it is asked
+  // to pick (padded clouds): the point is then the centre of SEVERAL groups, every one of which hands it a centre-row gradient.  The
+  // lowest such group g wins (atomicMin: deterministic) and the entry becomes -2 - g, which tells the backward to look the others up in
+  // fps_idx (ascending: a fixed summation order).  (one racing writer used to win and the other groups' gradients were lost.)
+  if (fps_idx) {
+    __syncthreads();
+    for (int p = tid; p < n; p += CSR_THREADS) { cnt[p] = 0; cur[p] = 0x7fffffff; }       // (the counters / cursors are spent: shared flags, lowest group)
+    __syncthreads();
+    for (int g = tid; g < m; g += CSR_THREADS) atomicMin(&cur[fps_idx[(long long)c * m + g]], c * m + g);
+    __syncthreads();
+    for (int g = tid; g < m; g += CSR_THREADS) { const int p = fps_idx[(long long)c * m + g]; if (cur[p] != c * m + g) cnt[p] = 1; }
+    __syncthreads();
+    for (int p = tid; p < n; p += CSR_THREADS)
+      if (cur[p] != 0x7fffffff) centre_of[p0 + p] = cnt[p] ? -2 - cur[p] : cur[p];
+  }
 }
 
 // The same inversion for ANY gather of packed batches (round 4): edge e reads source row src[e]; the edges of cloud c are
@@ -516,7 +529,7 @@ __global__ void __launch_bounds__(GR_THREADS)
 compact_gather_bwd_kernel(long long points, int cn, int cf, int cpos, int ctot, const float *__restrict__ grad_out,
                           const int *__restrict__ csr_off, const int *__restrict__ csr_rows, const int *__restrict__ centre_of,
                           float *__restrict__ grad_normal, float *__restrict__ grad_feature,
-                          const float *__restrict__ grad_new_normal, long long ldg) {
+                          const float *__restrict__ grad_new_normal, long long ldg, const int *__restrict__ fps_idx, int n, int m) {
   const int c0 = grad_normal ? 0 : cn, cw = (grad_normal ? cn : 0) + (grad_feature ? cf : 0);     // channels [c0, c0 + cw) behind cpos
   const long long total = points * cw;
   for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GR_THREADS) {
@@ -533,7 +546,15 @@ compact_gather_bwd_kernel(long long points, int cn, int cf, int cpos, int ctot, 
     }
     for (; j < hi; ++j) acc += col[(long long)csr_rows[j] * ctot];
     if (ch < cn) {
-      if (grad_new_normal) { const int g = centre_of[p]; if (g >= 0) acc += grad_new_normal[(long long)g * ldg + ch]; }
+      if (grad_new_normal) {
+        const int g = centre_of[p];
+        if (g >= 0) acc += grad_new_normal[(long long)g * ldg + ch];
+        else if (g < -1 && fps_idx) {                   // the centre of several groups (FPS repeated the row): all of them, ascending
+          const int g0 = -2 - g, gend = (g0 / m + 1) * m, pl = (int)(p - (long long)(g0 / m) * n);
+          for (int g2 = g0; g2 < gend; ++g2)
+            if (fps_idx[g2] == pl) acc += grad_new_normal[(long long)g2 * ldg + ch];
+        } else if (g < -1) acc += grad_new_normal[(long long)(-2 - g) * ldg + ch];
+      }
       grad_normal[p * cn + ch] = acc;
     } else {
       grad_feature[p * cf + (ch - cn)] = acc;
@@ -737,6 +758,7 @@ extern "C" int rs_compact_csr(int b, int n, int m, const int *src, const int *of
   if (b == 0 || n == 0) return RS_OK;
   RS_REQUIRE(src && offsets && csr_off && centre_of && csr_rows, "rs_compact_csr: null pointer");
   RS_REQUIRE(n <= 16384, "rs_compact_csr: %d points per cloud exceed the 16 384 the workgroup's counters hold", n);
+  RS_REQUIRE_LDS((size_t)2 * n * sizeof(int), "rs_compact_csr");
   hipLaunchKernelGGL(compact_csr_kernel, dim3(b), dim3(CSR_THREADS), (size_t)2 * n * sizeof(int), (hipStream_t)stream, n, m, src,
                      offsets, fps_idx, csr_off, centre_of, csr_rows);
   RS_CHECK_LAUNCH("rs_compact_csr");
@@ -749,8 +771,9 @@ extern "C" int rs_compact_csr(int b, int n, int m, const int *src, const int *of
 extern "C" int rs_group_features_compact_backward_csr(int b, int n, int cn, int cf, int polar, const float *grad_out,
                                                       const int *csr_off, const int *csr_rows, const int *centre_of,
                                                       float *grad_normal, float *grad_feature, const float *grad_new_normal,
-                                                      long long ldg, void *stream) {
+                                                      long long ldg, const int *fps_idx, int m, void *stream) {
   RS_REQUIRE(b >= 0 && n >= 0 && cn >= 0 && cf >= 0, "rs_group_features_compact_backward_csr: negative size");
+  RS_REQUIRE(!grad_new_normal || (fps_idx && m > 0), "rs_group_features_compact_backward_csr: the centre rows need fps_idx (b, m)");
   if (b == 0 || n == 0) return RS_OK;
   RS_REQUIRE(grad_out && csr_off && csr_rows && centre_of, "rs_group_features_compact_backward_csr: null pointer");
   RS_REQUIRE(!grad_new_normal || (grad_normal && ldg >= cn), "rs_group_features_compact_backward_csr: the centre rows add into grad_normal");
@@ -761,7 +784,7 @@ extern "C" int rs_group_features_compact_backward_csr(int b, int n, int cn, int 
   const int cw = (grad_normal ? cn : 0) + (grad_feature ? cf : 0);
   const long long points = (long long)b * n;
   hipLaunchKernelGGL(compact_gather_bwd_kernel, dim3(grid_for(points * cw)), dim3(GR_THREADS), 0, (hipStream_t)stream, points, cn, cf,
-                     cpos, ctot, grad_out, csr_off, csr_rows, centre_of, grad_normal, grad_feature, grad_new_normal, ldg);
+                     cpos, ctot, grad_out, csr_off, csr_rows, centre_of, grad_normal, grad_feature, grad_new_normal, ldg, fps_idx, n, m);
   RS_CHECK_LAUNCH("rs_group_features_compact_backward_csr");
   return RS_OK;
 }
@@ -776,6 +799,7 @@ extern "C" int rs_inverse_index(int b, int per, int max_points, const int *src, 
   if (b == 0) return RS_OK;
   RS_REQUIRE(src && edge_ends && point_ends && csr_off && csr_edges && overflow, "rs_inverse_index: null pointer");
   RS_REQUIRE(max_points > 0 && max_points <= 16384, "rs_inverse_index: max_points=%d outside 1..16384", max_points);
+  RS_REQUIRE_LDS((size_t)2 * max_points * sizeof(int), "rs_inverse_index");
   hipLaunchKernelGGL(inverse_index_kernel, dim3(b), dim3(CSR_THREADS), (size_t)2 * max_points * sizeof(int), (hipStream_t)stream, per, src,
                      edge_ends, point_ends, max_points, csr_off, csr_edges, overflow);
   RS_CHECK_LAUNCH("rs_inverse_index");
@@ -796,7 +820,8 @@ extern "C" int rs_group_features_backward_csr(long long points, int cn, int cf, 
   if (!grad_normal && !grad_feature) return RS_OK;
   const int cw = (grad_normal ? cn : 0) + (grad_feature ? cf : 0);
   hipLaunchKernelGGL(compact_gather_bwd_kernel, dim3(grid_for(points * cw)), dim3(GR_THREADS), 0, (hipStream_t)stream, points, cn, cf,
-                     c0, ldo, grad_out, csr_off, csr_edges, (const int *)nullptr, grad_normal, grad_feature, (const float *)nullptr, 0LL);
+                     c0, ldo, grad_out, csr_off, csr_edges, (const int *)nullptr, grad_normal, grad_feature, (const float *)nullptr, 0LL,
+                     (const int *)nullptr, 0, 1);
   RS_CHECK_LAUNCH("rs_group_features_backward_csr");
   return RS_OK;
 }

@@ -2328,11 +2328,18 @@ int check_operand(const char *who, const RowOperand *o, long long rows) {
   return RS_OK;
 }
 
+thread_local bool g_gemm_refused = false;      // set by launch_gemm_m when a tile's LDS does not fit the device
+
 template <int BM, int BN, int V, bool BF>
 void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_dev, int kdim, int cols, const RowOperand &E,
                    const float *w, int ldw, const Epilogue &ep) {
   const size_t lds = (BF && RS_SPLIT) ? sizeof(float) * 2 * 12 * ((BM * 4 + 16) + (BN * 4 + 16))      // unit 4: three parts of four planes per operand and stage
                                       : sizeof(float) * (2 * AStage<BM>::SIZE + 2 * WStage<BN>::SIZE);
+  if (lds > (size_t)rs_lds_limit()) {      // (fail with a message, not at dispatch; gemm_rows_impl returns the error)
+    rs_set_error("rs_mlp_gemm_rows: the %d x %d tile needs %zu bytes of LDS per workgroup, the device offers %d", BM, BN, lds, rs_lds_limit());
+    g_gemm_refused = true;
+    return;
+  }
   // wave-specialised instances (8 waves: 4 MFMA + 4 loader, see the kernel): fp32, 64-row tiles, vector operands
   static const int ws_on = env_int("RS_GEMM_WS", 0);       // measured slower on the fused backward instances and equal on the forward ones: DESIGN.md 5
   if constexpr (BM == 64 && !BF && V >= 2) {
@@ -2535,6 +2542,7 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
   } else if (bn == 32) launch_gemm<128, 32>(bf, v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
   else if (bn == 64) launch_gemm<128, 64>(bf, v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
   else launch_gemm<128, 128>(bf, v, grid, st, rows, rows_dev, kdim, cols, E, w, ldw, ep);
+  if (g_gemm_refused) { g_gemm_refused = false; return RS_ERR_ARG; }
   RS_CHECK_LAUNCH("rs_mlp_gemm_rows");
   return RS_OK;
 }

@@ -29,6 +29,13 @@ void rs_set_error(const char *fmt, ...);
 
 static inline int rs_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// LDS a workgroup may ask for on this device (rs_lib.cpp).  Several kernels size their dynamic LDS for MI355X's 160 KB: a launch that asks
+// for more than the device has fails HERE, with a message, instead of at dispatch.
+int rs_lds_limit(void);
+#define RS_REQUIRE_LDS(bytes, name)                                                                                          \
+  RS_REQUIRE((size_t)(bytes) <= (size_t)rs_lds_limit(), "%s: needs %zu bytes of LDS per workgroup, the device offers %d", name, \
+             (size_t)(bytes), rs_lds_limit())
+
 // ---- exact-arithmetic helpers -------------------------------------------------
 // The geometry translation units are compiled with -ffp-contract=off, so a*b+c
 // below is two roundings; rs_fma is the only fused form.

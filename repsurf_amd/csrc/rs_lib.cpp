@@ -15,6 +15,17 @@ void rs_set_error(const char *fmt, ...) {
 extern "C" const char *rs_last_error(void) { return g_err; }
 extern "C" int rs_abi_version(void) { return 33; }
 
+// bytes of LDS one workgroup may ask for on the current device (cached per process: this library targets one device model)
+int rs_lds_limit(void) {
+  static int cached = 0;
+  if (cached > 0) return cached;
+  int dev = 0;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 65536;      // (not cached: ask again)
+  cached = (int)p.sharedMemPerBlock;
+  return cached;
+}
+
 extern "C" int rs_device_info(int *cu_count, int *wave_size, int *lds_bytes, char *arch, int arch_len) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);

@@ -403,10 +403,33 @@ def inverse_index(src, per, edge_ends, point_ends):
     dev = src.device
     csr_off = torch.empty((points + 1,), dtype=torch.int32, device=dev)
     csr_edges = torch.empty((max(e, 1),), dtype=torch.int32, device=dev)
-    overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
     _lib.call("rs_inverse_index", edge_ends.numel(), per, largest, _p(src), _p(edge_ends), _p(point_ends), _p(csr_off), _p(csr_edges),
-              _p(overflow), _stream())
+              _p(_inverse_overflow(dev)), _stream())
     return csr_off, csr_edges
+
+
+_inv_overflow = {}
+
+
+def _inverse_overflow(device):
+    """Persistent per-device counter rs_inverse_index adds to when a cloud holds more rows than the host-side offsets said (a stale
+    `_rs_host` cache: the lists of that cloud are then not written).  Allocated eagerly -- inside a capture it would live in the graph's
+    pool and every replay would reset it -- and read by `inverse_index_overflow_count`."""
+    key = str(torch.device(device))
+    if key not in _inv_overflow:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("repsurf_amd.ops.inverse_index: the first call on a device must run eagerly (one warm-up pass) before capture")
+        _inv_overflow[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+    return _inv_overflow[key]
+
+
+def inverse_index_overflow_count(device=None):
+    """Clouds (since the process started) whose inverse index could not be built because the device offsets exceeded the host copy the
+    launch was sized from; the backward of such a cloud read unwritten lists.  0 in a healthy run: check it where the loss is read."""
+    if device is None:
+        return sum(int(t.item()) for t in _inv_overflow.values())
+    t = _inv_overflow.get(str(torch.device(device)))
+    return 0 if t is None else int(t.item())
 
 
 # ----------------------------------------------------------------------------- grouping
@@ -618,7 +641,7 @@ class _GroupFeaturesCompact(Function):
                     grad_new_normal, ldg = _f32c(grad_new_normal), cn
             csr_off, centre_of, csr_rows = ctx.csr
             _lib.call("rs_group_features_compact_backward_csr", b, n, cn, cf, polar, _p(grad_out), _p(csr_off), _p(csr_rows), _p(centre_of),
-                      _p(gn), _p(gf), _p(grad_new_normal) if centre else None, ldg, _stream())
+                      _p(gn), _p(gf), _p(grad_new_normal) if centre else None, ldg, _p(fps_idx) if centre else None, m, _stream())
             return None, None, gn, gf, None, None, None, None, None
         gn, gf = _zero_pair(b * n, cn if ctx.need[0] else 0, cf if (ctx.need[1] and grad_out is not None) else 0, (b, n), dev)
         if grad_out is None:       # only the centres' own rows were used downstream

@@ -384,6 +384,35 @@ def test_compact_grouping_with_prebuilt_index_and_fused_centre_rows(radius, ns, 
 
 
 @pytest.mark.gpu
+def test_compact_gather_backward_with_repeated_fps_rows():
+    """a cloud with fewer distinct points than FPS is asked to pick (padding by repetition) makes FPS return the same ROW
+    for several groups; every one of those groups hands its centre-row gradient to that row.  The gather backward kept one group per
+    point (a racing writer): it must give what the scatter backward gives, and the same bits on every run."""
+    from repsurf_amd import ops
+    b, n, s, cn, ns = 2, 128, 64, 10, 8
+    base = cloud(21, b, 24)                                   # 24 distinct points per cloud ...
+    xyz = torch.from_numpy(np.concatenate([base] * 6, 1)[:, :n].copy()).cuda()          # ... repeated to 128 rows: 64 picks must repeat rows
+    fps = ops.furthestsampling(xyz, s)
+    assert len(set(fps[0].tolist())) < s                      # the premise: FPS repeated rows
+    centres = ops.gather_rows(xyz, fps)
+    idx, cnt = ops.ballquery(0.3, ns, xyz, centres, return_count=True)
+    g = torch.Generator().manual_seed(4)
+    normal0 = torch.randn(b, n, cn, generator=g).cuda()
+    w_rows = torch.randn(b * s * ns, 6 + cn, generator=g).cuda()
+    w_centre = torch.randn(b * s, cn, generator=g).cuda()
+    grads = {}
+    for kind in ("scatter", "gather", "gather_again"):
+        normal = normal0.clone().requires_grad_()
+        index = ops.compact_index(idx, cnt, n, csr=kind.startswith("gather"), fps_idx=fps)
+        cg, new_normal = ops.group_features_compact(xyz, centres, normal, None, idx, cnt, polar=True, index=index, fps_idx=fps)
+        rows = int(cg.offsets[-1])
+        ((cg.x[:rows] * w_rows[:rows]).sum() + (new_normal.reshape(b * s, cn) * w_centre).sum()).backward()
+        grads[kind] = normal.grad.clone()
+    assert torch.allclose(grads["gather"], grads["scatter"], rtol=1e-5, atol=1e-5), (grads["gather"] - grads["scatter"]).abs().max()
+    assert torch.equal(grads["gather"], grads["gather_again"])
+
+
+@pytest.mark.gpu
 def test_group_all_gradients_are_column_slices():
     from repsurf_amd import ops
     from tests.util import cloud
