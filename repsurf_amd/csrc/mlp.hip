@@ -353,7 +353,10 @@ __device__ __forceinline__ void frag_store(float *stage, int plane, int k0, int 
 // on fp32 MFMAs "a wave that only loads" does not run BESIDE the matrix stream, it runs in its gaps: the kernel's
 // efficiency is 64 / (64 + issue cycles of the non-MFMA instructions per MFMA) whichever wave executes them.
 template <int BM, int BN, int V, int MODE, bool BF, bool WS = false>
-__global__ void __launch_bounds__(WS ? 2 * GM_THREADS : GM_THREADS, WS ? 4 : 2)     // >= 2 workgroups per CU: one computes while another stages
+// (the 64 x 64 forward instances of the split products -- 50 KB of LDS: THREE workgroups fit a CU -- are held to the 168 VGPRs that takes;
+//  they used 183-195 after the weights' units got registers of their own, and fit without a spill)
+__global__ void __launch_bounds__(WS ? 2 * GM_THREADS : GM_THREADS,
+                                  WS ? 4 : ((BF && RS_SPLIT && BM == 64 && BN == 64 && MODE >= 0 && MODE <= OPM_RELU2) ? 3 : 2))     // >= 2 workgroups per CU: one computes while another stages
 gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim, int cols, RowOperand E,
                  const float *__restrict__ w, int ldw, Epilogue ep) {
   // compacted inputs carry their row count on the device (no host sync); rows_arg is then the capacity
