@@ -647,18 +647,40 @@ constexpr int B3_SLACK = 8;                               // float4 entries behi
 constexpr int B3_MAXG = 11;                               // cells per axis (LDS: three workgroups per CU at n = 1024)
 constexpr int B3_MAXCELLS = B3_MAXG * B3_MAXG * B3_MAXG;
 
+// min / max over the 64 lanes, result in every lane: four DPP steps inside the rows of 16 (the permutation and the min in ONE
+// instruction: v_min_f32_dpp), then the gfx950 permlane swaps across rows.  Written as instructions: fminf / fmaxf through the
+// compiler cost a separate v_mov_dpp and a canonicalising v_max per step -- 35 VALU per butterfly, 210 of the build's 479 per wave
+// for the six bounding-box reductions (profiles/r05/ballquery_pmc.txt); this form is 10.  (s_nop 1: a VALU result needs two wait
+// states before a DPP instruction may read it, and the assembler does not insert them inside inline assembly.)  Inputs are finite.
+#define BQ_DPP4(OP)                                                                                                       \
+  float r;                                                                                                                \
+  asm("s_nop 1\n\t" OP "_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));            \
+  asm("s_nop 1\n\t" OP "_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(r));            \
+  asm("s_nop 1\n\t" OP "_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));                \
+  asm("s_nop 1\n\t" OP "_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(r));
 __device__ __forceinline__ float bq_wave_fmin(float x) {
+  BQ_DPP4("v_min_f32")
   unsigned v = __float_as_uint(x);
-#define BQ_STEP(EXPR) v = __float_as_uint(fminf(__uint_as_float(v), __uint_as_float(EXPR)))
-  BQ_STEP(rs_dpp<RS_DPP_QUAD_XOR1>(v)); BQ_STEP(rs_dpp<RS_DPP_QUAD_XOR2>(v));
-  BQ_STEP(rs_dpp<RS_DPP_ROW_HALF_MIRROR>(v)); BQ_STEP(rs_dpp<RS_DPP_ROW_MIRROR>(v));
-#undef BQ_STEP
-  auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-  v = __float_as_uint(fminf(__uint_as_float((unsigned)r[0]), __uint_as_float((unsigned)r[1])));
-  auto s = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-  return fminf(__uint_as_float((unsigned)s[0]), __uint_as_float((unsigned)s[1]));
+  auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  float m;
+  asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(__uint_as_float((unsigned)p[0])), "v"(__uint_as_float((unsigned)p[1])));
+  v = __float_as_uint(m);
+  auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(__uint_as_float((unsigned)q[0])), "v"(__uint_as_float((unsigned)q[1])));
+  return m;
 }
-__device__ __forceinline__ float bq_wave_fmax(float x) { return -bq_wave_fmin(-x); }
+__device__ __forceinline__ float bq_wave_fmax(float x) {
+  BQ_DPP4("v_max_f32")
+  unsigned v = __float_as_uint(x);
+  auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  float m;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(__uint_as_float((unsigned)p[0])), "v"(__uint_as_float((unsigned)p[1])));
+  v = __float_as_uint(m);
+  auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(__uint_as_float((unsigned)q[0])), "v"(__uint_as_float((unsigned)q[1])));
+  return m;
+}
+#undef BQ_DPP4
 
 __device__ __forceinline__ void b3_sort12(int (&v)[16]) {
   constexpr unsigned char P12[39][2] = {{0,8},{1,7},{2,6},{3,11},{4,10},{5,9},{0,1},{2,5},{3,4},{6,9},{7,8},{10,11},{0,2},{1,6},{5,10},{9,11},
@@ -808,9 +830,15 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
     // The walk: row r = 3 w + k puts its eight slots into word w; after the walk slot s of that row sits at bit 23 - (8 k + s).
     int cnt = 0;                                                // hits appended so far (the true count; the row keeps <= HCAP + 1)
     unsigned acc[3] = {0u, 0u, 0u}, valid[3] = {0u, 0u, 0u};
+    // (which row goes into which word: the centre's own row of cells holds ~1.5 of a centre's 4.9 hits, the four edge rows ~0.6 each, the
+    //  corners ~0.25 -- in natural order the middle word carries 2.7 of them and the decode loop, which runs as long as the busiest word of
+    //  the busiest lane has bits, pays for it; interleaved {4,0,2} {1,3,6} {5,7,8} the words expect 2.0 / 1.45 / 1.45)
+    constexpr int B3_ROW[9] = {4, 0, 2, 1, 3, 6, 5, 7, 8};
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int jbr = (int)(jl[r] & 0xffffu), lnr = (int)(jl[r] >> 16);
+    for (int ri = 0; ri < 9; ++ri) {
+      const int r = ri;                                           // position in the words; the row of cells it holds is B3_ROW[ri]
+      const unsigned jlr = jl[B3_ROW[ri]];
+      const int jbr = (int)(jlr & 0xffffu), lnr = (int)(jlr >> 16);
       const float4 *P = sp4 + jbr;
 #pragma unroll
       for (int h = 0; h < 8; h += 4) {                            // four gathers in flight together (eight would spill)
@@ -850,7 +878,8 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
           ++cnt;
         }
       };
-      const unsigned r0 = jl[0], r1 = jl[1], r2_ = jl[2], r3 = jl[3], r4 = jl[4], r5 = jl[5], r6 = jl[6], r7 = jl[7], r8 = jl[8];
+      const unsigned r0 = jl[B3_ROW[0]], r1 = jl[B3_ROW[1]], r2_ = jl[B3_ROW[2]], r3 = jl[B3_ROW[3]], r4 = jl[B3_ROW[4]], r5 = jl[B3_ROW[5]],
+                     r6 = jl[B3_ROW[6]], r7 = jl[B3_ROW[7]], r8 = jl[B3_ROW[8]];
       while (__ballot((a0 | a1 | a2) != 0u)) { take(a0, r0, r1, r2_); take(a1, r3, r4, r5); take(a2, r6, r7, r8); }
     }
     const bool over = cnt > B3_HCAP;

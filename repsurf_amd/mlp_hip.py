@@ -314,6 +314,8 @@ def _pack_items(items, device):
         if n:
             _lib.call("rs_pack_weights", ctypes.byref(a), _stream())
     if split:
+        if len(_split3) > 512:                      # (eager loops that never prepack: entries pin their operands, so bound the table)
+            _split3.clear()
         for (w, _), o, img, l3 in zip(items, outs, imgs, ld3s):
             _split3[o.data_ptr()] = (img, l3, _weights_epoch, w._version, w, o)
     return outs
