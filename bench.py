@@ -921,6 +921,8 @@ def main():
                "roofline": roofline, "roofline_ballquery": ball_line, "fps_us_per_pick": fps_line, "cpu_baseline": cpu}
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        if world > 1:
+            out["allreduce_us"] = None if allreduce_us is None else round(allreduce_us, 1)      # (also in config: the step's one data-path collective, alone)
         if world == 1 and args.dtype == "fp32" and mlp_hip_split3() and not args.no_alt_arithmetic:
             out["fp32_mfma_ms_per_step"] = alt_arithmetic_ms(args)      # the same step under RS_GEMM_SPLIT3=0, 30 steps, child process
         print(json.dumps(out), flush=True)
