@@ -3,7 +3,7 @@
 # product build.  Run HERE after `make`; the .so files travel to the GPU box under build_exp/ (git-ignored; ~21 MB each: a push of
 # several takes tens of seconds) and are selected with REPSURF_HIP_LIB=build_exp/librepsurf_<NAME>.so.
 #   (SP_PIPE, the software-pipelined loop, was measured in round 5 and removed: profiles/r05/sp_pipe_ab.txt)
-#   tools/build_exp_split.sh SP_ONE_MFMA SP_ONE_FRAG SP_ONE_STORE SP_ONE_MFMA+SP_ONE_FRAG+SP_ONE_STORE      the what-if builds (tools/_r04_bo.sh)
+#   tools/build_exp_split.sh SP_ONE_MFMA SP_ONE_FRAG SP_ONE_STORE SP_ONE_MFMA+SP_ONE_FRAG+SP_ONE_STORE      the what-if builds of round 4 (profiles/r04/gemm_split3_whatif.txt)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_exp

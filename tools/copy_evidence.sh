@@ -1,5 +1,5 @@
 #!/bin/bash
-# copy the merged outputs of tools/r03_evidence.sh (gpurun_out/) into profiles/<round>/ under the names DESIGN.md cites
+# copy the merged outputs of tools/r05_evidence.sh (gpurun_out/r0Nev, gpurun_out/prof_r0N_*) into profiles/<round>/ under the names DESIGN.md cites
 R=${1:-r03}; P=profiles/$R; H=gpurun_out/${R}h; [ -d gpurun_out/${R}ev ] && H=gpurun_out/${R}ev
 mkdir -p $P
 for f in bench_cls bench_cls_real bench_cls_dense bench_cls_2x bench_cls_nopipe bench_cls_bf16_b64 bench_seg; do [ -f $H/$f.json ] && tail -1 $H/$f.json > $P/$f.json; done

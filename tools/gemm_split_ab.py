@@ -3,7 +3,7 @@
 instances: error against an fp64 product and time per launch at the step's shapes.  The switch is read once per process:
     RS_GEMM_SPLIT3=0 python tools/gemm_split_ab.py      # fp32 MFMA
     python tools/gemm_split_ab.py                       # the default: six bf16 MFMAs over three-part operands
-(GPU box; tools/_r04_bb.sh runs both and the step A/B -> profiles/r04/gemm_split3_ab.txt)"""
+(GPU box; round 4 ran both and the step A/B: profiles/r04/gemm_split3_ab.txt)"""
 import os
 import sys
 
