@@ -62,14 +62,17 @@ __device__ __forceinline__ float pack_bf16(float lo, float hi) {
 // so h + m + l differs from x by at most the last rounding: 2^-8 of 2^-16 |x|.
 constexpr bool RS_SPLIT = RS_MLP_TU == 4;
 __device__ __forceinline__ void split_bf16(float x0, float x1, float (&d)[3]) {
+  // (the two residual subtractions of a pair as ONE v_pk_add_f32 each -- exact either way: 9 instead of 11 VALU per pair)
   d[0] = pack_bf16(x0, x1);
   unsigned u = __float_as_uint(d[0]);
-  float r0 = x0 - __uint_as_float(u << 16), r1 = x1 - __uint_as_float(u & 0xffff0000u);
-  d[1] = pack_bf16(r0, r1);
+  const f32x2 x = {x0, x1};
+  const f32x2 h = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  f32x2 r = x - h;
+  d[1] = pack_bf16(r[0], r[1]);
   u = __float_as_uint(d[1]);
-  r0 -= __uint_as_float(u << 16);
-  r1 -= __uint_as_float(u & 0xffff0000u);
-  d[2] = pack_bf16(r0, r1);
+  const f32x2 m = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  r = r - m;
+  d[2] = pack_bf16(r[0], r[1]);
 }
 
 // ---- on-the-fly row operands -----------------------------------------------------------------
