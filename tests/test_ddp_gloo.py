@@ -256,3 +256,39 @@ def test_sync_batchnorm_partials_span_the_ranks():
             factor, mean, var, ref_mean, ref_var = out[r]
             assert factor == world
             assert torch.allclose(mean, ref_mean, atol=1e-12) and torch.allclose(var, ref_var, atol=1e-12)
+
+
+def _helper_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from repsurf_amd import dist as rdist
+    rdist.init(backend="gloo")
+    a = torch.full((4,), float(rank + 1))
+    assert rdist.all_reduce(a) is None                       # synchronous form: reduced on return
+    b = torch.full((4,), float(rank + 1))
+    work = rdist.all_reduce(b, op=dist.ReduceOp.MAX, async_op=True)      # asynchronous form: something with wait()
+    work.wait()
+    closed = []
+
+    class Step:                                              # what finish() is handed: the graphed steps still alive
+        def close(self):
+            closed.append(dist.is_initialized())             # close() runs BEFORE the process group goes
+
+    rdist.barrier()
+    rdist.finish(Step(), None)
+    out[rank] = (a.tolist(), b.tolist(), closed, dist.is_initialized())
+
+
+def test_collective_helper_and_teardown_order():
+    """repsurf_amd.dist.all_reduce (the one way the package issues a collective: sync / async forms), barrier and finish(*steps): the
+    steps are closed first -- their graphs hold recorded collectives of the communicator -- then the group is destroyed."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_helper_worker, args=(world, port, out), nprocs=world, join=True)
+        for r in range(world):
+            a, b, closed, alive = out[r]
+            assert a == [3.0] * 4 and b == [2.0] * 4
+            assert closed == [True] and alive is False
