@@ -450,6 +450,11 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, NSET - 1>;
 
+#ifdef RS_EXP_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+  const long long tstart = tlast;
+#endif
   // Loads are never predicated: out-of-range rows / k are CLAMPED to the last valid element (always in bounds,
   // finite) and zeroed when the values are committed to LDS -- straight-line code, no exec-mask branches.
   // `part` < 0 issues the whole chunk.  (Spreading the parts 0..3 over the four MFMA groups of the running chunk was
@@ -490,6 +495,10 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   };
   auto commit = [&](auto set_, float *As, float *Ws, long long r0, int k0) {
     constexpr int S = decltype(set_)::value;
+#ifdef RS_EXP_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (timing build: the wait for the chunk's global loads on its own stamp)
+    RS_T(7);
+#endif
     const bool kok = (k0 + a_kq) < kdim;
 #pragma unroll
     for (int p = 0; p < A_VECS; ++p) {
@@ -565,11 +574,6 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
     }
   };
 
-#ifdef RS_EXP_TIMING
-  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tlast = clock64();
-  const long long tstart = tlast;
-#endif
   float st0[CT], st1[CT], st2[CT];                          // DIRECT: this lane's column sums over all its tiles
 #pragma unroll
   for (int c = 0; c < CT; ++c) { st0[c] = 0.f; st1[c] = 0.f; st2[c] = 0.f; }
@@ -1058,7 +1062,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
     long long *o = reinterpret_cast<long long *>(ep.pool_amax) + ((long long)blockIdx.y * gridDim.x + blockIdx.x + (loader ? 4096 : 0)) * 10;
     for (int i = 0; i < 7; ++i) o[i] = tacc[i];
     o[7] = clock64() - tstart;
-    o[8] = 0;
+    o[8] = tacc[7];
     o[9] = tiles;
   }
 #endif

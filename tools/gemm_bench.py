@@ -161,6 +161,7 @@ if __name__ == "__main__":
             print(f"{tag}: rows={rows} k={k} n={n} frac={frac}: {len(act)} workgroups reported, tiles={act[0, 9]}")
             for i, nm in enumerate(names):
                 print(f"  {nm:48s} {act[:, i].mean():10.0f} cycles  ({100 * act[:, i].mean() / act[:, 7].mean():5.1f}%)")
+            print(f"  {'(wait for the chunk global loads, own stamp)':48s} {act[:, 8].mean():10.0f} cycles  ({100 * act[:, 8].mean() / act[:, 7].mean():5.1f}%)")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "one":        # one shape, for PMC runs: one <rows> <k> <n> [frac]
         rows, k, n = (int(v) for v in sys.argv[2:5])
