@@ -294,6 +294,19 @@ for kind in ("uniform", "clustered", "grid", "dup"):
         assert np.array_equal(got.cpu().numpy(), ref), (kind, n, s, r, ns)
         distinct = np.array([[len(set(row.tolist())) for row in b_] for b_ in ref])
         assert np.array_equal(cnt.cpu().numpy(), distinct), (kind, "count")
+# degenerate clouds: every point the same (one cell, every row overflows), a line along x (one pencil of cells), a plane
+rs = np.random.RandomState(3)
+same = np.tile(np.array([[[0.3, -0.2, 0.1]]], np.float32), (2, 600, 1))
+line = np.zeros((2, 600, 3), np.float32); line[..., 0] = rs.rand(2, 600) * 2 - 1
+plane = (rs.rand(2, 600, 3) * 2 - 1).astype(np.float32); plane[..., 2] = 0.25
+for name, xyz in (("same", same), ("line", line), ("plane", plane)):
+    centres = xyz[:, ::4].copy()
+    for (r, ns) in ((0.2, 32), (0.05, 8), (3.0, 16)):
+        got, cnt = ops.ballquery(r, ns, torch.from_numpy(xyz).cuda(), torch.from_numpy(centres).cuda(), return_count=True)
+        ref = G.ballquery(r, ns, xyz, centres)
+        assert np.array_equal(got.cpu().numpy(), ref), (name, r, ns)
+        distinct = np.array([[len(set(row.tolist())) for row in b_] for b_ in ref])
+        assert np.array_equal(cnt.cpu().numpy(), distinct), (name, "count")
 far = np.full((1, 4, 3), 5.0, np.float32)
 xyz = cloud(1, 1, 256, "uniform")
 assert (ops.ballquery(0.1, 8, torch.from_numpy(xyz).cuda(), torch.from_numpy(far).cuda()).cpu().numpy() == 0).all()
