@@ -657,7 +657,7 @@ constexpr int B3_MAXCELLS = B3_MAXG * B3_MAXG * B3_MAXG;
   asm("s_nop 1\n\t" OP "_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));            \
   asm("s_nop 1\n\t" OP "_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(r));            \
   asm("s_nop 1\n\t" OP "_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));                \
-  asm("s_nop 1\n\t" OP "_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(r));
+  asm("s_nop 1\n\t" OP "_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "=v"(x) : "v"(r));      /* (trailing nop: the permlane swap below reads x, and the hazard pass does not see into the assembly) */
 __device__ __forceinline__ float bq_wave_fmin(float x) {
   BQ_DPP4("v_min_f32")
   unsigned v = __float_as_uint(x);
