@@ -309,8 +309,10 @@ def knnquery(nsample, xyz, new_xyz=None, return_dist=False):
 KNN_GRID = os.environ.get("REPSURF_KNN_GRID", "1") != "0"
 UMBRELLA_GRID = os.environ.get("REPSURF_UMBRELLA_GRID", "1") != "0"        # classification: rs_umbrella_features_grid ...
 # ... from this many points per cloud (k = 9, stand-alone: 32 x 1024: grid 126 us, scan 92; 64 x 2048: 145 / 383; 16 x 4096: 133 / 340;
-# 8 x 8192: 158 / 546 -- inside the 32 x 1024 step the two are level, 1.402 / 1.405 ms)
-UMBRELLA_GRID_MIN_ROWS = int(os.environ.get("REPSURF_UMBRELLA_GRID_MIN_ROWS", "2048"))
+# 8 x 8192: 158 / 546).  Round 5: 1 024 instead of 2 048 -- inside the 32 x 1024 step the grid form is the cheaper NEIGHBOUR of the
+# network it runs beside (fewer CU-microseconds, although longer alone): 1.2943 -> 1.2814 ms per step, four interleaved pairs on one box
+# (round 4 had them level, 1.402 / 1.405); identical lists and features (tests/test_geometry_gpu.py), whole GPU suite green either way.
+UMBRELLA_GRID_MIN_ROWS = int(os.environ.get("REPSURF_UMBRELLA_GRID_MIN_ROWS", "1024"))
 # rows per cell = fill * nsample.  The ball of the nsample nearest rows has the volume of nsample / density; one wave per query
 # (lists of 17 .. 64 entries) wants cells about as large as that ball -- 64 candidates per trip, the 27 cells around the query are
 # enough for most queries (16 384 queries over 16 x 4096 rows: fill 0.45 / 1.0 / 2.0 -> 76 / 71 / 68 us) --, one thread per query
