@@ -1986,22 +1986,28 @@ bn_finalize_kernel(int c, long long rows, int nblk, const double *__restrict__ p
   const int which[2] = {0, 1};
   double sq[2];
   bool owner;
+  // the owner's channel vectors are requested BEFORE the reduction (one memory round trip less behind it: these launches are a
+  // chain of dependent latencies, ~5 us each whatever their size)
+  // (unconditional loads at a clamped channel, absent vectors read `scale` instead: a load under a branch is waited for at the end of
+  // its block, in front of the reduction's own loads)
+  const int ch = blockIdx.x * 8 + (threadIdx.x & 7), chc = ch < c ? ch : c - 1;
+  const float g_ = (gamma ? gamma : scale)[chc], b_ = (beta ? beta : scale)[chc];
+  const float rm_ = (running_mean ? running_mean : scale)[chc], rv_ = (running_var ? running_var : scale)[chc];
   reduce_stat_rows<2>(blockIdx.x, c, nblk, 2, which, partial, sq, owner);
   if (!owner) return;
-  const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
   const double mean = sq[0] / (double)rows;
   double var = sq[1] / (double)rows - mean * mean;
   if (var < 0.0) var = 0.0;
   const double invstd = 1.0 / sqrt(var + (double)eps);
-  const double g = gamma ? (double)gamma[ch] : 1.0, bt = beta ? (double)beta[ch] : 0.0;
+  const double g = gamma ? (double)g_ : 1.0, bt = beta ? (double)b_ : 0.0;
   scale[ch] = (float)(g * invstd);
   shift[ch] = (float)(bt - mean * g * invstd);
   mean_out[ch] = (float)mean;
   invstd_out[ch] = (float)invstd;
   if (running_mean) {
     const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
-    running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mean);
-    running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
+    running_mean[ch] = (float)((1.0 - momentum) * (double)rm_ + momentum * mean);
+    running_var[ch] = (float)((1.0 - momentum) * (double)rv_ + momentum * unbiased);
   }
 }
 
@@ -2077,11 +2083,12 @@ backward_tail_kernel(rs_backward_tail_work w, TailStarts st) {
     const int sel[2] = {0, it.which};
     double v[2];
     bool owner;
+    const int ch = cb * 8 + (threadIdx.x & 7), chc = ch < it.c ? ch : it.c - 1;
+    const float s_ = it.scale[chc], is_ = it.invstd[chc], mu_ = it.mean[chc];       // requested before the reduction (see bn_finalize_kernel)
     reduce_stat_rows<2>(cb, it.c, it.nblk, it.nstat, sel, it.partial, v, owner);
     if (!owner) return;
-    const int ch = cb * 8 + (threadIdx.x & 7);
     const double db = v[0], dg = v[1];
-    const double s = it.scale[ch], is = it.invstd[ch], mu = it.mean[ch], m = (double)it.rows;
+    const double s = s_, is = is_, mu = mu_, m = (double)it.rows;
     const double qq = -s * is * dg / m;                 // dy = s * (dz - db/m - yhat * dg/m),  yhat = (y - mu) * is
     it.p[ch] = (float)s;
     it.q[ch] = (float)qq;
@@ -2107,23 +2114,25 @@ bn_finalize_batch_kernel(BnBatch w) {
   const int which[2] = {0, 1};
   double sq[2];
   bool owner;
+  const int ch = cb * 8 + (threadIdx.x & 7), chc = ch < it.c ? ch : it.c - 1;      // requested before the reduction (see bn_finalize_kernel)
+  const float g_ = (it.gamma ? it.gamma : it.scale)[chc], b_ = (it.beta ? it.beta : it.scale)[chc];
+  const float rm_ = (it.running_mean ? it.running_mean : it.scale)[chc], rv_ = (it.running_var ? it.running_var : it.scale)[chc];
   reduce_stat_rows<2>(cb, it.c, it.nblk, 2, which, it.partial, sq, owner);
   if (!owner) return;
-  const int ch = cb * 8 + (threadIdx.x & 7);
   const double rows = (double)it.rows;
   const double mean = sq[0] / rows;
   double var = sq[1] / rows - mean * mean;
   if (var < 0.0) var = 0.0;
   const double invstd = 1.0 / sqrt(var + (double)it.eps);
-  const double g = it.gamma ? (double)it.gamma[ch] : 1.0, bt = it.beta ? (double)it.beta[ch] : 0.0;
+  const double g = it.gamma ? (double)g_ : 1.0, bt = it.beta ? (double)b_ : 0.0;
   it.scale[ch] = (float)(g * invstd);
   it.shift[ch] = (float)(bt - mean * g * invstd);
   it.save_mean[ch] = (float)mean;
   it.save_invstd[ch] = (float)invstd;
   if (it.running_mean) {
     const double unbiased = it.rows > 1 ? var * rows / (rows - 1.0) : var;
-    it.running_mean[ch] = (float)((1.0 - it.momentum) * (double)it.running_mean[ch] + it.momentum * mean);
-    it.running_var[ch] = (float)((1.0 - it.momentum) * (double)it.running_var[ch] + it.momentum * unbiased);
+    it.running_mean[ch] = (float)((1.0 - it.momentum) * (double)rm_ + it.momentum * mean);
+    it.running_var[ch] = (float)((1.0 - it.momentum) * (double)rv_ + it.momentum * unbiased);
   }
 }
 
