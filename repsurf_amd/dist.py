@@ -106,7 +106,7 @@ def time_allreduce(numel, device, reps=10):
     cuda = torch.device(device).type == "cuda"
     if cuda:
         torch.cuda.synchronize()
-    dist.barrier()
+    barrier()
     import time
     t0 = time.perf_counter()
     for _ in range(reps):
