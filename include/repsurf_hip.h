@@ -340,10 +340,14 @@ typedef struct rs_mlp_epilogue {
    * is rounded to bf16 (nearest even) FIRST and the BatchNorm sums / fused pooling see the rounded values -- what the
    * consumers of the stored tensor will read (torch.autocast does the same: a bf16 conv output feeds an fp32 BatchNorm). */
   int out_bf16, my1_bf16, my2_bf16;
-  /* Round 5, optional: the weights of THIS launch already split into three bf16 parts (rs_pack_weights: dst3) -- w3[q][n][k],
-   * q = 0..2 (h, m, l), n < cols rows of ldw3 bf16 (a multiple of 32, zero beyond kdim), parts w3_part elements apart.  The
-   * split-product instances of the tiled kernel (rs_mlp_gemm_split3) then copy the parts into LDS instead of splitting the
-   * weight tile again in every row tile of every launch; NULL: they split `w` themselves.  Other kernels ignore it. */
+  /* Optional: the weights of THIS launch already split into three bf16 parts (rs_pack_weights: dst3), TILE-ORDERED (round 6):
+   * w3[q][k / 8][n][k % 8], q = 0..2 (h, m, l), n < w3_part / ldw3 rows (>= cols), k < ldw3 (a multiple of 32, zero beyond kdim),
+   * parts w3_part elements apart, base 16-byte aligned -- 16-byte units of 8 consecutive k, the units of one k-octet contiguous
+   * over n, so that the split-product instances of the tiled kernel (rs_mlp_gemm_split3) move a (part, k-octet) plane of their
+   * weight tile global -> LDS with one global_load_lds_dwordx4 per 64 columns instead of splitting the weight tile again in every
+   * row tile of every launch.  NULL: the launch runs the fp32-MFMA instances (v_mfma_f32_32x32x2_f32) -- the split-product
+   * instances exist only for pre-split weights.  A non-NULL image that breaks the rules above is an error (RS_ERR_ARG).  Other
+   * kernels ignore it. */
   const void *w3; int ldw3; long long w3_part;
 } rs_mlp_epilogue;
 
@@ -458,10 +462,10 @@ typedef struct rs_pack_weights_args {
   const float *src[RS_PACK_MAX]; float *dst[RS_PACK_MAX];
   int cout[RS_PACK_MAX], cin[RS_PACK_MAX], ld[RS_PACK_MAX], transpose[RS_PACK_MAX];
   int n;
-  /* round 5: dst3[e] (optional) receives the same n-major matrix as three bf16 parts h + m + l (each the nearest-even bf16 of what
-   * the parts before it left), dst3[e][q][row][k] with rows of ld3[e] bf16 (a multiple of 32 >= the inner dimension, zero filled)
-   * and parts (outer dimension) * ld3[e] elements apart -- the `w3` operand of rs_mlp_epilogue.  dst[e] may then be NULL (a
-   * forward weight that is used in place needs no fp32 copy). */
+  /* dst3[e] (optional) receives the same n-major matrix as three bf16 parts h + m + l (each the nearest-even bf16 of what the
+   * parts before it left), tile-ordered (round 6): dst3[e][q][k / 8][row][k % 8], k < ld3[e] (a multiple of 32 >= the inner
+   * dimension, zero filled), row < outer dimension, parts (outer dimension) * ld3[e] elements apart, 16-byte aligned -- the `w3`
+   * operand of rs_mlp_epilogue.  dst[e] may then be NULL (a forward weight that is used in place needs no fp32 copy). */
   void *dst3[RS_PACK_MAX]; int ld3[RS_PACK_MAX];
 } rs_pack_weights_args;
 int rs_pack_weights(const rs_pack_weights_args *args, void *stream);

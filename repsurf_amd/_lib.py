@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 33
+ABI_VERSION = 34
 KNN_GRID_CELLS = 4096          # RS_KNN_GRID_CELLS of include/repsurf_hip.h
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong

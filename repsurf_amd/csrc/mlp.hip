@@ -87,6 +87,13 @@ __device__ __forceinline__ void split_bf16(float x0, float x1, float (&d)[3]) {
 enum { OPM_ID = RS_OP_ID, OPM_RELU1 = RS_OP_RELU1, OPM_RELU2 = RS_OP_RELU2, OPM_AFF2 = RS_OP_AFF2,
        OPM_POOLED = RS_OP_POOLED, OPM_BCAST = RS_OP_BCAST };
 typedef rs_row_operand RowOperand;
+// Internal (template arguments of the tiled kernels only, round 6): RS_OP_POOLED with the group addressing fixed at compile time.  In the
+// instance that reads it from the descriptor, the branch `o.grp ? load (grp, slot) : r / ns` joins a path with pending index loads and a
+// path with none in front of the operand loads; the compiler's s_waitcnt pass must assume the loads at the join, so the DENSE path too
+// waited for every outstanding load -- the chunk's weight transfers and the first operand vector -- in the middle of its prefetch, twice per
+// chunk (seen in the ISA; the pooled data gradient of the group_all stage is the step's dominant launch).
+constexpr int OPM_POOLED_DENSE = 6, OPM_POOLED_RAGGED = 7;
+__host__ __device__ constexpr int opm_base(int m) { return (m == OPM_POOLED_DENSE || m == OPM_POOLED_RAGGED) ? (int)OPM_POOLED : m; }
 
 // ---- vectorised operand access ------------------------------------------------------------------
 // A thread always handles V consecutive columns (V = 4, 2 or 1, chosen by the launcher from the
@@ -198,7 +205,7 @@ template <int V> struct ColCoef { float s1[V], t1[V], s2[V], t2[V]; };
 // MODE < 0 reads it from the descriptor (generic fallback).
 template <int V, int MODE>
 __device__ __forceinline__ void op_coef(const RowOperand &o, int c, bool ok, ColCoef<V> &k) {
-  const int mode = MODE >= 0 ? MODE : o.mode;
+  const int mode = MODE >= 0 ? opm_base(MODE) : o.mode;
 #pragma unroll
   for (int i = 0; i < V; ++i) { k.s1[i] = 0.f; k.t1[i] = 0.f; k.s2[i] = 0.f; k.t2[i] = 0.f; }
   if (!ok || mode == OPM_ID || mode == OPM_BCAST) return;
@@ -210,9 +217,30 @@ __device__ __forceinline__ void op_coef(const RowOperand &o, int c, bool ok, Col
 
 // Rows are addressed as (wave-uniform base row r0, small local row rl): the 64-bit part of every
 // address stays in SGPRs and the per-lane offset is 32-bit.
+// What a row of the operand carries besides its values -- group, slot inside the group, multiplicity: functions of the ROW only.  The
+// row GEMM keeps a tile's rows per thread over the whole K loop, so it fetches them once per tile (op_row_meta, round 6) instead of with
+// every chunk: for ragged groups the (group, slot) pair is an index the chunk's gathers have to wait for -- a dependent global round trip
+// per operand vector and chunk in front of the prefetch.
+struct RowMeta { unsigned g; int k; float m; };
+template <int MODE>
+__device__ __forceinline__ void op_row_meta(const RowOperand &o, long long r0, int rl, RowMeta &rm) {
+  const int mode = MODE >= 0 ? opm_base(MODE) : o.mode;
+  rm.g = 0u; rm.k = 0; rm.m = 1.f;
+  const unsigned url = (unsigned)rl;
+  if (mode == OPM_POOLED) {
+    if (MODE == OPM_POOLED_RAGGED || (MODE != OPM_POOLED_DENSE && o.grp)) { rm.g = (unsigned)(o.grp + r0)[url]; rm.k = (o.slot + r0)[url]; }
+    else {
+      const unsigned ns = (unsigned)o.ns, r = (unsigned)(r0 + rl);
+      rm.g = (ns & (ns - 1)) == 0 ? r >> (31 - __clz((int)ns)) : r / ns;
+      rm.k = (int)(r - rm.g * ns);
+    }
+  }
+  if ((mode == OPM_POOLED || mode == OPM_AFF2) && o.mult) rm.m = (o.mult + r0)[url];
+}
+
 template <int V, int MODE>
-__device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int rl, int c, bool ok, RawVec<V> &raw) {
-  const int mode = MODE >= 0 ? MODE : o.mode;
+__device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int rl, int c, bool ok, RawVec<V> &raw, const RowMeta *rm = nullptr) {
+  const int mode = MODE >= 0 ? opm_base(MODE) : o.mode;
 #pragma unroll
   for (int i = 0; i < V; ++i) { raw.a[i] = 0.f; raw.b[i] = 0.f; raw.g[i] = -1; }
   raw.m = 1.f; raw.k = 0;
@@ -226,11 +254,13 @@ __device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int r
     case OPM_RELU2: ldxu<V>(ua, offa, sb_a(OPM_RELU2), raw.a); ldxu<V>(ub, offb, sb_b(OPM_RELU2), raw.b); break;
     case OPM_AFF2:
       ldxu<V>(ua, offa, sb_a(OPM_AFF2), raw.a); ldxu<V>(ub, offb, sb_b(OPM_AFF2), raw.b);
-      if (o.mult) raw.m = (o.mult + r0)[url];
+      if (rm) raw.m = rm->m;
+      else if (o.mult) raw.m = (o.mult + r0)[url];
       break;
     case OPM_POOLED: {
       unsigned g;
-      if (o.grp) { g = (unsigned)(o.grp + r0)[url]; raw.k = (o.slot + r0)[url]; }       // compacted (ragged) groups
+      if (rm) { g = rm->g; raw.k = rm->k; }                     // (the caller fetched the row's group / slot / multiplicity once per tile)
+      else if (MODE == OPM_POOLED_RAGGED || (MODE != OPM_POOLED_DENSE && o.grp)) { g = (unsigned)(o.grp + r0)[url]; raw.k = (o.slot + r0)[url]; }       // compacted (ragged) groups
       else {
         // dense groups: row / nsample.  nsample is a power of two in every shipped stack but the 2x classifier's (24): a
         // shift instead of the ~20-instruction 32-bit division sequence, per operand vector and chunk -- on fp32 MFMAs every
@@ -242,7 +272,8 @@ __device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int r
       ldx<V>(o.a, (long long)g * o.lda + c, sb_a(OPM_POOLED), raw.a);
       ldvi<V>(o.arg + (long long)g * o.lda + c, raw.g);
       ldxu<V>(ub, offb, sb_b(OPM_POOLED), raw.b);
-      if (o.mult) raw.m = (o.mult + r0)[url];
+      if (rm) raw.m = rm->m;
+      else if (o.mult) raw.m = (o.mult + r0)[url];
       break;
     }
     default: {
@@ -254,12 +285,30 @@ __device__ __forceinline__ void op_load(const RowOperand &o, long long r0, int r
   }
 }
 
+// The raw values of a prefetch, made opaque at the point of the call: whatever is computed from them is computed BEHIND this point.  The row
+// GEMM calls it between the MFMAs of the running chunk and the commit of the next -- without it nothing keeps the commit's arithmetic
+// (a pure function of the loaded values) from being placed right behind the loads, in front of the MFMAs, where it waits for the
+// whole prefetch (round 6: seen in the ISA of the AFF2 / pooled instances; __builtin_amdgcn_sched_barrier orders the machine
+// scheduler only, and only instructions that are already on its far side).
+template <int V, int MODE>
+__device__ __forceinline__ void op_pin(RawVec<V> &raw) {
+  if constexpr (MODE >= 0) {
+    constexpr int mode = opm_base(MODE);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      asm volatile("" : "+v"(raw.a[i]));
+      if constexpr (mode == OPM_RELU2 || mode == OPM_AFF2 || mode == OPM_POOLED) asm volatile("" : "+v"(raw.b[i]));
+      if constexpr (mode == OPM_POOLED) asm volatile("" : "+v"(raw.g[i]));
+    }
+  }
+}
+
 // The affine part (s2*b + t1) of the BatchNorm-backward operands is multiplied by the row's multiplicity:
 // a compacted row stands for `m` identical copies whose pooled/masked gradients were already summed.
 template <int V, int MODE>
 __device__ __forceinline__ void op_finish(const RowOperand &o, const ColCoef<V> &k, const RawVec<V> &raw,
                                           long long r, bool ok, float (&out)[V]) {
-  const int mode = MODE >= 0 ? MODE : o.mode;
+  const int mode = MODE >= 0 ? opm_base(MODE) : o.mode;
   float ra[V], rb[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) { ra[i] = raw.a[i]; rb[i] = raw.b[i]; }
@@ -279,6 +328,22 @@ __device__ __forceinline__ void op_finish(const RowOperand &o, const ColCoef<V> 
   }
 }
 
+// 16 bytes per lane global -> LDS without a register in between (LDS-DMA, global_load_lds_dwordx4): lane l's bytes land at
+// lds + 16 l (wave-uniform destination), read from base + voff (wave-uniform base in SGPRs, per-lane unsigned byte offset).
+// Written as an assembly statement ON PURPOSE: behind the builtin (__builtin_amdgcn_global_load_lds) the compiler's memory model
+// cannot tell which LDS bytes the transfer writes and puts s_waitcnt vmcnt(0) in front of the next LDS read of ANY address -- the
+// fragment reads of the running chunk then wait for the whole prefetch of the next one (measured, round 6: the step 3 % slower than
+// the register-staged weights, profiles/r06/gemm_w_lds_dma.txt).  The statement is invisible to that pass, so the caller orders it
+// itself: `glds_wait()` (s_waitcnt vmcnt(0)) in front of the barrier that publishes the stage.  M0 (the transfer's LDS base) is
+// compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const void *base, unsigned voff, const float *lds) {
+  const unsigned dst = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)lds;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
+}
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 namespace {
 
 constexpr int GM_THREADS = 256;
@@ -286,7 +351,8 @@ constexpr int GM_BM = 128;        // rows per workgroup tile (4 waves x 32)
 constexpr int GM_BK = 32;         // reduction chunk per pipeline stage
 
 enum { EPI_STORE = RS_EPI_STORE, EPI_STATS = RS_EPI_STATS, EPI_MASK = RS_EPI_MASK };
-typedef rs_mlp_epilogue Epilogue;
+// the ABI's epilogue + what the launcher derives from it: w3_rows = rows (n) of the weights' three-part image
+struct Epilogue : rs_mlp_epilogue { int w3_rows; };
 
 // out[rows, cols] = E[rows, kdim] . W^T,  W[n][k] = w[n*ldw + k]: weights n-major (the conv weight's own
 // (cout, cin) layout), ldw % 4 == 0, entries k in [kdim, ldw) zero.
@@ -358,8 +424,17 @@ __device__ __forceinline__ void frag_store(float *stage, int plane, int k0, int 
 template <int BM, int BN, int V, int MODE, bool BF, bool WS = false>
 // (the 64 x 64 forward instances of the split products -- 50 KB of LDS: THREE workgroups fit a CU -- are held to the 168 VGPRs that takes;
 //  they used 183-195 after the weights' units got registers of their own, and fit without a spill)
-__global__ void __launch_bounds__(WS ? 2 * GM_THREADS : GM_THREADS,
-                                  WS ? 4 : ((BF && RS_SPLIT && BM == 64 && BN == 64 && MODE >= 0 && MODE <= OPM_RELU2) ? 3 : 2))     // >= 2 workgroups per CU: one computes while another stages
+// (round 6: the occupancy the instruction scheduler aims for is pinned to that number -- amdgpu_waves_per_eu(n, n).  With the weights'
+//  registers gone the forward instances fell to 138 VGPRs, the scheduler took that as an invitation to reach FOUR waves per SIMD (128) and
+//  serialised the fragment reads -- ds_read, s_waitcnt lgkmcnt(0), MFMA, one pair at a time -- to get there; LDS allows three workgroups.)
+#ifdef RS_EXP_WG2
+#define RS_GEMM_WG_PER_CU (WS ? 4 : 2)
+#else
+#define RS_GEMM_WG_PER_CU (WS ? 4 : ((BF && RS_SPLIT && BM == 64 && BN == 64 && MODE >= 0 && MODE <= OPM_RELU2) ? 3 : 2))
+#endif
+// (the attribute takes effect only when __launch_bounds__ carries no second argument: that one writes "amdgpu-waves-per-eu"="n" -- a minimum -- over it)
+__global__ void __launch_bounds__(WS ? 2 * GM_THREADS : GM_THREADS)     // >= 2 workgroups per CU: one computes while another stages
+__attribute__((amdgpu_waves_per_eu(WS ? 8 : RS_GEMM_WG_PER_CU, WS ? 8 : RS_GEMM_WG_PER_CU)))
 gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim, int cols, RowOperand E,
                  const float *__restrict__ w, int ldw, Epilogue ep) {
   // compacted inputs carry their row count on the device (no host sync); rows_arg is then the capacity
@@ -438,14 +513,19 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   //  classification, 3.378 -> 3.628 ms segmentation, profiles/r05/sp_pipe_ab.txt.  Removed.)
   constexpr bool PIPE = false;
   constexpr int NSET = (WS || PIPE) ? 2 : 1;                // WS: the loaders keep two chunks of raw operands in flight
-  // Pre-split weights (round 5, ep.w3): a chunk's weight tile is 3 parts x BN columns x 4 planes of 16 bytes (8 bf16 of one column),
-  // 12 BN units for 256 threads -- loaded as they will lie in LDS, no split and no 8-byte stores in the loop
-  constexpr int W3_UNITS = 12 * BN, W3_VECS = PARTS == 3 ? (W3_UNITS + GM_THREADS - 1) / GM_THREADS : 0;
-  constexpr int WR_VECS = PARTS == 3 ? W3_VECS : W_VECS;    // (the split-product instances run ONLY on pre-split weights: the entry point sends launches without an image to the fp32 MFMA instances)
-  typedef const char __attribute__((address_space(1))) *gptr_t;      // (a global pointer: the generic one made the compiler test for the LDS aperture)
-  const gptr_t w3g = (gptr_t)(uintptr_t)ep.w3;
+  // Pre-split weights (round 5, ep.w3; round 6: tile-ordered image, LDS-DMA): a chunk's weight tile is 3 parts x 4 planes (8 k each) x BN
+  // columns of 16 bytes (8 bf16 of one column).  The image in HBM is w3[q][k / 8][n][8]: the BN units of one (part, plane) are
+  // CONTIGUOUS and in the order they lie in LDS, so a plane travels global -> LDS as one global_load_lds_dwordx4 per 64 columns
+  // (lane = column; destination = wave-uniform base + 16 lane) -- no VGPRs, no ds_write, no weight work in the commit.  Wave w
+  // moves plane w of every part: 3 ceil(BN / 64) instructions per wave and chunk.
+  constexpr int W_HALVES = (BN + 63) / 64;
+  constexpr int WR_VECS = PARTS == 3 ? 0 : W_VECS;          // (the split-product instances run ONLY on pre-split weights: the entry point sends launches without an image to the fp32 MFMA instances)
   RawVec<V> araw[NSET][A_VECS];
-  float4 wraw[NSET][WR_VECS];
+  // group / slot / multiplicity of this thread's rows: once per tile for the operand modes that have them (the specialised instances;
+  // the wave-specialised loaders run ahead of the tile loop and keep the per-chunk form)
+  constexpr bool ROW_META = !WS && !EARLY_PREFETCH && MODE >= 0 && (opm_base(MODE) == OPM_POOLED || MODE == OPM_AFF2);
+  RowMeta rmeta[A_VECS];
+  float4 wraw[NSET][WR_VECS > 0 ? WR_VECS : 1];
   ColCoef<V> coef[NSET];
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, NSET - 1>;
@@ -460,30 +540,32 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
   // `part` < 0 issues the whole chunk.  (Spreading the parts 0..3 over the four MFMA groups of the running chunk was
   // measured and is worse: a load that cannot issue stalls the wave in front of its next MFMA -- in-order issue --
   // 126 us against 116 us at 262144 x 128 x 128, weight gradient 410 us against 320 us.)
-  auto prefetch = [&](auto set_, long long r0, int k0, int part) {
+  auto prefetch = [&](auto set_, long long r0, int k0, int part, int wstage = 0) {
     constexpr int S = decltype(set_)::value;
     const int k = min(k0 + a_kq, kdim - V);                 // kdim % V == 0
     const int rlast = (int)min((long long)BM - 1, rows - 1 - r0);
+    if constexpr (PARTS == 3) {
+      // the chunk's weight planes straight into stage `wstage` (free: the caller is past the barrier behind that stage's last readers).
+      // Issued IN FRONT of the operand loads: the compiler's s_waitcnt pass does not see these transfers, and its vmcnt(n) for an operand
+      // load counts only the loads it knows BEHIND that one -- exact as long as nothing invisible is younger (return is in order)
+      float *wdst = smem + (2 * A_STAGE + wstage * W_STAGE) + wave * PLANE_W;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int h = 0; h < W_HALVES; ++h) {
+          const int nl = h * 64 + lane;
+          if (BN >= 64 || lane < BN) {
+            const int n = min(n0 + nl, cols - 1);               // a column beyond `cols` (clamped: finite) feeds only its own column of D
+            const unsigned off = (unsigned)q * (unsigned)ep.w3_part + (((unsigned)(k0 >> 3) + (unsigned)wave) * (unsigned)ep.w3_rows + (unsigned)n) * 8u;   // elements; an image is < 2^31 bytes
+            glds16(ep.w3, 2u * off, wdst + q * PART_W + h * 256);
+          }
+        }
+    }
     if (part <= 0) op_coef<V, MODE>(E, k, true, coef[S]);
 #pragma unroll
     for (int p = 0; p < A_VECS; ++p)
-      if (part < 0 || (p * 4) / A_VECS == part) op_load<V, MODE>(E, r0, min(p * A_RPP + a_r, rlast), k, true, araw[S][p]);
-    if constexpr (PARTS == 3) {
-      {
-#pragma unroll
-        for (int p = 0; p < W3_VECS; ++p) {
-          const int u = ltid + p * GM_THREADS;                // unit: part q, column nl of the tile, plane pl (k = 8 pl .. 8 pl + 7)
-          if (W3_UNITS % GM_THREADS == 0 || u < W3_UNITS) {
-            const int q = u / (BN * 4), nl = (u / 4) % BN, pl = u & 3;
-            const int n = min(n0 + nl, cols - 1);
-            const unsigned off = (unsigned)q * (unsigned)ep.w3_part + (unsigned)n * (unsigned)ep.ldw3 + (unsigned)(k0 + pl * 8);      // elements; k0 + 32 <= ldw3 (a multiple of 32 >= kdim); an image is < 2^31 bytes
-            typedef float v4f_t __attribute__((ext_vector_type(4)));
-            const v4f_t t4 = *reinterpret_cast<const v4f_t __attribute__((address_space(1))) *>(w3g + 2u * off);      // SGPR base + 32-bit offset
-            wraw[S][p] = make_float4(t4.x, t4.y, t4.z, t4.w);
-          }
-        }
-      }
-    } else {
+      if (part < 0 || (p * 4) / A_VECS == part) op_load<V, MODE>(E, r0, min(p * A_RPP + a_r, rlast), k, true, araw[S][p], ROW_META ? &rmeta[p] : nullptr);
+    if constexpr (PARTS != 3) {
       const int kw = min(k0 + w_kq, ldw - 4);
 #pragma unroll
       for (int p = 0; p < W_VECS; ++p)
@@ -536,16 +618,10 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
     // operand values that were committed as zero, and a column beyond `cols` (clamped to the last one: finite) feeds only its own
     // column of D, which no epilogue stores or sums.  (16 selects per chunk, 7 % of the loop, until round 3.)
     if constexpr (PARTS == 3) {
-      {                                                       // the parts as loaded: one 16-byte store per unit, conflict-free (4 planes x 16 columns per 16 lanes)
-#pragma unroll
-        for (int p = 0; p < W3_VECS; ++p) {
-          const int u = ltid + p * GM_THREADS;
-          if (W3_UNITS % GM_THREADS == 0 || u < W3_UNITS) {
-            const int q = u / (BN * 4), nl = (u / 4) % BN, pl = u & 3;
-            *reinterpret_cast<float4 *>(smem + (2 * A_STAGE + (Ws == Ws1 ? W_STAGE : 0)) + q * PART_W + pl * PLANE_W + nl * 4) = wraw[S][p];      // (indexed off the LDS symbol itself)
-          }
-        }
-      }
+      // the weight planes are written by the LDS-DMA the prefetch issued: nothing to commit, but the transfers must have landed
+      // before the barrier behind this commit lets any wave read the stage (a pending LDS-DMA counts on vmcnt; the operand loads
+      // above were waited for already, so this costs nothing extra)
+      glds_wait();
     } else {
 #pragma unroll
     for (int p = 0; p < W_VECS; ++p) {
@@ -588,6 +664,30 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         // already fill the chain's gaps.)
         const float *ap = As + lk * PLANE_A + (wave_r * 32 + lrow) * 4;
         const float *bp = Ws + lk * PLANE_W + (wave_c * CT * 32 + lrow) * 4;
+#if defined(RS_EXP_HOIST_CT1)      // (round 6 experiment, not in the product: equal or slower in both steps -- 48 fragment VGPRs; profiles/r06/gemm_w_lds_dma.txt)
+        if constexpr (CT == 1) {
+          // one column tile per wave (64 x 64 tiles): BOTH steps' fragments first -- 12 ds_read_b128, 48 VGPRs -- then the 12 MFMAs,
+          // waiting for the fragments in the order they were requested.  (Round 6: left to itself the scheduler issued the reads in
+          // pairs, each followed by s_waitcnt lgkmcnt(0) and its MFMA: six exposed LDS round trips per chunk.)
+          float4 a6[2][3], b6[2][3];
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int q = 2; q >= 0; --q) {                      // (l, m, h: the order the products below consume them)
+              a6[st][q] = *reinterpret_cast<const float4 *>(ap + q * PART_A + 2 * st * PLANE_A);
+              b6[st][q] = *reinterpret_cast<const float4 *>(bp + q * PART_W + 2 * st * PLANE_W);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          constexpr int TA1[6] = {2, 0, 1, 1, 0, 0}, TB1[6] = {0, 2, 1, 0, 1, 0};      // lh, hl, mm, mh, hm, hh
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+              acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a6[st][TA1[t]]),
+                                                               __builtin_bit_cast(bf16x8, b6[st][TB1[t]]), acc[0], 0, 0, 0);
+          return;
+        }
+#endif
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
           float4 a3[3], b3[3][CT];
@@ -727,9 +827,15 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
         ++gchunk;
       }
     } else {
+    if constexpr (ROW_META) {
+      const int rlast0 = (int)min((long long)BM - 1, rows - 1 - r0);
+#pragma unroll
+      for (int p = 0; p < A_VECS; ++p) op_row_meta<MODE>(E, r0, min(p * A_RPP + a_r, rlast0), rmeta[p]);
+    }
     // DIRECT: the first chunk of this tile was requested in front of the previous tile's epilogue (below)
     if (!EARLY_PREFETCH || tile == (long long)blockIdx.x) prefetch(S0{}, r0, 0, -1);
     RS_T(0);
+#if defined(RS_EXP_OLD_LOOP)
     for (int ch = 0; ch < nchunks; ++ch) {
       float *As = (ch & 1) ? As1 : As0;
       float *Ws = (ch & 1) ? Ws1 : Ws0;
@@ -737,11 +843,38 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
       RS_T(1);
       __syncthreads();                                        // tile chunk visible; stage ch-1 free again
       RS_T(2);
-      if (ch + 1 < nchunks) prefetch(S0{}, r0, (ch + 1) * GM_BK, -1);   // loads fly under the MFMAs below
+      if (ch + 1 < nchunks) prefetch(S0{}, r0, (ch + 1) * GM_BK, -1, (ch + 1) & 1);   // loads fly under the MFMAs below (unit 4: the weights' planes go straight into the other stage)
       RS_T(3);
       mma(acc, As, Ws, ch);
       RS_T(4);
     }
+#else
+    // Round 6: the loop is rotated -- an iteration requests chunk ch + 1, multiplies chunk ch and commits chunk ch + 1 -- so that the
+    // registers a prefetch fills are consumed in the SAME iteration.  (As `commit; barrier; prefetch; mma` the raw operand values were
+    // loop-carried, and the copies the register allocator placed on the back edge for two of them -- it reuses their registers as LDS
+    // address temporaries of the MFMA block -- sat behind an s_waitcnt vmcnt right after the prefetch: the whole load latency in
+    // front of the MFMAs it was meant to hide under.  Seen in the ISA once the weights' own registers were gone.)
+    commit(S0{}, As0, Ws0, r0, 0);
+    RS_T(1);
+    __syncthreads();
+    RS_T(2);
+    for (int ch = 0; ch + 1 < nchunks; ++ch) {
+      prefetch(S0{}, r0, (ch + 1) * GM_BK, -1, (ch + 1) & 1);   // loads fly under the MFMAs below (unit 4: the weights' planes go straight into the other stage)
+      RS_T(3);
+      __builtin_amdgcn_sched_barrier(0);                        // (one scheduling region otherwise: the loads sink to their uses in the commit, the commit's arithmetic rises into the MFMAs and waits for the loads there)
+      mma(acc, (ch & 1) ? As1 : As0, (ch & 1) ? Ws1 : Ws0, ch);
+      RS_T(4);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < A_VECS; ++p) op_pin<V, MODE>(araw[0][p]);
+      commit(S0{}, (ch & 1) ? As0 : As1, (ch & 1) ? Ws0 : Ws1, r0, (ch + 1) * GM_BK);
+      RS_T(1);
+      __syncthreads();                                        // chunk ch + 1 visible; every wave is done with chunk ch's stage
+      RS_T(2);
+    }
+    mma(acc, ((nchunks - 1) & 1) ? As1 : As0, ((nchunks - 1) & 1) ? Ws1 : Ws0, nchunks - 1);
+    RS_T(4);
+#endif
     }
     if (direct) {
       // ---- epilogue straight from the accumulators (64-row tiles; 128-row tiles without fused pooling).  D[i][j]: j = lane & 31 is the output column,
@@ -760,7 +893,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
                                                               // not hoisted out of the tile loop into ~100 long-lived VGPRs
       const int ldo = (int)ep.ldo, ldm1 = (int)ep.ldm1, ldm2 = (int)ep.ldm2;      // tile-relative offsets fit 32 bits
       const bool full = r0 + BM <= rows;
-      const bool obf = sb_out(MODE >= 0 ? MODE : E.mode);     // bf16 tensors: same element offsets, half the bytes
+      const bool obf = sb_out(MODE >= 0 ? opm_base(MODE) : E.mode);     // bf16 tensors: same element offsets, half the bytes
       float *out_t = tile_base(ep.out, r0 * ep.ldo, obf);
       const float *my1_t = ep.my1 ? tile_base(ep.my1, r0 * ep.ldm1, SB_MASK) : nullptr;
       const float *my2_t = ep.my2 ? tile_base(ep.my2, r0 * ep.ldm2, SB_MASK) : nullptr;
@@ -945,7 +1078,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
             if (ep.my2) { ms2[e] = ep.ms2[col + e]; mt2[e] = ep.mt2[col + e]; mu2[e] = ep.mean2[col + e]; is2[e] = ep.invstd2[col + e]; }
           }
         }
-        const bool obf = sb_out(MODE >= 0 ? MODE : E.mode);
+        const bool obf = sb_out(MODE >= 0 ? opm_base(MODE) : E.mode);
         float *out_t = tile_base(ep.out, r0 * ep.ldo, obf);     // wave-uniform tile bases
         const float *my1_t = ep.my1 ? tile_base(ep.my1, r0 * ep.ldm1, SB_MASK) : nullptr;
         const float *my2_t = ep.my2 ? tile_base(ep.my2, r0 * ep.ldm2, SB_MASK) : nullptr;
@@ -1018,7 +1151,7 @@ gemm_rows_kernel(long long rows_arg, const int *__restrict__ rows_dev, int kdim,
             int ax = 0, an = 0;
             for (int k = 0; k < ep.pool_ns; ++k) {
               float v = Cs[(g0 + k) * BN + c] + bb;
-              if (sb_out(MODE >= 0 ? MODE : E.mode)) v = bf16_round(v);       // pool what the stored tensor holds
+              if (sb_out(MODE >= 0 ? opm_base(MODE) : E.mode)) v = bf16_round(v);       // pool what the stored tensor holds
               if (v > mx) { mx = v; ax = k; }
               if (v < mn) { mn = v; an = k; }
             }
@@ -2369,7 +2502,7 @@ void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_de
         case OPM_RELU1: RS_GW(OPM_RELU1); break;
         case OPM_RELU2: RS_GW(OPM_RELU2); break;
         case OPM_AFF2: RS_GW(OPM_AFF2); break;
-        case OPM_POOLED: RS_GW(OPM_POOLED); break;
+        case OPM_POOLED: if (E.grp) RS_GW(OPM_POOLED_RAGGED); else RS_GW(OPM_POOLED_DENSE); break;
         default: RS_GW(OPM_BCAST); break;
       }
 #undef RS_GW
@@ -2383,7 +2516,7 @@ void launch_gemm_m(dim3 grid, hipStream_t st, long long rows, const int *rows_de
     case OPM_RELU1: RS_G(OPM_RELU1); break;
     case OPM_RELU2: RS_G(OPM_RELU2); break;
     case OPM_AFF2: RS_G(OPM_AFF2); break;
-    case OPM_POOLED: RS_G(OPM_POOLED); break;
+    case OPM_POOLED: if (E.grp) RS_G(OPM_POOLED_RAGGED); else RS_G(OPM_POOLED_DENSE); break;
     default: RS_G(OPM_BCAST); break;
   }
 #undef RS_G
@@ -2412,7 +2545,7 @@ void launch_wgrad_m(dim3 grid, hipStream_t st, long long rows, const int *rows_d
 #define RS_WGQ(PM_) do { if (Q.mode == OPM_ID) RS_WG(PM_, OPM_ID); else if (Q.mode == OPM_RELU1) RS_WG(PM_, OPM_RELU1); else if (Q.mode == OPM_RELU2) RS_WG(PM_, OPM_RELU2); else RS_WG(-1, -1); } while (0)
   if (VP == 1 || VQ == 1) { RS_WG(-1, -1); return; }
   if (P.mode == OPM_AFF2) RS_WGQ(OPM_AFF2);
-  else if (P.mode == OPM_POOLED) RS_WGQ(OPM_POOLED);
+  else if (P.mode == OPM_POOLED) { if (P.grp) RS_WGQ(OPM_POOLED_RAGGED); else RS_WGQ(OPM_POOLED_DENSE); }
   else if (P.mode == OPM_BCAST) RS_WGQ(OPM_BCAST);
   else RS_WG(-1, -1);
 #undef RS_WGQ
@@ -2466,7 +2599,9 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
              "rs_mlp_gemm_rows: weights must be n-major (cols x ldw) with a 16-byte aligned base and ldw %% 4 == 0 (ldw=%d, kdim=%d)", ldw, kdim);
   int rc = check_operand("rs_mlp_gemm_rows", x, rows);
   if (rc != RS_OK) return rc;
-  Epilogue ep = *epi;
+  Epilogue ep;
+  static_cast<rs_mlp_epilogue &>(ep) = *epi;
+  ep.w3_rows = (epi->w3 && epi->ldw3 > 0) ? (int)(epi->w3_part / epi->ldw3) : 0;
   RowOperand E = *x;
   if (E.ns <= 0) E.ns = 1;
   const int epi_mode = ep.mode;
@@ -2536,7 +2671,12 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
 #if RS_MLP_TU == 0
   // the launches of the tiled kernel with vector operands run unit 4's split-product instances (RS_GEMM_SPLIT3=0: the fp32 MFMA ones below)
   // ... when the caller handed the weights' three-part image along (rs_mlp_epilogue.w3, written by rs_pack_weights); without one: fp32 MFMAs
-  if (!bf && split3_on() && v >= 2 && epi->w3 && epi->ldw3 >= ((kdim + 31) & ~31) && epi->ldw3 % 32 == 0) return rs_sp_gemm_rows(rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
+  if (!bf && split3_on() && v >= 2 && epi->w3) {
+    RS_REQUIRE(epi->ldw3 >= ((kdim + 31) & ~31) && epi->ldw3 % 32 == 0 && epi->w3_part >= (long long)cols * epi->ldw3 && epi->w3_part % epi->ldw3 == 0 && aligned_to(epi->w3, 16),
+               "rs_mlp_gemm_rows: the weights' three-part image needs ldw3 (%d) a multiple of 32 >= kdim (%d), parts (%lld elements) of whole rows >= cols (%d) and a 16-byte aligned base",
+               epi->ldw3, kdim, epi->w3_part, cols);
+    return rs_sp_gemm_rows(rows, rows_dev, kdim, cols, x, w, ldw, epi, stream);
+  }
 #endif
   // tile height: 64-row tiles (2 x 2 waves) wherever the layout allows -- twice the workgroups, three per CU
   static const int bm64_on = env_int("RS_GEMM_BM64", 1);
@@ -2726,15 +2866,21 @@ extern "C" int rs_mlp_wgrad_bf16(long long rows, const int *rows_dev, int ncols,
 // transpose = 0:  dst[j*ld + k] = src[j*cin + k]  (k < cin, else 0), ld >= cin    -- forward operand of rs_mlp_gemm_rows
 //                 when cin is not a multiple of 4 (otherwise the conv weight is used in place);
 // transpose = 1:  dst[k*ld + j] = src[j*cin + k]  (j < cout, else 0), ld >= cout  -- data-gradient operand (dY . W).
-// one value -> its three bf16 parts (the scalar form of split_bf16: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); bits in the low half)
-__device__ __forceinline__ void split_bf16_1(float x, unsigned short (&d)[3]) {
-  unsigned u = __float_as_uint(pack_bf16(x, 0.f)) & 0xffffu;
-  d[0] = (unsigned short)u;
-  float r = x - __uint_as_float(u << 16);
-  u = __float_as_uint(pack_bf16(r, 0.f)) & 0xffffu;
-  d[1] = (unsigned short)u;
-  r -= __uint_as_float(u << 16);
-  d[2] = (unsigned short)(__float_as_uint(pack_bf16(r, 0.f)) & 0xffffu);
+// The three-part image (dst3) is TILE-ORDERED (round 6): dst3[q][k / 8][row][k % 8], row = the operand's n (outer) index, k its reduction
+// (inner) index -- 16-byte units of 8 consecutive k, the units of one k-octet contiguous over rows: what one global_load_lds_dwordx4 of the
+// row GEMM moves into an LDS plane.  A thread of this kernel writes whole units (three 16-byte stores, consecutive lanes = consecutive rows).
+__device__ __forceinline__ void split_store_unit(const float (&v)[8], unsigned short *dst3, long long part, long long unit) {
+  unsigned w[3][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float d[3];
+    split_bf16(v[2 * i], v[2 * i + 1], d);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) w[q][i] = __float_as_uint(d[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    *reinterpret_cast<uint4 *>(dst3 + q * part + unit * 8) = make_uint4(w[q][0], w[q][1], w[q][2], w[q][3]);
 }
 
 __global__ void __launch_bounds__(GM_THREADS)
@@ -2761,33 +2907,42 @@ pack_weights_kernel(rs_pack_weights_args a) {
         tile[ty + 8 * p2][tx] = (j < cout && k < cin) ? src[j * cin + k] : 0.f;
       }
       __syncthreads();
+      if (dst) {
 #pragma unroll
-      for (int p2 = 0; p2 < 4; ++p2) {
-        const int k = k0 + ty + 8 * p2, j = j0 + tx;
-        const float v = tile[tx][ty + 8 * p2];
-        if (dst && k < cin && j < ld) dst[k * ld + j] = v;
-        if (dst3 && k < cin && j < ld3) {
-          unsigned short d[3];
-          split_bf16_1(v, d);
+        for (int p2 = 0; p2 < 4; ++p2) {
+          const int k = k0 + ty + 8 * p2, j = j0 + tx;
+          if (k < cin && j < ld) dst[k * ld + j] = tile[tx][ty + 8 * p2];
+        }
+      }
+      // image rows = k (the data gradient's n), reduction index = j: the tile holds 4 j-octets x 32 rows = 128 units
+      if (dst3 && threadIdx.x < 128) {
+        const int jo = threadIdx.x >> 5, k = k0 + tx;
+        if (k < cin && j0 + 8 * jo < ld3) {
+          float v[8];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) dst3[q * part + (long long)k * ld3 + j] = d[q];
+          for (int i = 0; i < 8; ++i) v[i] = tile[8 * jo + i][tx];
+          split_store_unit(v, dst3, part, (long long)((j0 >> 3) + jo) * cin + k);
         }
       }
       __syncthreads();
     }
   } else {
-    const int wide = dst3 ? max(ld, ld3) : ld;
-    const int total = cout * wide;
     const long long part = (long long)cout * ld3;
-    for (int i = blockIdx.x * GM_THREADS + threadIdx.x; i < total; i += gridDim.x * GM_THREADS) {
-      const int j = i / wide, k = i - j * wide;
-      const float v = k < cin ? src[j * cin + k] : 0.f;
-      if (dst && k < ld) dst[j * ld + k] = v;
-      if (dst3 && k < ld3) {
-        unsigned short d[3];
-        split_bf16_1(v, d);
+    if (dst) {
+      const int total = cout * ld;
+      for (int i = blockIdx.x * GM_THREADS + threadIdx.x; i < total; i += gridDim.x * GM_THREADS) {
+        const int j = i / ld, k = i - j * ld;
+        dst[i] = k < cin ? src[j * cin + k] : 0.f;
+      }
+    }
+    if (dst3) {
+      const int units = (ld3 >> 3) * cout;                       // unit = (k-octet ko, row j), rows fastest
+      for (int u = blockIdx.x * GM_THREADS + threadIdx.x; u < units; u += gridDim.x * GM_THREADS) {
+        const int ko = u / cout, j = u - ko * cout;
+        float v[8];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) dst3[q * part + (long long)j * ld3 + k] = d[q];
+        for (int i = 0; i < 8; ++i) v[i] = (8 * ko + i) < cin ? src[j * cin + 8 * ko + i] : 0.f;
+        split_store_unit(v, dst3, part, u);
       }
     }
   }

@@ -262,16 +262,23 @@ class PackArgs(ctypes.Structure):            # rs_pack_weights_args
 # stores.  The pack launch at the top of a step now also writes every weight operand as three bf16 parts (the `w3` operand of
 # rs_mlp_epilogue), and the split-product instances run ONLY on such an image: `gemm_rows` finds it by the address of the fp32
 # operand it is handed, or makes it on the spot (one small launch: operands nobody prepacked -- unit tests, eval forwards).
-_split3 = {}      # address of the fp32 operand (n-major) -> (image (3, outer, ld3) bf16, ld3, weights epoch, source version, source, fp32 operand)
+# Round 6: the image is TILE-ORDERED -- (3, ld3 / 8, outer, 8): 16-byte units of 8 consecutive k, contiguous over the rows of one k-octet --
+# so that the row GEMM moves a plane of its weight tile global -> LDS with one global_load_lds_dwordx4 (include/repsurf_hip.h: rs_mlp_epilogue.w3).
+_split3 = {}      # (address, shape) of the fp32 operand (n-major) -> (image (3, ld3 / 8, outer, 8) bf16, ld3, weights epoch, source version, source, fp32 operand)
+
+
+def _split3_key(t):
+    return (t.data_ptr(), tuple(t.shape))
 
 
 def _presplit_on():
-    return gemm_split3()
+    from . import mlp as _mlp      # late: mlp imports this module on first use
+    return _mlp.PRECISION != "bf16" and gemm_split3()      # (the bf16-operand kernels never read an image)
 
 
 def _split3_of(wk):
-    hit = _split3.get(wk.data_ptr())
-    if hit is None or hit[2] != _weights_epoch or hit[3] != hit[4]._version or hit[5].shape != wk.shape:
+    hit = _split3.get(_split3_key(wk))
+    if hit is None or hit[2] != _weights_epoch or hit[3] != hit[4]._version:
         return None
     return hit
 
@@ -297,7 +304,7 @@ def _pack_items(items, device):
         flat3 = torch.empty((sum(-(-sz // 8) * 8 for sz in sz3),), dtype=torch.bfloat16, device=device)
         imgs, off = [], 0
         for o, l3, sz in zip(outer, ld3s, sz3):
-            imgs.append(flat3[off:off + sz].view(3, o, l3))
+            imgs.append(flat3[off:off + sz].view(3, l3 // 8, o, 8))
             off += -(-sz // 8) * 8                  # 16-byte aligned images
     for i in range(0, len(items), PACK_MAX):
         a = PackArgs()
@@ -317,7 +324,7 @@ def _pack_items(items, device):
         if len(_split3) > 512:                      # (eager loops that never prepack: entries pin their operands, so bound the table)
             _split3.clear()
         for (w, _), o, img, l3 in zip(items, outs, imgs, ld3s):
-            _split3[o.data_ptr()] = (img, l3, _weights_epoch, w._version, w, o)
+            _split3[_split3_key(o)] = (img, l3, _weights_epoch, w._version, w, o)
     return outs
 
 
@@ -416,12 +423,12 @@ def gemm_rows(rows, kdim, cols, x_op, wk, epi, rows_dev=None):
     """out[rows, cols] = E[rows, kdim] . wk[:cols, :kdim]^T   (wk n-major (cols, ld), ld % 4 == 0, zero beyond kdim)"""
     from . import mlp as _mlp      # late: mlp imports this module on first use
     epi.w3, epi.ldw3, epi.w3_part = None, 0, 0
-    if _mlp.PRECISION != "bf16" and _presplit_on():
+    if _presplit_on():
         hit = _split3_of(wk)
         if hit is None:            # nobody packed this operand in this step: its image now (n-major fp32 -> three bf16 parts)
             _pack_items([(wk, False)], wk.device)
             hit = _split3_of(wk)
-        epi.w3, epi.ldw3, epi.w3_part = hit[0].data_ptr(), hit[1], hit[0].shape[1] * hit[1]
+        epi.w3, epi.ldw3, epi.w3_part = hit[0].data_ptr(), hit[1], hit[0].shape[2] * hit[1]
     _lib.call("rs_mlp_gemm_rows_bf16" if _mlp.PRECISION == "bf16" else "rs_mlp_gemm_rows", rows, rows_dev, kdim, cols, ctypes.byref(x_op), _ptr(wk), wk.shape[1],
               ctypes.byref(epi), _stream())
 

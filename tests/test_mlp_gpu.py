@@ -874,6 +874,43 @@ def test_gemm_products_are_fp32_accurate():
     assert gw < 2e-6, gw
 
 
+@pytest.mark.parametrize("cout,cin", [(64, 128), (40, 19), (512, 1024), (37, 8), (130, 260)])
+@pytest.mark.parametrize("transpose", [False, True])
+def test_split_image_is_tile_ordered(cout, cin, transpose):
+    """rs_pack_weights' three-part image (include/repsurf_hip.h: rs_pack_weights_args.dst3, round 6): dst3[q][k / 8][row][k % 8] of the
+    n-major operand (the weight, or its transpose for the data gradient), parts = nearest-even bf16 of what the parts before left,
+    zero beyond the inner dimension -- bit for bit against the same arithmetic in torch."""
+    from repsurf_amd import mlp_hip as H
+    if not H._presplit_on():
+        pytest.skip("the fp32 MFMA instances read no image")
+    g = torch.Generator(device="cpu").manual_seed(cout * 1000 + cin)
+    w = (torch.randn(cout, cin, generator=g) * torch.logspace(-6, 3, cin)).cuda()
+    op = H.w_bwd(w) if transpose else H.w_fwd(w)
+    hit = H._split3_of(op)
+    if hit is None:
+        H._pack_items([(op, False)], op.device)
+        hit = H._split3_of(op)
+    img, ld3 = hit[0], hit[1]
+    mat = (w.t() if transpose else w).contiguous().cpu()                   # (outer, inner)
+    outer, inner = mat.shape
+    assert ld3 % 32 == 0 and ld3 >= inner and tuple(img.shape) == (3, ld3 // 8, outer, 8)
+    pad = torch.zeros(outer, ld3)
+    pad[:, :inner] = mat
+    h = pad.bfloat16()
+    m = (pad - h.float()).bfloat16()
+    lo = (pad - h.float() - m.float()).bfloat16()
+    want = torch.stack([t.view(outer, ld3 // 8, 8).permute(1, 0, 2) for t in (h, m, lo)])
+    assert torch.equal(img.cpu().view(torch.int16), want.contiguous().view(torch.int16))
+    # and the row GEMM over it (columns beyond a tile clamp to the last row of the image): against fp64
+    rows = 200
+    x = torch.randn(rows, inner, generator=g)
+    out = torch.empty(rows, outer, device="cuda")
+    if inner % 2 == 0:                                                      # (vector operands: the tiled kernels)
+        H.gemm_rows(rows, inner, outer, H.operand(H.OP_ID, x.cuda(), inner), op, H.Epilogue(bias=None, out=H._ptr(out), ldo=outer, mode=H.EPI_STORE))
+        ref = x.double() @ mat.double().t()
+        assert (out.cpu().double() - ref).abs().max() <= 1e-5 * max(ref.abs().max().item(), 1.0)
+
+
 def test_gemm_products_with_non_finite_and_denormal_operands():
     """Edge operands of the row GEMM under whichever product arithmetic this process runs (the child of
     test_fp32_mfma_instances_still_pass repeats it under the fp32 MFMA):
