@@ -427,8 +427,10 @@ template <int BM, int BN, int V, int MODE, bool BF, bool WS = false>
 // (round 6: the occupancy the instruction scheduler aims for is pinned to that number -- amdgpu_waves_per_eu(n, n).  With the weights'
 //  registers gone the forward instances fell to 138 VGPRs, the scheduler took that as an invitation to reach FOUR waves per SIMD (128) and
 //  serialised the fragment reads -- ds_read, s_waitcnt lgkmcnt(0), MFMA, one pair at a time -- to get there; LDS allows three workgroups.)
-#ifdef RS_EXP_WG2
+#if defined(RS_EXP_WG2)
 #define RS_GEMM_WG_PER_CU (WS ? 4 : 2)
+#elif defined(RS_EXP_WG3_ALL)      /* every 64 x 64 split instance at three workgroups per CU (168 VGPRs) */
+#define RS_GEMM_WG_PER_CU (WS ? 4 : ((BF && RS_SPLIT && BM == 64 && BN == 64 && MODE >= 0) ? 3 : 2))
 #else
 #define RS_GEMM_WG_PER_CU (WS ? 4 : ((BF && RS_SPLIT && BM == 64 && BN == 64 && MODE >= 0 && MODE <= OPM_RELU2) ? 3 : 2))
 #endif
@@ -1311,10 +1313,19 @@ wgrad_kernel(long long rows_arg, const int *__restrict__ rows_dev, int ncols, in
   auto prefetch = [&](long long r0, int part) {
     const int rlast = (int)min((long long)WG_BR - 1, rend - 1 - r0);
     const int pc = pc_ok ? n0 + p_c : n0, qc = qc_ok ? k0 + q_c : k0;
+    // rows with an index of their own (ragged pooled groups: group / slot; multiplicities): ALL of the stage's row metadata first, then the
+    // gathers -- one dependent round trip per stage instead of one per operand vector (round 6: the ISA had `load grp, load slot,
+    // s_waitcnt, three gathers` four times in a row)
+    constexpr bool P_META = PM >= 0 && (opm_base(PM) == OPM_POOLED || PM == OPM_AFF2);
+    RowMeta pmeta[P_VECS];
+    if constexpr (P_META) {
+#pragma unroll
+      for (int p = 0; p < P_VECS; ++p) op_row_meta<PM>(P, r0, min(p_row(p), rlast), pmeta[p]);
+    }
 #pragma unroll
     for (int p = 0; p < P_VECS; ++p) {
       if (part >= 0 && (p * 4) / P_VECS != part) continue;
-      op_load<VP, PM>(P, r0, min(p_row(p), rlast), pc, true, praw[p]);
+      op_load<VP, PM>(P, r0, min(p_row(p), rlast), pc, true, praw[p], P_META ? &pmeta[p] : nullptr);
     }
 #pragma unroll
     for (int p = 0; p < Q_VECS; ++p) {

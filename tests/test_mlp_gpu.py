@@ -112,7 +112,9 @@ def test_umbrella_stack_matches_torch(aggr):
         out = mlp.umbrella_mlp(x, m, 8, aggr)
         (out * w).sum().backward()
         res[backend] = (out.detach(), {n: p.grad.clone() for n, p in m.named_parameters()})
-    assert rel(res["hip"][0], res["torch"][0]) < 2e-5
+    from tests.util import parity_report
+    parity_report(f"umbrella_stack_{aggr}_vs_torch", out_rel=rel(res["hip"][0], res["torch"][0]))
+    assert rel(res["hip"][0], res["torch"][0]) < 1e-5       # the north-star's bound for fp32 activations (2e-5 until round 6)
     for name, gt in res["torch"][1].items():
         if name == "3.bias":
             continue
@@ -134,7 +136,9 @@ def test_plain_stack_matches_torch():
         out = mlp.sa_mlp_plain(x, c, b, 16)
         (out * w).sum().backward()
         res[backend] = (out.detach(), x.grad.clone(), [p.grad.clone() for p in c.parameters()])
-    assert rel(res["hip"][0], res["torch"][0]) < 2e-5
+    from tests.util import parity_report
+    parity_report("plain_stack_vs_torch", out_rel=rel(res["hip"][0], res["torch"][0]))
+    assert rel(res["hip"][0], res["torch"][0]) < 1e-5
     assert rel_l2(res["hip"][1], res["torch"][1]) < 3e-3
     for gh, gt in zip(res["hip"][2][::2], res["torch"][2][::2]):
         assert rel_l2(gh, gt) < 3e-3
@@ -174,7 +178,9 @@ def test_compacted_groups_match_dense(radius, ns):
                      {k: p.grad.clone() for k, p in m.named_parameters()},
                      [bn.running_var.clone() for bn in [m.bn_l0, m.bn_f0] + list(m.bns)])
     d, c = res["dense"], res["compact"]
-    assert rel(c[0], d[0]) < 2e-5
+    from tests.util import parity_report
+    parity_report(f"compacted_vs_dense_r{radius}_ns{ns}", out_rel=rel(c[0], d[0]))
+    assert rel(c[0], d[0]) < 1e-5
     assert rel_l2(c[1], d[1]) < 3e-3 and rel_l2(c[2], d[2]) < 3e-3
     for k in d[3]:
         if ".bias" in k and ("mlp_l0" in k or "mlp_f0" in k or "convs" in k):
@@ -575,7 +581,9 @@ def test_row_stack_of_single_row_groups_matches_torch(rows, cin, widths, relu_la
         (out * w).sum().backward()
         res[kind] = (out.detach(), x.grad.clone(), {n: p.grad.clone() for n, p in list(l.named_parameters()) + [("bn." + k, v) for k, v in b.named_parameters()]},
                      [bn.running_var.clone() for bn in b])
-    assert rel(res["hip"][0], res["torch"][0]) < 2e-5
+    from tests.util import parity_report
+    parity_report("plain_stack_vs_torch", out_rel=rel(res["hip"][0], res["torch"][0]))
+    assert rel(res["hip"][0], res["torch"][0]) < 1e-5
     assert rel_l2(res["hip"][1], res["torch"][1]) < 3e-3
     for name, gt in res["torch"][2].items():
         if name.endswith(".bias") and not name.startswith("bn."):
