@@ -79,6 +79,19 @@ class _Done:
         return True
 
 
+def broadcast(buf, src=0, group=None):
+    """dist.broadcast under the same rule as `all_reduce`: eager -> async_op=True + work.wait(), so that the collective
+    and its end event live on c10d's internal stream and never on a stream this package captures later; refused while capturing
+    (replica synchronisation is set-up work, not part of a step)."""
+    cuda = buf.is_cuda and dist.get_backend(group) == "nccl"
+    if not cuda:
+        dist.broadcast(buf, src=src, group=group)
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("repsurf_amd.dist.broadcast: called while the current stream is capturing")
+    dist.broadcast(buf, src=src, group=group, async_op=True).wait()
+
+
 def rank_seed(base, rank):
     """Distinct synthetic data / CPU-generator streams per rank (config 3: rank r uses seed base*8+r)."""
     return base * 8 + rank

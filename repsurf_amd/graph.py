@@ -403,7 +403,7 @@ def sync_replicas(net, dist, group=None):
         return
     with torch.no_grad():
         for t in list(net.parameters()) + list(net.buffers()):
-            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            _rdist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)      # (never a raw dist.broadcast: repsurf_amd.dist)
     mlp_hip.weights_changed()
 
 

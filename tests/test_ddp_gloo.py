@@ -194,6 +194,67 @@ def test_flatgrads_two_buckets_in_reverse_execution_order():
     assert torch.allclose(f0, (p0 + p1) / 2, atol=1e-6) and f0.abs().sum() > 0
 
 
+def _bucket_steps_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import copy
+    import torch.distributed as dist
+    from repsurf_amd import dist as rdist
+    from repsurf_amd.graph import FlatGrads, sync_replicas
+    rdist.init(backend="gloo")
+    torch.manual_seed(100 + rank)              # replicas start DIFFERENT: sync_replicas (repsurf_amd.dist.broadcast) must make them rank 0's
+    base = torch.nn.Sequential(torch.nn.Linear(6, 12), torch.nn.ReLU(), torch.nn.Linear(12, 12), torch.nn.ReLU(), torch.nn.Linear(12, 4))
+    sync_replicas(base, dist)
+    g = torch.Generator().manual_seed(rdist.rank_seed(9, rank))
+    batches = [torch.randn(16, 6, generator=g) for _ in range(5)]
+    finals = {}
+    for form in ("one_bucket", "two_buckets"):
+        model = copy.deepcopy(base)
+        early = list(model[4].parameters()) + list(model[2].parameters()) if form == "two_buckets" else None
+        grads = FlatGrads(list(model.parameters()), early=early)
+        assert len(grads.buckets) == (2 if early else 1)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, foreach=False)
+        for x in batches:
+            grads.clear()
+            h = model[1](model[0](x))
+            seen = {}
+            if early:
+                def early_bucket(grad, seen=seen):      # PipelinedStep._early_bucket (graph.py): bucket 0 leaves from a hook mid-backward
+                    grads.pack(0)
+                    seen["work"] = grads.all_reduce_mean(dist, bucket=0, async_op=True)
+                h.register_hook(early_bucket)
+            model[4](model[3](model[2](h))).pow(2).mean().backward()
+            if early:
+                grads.pack(1)
+                grads.all_reduce_mean(dist, bucket=1)
+                seen["work"].wait()
+            else:
+                grads.pack()
+                grads.all_reduce_mean(dist)
+            opt.step()
+        finals[form] = torch.cat([p.detach().flatten() for p in model.parameters()])
+    out[rank] = (finals["one_bucket"], finals["two_buckets"])
+    rdist.finish()
+
+
+def test_early_bucket_path_ends_with_the_single_bucket_parameters():
+    """five optimizer steps on 2 gloo ranks -- gradients reduced as ONE flat bucket after backward, and as two
+    buckets with bucket 0 (the layers closest to the loss) packed and all-reduced asynchronously from a tensor hook in the middle
+    of backward (what PipelinedStep does under REPSURF_GRAD_BUCKETS=2, repsurf_amd/graph.py `_early_bucket` / `_reduce`): the same
+    parameters on both ranks and in both forms, to the last bit (the reductions add the same two numbers either way).  The
+    replicas are seeded differently and meet through sync_replicas (repsurf_amd.dist.broadcast)."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_bucket_steps_worker, args=(world, port, out), nprocs=world, join=True)
+        (a0, b0), (a1, b1) = out[0], out[1]
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)          # replicas stay replicas
+    assert torch.equal(a0, b0)                                  # the early-bucket form is the single-bucket form
+    assert a0.abs().sum() > 0
+
+
 def test_bench_spawns_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` PLAIN (no torch.distributed.run around it: the form a driver may use) re-executes itself under
     the launcher on 127.0.0.1 with a free port, the ranks join and reduce, rank 0 prints exactly one JSON line.  --dry-run stops
