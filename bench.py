@@ -358,17 +358,52 @@ def gemm_family_in_graph(net, criterion, points, label, replays=20):
     # a class on its own: its launches, ten copies per graph (a one-kernel graph would time the graph launch): back to back with
     # itself on a warm cache -- an optimistic bound, reported next to the in-step estimate roofline_from_profile makes
     out["by_class_us"] = {k: timed_graph(v * 10) * 1e3 / (10 * len(v)) for k, v in classes.items()}
-    # ... and INSIDE the step's family graph: the graph of all launches minus the graph of all launches but this
-    # class's, per launch of the class -- the class between the launches that precede and follow it in the step, on the cache state
-    # they leave (the alone-replay above runs ten copies back to back on a warm cache and is optimistic).  For the three classes with
-    # the largest alone totals (one of them is the line's dominant kernel).
-    all_ms = out["ms_per_step"]
+    # ... and INSIDE the step's family graph: the recorded launches captured as one graph again, with a device
+    # wall-clock stamp (rs_timestamp: a one-thread launch storing s_memrealtime) in front of and behind every launch of the class --
+    # HIP events cannot be recorded inside a replayed graph on this runtime (tools/probe_graph_events.py).  A launch's duration is the
+    # stamp-to-stamp interval minus ONE stamp-to-stamp gap (calibrated by three stamps back to back at the head of the same graph; the
+    # interval holds two such gaps, but a 512-workgroup launch takes longer to start than a one-thread stamp: with one gap taken off the
+    # figure agrees with the rocprofv3 kernel trace of the replayed step within ~1 %, with two it is 3 % BELOW it -- the conservative
+    # form is the one reported); averaged over the launches of the class and 10 replays.  The class runs between the launches that precede and follow
+    # it in the step, on the cache state they leave (the alone-replay above is ten copies back to back on a warm cache: optimistic).
+    # For the three classes with the largest alone totals (one of them is the line's dominant kernel).
     top = sorted(classes, key=lambda k: -out["by_class_us"][k] * len(classes[k]))[:3]
     out["in_step_us"] = {}
+    khz = _lib.load().rs_timestamp_khz()
     for k in top:
         members = {id(a) for _, a in classes[k]}
-        rest = [(n_, a) for n_, a in calls if id(a) not in members]
-        out["in_step_us"][k] = (all_ms - timed_graph(rest)) * 1e3 / len(classes[k]) if rest else all_ms * 1e3 / len(classes[k])
+        nst = 3 + 2 * len(members)
+        stamps = torch.zeros(nst, dtype=torch.int64, device="cuda")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            st = torch.cuda.current_stream().cuda_stream
+            for j in range(3):
+                _lib.call("rs_timestamp", stamps.data_ptr() + 8 * j, st)
+            j = 3
+            for name, a in calls:
+                if id(a) in members:
+                    _lib.call("rs_timestamp", stamps.data_ptr() + 8 * j, st)
+                    _lib.replay_calls([(name, a)], st)
+                    _lib.call("rs_timestamp", stamps.data_ptr() + 8 * (j + 1), st)
+                    j += 2
+                else:
+                    _lib.replay_calls([(name, a)], st)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        acc, gaps = [], []
+        for _ in range(10):
+            g.replay()
+            torch.cuda.synchronize()
+            t = stamps.cpu().numpy().astype(np.float64) * (1e3 / khz)         # microseconds
+            gap = 0.5 * (t[2] - t[0])                                          # one stamp -> next stamp: launch gap + the stamp itself
+            gaps.append(gap)
+            acc.append(float(np.mean([t[i + 1] - t[i] - gap for i in range(3, nst, 2)])))
+        out["in_step_us"][k] = float(np.mean(acc))
+        out.setdefault("stamp_gap_us", round(float(np.mean(gaps)), 2))
+        del g
     del holder
     return out
 
@@ -449,11 +484,13 @@ def roofline_from_profile(prof, timed_steps, dtype, in_graph=None):
                 alone_sec = row["alone_avg_us"] * 1e-6
                 roofline["alone_avg_launch_us"] = round(row["alone_avg_us"], 2)
                 roofline["alone_frac"] = round(row["amount"] / alone_sec / (1e12 if row["unit"] == "flops" else 1e9) / roofline["peak"], 4)
-                roofline["timed"] = ("avg_launch_us / frac: IN the step's GEMM family -- (hipGraph of the recorded step's GEMM + weight-gradient launches) minus (the same "
-                                     "graph without this class's launches), per launch of the class, 20 replays each between two HIP events (gemm_family_in_graph; "
-                                     "rocprofv3 of the replayed step by kernel instance and grid: profiles/r06/cls_graph_kernel_stats_by_grid.csv); alone_*: this class's "
-                                     "launches alone, ten copies per graph, back to back on a warm cache (optimistic); eager_avg_launch_us: per-launch HIP events "
-                                     "of an eager pass (host-paced: idle device in front of every launch)")
+                roofline["timed"] = ("avg_launch_us / frac: IN the step's GEMM family -- the recorded step's GEMM + weight-gradient launches replayed as one hipGraph with a "
+                                     "device wall-clock stamp (rs_timestamp, s_memrealtime) in front of and behind this class's launches; stamp-to-stamp interval minus one "
+                                     "calibrated stamp-to-stamp gap (stamp_gap_us), 10 replays (HIP events cannot be recorded inside a replayed graph on this runtime; the rocprofv3 kernel trace of "
+                                     "the replayed step by kernel instance and grid is profiles/r06/cls_graph_kernel_stats_by_grid.csv); alone_*: this class's launches "
+                                     "alone, ten copies per graph, back to back on a warm cache (optimistic); eager_avg_launch_us: per-launch HIP events of an eager "
+                                     "pass (host-paced: idle device in front of every launch)")
+                roofline["stamp_gap_us"] = in_graph.get("stamp_gap_us")
             else:
                 roofline["timed"] = ("avg_launch_us: inside a replayed hipGraph -- this class's launches of one recorded step, ten copies per graph, back to "
                                      "back, 20 replays between two HIP events (gemm_family_in_graph); "

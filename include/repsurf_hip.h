@@ -556,6 +556,12 @@ typedef struct rs_adam_table {
 } rs_adam_table;
 int rs_adam_step(const rs_adam_table *t, double *hyper, int *step, int *done, int advance, void *stream);
 
+/* Measurement aid (round 6): one-thread launch that stores the device's constant-rate wall clock (s_memrealtime) in *dst when it runs;
+ * rs_timestamp_khz() = ticks per millisecond.  bench.py brackets a launch inside the step's replayed hipGraph with two of them (HIP
+ * events cannot be recorded inside a replayed graph on this runtime).  Not used by the product path. */
+int rs_timestamp(long long *dst, void *stream);
+int rs_timestamp_khz(void);
+
 /* ---- fused 10-channel MLP of UmbrellaSurfaceConstructor ---------------------------------------
  * self.mlps = Conv2d(10,10,bias=False)-BN-ReLU-Conv2d(10,10)-BN-ReLU-Conv2d(10,10) + sum/avg over the fan
  * (classification/modules/repsurface_utils.py:266-274, 296-305) as six register-resident passes over the

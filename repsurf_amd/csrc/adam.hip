@@ -139,3 +139,26 @@ extern "C" int rs_adam_step(const rs_adam_table *t, double *hyper, int *step, in
   RS_CHECK_LAUNCH("rs_adam_step");
   return RS_OK;
 }
+
+// ---- device wall-clock stamp (measurement aid, round 6) -----------------------------------------------------------------------------
+// HIP events cannot be recorded inside a replayed hipGraph on this runtime (hipEventRecordWithFlags(.., hipEventRecordExternal) under
+// capture: hipErrorInvalidValue, tools/probe_graph_events.py), so bench.py brackets a launch INSIDE the step's replayed graph with two
+// of these one-thread launches: each stores the constant-rate wall clock (s_memrealtime, rs_timestamp_khz() ticks per millisecond).
+namespace {
+__global__ void stamp_kernel(long long *dst) {
+  if (threadIdx.x == 0) *dst = (long long)wall_clock64();
+}
+}  // namespace
+
+extern "C" int rs_timestamp(long long *dst, void *stream) {
+  RS_REQUIRE(dst, "rs_timestamp: null pointer");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst);
+  RS_CHECK_LAUNCH("rs_timestamp");
+  return RS_OK;
+}
+
+extern "C" int rs_timestamp_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) return 100000;   // gfx9: 100 MHz
+  return khz;
+}

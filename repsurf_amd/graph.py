@@ -59,7 +59,8 @@ class GraphedStep:
                 p.grad = None
         mlp_hip.owned_pass.check(self.net.parameters())
         with mlp_hip.owned_pass():        # gradients start as None and are read only after backward (mlp_hip.owned_pass)
-            loss = self.criterion(self.net(self.points), self.label)
+            self.pred = self.net(self.points)
+            loss = self.criterion(self.pred, self.label)
             loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
         if self.optimizer is not None:
             self.optimizer.step()
@@ -77,6 +78,92 @@ class GraphedStep:
         self.graph.replay()
         mlp_hip.weights_changed()      # the replay updated the parameters through raw pointers
         return self.loss
+
+
+class TrainLoopStep:
+    """The body of the reference's training loop as ONE hipGraph replay, for a loop that is otherwise left as it is.
+
+    classification/tool/train_cls_scanobjectnn.py:226-238 runs, per batch,
+        optimizer.zero_grad(); pred = classifier(points); loss = criterion(pred, target.long()); loss.backward(); optimizer.step()
+    as ~450 launches issued eagerly from Python: on this package's kernels that loop is HOST-bound (bench.py `eager_clouds_per_s`:
+    ~1 000 clouds/s at B = 32 against ~21 000 for the same step replayed as a graph).  With this adapter the five statements become
+        step = TrainLoopStep(classifier, criterion, optimizer)            # once, before the epoch loop
+        pred, loss = step(points, target.long())                          # per batch
+    and everything around them -- loader, sample(), augmentation, accuracy bookkeeping, scheduler.step(), checkpoints -- stays.
+
+    * The step is captured the first time a batch shape is seen (the last, shorter batch of an epoch gets a graph of its own; at most
+      `max_graphs` shapes are kept, further ones run eagerly).  Capturing needs a few eager warm-up passes; parameters, BatchNorm
+      running statistics and the optimizer's moments / step count are snapshotted before and restored IN PLACE after them, so the
+      sequence of updates is the eager loop's: one per batch, on that batch.
+    * `optimizer` must be repsurf_amd.optim.Adam (torch.optim.Adam's rule, state dict and param_groups; its learning rate lives
+      on the device, so LR schedulers keep working across replays).  `classifier.train()` must be in effect.
+    * `pred` and `loss` are the graph's static output tensors: read them (`.max(1)`, `.item()`) before the next call.
+    * The reference's CPU-generator draws (FPS start points, normal flips) are consumed in the eager order (rng.StaticDraws).
+    * Classification only: a packed segmentation batch changes its cloud boundaries every step -- use PipelinedStep with a capacity."""
+
+    def __init__(self, net, criterion, optimizer, warmup=2, max_graphs=3):
+        from .optim import Adam
+        if not isinstance(optimizer, Adam):
+            raise TypeError("TrainLoopStep needs repsurf_amd.optim.Adam (torch.optim.Adam keeps its step count on the host and cannot be replayed)")
+        self.net, self.criterion, self.optimizer = net, criterion, optimizer
+        self.warmup, self.max_graphs = warmup, max_graphs
+        self.steps = {}
+
+    def _snapshot(self):
+        tensors = list(self.net.parameters()) + list(self.net.buffers())
+        had_state = {id(p): set(st.keys()) for p, st in self.optimizer.state.items()}
+        for st in self.optimizer.state.values():
+            tensors += [v for v in st.values() if torch.is_tensor(v) and v.is_cuda]
+        counters = [c for gst in self.optimizer._dev.values() for c in (gst["step"], gst["done"])]
+        return [(t, t.detach().clone()) for t in tensors + counters], had_state
+
+    def _restore(self, snap):
+        saved, had_state = snap
+        with torch.no_grad():
+            for t, v in saved:
+                t.copy_(v)
+            for p, st in self.optimizer.state.items():        # moments that did not exist before the warm-up: back to zero, in place
+                for k, v in st.items():
+                    if torch.is_tensor(v) and v.is_cuda and k not in had_state.get(id(p), ()):
+                        v.zero_()
+            for gi, gst in self.optimizer._dev.items():
+                if not any(gst["step"] is t for t, _ in saved):
+                    gst["step"].zero_()
+                    gst["done"].zero_()
+        mlp_hip.weights_changed()
+
+    def __call__(self, points, target):
+        if not self.net.training:
+            raise RuntimeError("TrainLoopStep: the network is in eval mode")
+        key = (tuple(points.shape), points.dtype, tuple(target.shape), target.dtype)
+        step = self.steps.get(key)
+        if step is None and len(self.steps) >= self.max_graphs:
+            self.optimizer.zero_grad()
+            pred = self.net(points)
+            loss = self.criterion(pred, target)
+            loss.backward()
+            self.optimizer.step()
+            return pred, loss
+        if step is None:
+            torch.cuda.synchronize()
+            cpu_rng, snap = torch.get_rng_state(), self._snapshot()
+            cuda_rng = torch.cuda.get_rng_state()
+            step = GraphedStep(self.net, self.criterion, self.optimizer, points.clone(), target.clone(), warmup=max(1, self.warmup))
+            torch.cuda.synchronize()
+            self._restore(snap)
+            torch.set_rng_state(cpu_rng)                   # the warm-up passes drew FPS starts / flips / dropout masks: the loop's sequence starts here
+            torch.cuda.set_rng_state(cuda_rng)
+            self.steps[key] = step
+        else:
+            step.points.copy_(points, non_blocking=True)
+            step.label.copy_(target, non_blocking=True)
+        loss = step()
+        return step.pred, loss
+
+    def close(self):
+        for st in self.steps.values():
+            st.close()
+        self.steps = {}
 
 
 def _offset_slot(x):

@@ -110,3 +110,60 @@ def test_pipelined_step_matches_eager_step_for_step(monkeypatch):
     g_e = torch.cat([p.grad.flatten() for p in eager.parameters()])
     assert np.allclose(got, want, atol=2e-5), (got, want)
     assert (g_p - g_e).norm() / g_e.norm() < 1e-3
+
+
+def test_train_loop_step_is_the_eager_loop_batch_for_batch():
+    """repsurf_amd.graph.TrainLoopStep: the five statements of the reference's loop body
+    (classification/tool/train_cls_scanobjectnn.py:226-238) as one hipGraph replay.  Four batches -- three of 8 clouds and a last,
+    shorter one of 5 (a second graph) -- through the adapter and through the plain eager loop on a twin model, both consuming the
+    torch CPU generator from the same seed (FPS starts, normal flips): the predictions of every batch and the parameters, BatchNorm
+    running statistics and Adam moments at the end agree -- the capture's warm-up passes leave no trace (snapshot / in-place restore)."""
+    from models.repsurf.repsurf_ssg_umb import Model
+    from repsurf_amd.graph import TrainLoopStep
+    from repsurf_amd.optim import Adam
+    from util.utils import SmoothClsLoss
+    torch_executor.set_backend("hip")
+    crit = SmoothClsLoss()
+    batches = []
+    for i, b in enumerate((8, 8, 8, 5)):
+        pts = torch.from_numpy(cloud(20 + i, b, 1024)).cuda().permute(0, 2, 1).contiguous()
+        batches.append((pts, (torch.arange(b).cuda() * (i + 1)) % 15))
+
+    def fresh():
+        m = Model(ref_args())
+        name_seeded_init(m)
+        disable_dropout(m)           # (dropout masks come from the device generator, whose stream differs between capture and eager)
+        m = m.cuda().train()
+        return m, Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+
+    def state(m, opt):
+        t = [p.detach().flatten() for p in m.parameters()] + [b.detach().flatten().float() for b in m.buffers()]
+        t += [opt.state[p][k].flatten() for p in m.parameters() for k in ("exp_avg", "exp_avg_sq")]
+        return torch.cat(t).cpu()
+
+    eager, eopt = fresh()
+    torch.manual_seed(77)
+    want = []
+    for pts, lab in batches:
+        eopt.zero_grad()
+        pred = eager(pts)
+        loss = crit(pred, lab.long())
+        loss.backward()
+        eopt.step()
+        want.append((pred.detach().cpu().clone(), loss.item()))
+    graphed, gopt = fresh()
+    step = TrainLoopStep(graphed, crit, gopt)
+    torch.manual_seed(77)
+    got = []
+    for pts, lab in batches:
+        pred, loss = step(pts, lab.long())
+        got.append((pred.detach().cpu().clone(), loss.item()))
+    assert len(step.steps) == 2                                   # one graph per batch shape
+    for (pg, lg), (pw, lw) in zip(got, want):
+        assert (pg - pw).abs().max() <= 1e-4 * max(pw.abs().max().item(), 1.0), (pg - pw).abs().max()
+        assert abs(lg - lw) <= 1e-4
+    sg, se = state(graphed, gopt), state(eager, eopt)
+    assert torch.isfinite(sg).all()
+    assert (sg - se).norm() / se.norm() < 1e-3, ((sg - se).norm() / se.norm()).item()
+    assert int(gopt._dev[0]["step"].item()) == len(batches) == int(eopt._dev[0]["step"].item())
+    step.close()
