@@ -246,6 +246,25 @@ def geometry_lines(device, points):
         nbytes = 4.0 * (3 * b * n + 3 * b * s_ + b * s_ * ns)
         ball[str(b)] = {"us": round(t * 1e6, 2), "achieved": round(nbytes / t / 1e9, 1), "frac": round(nbytes / t / 1e9 / PEAK_HBM_GBS, 4),
                         "algorithmic_bytes": nbytes}
+        # Round 6: the cell list built once per cloud as an image in HBM (rs_ballquery_grid_build) and the query alone
+        # against it (rs_ballquery_grid_query) -- what a consumer pays that queries the same coordinates more than once.  Algorithmic bytes
+        # of the query: the image it reads (16 B per point sorted as float4 + 2 B index + the cells' starts) + centres + rows written;
+        # of the build: the cloud read + the image written.
+        if ops.ballquery_grid_ok(n, ns):
+            grid = ops.BallGrid(r, xyz)
+            image = grid.image.numel()
+            tq = timed(lambda: grid.query(ns, centres))
+            tb = timed(lambda: ops.BallGrid(r, xyz))
+            qbytes = float(image) + 4.0 * (3 * b * s_ + b * s_ * ns)
+            bbytes = 4.0 * 3 * b * n + float(image)
+            ball[str(b)]["prebuilt_grid"] = {
+                "query_us": round(tq * 1e6, 2), "query_algorithmic_bytes": qbytes, "query_achieved": round(qbytes / tq / 1e9, 1),
+                "query_frac": round(qbytes / tq / 1e9 / PEAK_HBM_GBS, 4),
+                # the SAME rows priced on the fused launch's algorithmic bytes (what the north-star's 40 % is quoted on)
+                "query_frac_on_fused_bytes": round(nbytes / tq / 1e9 / PEAK_HBM_GBS, 4),
+                "build_us": round(tb * 1e6, 2), "build_algorithmic_bytes": bbytes, "build_frac": round(bbytes / tb / 1e9 / PEAK_HBM_GBS, 4),
+                "build_plus_query_us": round((tb + tq) * 1e6, 2)}
+            del grid
         del xyz, centres
     fps = {}
     # A pick is a dependent reduction inside ONE workgroup (one cloud = one CU): the launch time does not depend on the

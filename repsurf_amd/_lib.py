@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 35
+ABI_VERSION = 36
 KNN_GRID_CELLS = 4096          # RS_KNN_GRID_CELLS of include/repsurf_hip.h
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
@@ -86,12 +86,15 @@ SIGNATURES = {
     "rs_furthestsampling_sectors": [c_int, c_int, P, P, P, P, P, P, P],
     "rs_take_int": [c_int, P, P, P, P],
     "rs_timestamp": [P, P],
+    "rs_ballquery_grid_build": [c_int, c_int, c_float, P, P, P],
+    "rs_ballquery_grid_query": [c_int, c_int, c_int, c_float, c_int, P, P, P, P, P],
 }
 _SPECIAL = {
     "rs_last_error": ([], ctypes.c_char_p),
     "rs_abi_version": ([], c_int),
     "rs_mlp_gemm_split3": ([], c_int),
     "rs_timestamp_khz": ([], c_int),
+    "rs_ballquery_grid_bytes": ([c_int, c_int], c_ll),
     "rs_device_info": ([ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.c_char_p, c_int], c_int),
 }
 

@@ -694,10 +694,22 @@ __device__ __forceinline__ void b3_record(unsigned &acc, float d, float r2) {
   asm("v_cmp_nlt_f32_e64 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(d), "s"(r2) : "vcc");
 }
 
-template <int PP, int B3_HCAP, int B3_WAVES>
+// PHASE (round 6): 0 = build + query in one launch (above); 1 = BUILD only -- the cloud's cell list leaves LDS for a per-cloud image in
+// HBM (rs_ballquery_grid_build); 2 = QUERY only -- the image comes back into LDS as it lay there, a straight copy, and the centres
+// are walked (rs_ballquery_grid_query).  One build serves every query on the same coordinates and radius; the per-launch build was 380
+// of the 1 976 VALU instructions per wave and 18.6 of 66 us at 2 048 clouds (profiles/r05/ballquery_pmc.txt).
+// Image of one cloud (B3_HEADER bytes of header, then the LDS bytes [sp4 | sid | cstart]):
+//   header: float lo[3], inv; int g[3], ncell
+constexpr int B3_HEADER = 32;
+__host__ __device__ constexpr long long b3_image_bytes(int n) {
+  return (long long)(n + B3_SLACK) * 16 + (long long)((n + 1) & ~1) * 2 + (long long)sizeof(int) * (B3_MAXCELLS + 1);
+}
+__host__ __device__ constexpr long long b3_image_stride(int n) { return (B3_HEADER + b3_image_bytes(n) + 15) & ~15LL; }
+
+template <int PP, int B3_HCAP, int B3_WAVES, int PHASE = 0>
 __global__ void __launch_bounds__(B3_THREADS, B3_WAVES)
 ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
-                        const float *__restrict__ xyz, int *__restrict__ idx, int *__restrict__ cnt_out, int dbg) {
+                        const float *__restrict__ xyz, int *__restrict__ idx, int *__restrict__ cnt_out, int dbg, char *__restrict__ image = nullptr) {
   constexpr int B3_RSTRIDE = B3_HCAP + 2, B3_COUNT = B3_RSTRIDE - 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float4 *sp4 = reinterpret_cast<float4 *>(lds);                       // (x, y, z, |p|^2) sorted by cell (+ B3_SLACK entries)
@@ -712,13 +724,29 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float r2u = rs_uniform(radius2);
 
-  // the first centre of this thread: in flight while the grid is built
+  // the first centre of this thread: in flight while the grid is built (or copied in)
   float cq0 = 0.f, cq1 = 0.f, cq2 = 0.f;
-  if (tid < m) { const float *c = new_xyz + ((size_t)cloud * m + tid) * 3; cq0 = c[0]; cq1 = c[1]; cq2 = c[2]; }
+  if (PHASE != 1 && tid < m) { const float *c = new_xyz + ((size_t)cloud * m + tid) * 3; cq0 = c[0]; cq1 = c[1]; cq2 = c[2]; }
 
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  float inv = 0.f;
+  int g[3] = {1, 1, 1};
+  char *img = image ? image + (size_t)cloud * (size_t)b3_image_stride(n) : nullptr;
+  if constexpr (PHASE == 2) {
+    // the image as it lay in LDS when the build left it: 16-byte units, consecutive lanes consecutive addresses
+    const int units = (int)(b3_image_bytes(n) >> 4), tail = (int)(b3_image_bytes(n) & 15) >> 2;
+    const uint4 *src = reinterpret_cast<const uint4 *>(img + B3_HEADER);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (int u = tid; u < units; u += B3_THREADS) dst[u] = src[u];
+    if (tid < tail) reinterpret_cast<unsigned *>(lds)[units * 4 + tid] = reinterpret_cast<const unsigned *>(img + B3_HEADER)[units * 4 + tid];
+    const float4 h0 = *reinterpret_cast<const float4 *>(img);
+    const int4 h1 = *reinterpret_cast<const int4 *>(img + 16);
+    lo[0] = rs_uniform(h0.x); lo[1] = rs_uniform(h0.y); lo[2] = rs_uniform(h0.z); inv = rs_uniform(h0.w);
+    g[0] = __builtin_amdgcn_readfirstlane(h1.x); g[1] = __builtin_amdgcn_readfirstlane(h1.y); g[2] = __builtin_amdgcn_readfirstlane(h1.z);
+    __syncthreads();
+  } else {
   // A. this thread's points (registers), bounding box; counts zeroed
   float px[PP], py[PP], pz[PP];
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
   for (int k = 0; k < PP; ++k) {
     const int p = tid + k * B3_THREADS;
@@ -747,8 +775,7 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
   }
   // B. grid geometry (cell edge >= 1.001 r: a point inside the computed radius lies in the 27 cells around the centre's)
   const float cell = fmaxf(sqrtf(radius2) * 1.001f, ext * (1.0001f / B3_MAXG));
-  const float inv = 1.0f / cell;
-  int g[3];
+  inv = 1.0f / cell;
 #pragma unroll
   for (int a = 0; a < 3; ++a) g[a] = min(B3_MAXG, (int)((hi[a] - lo[a]) * inv) + 1);
   const int ncell = g[0] * g[1] * g[2];
@@ -792,7 +819,21 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
     }
   }
   __syncthreads();
+  if constexpr (PHASE == 1) {
+    // the cell list leaves for the cloud's image: [sp4 | sid | cstart] as it lies here (the query copies it straight back)
+    const int units = (int)(b3_image_bytes(n) >> 4), tail = (int)(b3_image_bytes(n) & 15) >> 2;
+    const uint4 *src = reinterpret_cast<const uint4 *>(lds);
+    uint4 *dst = reinterpret_cast<uint4 *>(img + B3_HEADER);
+    for (int u = tid; u < units; u += B3_THREADS) dst[u] = src[u];
+    if (tid < tail) reinterpret_cast<unsigned *>(img + B3_HEADER)[units * 4 + tid] = reinterpret_cast<const unsigned *>(lds)[units * 4 + tid];
+    if (tid == 0) {
+      *reinterpret_cast<float4 *>(img) = make_float4(lo[0], lo[1], lo[2], inv);
+      *reinterpret_cast<int4 *>(img + 16) = make_int4(g[0], g[1], g[2], ncell);
+    }
+    return;
+  }
   if (dbg == 1) return;                                         // (experiment: cost of the build alone)
+  }
 
   // F. centres, B3_THREADS at a time
   unsigned short *row = rows + tid * B3_RSTRIDE;
@@ -1017,6 +1058,43 @@ ballquery_cells3_kernel(int b, int n, int m, float radius2, int nsample, const f
 }
 
 }  // namespace
+
+// ---- the cell list as a reusable per-cloud image (round 6) ----------------------------------------------------------------------------
+extern "C" long long rs_ballquery_grid_bytes(int b, int n) {
+  if (b <= 0 || n <= 0) return 0;
+  return (long long)b * b3_image_stride(n);
+}
+
+static bool b3_grid_shape_ok(int n, int nsample) { return n >= 64 && n <= 8 * B3_THREADS && n <= BG_MAXN && nsample >= 1 && nsample <= 64; }
+
+extern "C" int rs_ballquery_grid_build(int b, int n, float radius2, const float *xyz, void *image, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0, "rs_ballquery_grid_build: negative size");
+  if (b == 0) return RS_OK;
+  RS_REQUIRE(xyz && image && ((uintptr_t)image & 15) == 0, "rs_ballquery_grid_build: null or unaligned pointer");
+  RS_REQUIRE(b3_grid_shape_ok(n, 1) && radius2 > 0.f, "rs_ballquery_grid_build: clouds of 64 .. %d points and a positive radius (n=%d)", 8 * B3_THREADS, n);
+  const size_t lds = (size_t)b3_image_bytes(n) + (size_t)B3_THREADS * (16 + 2) * 2;
+  RS_REQUIRE_LDS(lds, "rs_ballquery_grid_build");
+  hipStream_t st = (hipStream_t)stream;
+#define RS_B3_BUILD(PP) hipLaunchKernelGGL((ballquery_cells3_kernel<PP, 16, 6, 1>), dim3(b), dim3(B3_THREADS), lds, st, b, n, 0, radius2, 0, nullptr, xyz, nullptr, nullptr, 0, (char *)image)
+  if (n <= 2 * B3_THREADS) RS_B3_BUILD(2); else if (n <= 4 * B3_THREADS) RS_B3_BUILD(4); else RS_B3_BUILD(8);
+#undef RS_B3_BUILD
+  RS_CHECK_LAUNCH("rs_ballquery_grid_build");
+  return RS_OK;
+}
+
+extern "C" int rs_ballquery_grid_query(int b, int n, int m, float radius2, int nsample, const float *new_xyz, const void *image,
+                                       int *idx, int *cnt, void *stream) {
+  RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "rs_ballquery_grid_query: negative size");
+  if (b == 0 || m == 0 || nsample == 0) return RS_OK;
+  RS_REQUIRE(new_xyz && image && idx && ((uintptr_t)image & 15) == 0, "rs_ballquery_grid_query: null or unaligned pointer");
+  RS_REQUIRE(b3_grid_shape_ok(n, nsample), "rs_ballquery_grid_query: clouds of 64 .. %d points, nsample 1 .. 64 (n=%d, nsample=%d)", 8 * B3_THREADS, n, nsample);
+  const size_t lds = (size_t)b3_image_bytes(n) + (size_t)B3_THREADS * (16 + 2) * 2;
+  RS_REQUIRE_LDS(lds, "rs_ballquery_grid_query");
+  hipLaunchKernelGGL((ballquery_cells3_kernel<2, 16, 6, 2>), dim3(b), dim3(B3_THREADS), lds, (hipStream_t)stream, b, n, m, radius2, nsample, new_xyz,
+                     nullptr, idx, cnt, 0, (char *)image);
+  RS_CHECK_LAUNCH("rs_ballquery_grid_query");
+  return RS_OK;
+}
 
 extern "C" int rs_ballquery(int b, int n, int m, float radius2, int nsample, const float *new_xyz,
                             const float *xyz, int *idx, int *cnt, void *stream) {

@@ -292,6 +292,36 @@ def ballquery(radius, nsample, xyz, new_xyz, return_count=False):
     return (idx, cnt) if return_count else idx
 
 
+class BallGrid:
+    """The per-cloud cell list of a ball query as a reusable image (include/repsurf_hip.h: rs_ballquery_grid_build): one build
+    serves every query on the same coordinates and radius."""
+
+    def __init__(self, radius, xyz):
+        _need_gpu(xyz)
+        self.xyz = _f32c(xyz)
+        self.b, self.n, _ = self.xyz.shape
+        self.radius = float(radius)
+        self.r2 = torch.tensor(self.radius ** 2, dtype=torch.float32).item()
+        nbytes = _lib.load().rs_ballquery_grid_bytes(self.b, self.n)
+        self.image = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=xyz.device)
+        _lib.call("rs_ballquery_grid_build", self.b, self.n, self.r2, _p(self.xyz), _p(self.image), _stream())
+
+    def query(self, nsample, new_xyz, return_count=False):
+        """-> (B,S,nsample) int32 [, (B,S) counts]: the rows rs_ballquery returns for the same clouds, centres and radius, bit for bit"""
+        _need_gpu(new_xyz)
+        new_xyz = _f32c(new_xyz)
+        m = new_xyz.shape[1]
+        idx = torch.empty((self.b, m, nsample), dtype=torch.int32, device=new_xyz.device)
+        cnt = torch.empty((self.b, m), dtype=torch.int32, device=new_xyz.device) if return_count else None
+        _lib.call("rs_ballquery_grid_query", self.b, self.n, m, self.r2, nsample, _p(new_xyz), _p(self.image), _p(idx), _p(cnt), _stream())
+        return (idx, cnt) if return_count else idx
+
+
+def ballquery_grid_ok(n, nsample):
+    """shapes the reusable cell-list image covers (otherwise: ops.ballquery)"""
+    return 64 <= n <= 4096 and 1 <= nsample <= 64
+
+
 def knnquery(nsample, xyz, new_xyz=None, return_dist=False):
     """-> (B,S,nsample) int32 [, squared distances]; query_knn_point(cuda=False) semantics (:102-111)."""
     if new_xyz is None:

@@ -268,6 +268,38 @@ def test_full_size_properties(ops):
 
 
 @pytest.mark.gpu
+def test_ballquery_prebuilt_grid_bit_exact(ops):
+    """ops.BallGrid (rs_ballquery_grid_build / rs_ballquery_grid_query, round 6): the cell list built ONCE per cloud and queried from its
+    image returns the brute-force rows and the distinct counts bit for bit -- uniform, clustered (rows overflow nsample), lattice (exact
+    distance ties at the radius) and duplicated clouds, several centre sets (FPS picks, random picks, the cloud itself, points outside the
+    bounding box) against ONE image, degenerate clouds (a single point repeated, a line, a plane)."""
+    rs = np.random.RandomState(11)
+    cases = [("uniform", 3, 1024, 0.2, 32), ("clustered", 2, 1024, 0.2, 32), ("grid", 2, 1000, 0.25, 16), ("dup", 2, 512, 0.3, 32),
+             ("uniform", 2, 512, 0.4, 64), ("uniform", 1, 4096, 0.12, 8), ("uniform", 2, 2048, 0.15, 16), ("uniform", 2, 200, 0.6, 16),
+             ("uniform", 2, 1024, 0.05, 4)]
+    for kind, b, n, r, ns in cases:
+        xyz = cloud(31 + n, b, n, kind)
+        n = xyz.shape[1]
+        grid = ops.BallGrid(r, dev(xyz))
+        sets = [take(xyz, G.fps(xyz, min(n, 300), None)), xyz[:, ::3].copy(), xyz.copy(),
+                (xyz[:, :64] + rs.uniform(-2.5 * r, 2.5 * r, (b, 64, 3))).astype(np.float32)]
+        for centres in sets:
+            got, cnt = grid.query(ns, dev(centres), return_count=True)
+            ref = G.ballquery(r, ns, xyz, centres)
+            assert np.array_equal(got.cpu().numpy(), ref), (kind, n, r, ns, centres.shape)
+            distinct = np.array([[len(set(row.tolist())) for row in b_] for b_ in ref])
+            assert np.array_equal(cnt.cpu().numpy(), distinct), (kind, "count")
+            assert np.array_equal(got.cpu().numpy(), ops.ballquery(r, ns, dev(xyz), dev(centres)).cpu().numpy())
+    same = np.tile(np.array([[[0.3, -0.2, 0.1]]], np.float32), (2, 600, 1))
+    line = np.zeros((2, 600, 3), np.float32); line[..., 0] = rs.rand(2, 600) * 2 - 1
+    plane = (rs.rand(2, 600, 3) * 2 - 1).astype(np.float32); plane[..., 2] = 0.25
+    for xyz in (same, line, plane):
+        grid = ops.BallGrid(0.2, dev(xyz))
+        got = grid.query(32, dev(xyz[:, :200].copy())).cpu().numpy()
+        assert np.array_equal(got, G.ballquery(0.2, 32, xyz, xyz[:, :200]))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cells", ["2", "1", "0"])
 def test_ballquery_grid_variant_bit_exact(cells):
     """The cell-list variants of rs_ballquery (forced with RS_BALLQUERY_GRID=1; RS_BALLQUERY_CELLS=2: the straight-line pair walk of
