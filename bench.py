@@ -76,6 +76,10 @@ def parse():
                     help="uniform: synthetic uniform clouds in [-1,1]^3 (the metric's data); real: the 4 scanned objects of "
                          "tests/golden/geom_real.npz (first 1024 rows of the reference's visualization/*.txt clouds) tiled to the batch "
                          "-- surfaces, not volumes: 4-6x more DISTINCT ball-query slots, i.e. more shared-MLP rows (DESIGN 6/7)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="--workload seg: what the reference's loader emits -- every step a DIFFERENT packed batch (cloud sizes drawn in "
+                         "[points/2, points], segmentation/util/data_util.py:15-23), launched eagerly: the captured PipelinedStep holds the cloud "
+                         "boundaries as shapes and refuses such batches (DESIGN.md 6), so this is the throughput real S3DIS training gets")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check: spawn / join the ranks, one all-reduce over the process group (gloo where there is no "
                          "HIP device), rank 0 prints one JSON line; no model, no kernels (tests/test_ddp_gloo.py)")
@@ -712,6 +716,44 @@ def main_seg(args):
             rdist.barrier()
         torch.cuda.synchronize()
 
+    if args.ragged:
+        # eight different ragged batches (sizes in [pts / 2, pts], mean 3/4 pts), cycled: every step sees other cloud boundaries than the
+        # step before -- host offsets, grids, BatchNorm row counts and every intermediate shape change per step
+        batches = []
+        for i in range(8):
+            sizes = r.randint(pts // 2, pts + 1, clouds)
+            nn = int(sizes.sum())
+            batches.append(([torch.from_numpy((r.rand(nn, 3) * 2 - 1).astype(np.float32)).to(device), torch.from_numpy(r.rand(nn, 3).astype(np.float32)).to(device),
+                             ops.offsets_tensor(np.cumsum(sizes).tolist(), device)], torch.from_numpy(r.randint(0, 13, nn).astype(np.int64)).to(device), nn))
+
+        def ragged_step(i):
+            inp, lab, _ = batches[i % len(batches)]
+            for q in model.parameters():
+                q.grad = None
+            loss = criterion(model(inp), lab)
+            loss.backward()
+            if optim is not None:
+                optim.step()
+            return loss
+        for i in range(max(args.warmup, len(batches))):
+            ragged_step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss = ragged_step(i)
+        fence()
+        dt = rdist.max_over_ranks(time.perf_counter() - t0, device)
+        rows = sum(batches[i % len(batches)][2] for i in range(args.steps))
+        if rank == 0:
+            print(json.dumps({"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, RAGGED packed batches (eager launches)",
+                              "value": round(clouds * world * args.steps / dt, 2), "unit": "clouds/s", "points_per_s": round(rows * world / dt), "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "f32", "data": "synthetic uniform clouds, 8 different ragged batches cycled, random-init weights",
+                              "config": {"workload": f"configs[3] shape with ragged clouds: B={clouds} clouds of {pts // 2}..{pts} points (mean {int(np.mean([b_[2] for b_ in batches]))} rows per batch), "
+                                                     "eager launches -- the captured step refuses batches whose cloud boundaries differ from the captured ones",
+                                         "launch": "eager", "parallelism": f"dp{world}", "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5)}}), flush=True)
+        rdist.finish()
+        return
     if args.no_graph:
         # eager launches in program order, one dispatch per instrumented call: what the PMC passes of tools/gpu_profile.sh align
         # with the launch log (--launch-log); not a throughput configuration
