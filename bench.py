@@ -600,7 +600,8 @@ def bracketing_legs(args, value, cpu):
       real_scans_clouds_per_s  --data real -- the reference's scanned objects (surfaces: 4-6x more distinct slots than uniform cubes);
       eager_clouds_per_s       --no-graph -- the reference's own loop shape (classification/tool/train_cls_scanobjectnn.py:212-234:
                                zero_grad, classifier(points), loss, backward, step, launched eagerly from Python): what a user gets by
-                               changing PYTHONPATH only, host-paced.
+                               changing PYTHONPATH only, host-paced; 60 steps, mean (with the interpreter's
+                               collection pauses) and `eager_ms_per_step_median` (the steady state).
     gpu_over_cpu_dense = dense GPU step / dense CPU step: both sides run the same dense formulation."""
     out = {}
     for key, extra, env in (("dense_clouds_per_s", (), {"REPSURF_COMPACT": "0"}),
@@ -610,10 +611,12 @@ def bracketing_legs(args, value, cpu):
             continue
         if key == "eager_clouds_per_s" and args.no_graph:
             continue
-        rec = child_leg(args, extra, env, steps=20)
+        rec = child_leg(args, extra, env, steps=60 if key == "eager_clouds_per_s" else 20)
         out[key] = None if rec is None else rec["value"]
         if rec is not None:
             out[key.replace("_clouds_per_s", "_ms_per_step")] = rec["ms_per_step"]
+            if "ms_per_step_median" in rec:
+                out[key.replace("_clouds_per_s", "_ms_per_step_median")] = rec["ms_per_step_median"]
     if cpu and out.get("dense_clouds_per_s"):
         out["gpu_over_cpu_dense"] = round(out["dense_clouds_per_s"] / cpu["value"], 1)
     return out
@@ -1017,8 +1020,10 @@ def main():
     steps_timed = timed_step_count(args, step, fence, world, device, rdist) if use_graph else args.steps
     fence()
     t0 = time.perf_counter()
+    stamps = [t0]
     for _ in range(steps_timed):
         loss = step()
+        stamps.append(time.perf_counter())      # (host issue times: what paces an eagerly launched step)
     fence()
     dt = time.perf_counter() - t0
     if timing and not use_graph:
@@ -1088,6 +1093,10 @@ def main():
                "roofline": roofline, "roofline_ballquery": ball_line, "fps_us_per_pick": fps_line, "cpu_baseline": cpu}
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        if not use_graph:
+            # an eager step is paced by the host: the median of the per-step issue intervals is the steady state, the mean (ms_per_step)
+            # also carries Python's full collections (one 80-90 ms pause every few dozen steps on this image: tools/eager_step_times.py)
+            out["ms_per_step_median"] = round(float(np.median(np.diff(stamps))) * 1e3, 4)
         if world > 1:
             out["allreduce_us"] = None if allreduce_us is None else round(allreduce_us, 1)      # (also in config: the step's one data-path collective, alone)
         if world == 1 and args.dtype == "fp32" and mlp_hip_split3() and not args.no_alt_arithmetic:

@@ -830,7 +830,10 @@ class _SAStack(Function):
                       _ptr(v_last.shift), _ptr(out), None if arg is None else arg.data_ptr(), _stream())
         else:
             raise NotImplementedError("a stack needs at least one layer after the first")
-        saved.update(ys=ys, vecs=vecs, w2ds=w2ds, out=out, arg=arg)
+        # `out` becomes an output of this node: a plain reference from ctx would close a cycle (node -> saved -> out -> grad_fn = node)
+        # that only Python's generation-2 collector breaks -- an eager loop then keeps ~30 steps of activations alive (1.5 GB per
+        # classification step).  Detached aliases share the storage and carry no edge.
+        saved.update(ys=[y.detach() if y is out else y for y in ys], vecs=vecs, w2ds=w2ds, out=out.detach(), arg=arg)
         _flush_counters()
         ctx.saved = saved
         ctx.meta = meta
@@ -980,10 +983,27 @@ class LazyRows:
     backward, its data-gradient GEMM masks with relu'(.) and sums the BatchNorm-backward moments in its epilogue -- what the layers
     INSIDE a stack do for each other -- and leaves them here (`part`) for the producer's backward, which receives the masked
     gradient through autograd.  Saves the BatchNorm + ReLU pass over (rows, C) each way.  One consumer only."""
-    __slots__ = ("y", "vec", "part")
+    __slots__ = ("y", "vec", "box")
+
+    class Box:
+        """The one field producer and consumer exchange in backward.  The producer's node keeps THIS, not the LazyRows: `y` is that
+        node's own output, and holding it from the node would be a reference cycle (freed by the cycle collector only)."""
+        __slots__ = ("part",)
+
+        def __init__(self):
+            self.part = None
 
     def __init__(self):
-        self.y = self.vec = self.part = None
+        self.y = self.vec = None
+        self.box = LazyRows.Box()
+
+    @property
+    def part(self):
+        return self.box.part
+
+    @part.setter
+    def part(self, v):
+        self.box.part = v
 
     @property
     def shape(self):
@@ -1016,7 +1036,7 @@ def sa_mlp_plain(x, convs, bns, nsample, relu_last=True, lazy_out=False):
     if lazy_out:
         assert nsample == 1 and relu_last and mods[0].training, "lazy_out: ungrouped rows ending in BatchNorm + ReLU, training mode"
         lazy = LazyRows()
-        meta["lazy_out"] = lazy
+        meta["lazy_out"] = lazy.box
         lazy.y = _SAStack.apply(x, meta, *params)
         lazy.vec = meta["vec_last"]
         return lazy
@@ -1469,7 +1489,7 @@ class _FPFront(Function):
         _lib.call("rs_three_interpolate_affine", 1, c, m, n, _ptr(y2), _ptr(v2.scale), _ptr(v2.shift), idx.data_ptr(), _ptr(weight),
                   _ptr(y1), _ptr(v1.scale), _ptr(v1.shift), 1, _ptr(out), _stream())
         _flush_counters()
-        ctx.saved = dict(points2=points2, points1=points1, idx=idx, weight=weight, y2=y2, y1=y1, v2=v2, v1=v1, out=out, wf2=wf2, ws2=ws2, lazy2=lazy2,
+        ctx.saved = dict(points2=points2, points1=points1, idx=idx, weight=weight, y2=y2, y1=y1, v2=v2, v1=v1, out=out.detach(), wf2=wf2, ws2=ws2, lazy2=lazy2,
                          csr=meta.get("csr") if (meta.get("csr") is not None and meta["csr"][0].numel() == m + 1 and m * c < 2 ** 31) else None)
         return out
 

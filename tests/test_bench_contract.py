@@ -1,5 +1,6 @@
 """The bench line contract (driver + tier framing): bench.py's defaults and the line the last GPU evidence run printed
-(profiles/r05/bench_cls.json, bench_seg.json) -- keys, units, and the arithmetic between its fields.  CPU only: nothing is launched."""
+(profiles/r06/bench_cls.json, bench_seg.json; the round-5 lines where a round-6 one is not committed) -- keys, units, and the arithmetic
+between its fields.  CPU only: nothing is launched."""
 import json
 import os
 import sys
@@ -7,17 +8,18 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = os.path.join(ROOT, "profiles", "r05")
+LINES = [os.path.join(ROOT, "profiles", r) for r in ("r06", "r05")]
 
 DRIVER_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                "dtype", "data", "config")
 
 
-def _line(name):
-    path = os.path.join(LINES, name)
-    if not os.path.exists(path):
-        pytest.skip(f"{path} not committed")
-    return json.loads(open(path).read().strip().splitlines()[-1])
+def _line(name, rounds=LINES):
+    for d in rounds:
+        path = os.path.join(d, name)
+        if os.path.exists(path):
+            return json.loads(open(path).read().strip().splitlines()[-1])
+    pytest.skip(f"{name} not committed")
 
 
 def test_defaults_are_one_gpu_and_a_run_of_minutes(monkeypatch):
@@ -69,3 +71,32 @@ def test_classification_line_names_the_metric_and_the_ball_query_roofline():
     for clouds, rec in b["clouds_per_launch"].items():
         assert abs(rec["frac"] - rec["achieved"] / b["peak"]) <= 2e-3
         assert abs(rec["achieved"] - rec["algorithmic_bytes"] / (rec["us"] * 1e-6) / 1e9) <= 1e-2 * rec["achieved"]
+
+
+def test_round6_line_carries_the_in_step_roofline_and_the_bracketing_legs():
+    """VERDICT r5 items 1d / 3 / 4 on the driver's line: `roofline.frac` is the dominant class INSIDE the step's family graph with the
+    optimistic alone-replay beside it; the dense / real-scan / eager throughputs and the dense GPU : dense CPU ratio; the ball query's
+    build / query split."""
+    d = _line("bench_cls.json", LINES[:1])
+    r = d["roofline"]
+    assert r["kernel"].startswith("rs_mlp_") and r["unit"] == "TFLOP/s"
+    assert "alone_frac" in r and "alone_avg_launch_us" in r and r["stamp_gap_us"] > 0
+    assert r["alone_frac"] >= r["frac"] > 0                                  # the warm-cache alone-replay is the optimistic one
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 2e-3
+    amount = 2.0 * r["dims"][0] * r["dims"][1] * r["dims"][2]
+    assert abs(r["achieved"] - amount / (r["avg_launch_us"] * 1e-6) / 1e12) <= 2e-2 * r["achieved"]
+    for k in ("dense_clouds_per_s", "real_scans_clouds_per_s", "eager_clouds_per_s", "gpu_over_cpu_dense"):
+        assert d.get(k) is not None and d[k] > 0, k
+    assert d["dense_clouds_per_s"] < d["value"] and d["eager_clouds_per_s"] < d["dense_clouds_per_s"]
+    assert abs(d["gpu_over_cpu_dense"] - d["dense_clouds_per_s"] / d["cpu_baseline"]["value"]) <= 0.01 * d["gpu_over_cpu_dense"]
+    g = d["roofline_ballquery"]["clouds_per_launch"]["2048"]["prebuilt_grid"]
+    assert abs(g["query_frac"] - g["query_algorithmic_bytes"] / (g["query_us"] * 1e-6) / 1e9 / 8000.0) <= 2e-3
+    assert g["query_us"] < d["roofline_ballquery"]["clouds_per_launch"]["2048"]["us"] < g["build_plus_query_us"] * 1.2
+
+
+def test_bench_parses_the_round6_flags(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "seg", "--ragged", "--no-extra-legs"])
+    a = bench.parse()
+    assert a.ragged and a.no_extra_legs and a.workload == "seg"

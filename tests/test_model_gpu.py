@@ -216,3 +216,42 @@ def test_mirror_pointops_wrappers_the_reference_exports():
         ref_f = torch.gather(feats, 2, gidx.reshape(2, 1, -1).expand(-1, 5, -1)).view(2, 5, 64, 16)
         assert torch.equal(gxyz, ref_xyz) and torch.equal(nf[:, 3:], ref_f)
         assert torch.equal(nf[:, :3], ref_xyz - new_xyz.transpose(1, 2).unsqueeze(-1))
+
+
+def test_an_eager_step_frees_its_activations_without_the_cycle_collector():
+    """The reference's loop launches eagerly (classification/tool/train_cls_scanobjectnn.py:227-238).  An autograd node that keeps one of
+    its OWN outputs in a plain attribute is a reference cycle: the step's activations (1.5 GB at B=32) then live until Python's
+    generation-2 collection, tens of steps later (round 6: `tools/eager_cycle_probe.py`).  With the collector off, the allocated bytes
+    must return to their level after a step and nothing a step made may be unreachable-but-alive tensors."""
+    import gc
+    from util.utils import SmoothClsLoss
+    model = build_model()
+    pts = torch.from_numpy(cloud(5, 8, 1024)).cuda().permute(0, 2, 1).contiguous()
+    lab = torch.arange(8).cuda() % 15
+    crit = SmoothClsLoss()
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        crit(model(pts), lab).backward()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    try:
+        a0 = torch.cuda.memory_allocated()
+        step()
+        step()
+        torch.cuda.synchronize()
+        a1 = torch.cuda.memory_allocated()
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        gc.collect()
+        gc.set_debug(0)
+        pinned = [o for o in gc.garbage if torch.is_tensor(o) and o.is_cuda]
+        gc.garbage.clear()
+    finally:
+        gc.enable()
+    assert not pinned, f"{len(pinned)} device tensors were reachable only through a reference cycle"
+    assert a1 - a0 <= (1 << 20), f"{(a1 - a0) >> 20} MiB stayed allocated after two eager steps"

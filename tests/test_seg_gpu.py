@@ -690,3 +690,44 @@ def test_interpolation_backward_as_a_gather(ops, n, m, c):
     assert torch.equal(res["gather"][0], res["scatter"][0])
     assert torch.allclose(res["gather"][1], res["scatter"][1], rtol=1e-5, atol=1e-5)
     assert torch.equal(res["gather"][1], res["gather_again"][1])
+
+
+def test_an_eager_seg_step_frees_its_activations_without_the_cycle_collector():
+    """Same property as the classification test of this name (tests/test_model_gpu.py), on the segmentation step: the row stacks hand
+    their raw last output over as LazyRows and the feature-propagation front keeps its output for the ReLU mask -- neither may be
+    referenced from the node that produced it (reference loop: segmentation/tool/train.py:280-300, eager launches)."""
+    import gc
+    model = _seg_model()
+    r = np.random.RandomState(3)
+    sizes = np.array([700, 1024, 513, 900])
+    n = int(sizes.sum())
+    coord, rgb = dev((r.rand(n, 3) * 2 - 1).astype(np.float32)), dev(r.rand(n, 3).astype(np.float32))
+    offset = dev(np.cumsum(sizes).astype(np.int32))
+    label = dev(r.randint(0, 13, n).astype(np.int64))
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        with subproject("segmentation"):
+            torch.nn.functional.cross_entropy(model([coord, rgb, offset]), label).backward()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    try:
+        a0 = torch.cuda.memory_allocated()
+        step()
+        step()
+        torch.cuda.synchronize()
+        a1 = torch.cuda.memory_allocated()
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        gc.collect()
+        gc.set_debug(0)
+        pinned = [o for o in gc.garbage if torch.is_tensor(o) and o.is_cuda]
+        gc.garbage.clear()
+    finally:
+        gc.enable()
+    assert not pinned, f"{len(pinned)} device tensors were reachable only through a reference cycle"
+    assert a1 - a0 <= (1 << 20), f"{(a1 - a0) >> 20} MiB stayed allocated after two eager steps"
