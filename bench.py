@@ -78,8 +78,8 @@ def parse():
                          "-- surfaces, not volumes: 4-6x more DISTINCT ball-query slots, i.e. more shared-MLP rows (DESIGN 6/7)")
     ap.add_argument("--ragged", action="store_true",
                     help="--workload seg: what the reference's loader emits -- every step a DIFFERENT packed batch (cloud sizes drawn in "
-                         "[points/2, points], segmentation/util/data_util.py:15-23), launched eagerly: the captured PipelinedStep holds the cloud "
-                         "boundaries as shapes and refuses such batches (DESIGN.md 6), so this is the throughput real S3DIS training gets")
+                         "[points/2, points], segmentation/util/data_util.py:15-23) through ONE captured network graph (RaggedSegStep: row counts "
+                         "as device data); the eager loop is timed beside it (--no-graph: only the eager loop)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check: spawn / join the ranks, one all-reduce over the process group (gloo where there is no "
                          "HIP device), rank 0 prints one JSON line; no model, no kernels (tests/test_ddp_gloo.py)")
@@ -738,23 +738,54 @@ def main_seg(args):
             if optim is not None:
                 optim.step()
             return loss
-        for i in range(max(args.warmup, len(batches))):
-            ragged_step(i)
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            loss = ragged_step(i)
-        fence()
-        dt = rdist.max_over_ranks(time.perf_counter() - t0, device)
+
+        def timed_eager(steps):
+            for i in range(max(args.warmup, len(batches))):
+                ragged_step(i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                loss = ragged_step(i)
+            fence()
+            return rdist.max_over_ranks(time.perf_counter() - t0, device), loss
         rows = sum(batches[i % len(batches)][2] for i in range(args.steps))
+        graphed = world == 1 and not args.no_graph
+        if graphed:
+            # ONE captured network graph for every batch layout (repsurf_amd.graph.RaggedSegStep: launches sized for a row capacity,
+            # counts read from a device table; the next batch's geometry launched eagerly on a side stream under the running graph)
+            from repsurf_amd.graph import RaggedSegStep
+            rstep = RaggedSegStep(model, criterion, optim, batches[0][0], batches[0][1], capacity=clouds * pts, warmup=max(2, args.warmup))
+            for i in range(max(args.warmup, len(batches))):
+                rstep(batches[(i + 1) % len(batches)][0], batches[(i + 1) % len(batches)][1], sync=False)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.steps):      # (the warm-up left batch `max(warmup, 8) % 8` = 0's successor chain intact: step i trains batch i % 8)
+                nxt = batches[(max(args.warmup, len(batches)) + i + 1) % len(batches)]
+                loss = rstep(nxt[0], nxt[1], sync=False)
+            fence()
+            dt = time.perf_counter() - t0
+            loss_val = float(loss.item())
+            rstep.close()
+            eager_dt, _ = timed_eager(min(args.steps, 16))
+            eager_ms = eager_dt / min(args.steps, 16) * 1e3
+        else:
+            dt, loss = timed_eager(args.steps)
+            loss_val, eager_ms = float(loss.item()), None
         if rank == 0:
-            print(json.dumps({"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, RAGGED packed batches (eager launches)",
-                              "value": round(clouds * world * args.steps / dt, 2), "unit": "clouds/s", "points_per_s": round(rows * world / dt), "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "f32", "data": "synthetic uniform clouds, 8 different ragged batches cycled, random-init weights",
-                              "config": {"workload": f"configs[3] shape with ragged clouds: B={clouds} clouds of {pts // 2}..{pts} points (mean {int(np.mean([b_[2] for b_ in batches]))} rows per batch), "
-                                                     "eager launches -- the captured step refuses batches whose cloud boundaries differ from the captured ones",
-                                         "launch": "eager", "parallelism": f"dp{world}", "optimizer_step": not args.no_optim, "loss": round(float(loss.item()), 5)}}), flush=True)
+            launch = ("ONE captured network hipGraph for every batch layout: launches sized for the row capacity, row counts read from a device table "
+                      "(include/repsurf_hip.h: rows_dev), the next batch's geometry launched eagerly on a side stream under the running graph "
+                      "(repsurf_amd.graph.RaggedSegStep)") if graphed else "eager launches"
+            out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, RAGGED packed batches" + ("" if graphed else " (eager launches)"),
+                   "value": round(clouds * world * args.steps / dt, 2), "unit": "clouds/s", "points_per_s": round(rows * world / dt), "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None, "dtype": "f32", "data": "synthetic uniform clouds, 8 different ragged batches cycled, random-init weights",
+                   "config": {"workload": f"configs[3] shape with ragged clouds: B={clouds} clouds of {pts // 2}..{pts} points (mean {int(np.mean([b_[2] for b_ in batches]))} rows per batch, "
+                                          f"capacity {clouds * pts}): what the reference's loader emits (segmentation/util/data_util.py:15-23)",
+                              "launch": launch, "parallelism": f"dp{world}", "optimizer_step": not args.no_optim, "loss": round(loss_val, 5)}}
+            if eager_ms is not None:
+                out["eager_ms_per_step"] = round(eager_ms, 4)
+                out["eager_clouds_per_s"] = round(clouds * 1e3 / eager_ms, 2)
+            print(json.dumps(out), flush=True)
         rdist.finish()
         return
     if args.no_graph:

@@ -73,6 +73,10 @@ int rs_gather_rows(int b, int n, int m, int c, const float *points, const int *i
 /* grad_points[b, idx[b,j], :] += grad_out[b, j, :]  (grad_points pre-zeroed by caller) */
 int rs_gather_rows_backward(int b, int n, int m, int c, const float *grad_out, const int *idx,
                             float *grad_points, void *stream);
+/* the same with the gathered rows' count as device data (b = 1, packed batches under a captured capacity: rs_bn_item): rows
+ * [min(m, *rows_dev), m) of grad_out are not read */
+int rs_gather_rows_backward_dev(int b, int n, int m, int c, const float *grad_out, const int *idx,
+                                float *grad_points, const int *rows_dev, void *stream);
 
 /* ---- ball query --------------------------------------------------------
  * Replaces ballquery_cuda_launcher_fast(b,n,m,radius,nsample,new_xyz,xyz,idx,stream)
@@ -162,18 +166,23 @@ int rs_three_interpolate_fused(int b, int c, int m, int n, const float *points, 
                                const float *add, int relu, float *out, void *stream);
 int rs_three_interpolate_fused_backward(int b, int c, int n, int m, const float *grad_out, const float *fwd_out,
                                         const int *idx, const float *weight, float *grad_points, float *grad_add, void *stream);
+/* the same with the fine rows' count as device data (b = 1; see rs_bn_item): rows [min(n, *rows_dev), n) are not read or scattered */
+int rs_three_interpolate_fused_backward_dev(int b, int c, int n, int m, const float *grad_out, const float *fwd_out,
+                                            const int *idx, const float *weight, float *grad_points, float *grad_add,
+                                            const int *rows_dev, void *stream);
 /* Feature propagation, first layers (segmentation/modules/repsurface_utils.py:256-270; round 4): out = relu(interpolate(BN_f(points))
  * + BN_s(add)), both BatchNorms as per-channel (scale, shift) applied on the fly to the raw Linear outputs (z = fma(scale, y,
  * shift): what the BatchNorm pass computes) -- and its backward: g = grad_out * (fwd_out > 0) to grad_add, scattered with the
  * weights into grad_points (zeroed by the caller), BN_s's backward sums {sum g, sum g * (add - mean) * invstd} to
- * partial (partial_blocks, 2, c) doubles (c <= 256). */
+ * partial (partial_blocks, 2, c) doubles (c <= 256).  rows_dev (optional, b = 1): the fine rows' count as device data -- min(n, *rows_dev)
+ * rows are read, scattered and summed (see rs_bn_item). */
 int rs_three_interpolate_affine(int b, int c, int m, int n, const float *points, const float *pscale, const float *pshift,
                                 const int *idx, const float *weight, const float *add, const float *ascale, const float *ashift,
                                 int relu, float *out, void *stream);
 int rs_three_interpolate_affine_backward(int b, int c, int n, int m, const float *grad_out, const float *fwd_out, const int *idx,
                                          const float *weight, float *grad_points, float *grad_add, const float *add,
                                          const float *add_mean, const float *add_invstd, double *partial, int partial_blocks,
-                                         void *stream);
+                                         const int *rows_dev, void *stream);
 /* The interpolation's backward towards the coarse rows as a gather (round 4) over rs_inverse_index of idx (per = 3, built with the
  * geometry): grad_points (m_rows, c) WRITTEN, ascending sums, no atomics.  g: the masked gradient (rs_three_interpolate_affine_backward
  * with grad_points = NULL makes it), or NULL: grad_out where fwd_out > 0.  partial (optional): BatchNorm-backward sums of the coarse
@@ -429,14 +438,20 @@ int rs_bn_backward_finalize(int c, long long rows, int nblk, int nstat, int whic
 #define RS_BN_BATCH_MAX 4
 #define RS_TAIL_FIN_MAX 2
 #define RS_TAIL_RED_MAX 4
+/* rows_dev (round 6, optional): the row count as DEVICE data -- min(rows, *rows_dev) rows were summed.  A packed segmentation batch
+ * changes its row counts every step (segmentation/util/data_util.py:15-23) while a captured hipGraph freezes every scalar argument:
+ * launches are sized for a capacity (`rows`) and read the batch's counts from a small device table the host refills before each
+ * replay (repsurf_amd.graph.RaggedSegStep).  Same convention as rs_mlp_gemm_rows' rows_dev. */
 typedef struct {
   int c, nblk; long long rows; const double *partial; const float *gamma, *beta; float eps, momentum;
   float *scale, *shift, *save_mean, *save_invstd, *running_mean, *running_var;
-} rs_bn_item;                                         /* the arguments of rs_bn_finalize */
+  const int *rows_dev;
+} rs_bn_item;                                         /* the arguments of rs_bn_finalize (+ rows_dev) */
 typedef struct {
   int c, nblk, nstat, which; long long rows; const double *partial; const float *scale, *mean, *invstd;
   float *p, *q, *r, *dgamma, *dbeta;
-} rs_bn_bwd_item;                                     /* the arguments of rs_bn_backward_finalize */
+  const int *rows_dev;
+} rs_bn_bwd_item;                                     /* the arguments of rs_bn_backward_finalize (+ rows_dev) */
 typedef struct { int chunks; long long n; const float *partial; float *out; } rs_reduce_item;   /* ... of rs_reduce_partials */
 typedef struct { int nfin, nred; rs_bn_bwd_item fin[RS_TAIL_FIN_MAX]; rs_reduce_item red[RS_TAIL_RED_MAX]; } rs_backward_tail_work;
 int rs_bn_finalize_batch(const rs_bn_item *items, int n, void *stream);
@@ -459,10 +474,11 @@ int rs_pool_select(long long groups, int c, const float *ymax, const float *ymin
 /* v = dout * (out > 0) and the BatchNorm-backward sums of the pooled layer from (groups, c) data only:
  * partial (partial_blocks, 2, c) = {sum v, sum v * yhat[arg row]}.  out = NULL: the pooled layer ended without a
  * ReLU (rs_pool_max called with relu = 0), v = dout (v may then be NULL: only the sums).  dout: (groups, c) rows `ldd` floats apart (0 = c): the pooled
- * activations' gradient is often a column slice of a wider tensor. */
+ * activations' gradient is often a column slice of a wider tensor.
+ * groups_dev (optional): the group count as device data, min(groups, *groups_dev) groups are processed (see rs_bn_item). */
 int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout, long long ldd,
                          const float *out, const int *arg, const float *y, int y_bf16, const float *mean,
-                         const float *invstd, float *v, double *partial, int partial_blocks, void *stream);
+                         const float *invstd, float *v, double *partial, int partial_blocks, const int *groups_dev, void *stream);
 /* out[g][c] = sum_k y[g*nsample+k][c]   (umbrella aggregation 'sum', :305) */
 int rs_pool_sum(long long groups, int nsample, int c, const float *y, float *out, void *stream);
 
@@ -547,6 +563,9 @@ int rs_scale_by_scalars(long long n, const float *x, const float *a, const float
  * classifier's output nn.Linear (segmentation/models/repsurf/repsurf_umb_ssg.py:36-41) and the constructor's last Conv1d
  * (segmentation/modules/repsurface_utils.py:298-303). */
 int rs_col_sum_partials(long long rows, int n, const float *x, long long ldx, float scale, float *partial, int nblk, void *stream);
+/* the same with the row count as device data (see rs_bn_item): rows [min(rows, *rows_dev), rows) are not read */
+int rs_col_sum_partials_dev(long long rows, int n, const float *x, long long ldx, float scale, float *partial, int nblk,
+                            const int *rows_dev, void *stream);
 
 /* ---- optimizer step -------------------------------------------------------------------------------
  * torch.optim.Adam(lr, betas, eps, weight_decay) as the reference configures it
@@ -641,6 +660,7 @@ typedef struct rs_umbrella_mfma {
   float *part_b2; int nblk_b2;
   float out_scale; float *out;
   float *grads;
+  const int *rows_dev;      /* optional: the row count as device data, min(rows, *rows_dev) rows are walked (rs_bn_item); a multiple of group */
 } rs_umbrella_mfma;
 int rs_umbrella_moments(const float *x, long long rows, float *partial, int nblk, double *moments, void *stream);
 int rs_umbrella_mfma_pass(int pass, const rs_umbrella_mfma *m, int nblk, void *stream);

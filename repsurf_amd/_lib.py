@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPSURF_HIP_LIB") or os.path.join(_HERE, "lib", "librepsurf_hip.so")   # override: experiment builds only
-ABI_VERSION = 36
+ABI_VERSION = 37
 KNN_GRID_CELLS = 4096          # RS_KNN_GRID_CELLS of include/repsurf_hip.h
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
@@ -21,6 +21,7 @@ SIGNATURES = {
     "rs_furthestsampling_offset": [c_int, c_int, P, P, P, P, P, P],
     "rs_gather_rows": [c_int, c_int, c_int, c_int, P, P, P, P],
     "rs_gather_rows_backward": [c_int, c_int, c_int, c_int, P, P, P, P],
+    "rs_gather_rows_backward_dev": [c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_ballquery": [c_int, c_int, c_int, c_float, c_int, P, P, P, P, P],
     "rs_knnquery": [c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_knnquery_offset": [c_int, c_int, P, P, P, P, c_int, P, P, P],
@@ -46,8 +47,9 @@ SIGNATURES = {
     "rs_three_interpolate_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_three_interpolate_fused": [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P],
     "rs_three_interpolate_fused_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
+    "rs_three_interpolate_fused_backward_dev": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P],
     "rs_three_interpolate_affine": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P, P],
-    "rs_three_interpolate_affine_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P],
+    "rs_three_interpolate_affine_backward": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, P],
     "rs_three_interpolate_backward_csr": [c_ll, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P],
     "rs_mlp_gemm_rows": [c_ll, P, c_int, c_int, P, P, c_int, P, P],
     "rs_mlp_gemm_rows_bf16": [c_ll, P, c_int, c_int, P, P, c_int, P, P],
@@ -56,7 +58,7 @@ SIGNATURES = {
     "rs_bn_finalize": [c_int, c_ll, c_int, P, P, P, c_float, c_float, P, P, P, P, P, P, P],
     "rs_bn_backward_finalize": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P],
     "rs_pool_max": [c_ll, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P],
-    "rs_pool_max_backward": [c_ll, c_int, c_int, P, P, c_ll, P, P, P, c_int, P, P, P, P, c_int, P],
+    "rs_pool_max_backward": [c_ll, c_int, c_int, P, P, c_ll, P, P, P, c_int, P, P, P, P, c_int, P, P],
     "rs_pool_sum": [c_ll, c_int, c_int, P, P, P],
     "rs_pool_select": [c_ll, c_int, P, P, P, P, P, P, P, P, P],
     "rs_reduce_partials": [c_int, c_ll, P, P, P],
@@ -64,6 +66,7 @@ SIGNATURES = {
     "rs_cross_entropy_forward": [c_ll, c_int, c_ll, P, P, P, P, P, P, P, P],
     "rs_scale_by_scalars": [c_ll, P, P, P, P, P],
     "rs_col_sum_partials": [c_ll, c_int, P, c_ll, ctypes.c_float, P, c_int, P],
+    "rs_col_sum_partials_dev": [c_ll, c_int, P, c_ll, ctypes.c_float, P, c_int, P, P],
     "rs_bn_finalize_batch": [P, c_int, P],
     "rs_bn_backward_finalize_reduce": [c_int, c_ll, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, c_ll, P, P, P],
     "rs_pack_weights": [P, P],

@@ -36,8 +36,9 @@ gather_rows_kernel(long long rows, int per_cloud, int n, int c, const float *__r
 
 // grad_points[cloud(r), idx[r], :] += grad_out[r, :]
 __global__ void __launch_bounds__(GR_THREADS)
-gather_rows_bwd_kernel(long long rows, int per_cloud, int n, int c, const float *__restrict__ grad_out,
+gather_rows_bwd_kernel(long long rows_arg, const int *__restrict__ rows_dev, int per_cloud, int n, int c, const float *__restrict__ grad_out,
                        const int *__restrict__ idx, float *__restrict__ grad_points) {
+  const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;
   const long long total = rows * c;
   for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total;
        e += (long long)gridDim.x * GR_THREADS) {
@@ -584,16 +585,22 @@ extern "C" int rs_gather_rows(int b, int n, int m, int c, const float *points, c
   return RS_OK;
 }
 
-extern "C" int rs_gather_rows_backward(int b, int n, int m, int c, const float *grad_out, const int *idx,
-                                       float *grad_points, void *stream) {
+extern "C" int rs_gather_rows_backward_dev(int b, int n, int m, int c, const float *grad_out, const int *idx,
+                                           float *grad_points, const int *rows_dev, void *stream) {
   RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 0, "rs_gather_rows_backward: negative size");
+  RS_REQUIRE(!rows_dev || b == 1, "rs_gather_rows_backward_dev: a device row count needs a packed batch (b = 1)");
   const long long rows = (long long)b * m;
   if (rows == 0 || c == 0) return RS_OK;
   RS_REQUIRE(grad_out && idx && grad_points, "rs_gather_rows_backward: null pointer");
   hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3(grid_for(rows * c)), dim3(GR_THREADS), 0,
-                     (hipStream_t)stream, rows, m, n, c, grad_out, idx, grad_points);
+                     (hipStream_t)stream, rows, rows_dev, m, n, c, grad_out, idx, grad_points);
   RS_CHECK_LAUNCH("rs_gather_rows_backward");
   return RS_OK;
+}
+
+extern "C" int rs_gather_rows_backward(int b, int n, int m, int c, const float *grad_out, const int *idx,
+                                       float *grad_points, void *stream) {
+  return rs_gather_rows_backward_dev(b, n, m, c, grad_out, idx, grad_points, nullptr, stream);
 }
 
 extern "C" int rs_group_rows(int b, int n, int m, int nsample, int c, const float *points,

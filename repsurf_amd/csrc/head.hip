@@ -598,9 +598,10 @@ ce_scale_kernel(long long n, const float *__restrict__ x, const float *__restric
 // column sums of x (rows, n) with row pitch ldx, stage 1: workgroup b sums rows [b * per, (b + 1) * per) -> partial[b][:]
 // (the bias gradient of a row Linear: dout.sum(0); stage 2 is rs_reduce_partials' fixed-order sum)
 __global__ void __launch_bounds__(256)
-col_sum_kernel(long long rows, int n, const float *__restrict__ x, long long ldx, long long per, float scale, float *__restrict__ partial) {
+col_sum_kernel(long long rows_arg, const int *__restrict__ rows_dev, int n, const float *__restrict__ x, long long ldx, long long per, float scale, float *__restrict__ partial) {
   __shared__ float red[256];
   const int tid = threadIdx.x;
+  const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;      // (rows beyond a device count are not read)
   const long long r0 = (long long)blockIdx.x * per, r1 = min(rows, r0 + per);
   if (n <= 16) {      // few columns (13 classes): a thread walks whole rows, 256 consecutive rows per trip, sums in registers
     float acc[16];
@@ -666,13 +667,18 @@ extern "C" int rs_scale_by_scalars(long long n, const float *x, const float *a, 
   return RS_OK;
 }
 
-extern "C" int rs_col_sum_partials(long long rows, int n, const float *x, long long ldx, float scale, float *partial, int nblk, void *stream) {
+extern "C" int rs_col_sum_partials_dev(long long rows, int n, const float *x, long long ldx, float scale, float *partial, int nblk,
+                                       const int *rows_dev, void *stream) {
   RS_REQUIRE(rows > 0 && n > 0 && nblk > 0 && ldx >= n, "rs_col_sum_partials: bad size");
   RS_REQUIRE(x && partial, "rs_col_sum_partials: null pointer");
   const long long per = (rows + nblk - 1) / nblk;
-  hipLaunchKernelGGL(col_sum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, rows, n, x, ldx, per, scale, partial);
+  hipLaunchKernelGGL(col_sum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, rows, rows_dev, n, x, ldx, per, scale, partial);
   RS_CHECK_LAUNCH("rs_col_sum_partials");
   return RS_OK;
+}
+
+extern "C" int rs_col_sum_partials(long long rows, int n, const float *x, long long ldx, float scale, float *partial, int nblk, void *stream) {
+  return rs_col_sum_partials_dev(rows, n, x, ldx, scale, partial, nblk, nullptr, stream);
 }
 
 extern "C" int rs_head_layer_forward(const rs_head_layer *l, void *stream) {

@@ -115,7 +115,7 @@ interp_fwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
 }
 
 __global__ void __launch_bounds__(IT_THREADS)
-interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__ grad_out,
+interp_bwd_kernel(long long rows_arg, const int *__restrict__ rows_dev, int n, int m, int c, const float *__restrict__ grad_out,
                   const int *__restrict__ idx, const float *__restrict__ weight,
                   float *__restrict__ grad_points, const float *__restrict__ fwd_out, float *__restrict__ grad_add,
                   const float *__restrict__ sy, const float *__restrict__ smean, const float *__restrict__ sinvstd,
@@ -125,6 +125,7 @@ interp_bwd_kernel(long long rows, int n, int m, int c, const float *__restrict__
   // multiple of c, c <= 256: a thread meets one channel only), instead of a second pass over g and sy (rs_pool_max_backward)
   __shared__ double red[IT_THREADS][2];
   double acc0 = 0.0, acc1 = 0.0;
+  const long long rows = rows_dev ? min(rows_arg, (long long)*rows_dev) : rows_arg;      // (rows beyond a device count: not read, not scattered, not summed)
   // fwd_out != NULL: the forward ended in a ReLU -- the incoming gradient counts where fwd_out > 0; grad_add != NULL: the masked
   // gradient is also written out (the skip connection's gradient), one pass instead of threshold_backward + this kernel
   const long long total = rows * c, stride = (long long)gridDim.x * IT_THREADS;
@@ -287,17 +288,24 @@ extern "C" int rs_three_interpolate_fused(int b, int c, int m, int n, const floa
   return RS_OK;
 }
 
-extern "C" int rs_three_interpolate_fused_backward(int b, int c, int n, int m, const float *grad_out, const float *fwd_out,
-                                                   const int *idx, const float *weight, float *grad_points, float *grad_add,
-                                                   void *stream) {
+extern "C" int rs_three_interpolate_fused_backward_dev(int b, int c, int n, int m, const float *grad_out, const float *fwd_out,
+                                                       const int *idx, const float *weight, float *grad_points, float *grad_add,
+                                                       const int *rows_dev, void *stream) {
   RS_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "rs_three_interpolate_fused_backward: negative size");
+  RS_REQUIRE(!rows_dev || b == 1, "rs_three_interpolate_fused_backward_dev: a device row count needs a packed batch (b = 1)");
   const long long rows = (long long)b * n;
   if (rows == 0 || c == 0) return RS_OK;
   RS_REQUIRE(grad_out && idx && weight && grad_points, "rs_three_interpolate_fused_backward: null pointer");
   hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
-                     rows, n, m, c, grad_out, idx, weight, grad_points, fwd_out, grad_add, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (double *)nullptr, 0);
+                     rows, rows_dev, n, m, c, grad_out, idx, weight, grad_points, fwd_out, grad_add, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (double *)nullptr, 0);
   RS_CHECK_LAUNCH("rs_three_interpolate_fused_backward");
   return RS_OK;
+}
+
+extern "C" int rs_three_interpolate_fused_backward(int b, int c, int n, int m, const float *grad_out, const float *fwd_out,
+                                                   const int *idx, const float *weight, float *grad_points, float *grad_add,
+                                                   void *stream) {
+  return rs_three_interpolate_fused_backward_dev(b, c, n, m, grad_out, fwd_out, idx, weight, grad_points, grad_add, nullptr, stream);
 }
 
 extern "C" int rs_three_interpolate_backward(int b, int c, int n, int m, const float *grad_out,
@@ -308,7 +316,7 @@ extern "C" int rs_three_interpolate_backward(int b, int c, int n, int m, const f
   if (rows == 0 || c == 0) return RS_OK;
   RS_REQUIRE(grad_out && idx && weight && grad_points, "rs_three_interpolate_backward: null pointer");
   hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(rows * c)), dim3(IT_THREADS), 0, (hipStream_t)stream,
-                     rows, n, m, c, grad_out, idx, weight, grad_points, (const float *)nullptr, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (double *)nullptr, 0);
+                     rows, (const int *)nullptr, n, m, c, grad_out, idx, weight, grad_points, (const float *)nullptr, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (double *)nullptr, 0);
   RS_CHECK_LAUNCH("rs_three_interpolate_backward");
   return RS_OK;
 }
@@ -338,8 +346,9 @@ extern "C" int rs_three_interpolate_affine(int b, int c, int m, int n, const flo
 extern "C" int rs_three_interpolate_affine_backward(int b, int c, int n, int m, const float *grad_out, const float *fwd_out,
                                                     const int *idx, const float *weight, float *grad_points, float *grad_add,
                                                     const float *add, const float *add_mean, const float *add_invstd,
-                                                    double *partial, int partial_blocks, void *stream) {
+                                                    double *partial, int partial_blocks, const int *rows_dev, void *stream) {
   RS_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "rs_three_interpolate_affine_backward: negative size");
+  RS_REQUIRE(!rows_dev || b == 1, "rs_three_interpolate_affine_backward: a device row count needs a packed batch (b = 1)");
   const long long rows = (long long)b * n;
   if (rows == 0 || c == 0) return RS_OK;
   RS_REQUIRE(grad_out && idx && weight && grad_add && add && add_mean && add_invstd && partial && partial_blocks > 0,
@@ -353,7 +362,7 @@ extern "C" int rs_three_interpolate_affine_backward(int b, int c, int n, int m, 
   const int step = c / a;
   g = g / step * step;
   RS_REQUIRE(g >= step && g >= 1, "rs_three_interpolate_affine_backward: partial_blocks=%d below %d", partial_blocks, step);
-  hipLaunchKernelGGL(interp_bwd_kernel, dim3(g), dim3(IT_THREADS), 0, (hipStream_t)stream, rows, n, m, c, grad_out, idx, weight,
+  hipLaunchKernelGGL(interp_bwd_kernel, dim3(g), dim3(IT_THREADS), 0, (hipStream_t)stream, rows, rows_dev, n, m, c, grad_out, idx, weight,
                      grad_points, fwd_out, grad_add, add, add_mean, add_invstd, partial, partial_blocks);
   RS_CHECK_LAUNCH("rs_three_interpolate_affine_backward");
   return RS_OK;

@@ -2232,7 +2232,7 @@ backward_tail_kernel(rs_backward_tail_work w, TailStarts st) {
     reduce_stat_rows<2>(cb, it.c, it.nblk, it.nstat, sel, it.partial, v, owner);
     if (!owner) return;
     const double db = v[0], dg = v[1];
-    const double s = s_, is = is_, mu = mu_, m = (double)it.rows;
+    const double s = s_, is = is_, mu = mu_, m = it.rows_dev ? (double)min(it.rows, (long long)*it.rows_dev) : (double)it.rows;
     const double qq = -s * is * dg / m;                 // dy = s * (dz - db/m - yhat * dg/m),  yhat = (y - mu) * is
     it.p[ch] = (float)s;
     it.q[ch] = (float)qq;
@@ -2263,7 +2263,8 @@ bn_finalize_batch_kernel(BnBatch w) {
   const float rm_ = (it.running_mean ? it.running_mean : it.scale)[chc], rv_ = (it.running_var ? it.running_var : it.scale)[chc];
   reduce_stat_rows<2>(cb, it.c, it.nblk, 2, which, it.partial, sq, owner);
   if (!owner) return;
-  const double rows = (double)it.rows;
+  const long long nrows = it.rows_dev ? min(it.rows, (long long)*it.rows_dev) : it.rows;      // (a packed batch under a captured capacity: the count is device data)
+  const double rows = (double)nrows;
   const double mean = sq[0] / rows;
   double var = sq[1] / rows - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -2274,7 +2275,7 @@ bn_finalize_batch_kernel(BnBatch w) {
   it.save_mean[ch] = (float)mean;
   it.save_invstd[ch] = (float)invstd;
   if (it.running_mean) {
-    const double unbiased = it.rows > 1 ? var * rows / (rows - 1.0) : var;
+    const double unbiased = nrows > 1 ? var * rows / (rows - 1.0) : var;
     it.running_mean[ch] = (float)((1.0 - it.momentum) * (double)rm_ + it.momentum * mean);
     it.running_var[ch] = (float)((1.0 - it.momentum) * (double)rv_ + it.momentum * unbiased);
   }
@@ -2385,10 +2386,11 @@ pool_select_kernel(long long groups, int c, const float *__restrict__ ymax, cons
 // of the pooled layer computed from G x C data only)
 template <bool BF>
 __global__ void __launch_bounds__(GM_THREADS)
-pool_max_bwd_kernel(long long groups, int ns, int c, const int *__restrict__ offsets, const float *__restrict__ dout, long long ldd,
+pool_max_bwd_kernel(long long groups_arg, const int *__restrict__ groups_dev, int ns, int c, const int *__restrict__ offsets, const float *__restrict__ dout, long long ldd,
                     const float *__restrict__ out, const int *__restrict__ arg, const float *__restrict__ y,
                     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ v,
                     double *__restrict__ partial, int partial_blocks) {
+  const long long groups = groups_dev ? min(groups_arg, (long long)*groups_dev) : groups_arg;      // (groups beyond the device count: not read, not written, not summed)
   // workgroup = 64 columns x 4 group lanes; column sums stay in registers over the group loop and are
   // combined across the 4 lanes through LDS (fixed order)
   __shared__ double red[4][64][2];
@@ -2625,7 +2627,8 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
   // of <= 64 columns); other group sizes, and 128 x 128 tiles, through the C tile in LDS
   const bool pool32 = ep.pool_ns == 32 && epi_mode == EPI_STATS;
   if (ep.pool_ns > 0) {
-    RS_REQUIRE(!rows_dev, "rs_mlp_gemm_rows: fused pooling needs dense groups (not a compacted row set)");
+    RS_REQUIRE(!rows_dev || (pool32 && !ep.row_mult && !E.mult),
+               "rs_mlp_gemm_rows: fused pooling needs dense groups (not a compacted row set; a device row count only with groups of 32: whole groups, a multiple of the wave's 32-row tile)");
     RS_REQUIRE(ep.pool_max && ep.pool_min && ep.pool_amax && ep.pool_amin, "rs_mlp_gemm_rows: fused pooling needs its four outputs");
     const int rpt = GM_BM / (GM_THREADS / (cols <= 32 ? 32 : (cols <= 64 ? 64 : 128)));   // (pooling keeps 128-wide tiles)
     RS_REQUIRE(rows % ep.pool_ns == 0 && (pool32 || rpt % ep.pool_ns == 0),
@@ -3124,7 +3127,7 @@ extern "C" int rs_pool_select(long long groups, int c, const float *ymax, const 
 
 extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const int *offsets, const float *dout, long long ldd,
                                     const float *out, const int *arg, const float *y, int y_bf16, const float *mean,
-                                    const float *invstd, float *v, double *partial, int partial_blocks, void *stream) {
+                                    const float *invstd, float *v, double *partial, int partial_blocks, const int *groups_dev, void *stream) {
   RS_REQUIRE(groups >= 0 && nsample > 0 && c >= 0 && partial_blocks > 0, "rs_pool_max_backward: bad size");
   if (groups == 0 || c == 0) return RS_OK;
   RS_REQUIRE(dout && (arg || (nsample == 1 && !offsets)) && y && mean && invstd && (v || !out) && partial, "rs_pool_max_backward: null pointer (arg may be NULL for dense groups of one row only; v for a layer without ReLU: it would equal dout)");
@@ -3133,9 +3136,9 @@ extern "C" int rs_pool_max_backward(long long groups, int nsample, int c, const 
   const long long want = (groups + 3) / 4;
   int gx = (int)(want < partial_blocks ? want : partial_blocks);
   hipStream_t st = (hipStream_t)stream;
-  if (y_bf16) hipLaunchKernelGGL(pool_max_bwd_kernel<true>, dim3(gx, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, st, groups, nsample, c,
+  if (y_bf16) hipLaunchKernelGGL(pool_max_bwd_kernel<true>, dim3(gx, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, st, groups, groups_dev, nsample, c,
                                  offsets, dout, ldd, out, arg, y, mean, invstd, v, partial, partial_blocks);
-  else hipLaunchKernelGGL(pool_max_bwd_kernel<false>, dim3(gx, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, st, groups, nsample, c,
+  else hipLaunchKernelGGL(pool_max_bwd_kernel<false>, dim3(gx, rs_cdiv(c, 64)), dim3(GM_THREADS), 0, st, groups, groups_dev, nsample, c,
                           offsets, dout, ldd, out, arg, y, mean, invstd, v, partial, partial_blocks);
   RS_CHECK_LAUNCH("rs_pool_max_backward");
   return RS_OK;

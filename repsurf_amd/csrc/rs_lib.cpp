@@ -13,7 +13,7 @@ void rs_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *rs_last_error(void) { return g_err; }
-extern "C" int rs_abi_version(void) { return 36; }
+extern "C" int rs_abi_version(void) { return 37; }
 
 // bytes of LDS one workgroup may ask for on the current device (cached per process: this library targets one device model)
 int rs_lds_limit(void) {

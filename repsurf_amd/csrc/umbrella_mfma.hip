@@ -594,6 +594,7 @@ template <int G>
 __global__ void __launch_bounds__(TH, 3)
 umb_f1_kernel(rs_umbrella_mfma m) {
   __shared__ Sh L;
+  if (m.rows_dev) m.rows = min(m.rows, (long long)*m.rows_dev);      // (a packed batch under a captured capacity: include/repsurf_hip.h, rs_bn_item)
   Walk w(m);
   f4 xr[G];
   long long pl;
@@ -610,6 +611,7 @@ template <int LAYERS, int G>
 __global__ void __launch_bounds__(TH, 3)
 umb_f2_kernel(rs_umbrella_mfma m) {
   __shared__ Sh L;
+  if (m.rows_dev) m.rows = min(m.rows, (long long)*m.rows_dev);      // (a packed batch under a captured capacity: include/repsurf_hip.h, rs_bn_item)
   Walk w(m);
   f4 xr[G];
   long long pl;
@@ -630,6 +632,7 @@ template <int G>
 __global__ void __launch_bounds__(TH, 3)
 umb_b1_kernel(rs_umbrella_mfma m) {
   __shared__ Sh L;
+  if (m.rows_dev) m.rows = min(m.rows, (long long)*m.rows_dev);      // (a packed batch under a captured capacity: include/repsurf_hip.h, rs_bn_item)
   Walk w(m);
   f4 xr[G];
   long long pl;
@@ -646,6 +649,7 @@ template <int LAYERS, int G>
 __global__ void __launch_bounds__(TH, 3)
 umb_b2_kernel(rs_umbrella_mfma m) {
   __shared__ Sh L;
+  if (m.rows_dev) m.rows = min(m.rows, (long long)*m.rows_dev);      // (a packed batch under a captured capacity: include/repsurf_hip.h, rs_bn_item)
   Walk w(m);
   f4 xr[G];
   long long pl;
@@ -755,6 +759,7 @@ template <int LAYERS>
 __global__ void __launch_bounds__(TH)
 umb_fin_kernel(rs_umbrella_mfma m) {
   __shared__ Sh L;
+  if (m.rows_dev) m.rows = min(m.rows, (long long)*m.rows_dev);
   fin_body<LAYERS>(m, L, blockIdx.x);
 }
 

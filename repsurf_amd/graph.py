@@ -80,6 +80,36 @@ class GraphedStep:
         return self.loss
 
 
+def snapshot_training_state(net, optimizer):
+    """Parameters, buffers (BatchNorm running statistics) and the optimizer's device state, cloned: what the eager warm-up passes of a
+    capture change and `restore_training_state` puts back IN PLACE (the captured graphs hold the tensors' addresses)."""
+    tensors = list(net.parameters()) + list(net.buffers())
+    had_state, counters = {}, []
+    if optimizer is not None:
+        had_state = {id(p): set(st.keys()) for p, st in optimizer.state.items()}
+        for st in optimizer.state.values():
+            tensors += [v for v in st.values() if torch.is_tensor(v) and v.is_cuda]
+        counters = [c for gst in getattr(optimizer, "_dev", {}).values() for c in (gst["step"], gst["done"])]
+    return [(t, t.detach().clone()) for t in tensors + counters], had_state
+
+
+def restore_training_state(optimizer, snap):
+    saved, had_state = snap
+    with torch.no_grad():
+        for t, v in saved:
+            t.copy_(v)
+        if optimizer is not None:
+            for p, st in optimizer.state.items():        # moments that did not exist before the warm-up: back to zero, in place
+                for k, v in st.items():
+                    if torch.is_tensor(v) and v.is_cuda and k not in had_state.get(id(p), ()):
+                        v.zero_()
+            for gi, gst in getattr(optimizer, "_dev", {}).items():
+                if not any(gst["step"] is t for t, _ in saved):
+                    gst["step"].zero_()
+                    gst["done"].zero_()
+    mlp_hip.weights_changed()
+
+
 class TrainLoopStep:
     """The body of the reference's training loop as ONE hipGraph replay, for a loop that is otherwise left as it is.
 
@@ -99,7 +129,7 @@ class TrainLoopStep:
       on the device, so LR schedulers keep working across replays).  `classifier.train()` must be in effect.
     * `pred` and `loss` are the graph's static output tensors: read them (`.max(1)`, `.item()`) before the next call.
     * The reference's CPU-generator draws (FPS start points, normal flips) are consumed in the eager order (rng.StaticDraws).
-    * Classification only: a packed segmentation batch changes its cloud boundaries every step -- use PipelinedStep with a capacity."""
+    * Classification only: a packed segmentation batch changes its cloud boundaries every step -- RaggedSegStep serves those."""
 
     def __init__(self, net, criterion, optimizer, warmup=2, max_graphs=3):
         from .optim import Adam
@@ -110,27 +140,10 @@ class TrainLoopStep:
         self.steps = {}
 
     def _snapshot(self):
-        tensors = list(self.net.parameters()) + list(self.net.buffers())
-        had_state = {id(p): set(st.keys()) for p, st in self.optimizer.state.items()}
-        for st in self.optimizer.state.values():
-            tensors += [v for v in st.values() if torch.is_tensor(v) and v.is_cuda]
-        counters = [c for gst in self.optimizer._dev.values() for c in (gst["step"], gst["done"])]
-        return [(t, t.detach().clone()) for t in tensors + counters], had_state
+        return snapshot_training_state(self.net, self.optimizer)
 
     def _restore(self, snap):
-        saved, had_state = snap
-        with torch.no_grad():
-            for t, v in saved:
-                t.copy_(v)
-            for p, st in self.optimizer.state.items():        # moments that did not exist before the warm-up: back to zero, in place
-                for k, v in st.items():
-                    if torch.is_tensor(v) and v.is_cuda and k not in had_state.get(id(p), ()):
-                        v.zero_()
-            for gi, gst in self.optimizer._dev.items():
-                if not any(gst["step"] is t for t, _ in saved):
-                    gst["step"].zero_()
-                    gst["done"].zero_()
-        mlp_hip.weights_changed()
+        restore_training_state(self.optimizer, snap)
 
     def __call__(self, points, target):
         if not self.net.training:
@@ -680,3 +693,221 @@ class ShardedGraphedStep:
             self.graph_b.replay()
         mlp_hip.weights_changed()
         return self.loss
+
+
+class RaggedSegStep:
+    """ONE captured network graph for packed segmentation batches whose cloud boundaries change every step.
+
+    The reference's loader concatenates clouds of whatever sizes it drew (segmentation/util/data_util.py:15-23, consumed at
+    segmentation/tool/train.py:280-290): the total row count, every cloud's rows and therefore the row count of every level differ from
+    batch to batch, while a hipGraph freezes grids and scalar arguments -- `PipelinedStep` refuses such batches, and the eager loop is
+    host-bound (8.4 ms per 16-cloud step against 3.3 ms captured, profiles/r06).  Here
+      * the NETWORK (forward, loss, backward, optimizer: ~400 launches) is captured once for a row CAPACITY: tensors are allocated for
+        `capacity` rows at level 0 (capacity // stride at level 1, ...), every launch is sized for its level's capacity, and the
+        kernels that reduce over rows read the batch's counts from a device table the host refills before each replay
+        (repsurf_amd.ragged: `rows_dev` of include/repsurf_hip.h).  Labels beyond the batch's rows hold `ignore_index`;
+      * the GEOMETRY (FPS, kNN, fan features, 3-NN: ~50 launches that read coordinates only) runs EAGERLY -- its launches are sized by
+        the cloud boundaries the host knows from the collate function -- on a side stream, for the NEXT batch while the current
+        batch's network graph runs (as in PipelinedStep), and its results are copied into capacity-sized state buffers (indices
+        beyond the batch's rows keep older, in-range values; the inverse index' offsets are padded with their last value).
+
+        step = RaggedSegStep(net, criterion, optimizer, batch0, label0, capacity=16 * 4096)     # geometry of batch 0 runs here
+        loss0 = step(batch1, label1)          # trains on batch 0, prepares batch 1
+        loss1 = step(batch2, label2)          # trains on batch 1, prepares batch 2 ...
+    Results: those of the eager loop up to the summation order of the row reductions (their slab boundaries follow the capacity,
+    not the batch): tests/test_seg_gpu.py::test_ragged_seg_step_* compares three different ragged batches step for step.
+    Limits: every cloud at most 16 384 rows (the gather form of the grouping's backward, ops.inverse_index); level-0 capacity a
+    multiple of 256; fp32; per-GPU BatchNorm statistics; criterion = repsurf_amd.head.CrossEntropyLoss (ignored rows get exact
+    zero gradients) with mean reduction."""
+
+    def __init__(self, net, criterion, optimizer, batch, label, capacity=None, warmup=2, ignore_index=None, restore=True, capture=True):
+        """restore=True: parameters, BatchNorm running statistics and optimizer state are put back after the eager warm-up passes (in
+        place), so that the sequence of updates is the eager loop's: one per batch.
+        capture=False: the same capacity-sized network launched EAGERLY under the device row counts (no hipGraph) -- the reference a
+        replay must equal bit for bit (same kernels, same launch sizes, same summation order), and the fallback when capture fails."""
+        from . import ops, ragged
+        coord, feat, offset = batch
+        dev = coord.device
+        self.net, self.criterion, self.optimizer = net, criterion, optimizer
+        self.ignore = int(ignore_index if ignore_index is not None else getattr(criterion, "ignore_index", 255))
+        sas = [net.sa1, net.sa2, net.sa3, net.sa4]
+        self.strides = [sa.stride for sa in sas]
+        nsample = {sa.nsample for sa in sas}
+        if len(nsample) != 1:
+            raise ValueError("RaggedSegStep: the abstraction stages must share one nsample")
+        n0 = int(coord.shape[0])
+        capacity = int(capacity if capacity is not None else n0)
+        capacity = -(-max(capacity, n0) // 256) * 256
+        self.levels = [capacity]
+        for st in self.strides:
+            self.levels.append(self.levels[-1] // st)
+        self.fan = net.surface_constructor.k
+        ns = nsample.pop()
+        self.caps = [ragged.Capacity(self.levels, ns, self.fan, dev) for _ in (0, 1)]
+        self.coord = [torch.zeros((capacity, 3), dtype=torch.float32, device=dev) for _ in (0, 1)]
+        self.feat = [torch.zeros((capacity, feat.shape[1]), dtype=torch.float32, device=dev) for _ in (0, 1)]
+        self.label = [torch.full((capacity,), self.ignore, dtype=label.dtype, device=dev) for _ in (0, 1)]
+        self.offset = ops.offsets_tensor([capacity], dev)      # (the network never reads offsets: a placeholder of the list input)
+        self.main, self.side = torch.cuda.Stream(), torch.cuda.Stream()
+        self.state = [None, None]
+        self.counts = [None, None]
+        caller = torch.cuda.current_stream()
+        self.side.wait_stream(caller)
+        with torch.cuda.stream(self.side):
+            for q in (0, 1):
+                self._prepare(q, batch, label, first=True)
+        self.main.wait_stream(self.side)
+        torch.cuda.synchronize()
+        self.captured = bool(capture)
+        snap = snapshot_training_state(net, optimizer) if restore else None
+        cpu_rng, cuda_rng = torch.get_rng_state(), torch.cuda.get_rng_state()
+        with torch.cuda.stream(self.main):      # eager warm-up of the network on the capture stream
+            for _ in range(warmup if capture else 0):
+                with self.caps[0]:
+                    self._network(0)
+        torch.cuda.synchronize()
+        self.g_net, self.loss, self.grads = [], [None, None], []
+        for p in ((0, 1) if capture else ()):
+            g = torch.cuda.CUDAGraph()
+            with self.caps[p]:
+                with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, stream=self.main, **_capture_mode()):
+                    self.loss[p] = self._network(p)
+            self.g_net.append(g)
+            self.grads.append([q.grad for q in net.parameters()])      # graph p's gradient tensors (what its optimizer launch reads)
+        torch.cuda.synchronize()
+        if restore and capture:
+            restore_training_state(optimizer, snap)
+            torch.set_rng_state(cpu_rng)
+            torch.cuda.set_rng_state(cuda_rng)
+        torch.cuda.synchronize()
+        self.geo_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.net_done = [torch.cuda.Event(), torch.cuda.Event()]
+        for q in (0, 1):
+            self.geo_done[q].record(self.side)
+            self.net_done[q].record(self.main)
+        self.parity = 0
+        mlp_hip.weights_changed()
+
+    # ---- the batch -> the capacity-sized buffers of parity q (side stream, eager)
+    def _level_counts(self, offset):
+        from . import ops
+        counts, offs = [], [offset]
+        for st in self.strides:
+            offs.append(ops.strided_offset(offs[-1], st) if st > 1 else offs[-1])
+        for o in offs:
+            host = ops.host_offsets(o)
+            counts.append(host[-1] if host else 0)
+        host0 = ops.host_offsets(offset)
+        largest = max((e - s for s, e in zip((0,) + host0[:-1], host0)), default=0)
+        return counts, largest
+
+    def _prepare(self, q, batch, label, first=False):
+        coord, feat, offset = batch
+        counts, largest = self._level_counts(offset)
+        for li, (n, cap) in enumerate(zip(counts, self.levels)):
+            if n > cap:
+                raise ValueError(f"RaggedSegStep: this batch holds {n} rows at level {li}, the step was captured for at most {cap} (capacity {self.levels[0]})")
+        if largest > 16384:
+            raise ValueError(f"RaggedSegStep: a cloud of {largest} rows (at most 16 384: the gather form of the grouping's backward)")
+        if feat.shape[1] != self.feat[q].shape[1]:
+            raise ValueError("RaggedSegStep: feature width differs from the captured one")
+        n0 = counts[0]
+        self.coord[q][:n0].copy_(coord, non_blocking=True)
+        self.feat[q][:n0].copy_(feat, non_blocking=True)
+        self.label[q].fill_(self.ignore)
+        self.label[q][:n0].copy_(label, non_blocking=True)
+        fresh = self.net.geometry([self.coord[q][:n0], self.feat[q][:n0], offset])
+        if first and self.state[q] is None:
+            self.state[q] = self._capacity_state(fresh)
+        self._scatter(self.state[q], fresh, counts)
+        self.caps[q].fill(counts)
+        self.counts[q] = counts
+
+    def _capacity_state(self, fresh):
+        """zero-filled capacity-sized twins of the geometry tensors (indices 0 = in range everywhere)"""
+        from models.repsurf.repsurf_umb_ssg import SegGeoState
+        from modules.repsurface_utils import StageGeometry
+        lv, dev = self.levels, fresh.feat.device
+
+        def z(shape, like):
+            return torch.zeros(shape, dtype=like.dtype, device=dev)
+        feat = z((lv[0],) + tuple(fresh.feat.shape[1:]), fresh.feat)
+        stages = []
+        for li, g in enumerate(fresh.stages):
+            if g.fps_idx is None or g.csr is None:
+                raise ValueError("RaggedSegStep: every stage must sample (stride > 1) and carry the inverse grouping index (training mode, clouds <= 16 384 rows)")
+            m = lv[li + 1]
+            stages.append(StageGeometry(z((m,), g.fps_idx), z((m, 3), g.new_center), self.offset, z((m,) + tuple(g.group_idx.shape[1:]), g.group_idx),
+                                        (z((lv[li] + 1,), g.csr[0]), z((m * g.group_idx.shape[1],), g.csr[1]))))
+        fps = []
+        for (fine, _coarse), f in zip(((3, 4), (2, 3), (1, 2), (0, 1)), fresh.fps):
+            if len(f) > 2 and f[2] is not None:
+                raise ValueError("RaggedSegStep: REPSURF_INTERP_GATHER=1 is not supported (the interpolation's backward scatters under a capacity)")
+            fps.append((z((lv[fine], 3), f[0]), z((lv[fine], 3), f[1]), None))
+        return SegGeoState(feat, stages, fps, None if fresh.moments is None else torch.zeros_like(fresh.moments))
+
+    def _scatter(self, state, fresh, counts):
+        pairs = [(state.feat, fresh.feat)]
+        if fresh.moments is not None:
+            pairs.append((state.moments, fresh.moments))
+        for li, (s_, g) in enumerate(zip(state.stages, fresh.stages)):
+            pairs += [(s_.fps_idx, g.fps_idx), (s_.new_center, g.new_center), (s_.group_idx, g.group_idx), (s_.csr[1], g.csr[1]), (s_.csr[0], g.csr[0])]
+        for s_, f in zip(state.fps, fresh.fps):
+            pairs += [(s_[0], f[0]), (s_[1], f[1])]
+        for dt in sorted({d.dtype for d, _ in pairs}, key=str):      # one multi-tensor launch per dtype
+            sel = [(d[:s_.shape[0]], s_) for d, s_ in pairs if d.dtype == dt]
+            torch._foreach_copy_([a for a, _ in sel], [b_ for _, b_ in sel])
+        for li, (s_, g) in enumerate(zip(state.stages, fresh.stages)):
+            # source rows beyond the batch's count read zero edges: the offsets continue with the total
+            s_.csr[0][g.csr[0].shape[0]:].fill_(int(g.csr[1].shape[0]))
+
+    def _network(self, p):
+        if self.optimizer is not None:
+            self.optimizer.zero_grad(set_to_none=True)
+        else:
+            for q in self.net.parameters():
+                q.grad = None
+        mlp_hip.owned_pass.check(self.net.parameters())
+        with mlp_hip.owned_pass():
+            self.pred = self.net([self.coord[p], self.feat[p], self.offset], geo=self.state[p])
+            loss = self.criterion(self.pred, self.label[p])
+            loss.backward(_head.unit_gradient(loss.device)) if loss.dim() == 0 and loss.dtype == torch.float32 else loss.backward()
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return loss
+
+    def rows(self, parity=None):
+        """level row counts of the batch the NEXT call trains on (or of the given parity)"""
+        return self.counts[self.parity if parity is None else parity]
+
+    def close(self):
+        torch.cuda.synchronize()
+        self.g_net, self.loss, self.grads = [], [None, None], []
+        torch.cuda.synchronize()
+
+    def __call__(self, next_batch=None, next_label=None, sync=True):
+        """Replay the network on the batch prepared by the previous call (or the constructor), then prepare `next_batch` (its eager
+        geometry runs on the side stream while the network graph runs).  The returned loss is ready on the caller's stream (sync=True)."""
+        p = self.parity
+        caller = torch.cuda.current_stream()
+        self.geo_done[p].synchronize()
+        with torch.cuda.stream(self.main):
+            if hasattr(self.optimizer, "sync_hyper"):
+                self.optimizer.sync_hyper()
+            if self.captured:
+                self.g_net[p].replay()
+            else:
+                with self.caps[p]:
+                    self.loss[p] = self._network(p)
+            self.net_done[p].record(self.main)
+        self.net_done[1 - p].synchronize()
+        if next_batch is not None:
+            with torch.cuda.stream(self.side):
+                self.side.wait_stream(caller)
+                self._prepare(1 - p, next_batch, next_label)
+                self.geo_done[1 - p].record(self.side)
+        if sync:
+            caller.wait_event(self.net_done[p])
+        self.parity = 1 - p
+        mlp_hip.weights_changed()
+        return self.loss[p]

@@ -310,7 +310,12 @@ def col_sum(x, scale=1.0):
     nblk = max(1, min(256, rows // 256))
     part = torch.empty((nblk, n), dtype=torch.float32, device=x.device)
     out = torch.empty((n,), dtype=torch.float32, device=x.device)
-    _lib.call("rs_col_sum_partials", rows, n, x.data_ptr(), x.stride(0), float(scale), part.data_ptr(), nblk, _stream())
+    from . import ragged as _ragged
+    rows_dev = _ragged.dev(rows)      # (a packed batch under a captured capacity: rows beyond the count are not summed)
+    if rows_dev is not None:
+        _lib.call("rs_col_sum_partials_dev", rows, n, x.data_ptr(), x.stride(0), float(scale), part.data_ptr(), nblk, rows_dev, _stream())
+    else:
+        _lib.call("rs_col_sum_partials", rows, n, x.data_ptr(), x.stride(0), float(scale), part.data_ptr(), nblk, _stream())
     _lib.call("rs_reduce_partials", nblk, n, part.data_ptr(), out.data_ptr(), _stream())
     return out
 

@@ -22,6 +22,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
+from . import ragged as _ragged
 from . import zeros as _zeros
 
 c_int, c_ll, P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
@@ -63,12 +64,12 @@ class Epilogue(ctypes.Structure):            # rs_mlp_epilogue
 class BnItem(ctypes.Structure):              # rs_bn_item
     _fields_ = [("c", c_int), ("nblk", c_int), ("rows", c_ll), ("partial", P), ("gamma", P), ("beta", P), ("eps", ctypes.c_float),
                 ("momentum", ctypes.c_float), ("scale", P), ("shift", P), ("save_mean", P), ("save_invstd", P), ("running_mean", P),
-                ("running_var", P)]
+                ("running_var", P), ("rows_dev", P)]
 
 
 class BnBwdItem(ctypes.Structure):           # rs_bn_bwd_item
     _fields_ = [("c", c_int), ("nblk", c_int), ("nstat", c_int), ("which", c_int), ("rows", c_ll), ("partial", P), ("scale", P),
-                ("mean", P), ("invstd", P), ("p", P), ("q", P), ("r", P), ("dgamma", P), ("dbeta", P)]
+                ("mean", P), ("invstd", P), ("p", P), ("q", P), ("r", P), ("dgamma", P), ("dbeta", P), ("rows_dev", P)]
 
 
 class ReduceItem(ctypes.Structure):          # rs_reduce_item
@@ -422,6 +423,8 @@ def w_bwd(w2d):
 def gemm_rows(rows, kdim, cols, x_op, wk, epi, rows_dev=None):
     """out[rows, cols] = E[rows, kdim] . wk[:cols, :kdim]^T   (wk n-major (cols, ld), ld % 4 == 0, zero beyond kdim)"""
     from . import mlp as _mlp      # late: mlp imports this module on first use
+    if rows_dev is None:
+        rows_dev = _ragged.dev(rows)      # a packed batch under a captured capacity (repsurf_amd.ragged): the count is device data
     epi.w3, epi.ldw3, epi.w3_part = None, 0, 0
     if _presplit_on():
         hit = _split3_of(wk)
@@ -482,16 +485,21 @@ def fwd_layer(rows, x_op, kdim, w2d, bias, bn_mod, training, device, pool_ns=0, 
         if track:
             _pending_counters.append(bn_mod.num_batches_tracked)
         mom = bn_mod.momentum if bn_mod.momentum is not None else 0.1
-        if not finalize:       # the caller batches this layer's statistics with another layer's (bn_finalize_batch)
-            assert pool is None
+        bn_dev = _ragged.dev(bn_rows)
+        if not finalize or bn_dev is not None:
             item = BnItem(c=cout, nblk=nblk, rows=bn_rows, partial=part.data_ptr(), gamma=_ptr(bn_mod.weight), beta=_ptr(bn_mod.bias),
                           eps=float(bn_mod.eps), momentum=float(mom), scale=_ptr(vec.scale), shift=_ptr(vec.shift), save_mean=_ptr(vec.mean),
                           save_invstd=_ptr(vec.invstd), running_mean=_ptr(bn_mod.running_mean) if track else None,
-                          running_var=_ptr(bn_mod.running_var) if track else None)
+                          running_var=_ptr(bn_mod.running_var) if track else None, rows_dev=bn_dev)
+        if not finalize:       # the caller batches this layer's statistics with another layer's (bn_finalize_batch)
+            assert pool is None
             return y, vec, (item, part, vec)
-        _lib.call("rs_bn_finalize", cout, bn_rows, nblk, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
-                  float(bn_mod.eps), float(mom), _ptr(vec.scale), _ptr(vec.shift), _ptr(vec.mean), _ptr(vec.invstd),
-                  _ptr(bn_mod.running_mean) if track else None, _ptr(bn_mod.running_var) if track else None, _stream())
+        if bn_dev is not None:      # the count lives on the device: the item form carries its address
+            bn_finalize_batch([(item, part, vec)])
+        else:
+            _lib.call("rs_bn_finalize", cout, bn_rows, nblk, part.data_ptr(), _ptr(bn_mod.weight), _ptr(bn_mod.bias),
+                      float(bn_mod.eps), float(mom), _ptr(vec.scale), _ptr(vec.shift), _ptr(vec.mean), _ptr(vec.invstd),
+                      _ptr(bn_mod.running_mean) if track else None, _ptr(bn_mod.running_var) if track else None, _stream())
         if pool is not None:
             ext, pos = pool
             groups = rows // pool_ns
@@ -557,6 +565,8 @@ def wgrad(rows, ncols, kcols, p_op, q_op, device, rows_dev=None, defer=False):
     # a compacted row set fills a fraction of its capacity (the count is on the device): size the slab split
     # for a quarter of it so that slabs keep several pipeline stages and fewer partials need reducing
     chunks = wgrad_chunks(rows if rows_dev is None else max(rows // 4, 256), ncols, kcols)
+    if rows_dev is None:
+        rows_dev = _ragged.dev(rows)      # (a capacity that is nearly full: slabs sized for all of it)
     part = torch.empty((chunks, ncols * kcols), dtype=torch.float32, device=device)
     dw = torch.empty((ncols, kcols), dtype=torch.float32, device=device)
     from . import mlp as _mlp
@@ -675,7 +685,7 @@ def bwd_coeffs_multi(specs, device):
         synced.append(reduced.get(part.data_ptr(), 1) if (vec.sync is not None and not frozen) else 1)
         items.append(BnBwdItem(c=c, nblk=part.shape[0] if nblk is None else nblk, nstat=nstat, which=which, rows=rows, partial=part.data_ptr(),
                                scale=_ptr(vec.scale), mean=_ptr(vec.mean), invstd=_ptr(vec.invstd), p=_ptr(buf[0]), q=_ptr(buf[1]), r=_ptr(buf[2]),
-                               dgamma=_ptr(buf[3]), dbeta=_ptr(buf[4])))
+                               dgamma=_ptr(buf[3]), dbeta=_ptr(buf[4]), rows_dev=_ragged.dev(rows)))
         outs.append((buf, vec, frozen, c))
     _tail(items)
     for (buf, _, _, _), world in zip(outs, synced):
@@ -875,7 +885,7 @@ class _SAStack(Function):
             part = torch.empty((pool_blk, 2, c_last), dtype=torch.float64, device=dev)
             _lib.call("rs_pool_max_backward", groups, ns, c_last, _ptr(rs.offsets), _ptr(dout), dout.stride(0), _ptr(s["out"]) if meta.get("relu_last", True) else None,
                       None if s["arg"] is None else s["arg"].data_ptr(), _ptr(ys[-1]), _bf(ys[-1]), _ptr(vecs[-1].mean), _ptr(vecs[-1].invstd), _ptr(v), part.data_ptr(),
-                      pool_blk, _stream())
+                      pool_blk, _ragged.dev(groups), _stream())
             p, q, r, dg, db = bwd_coeffs(c_last, full, part, 2, 1, vecs[-1], dev, frozen=frozen)
         if s["arg"] is None:      # one-row groups: the pooled-gradient operand IS the two-tensor BatchNorm-backward affine (no index compare)
             p_op = operand(OP_AFF2, v, c_last, ys[-1], c_last, s1=p, t1=r, s2=q, rs=rs)
@@ -914,6 +924,8 @@ class _SAStack(Function):
                 p, q, r, dg, db = bwd_coeffs(cin, full, part, nstat, 1, vecs[li - 1], dev, frozen=frozen)
                 if DEBUG is not None:
                     DEBUG["layer%d" % li] = dict(dz=dz, part=part, p=p, q=q, r=r, dg=dg, db=db, y=ys[li - 1], vec=vecs[li - 1])
+                    if "log" in DEBUG:
+                        DEBUG["log"].append(dict(li=li, rows=rows, full=full, dz=dz, part=part, p=p, q=q, r=r, dg=dg, db=db, y=ys[li - 1]))
                 p_op = operand(OP_AFF2, dz, cin, ys[li - 1], cin, s1=p, t1=r, s2=q, rs=rs)
                 fork.keep += [dz, p, q, r]
             elif pos > 0:   # two-branch first layer: one masked gradient, two BatchNorms
@@ -1198,7 +1210,7 @@ class UmbrellaMFMADesc(ctypes.Structure):      # rs_umbrella_mfma
                 ("eps0", ctypes.c_float), ("eps1", ctypes.c_float), ("mom0", ctypes.c_float), ("mom1", ctypes.c_float),
                 ("bn0", P), ("bn1", P), ("run_mean0", P), ("run_var0", P), ("run_mean1", P), ("run_var1", P),
                 ("moments", P), ("dout", P), ("stat", P), ("nblk_f1", c_int), ("part_b1", P), ("nblk_b1", c_int),
-                ("part_b2", P), ("nblk_b2", c_int), ("out_scale", ctypes.c_float), ("out", P), ("grads", P)]
+                ("part_b2", P), ("nblk_b2", c_int), ("out_scale", ctypes.c_float), ("out", P), ("grads", P), ("rows_dev", P)]
 
 
 UMB_F1, UMB_F2, UMB_B1, UMB_B2, UMB_FIN = 1, 2, 3, 4, 5
@@ -1275,7 +1287,7 @@ class _UmbrellaMFMA(Function):
                                 bn0=_ptr(v0.scale), bn1=None if v1 is None else _ptr(v1.scale),
                                 run_mean0=_ptr(bn0.running_mean) if tr0 else None, run_var0=_ptr(bn0.running_var) if tr0 else None,
                                 run_mean1=_ptr(bn1.running_mean) if tr1 else None, run_var1=_ptr(bn1.running_var) if tr1 else None,
-                                moments=_ptr(moments))
+                                moments=_ptr(moments), rows_dev=_ragged.dev(rows))
         out = torch.empty((rows // group, 10), dtype=torch.float32, device=dev)
         desc.out, desc.out_scale = _ptr(out), (1.0 / group if meta.get("aggr") == "avg" else 1.0)
         if layers == 3:
@@ -1304,7 +1316,8 @@ class _UmbrellaMFMA(Function):
         grads = torch.empty((UMB_GRADS,), dtype=torch.float32, device=dev)
         desc = UmbrellaMFMADesc(x=_ptr(x), rows=rows, group=group, layers=layers, w0=_ptr(s["w0"]), b0=_ptr(s["cb0"]), w1=_ptr(s["w1"]), b1=_ptr(s["c1"]),
                                 w2=_ptr(s["w2"]), b2=_ptr(s["c2"]), bn0=_ptr(v0.scale), bn1=None if v1 is None else _ptr(v1.scale),
-                                moments=_ptr(s["moments"]), dout=_ptr(dout), part_b2=_ptr(part_b2), nblk_b2=nblk, grads=_ptr(grads))
+                                moments=_ptr(s["moments"]), dout=_ptr(dout), part_b2=_ptr(part_b2), nblk_b2=nblk, grads=_ptr(grads),
+                                rows_dev=_ragged.dev(rows))
         if layers == 3:
             part_b1 = torch.empty((nblk, UMB_B1_ROW), dtype=torch.float32, device=dev)
             desc.part_b1, desc.nblk_b1 = _ptr(part_b1), nblk
@@ -1512,7 +1525,7 @@ class _FPFront(Function):
             # moments, one pass gathers the coarse rows' gradient in ascending edge order and sums THEIR moments -- no atomics, no fill
             d2 = torch.empty((m, c), dtype=torch.float32, device=dev)
             _lib.call("rs_three_interpolate_affine_backward", 1, c, n, m, _ptr(dout), _ptr(s["out"]), s["idx"].data_ptr(), _ptr(s["weight"]),
-                      None, _ptr(g), _ptr(y1), _ptr(v1.mean), _ptr(v1.invstd), part1.data_ptr(), nb1, _stream())
+                      None, _ptr(g), _ptr(y1), _ptr(v1.mean), _ptr(v1.invstd), part1.data_ptr(), nb1, _ragged.dev(n), _stream())
             nb2 = max(1, min(2048, -(-(m * c) // 256)))
             part2 = torch.empty((nb2, 2, c), dtype=torch.float64, device=dev)
             _lib.call("rs_three_interpolate_backward_csr", m, c, _ptr(g), None, None, _ptr(s["weight"]), _ptr(csr[0]), _ptr(csr[1]), _ptr(d2),
@@ -1520,11 +1533,11 @@ class _FPFront(Function):
         else:
             d2 = torch.zeros((m, c), dtype=torch.float32, device=dev)            # gradient at BN_f's output (scatter target)
             _lib.call("rs_three_interpolate_affine_backward", 1, c, n, m, _ptr(dout), _ptr(s["out"]), s["idx"].data_ptr(), _ptr(s["weight"]),
-                      _ptr(d2), _ptr(g), _ptr(y1), _ptr(v1.mean), _ptr(v1.invstd), part1.data_ptr(), nb1, _stream())
+                      _ptr(d2), _ptr(g), _ptr(y1), _ptr(v1.mean), _ptr(v1.invstd), part1.data_ptr(), nb1, _ragged.dev(n), _stream())
             nb2 = partial_rows(m, 4)
             part2 = torch.empty((nb2, 2, c), dtype=torch.float64, device=dev)
             _lib.call("rs_pool_max_backward", m, 1, c, None, _ptr(d2), c, None, None, _ptr(y2), 0, _ptr(v2.mean), _ptr(v2.invstd), None,
-                      part2.data_ptr(), nb2, _stream())
+                      part2.data_ptr(), nb2, _ragged.dev(m), _stream())
         (p1, q1, r1, dg1, db1), (p2, q2, r2, dg2, db2) = bwd_coeffs_multi(
             [(c, n, part1, 2, 1, v1, None, False), (c, m, part2, 2, 1, v2, None, False)], dev)
         op1 = operand(OP_AFF2, g, c, y1, c, s1=p1, t1=r1, s2=q1)

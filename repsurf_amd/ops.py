@@ -13,6 +13,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
+from . import ragged as _ragged
 
 
 def _stream():
@@ -266,7 +267,11 @@ class _GatherRows(Function):
         b, n, per, c = ctx.dims
         grad_out = _f32c(grad_out)
         grad = torch.zeros((b, n, c), dtype=torch.float32, device=grad_out.device)
-        _lib.call("rs_gather_rows_backward", b, n, per, c, _p(grad_out), _p(idx), _p(grad), _stream())
+        rows_dev = _ragged.dev(per) if b == 1 else None      # (a packed batch under a captured capacity: rows beyond the count are not scattered)
+        if rows_dev is not None:
+            _lib.call("rs_gather_rows_backward_dev", b, n, per, c, _p(grad_out), _p(idx), _p(grad), rows_dev, _stream())
+        else:
+            _lib.call("rs_gather_rows_backward", b, n, per, c, _p(grad_out), _p(idx), _p(grad), _stream())
         return grad, None
 
 
@@ -809,7 +814,11 @@ class _ThreeInterpolateAddRelu(Function):
             return grad, None, None, None, None
         grad = torch.zeros((b, m, c), dtype=torch.float32, device=grad_out.device)
         gadd = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device) if (ctx.has_add and ctx.needs_input_grad[3]) else None
-        _lib.call("rs_three_interpolate_fused_backward", b, c, n, m, _p(grad_out), _p(out), _p(idx), _p(weight), _p(grad), _p(gadd), _stream())
+        rows_dev = _ragged.dev(n) if b == 1 else None      # (a packed batch under a captured capacity)
+        if rows_dev is not None:
+            _lib.call("rs_three_interpolate_fused_backward_dev", b, c, n, m, _p(grad_out), _p(out), _p(idx), _p(weight), _p(grad), _p(gadd), rows_dev, _stream())
+        else:
+            _lib.call("rs_three_interpolate_fused_backward", b, c, n, m, _p(grad_out), _p(out), _p(idx), _p(weight), _p(grad), _p(gadd), _stream())
         return grad, None, None, gadd, None
 
 

@@ -472,9 +472,9 @@ def test_bf16_stored_activation_pools_exactly(groups, ns, c, relu):
         wide = torch.cat([torch.zeros(groups, 3, device="cuda"), dout, torch.ones(groups, 2, device="cuda")], 1)      # dout as a column slice
         v2, part2 = torch.empty_like(dout), torch.empty_like(part)
         _lib.call("rs_pool_max_backward", groups, ns, c, None, wide.data_ptr() + 12, c + 5, H._ptr(out) if relu else None, arg.data_ptr(), H._ptr(y), H._bf(y),
-                  H._ptr(mean), H._ptr(invstd), H._ptr(v2), part2.data_ptr(), H.PARTIAL_BLOCKS, H._stream())
+                  H._ptr(mean), H._ptr(invstd), H._ptr(v2), part2.data_ptr(), H.PARTIAL_BLOCKS, None, H._stream())
         _lib.call("rs_pool_max_backward", groups, ns, c, None, H._ptr(dout), 0, H._ptr(out) if relu else None, arg.data_ptr(), H._ptr(y), H._bf(y),
-                  H._ptr(mean), H._ptr(invstd), H._ptr(v), part.data_ptr(), H.PARTIAL_BLOCKS, H._stream())
+                  H._ptr(mean), H._ptr(invstd), H._ptr(v), part.data_ptr(), H.PARTIAL_BLOCKS, None, H._stream())
         assert torch.equal(v, v2) and torch.equal(part, part2)            # row pitch of dout; spare partial rows zeroed by the kernel
         res.append((out, arg, v, part.sum(0)))
     for a, b in zip(*res):

@@ -731,3 +731,119 @@ def test_an_eager_seg_step_frees_its_activations_without_the_cycle_collector():
         gc.enable()
     assert not pinned, f"{len(pinned)} device tensors were reachable only through a reference cycle"
     assert a1 - a0 <= (1 << 20), f"{(a1 - a0) >> 20} MiB stayed allocated after two eager steps"
+
+
+def _ragged_batches():
+    from repsurf_amd import ops as _ops
+    cuda = torch.device("cuda")
+    layouts = [[1024, 700, 513, 900], [600, 1024, 1024, 777], [512, 512, 900, 640], [1000, 333, 1024, 801]]      # rows per cloud, four batches
+    batches, labels = [], []
+    for seed, sizes in enumerate(layouts):
+        xyz, _ = packed_cloud(20 + seed, sizes)
+        r = np.random.RandomState(40 + seed)
+        n = sum(sizes)
+        batches.append([dev(xyz), dev(r.rand(n, 3).astype(np.float32)), _ops.offsets_tensor(np.cumsum(sizes).tolist(), cuda)])
+        lab = r.randint(0, 13, n).astype(np.int64)
+        lab[r.rand(n) < 0.05] = 255                                   # a few ignored labels, as S3DIS has
+        labels.append(dev(lab))
+    return layouts, batches, labels
+
+
+def test_ragged_seg_step_serves_different_batches_from_one_capture():
+    """the reference's loader emits packed batches whose cloud boundaries -- and with them every level's row count --
+    differ from step to step (segmentation/util/data_util.py:15-23, segmentation/tool/train.py:280-290).  ONE captured network graph
+    (RaggedSegStep: launches sized for a capacity, row counts read from a device table, eager geometry on the side stream) serves
+    four different ragged batches, six calls.  Against the same capacity-sized network launched eagerly (capture=False: same kernels,
+    same launch sizes, same summation order) every loss is BIT-EQUAL -- the forward has no atomics -- and every gradient agrees to the
+    noise of the interpolation / gather backward's float atomics: what the capture, the two buffer sets, the refilled count tables
+    and the stale rows of earlier, larger batches must not change.  Then the same with Adam inside the graph."""
+    import copy
+    from repsurf_amd import ops as _ops
+    from repsurf_amd.graph import RaggedSegStep
+    from repsurf_amd.head import CrossEntropyLoss
+    from repsurf_amd.optim import Adam
+    cuda = torch.device("cuda")
+    layouts, batches, labels = _ragged_batches()
+    crit = CrossEntropyLoss(ignore_index=255)
+    with subproject("segmentation"):
+        base = _seg_model()
+        base.surface_constructor.random_inv = False                  # (the flips are drawn one call earlier by the pipelined geometry: no draws here)
+        runs = []
+        for capture in (False, True):
+            model = copy.deepcopy(base)
+            step = RaggedSegStep(model, crit, None, batches[0], labels[0], capacity=4 * 1024, capture=capture)
+            losses, grads = [], []
+            for s in range(6):
+                nxt = (s + 1) % 4
+                par = step.parity
+                assert step.rows()[0] == sum(layouts[s % 4])
+                losses.append(step(batches[nxt], labels[nxt]).item())
+                torch.cuda.synchronize()
+                grads.append([g.detach().clone() for g in (step.grads[par] if capture else [p.grad for p in model.parameters()])])
+            step.close()
+            runs.append((losses, grads))
+        (l0, g0), (l1, g1) = runs
+        assert l0 == l1, (l0, l1)
+        # ||a - b|| against 1e-5 ||a|| + 5e-7: the noise floor of two EAGER runs (tools/ragged_noise.py: median 4e-7 relative; the sums that
+        # cancel to ~1e-6 .. 1e-3 -- biases behind a BatchNorm, the constructor's output bias -- carry the atomics' noise at full size, 2e-7 absolute)
+        worst = 0.0
+        for ga, gb in zip(g0, g1):
+            for a, b_ in zip(ga, gb):
+                worst = max(worst, float((a.double() - b_.double()).norm()) / (1e-5 * float(a.double().norm()) + 5e-7))
+        parity_report("ragged_seg_step_graph_vs_eager_capacity", grad_err_over_bound=worst)
+        assert worst <= 1.0, worst
+        # ... and with the optimizer inside the graph: six updates on four batch layouts, a batch above the capacity refused
+        model, ref = copy.deepcopy(base), copy.deepcopy(base)
+        opt, opt_ref = Adam(model.parameters(), lr=1e-3), Adam(ref.parameters(), lr=1e-3)
+        step = RaggedSegStep(model, crit, opt, batches[0], labels[0], capacity=4 * 1024)
+        step_ref = RaggedSegStep(ref, crit, opt_ref, batches[0], labels[0], capacity=4 * 1024, capture=False)
+        got = [step(batches[(s + 1) % 4], labels[(s + 1) % 4]).item() for s in range(6)]
+        want = [step_ref(batches[(s + 1) % 4], labels[(s + 1) % 4]).item() for s in range(2)]
+        assert got[0] == want[0] and abs(got[1] - want[1]) <= 1e-5, (got, want)      # (the warm-up passes of the capture left no trace: the first update is the eager one)
+        assert all(np.isfinite(got)) and got[5] < got[1]                              # batch 1 again after four more updates: its loss fell
+        big, _ = packed_cloud(7, [1024] * 5)
+        with pytest.raises(ValueError, match="captured for at most"):
+            step([dev(big), dev(np.zeros((5 * 1024, 3), np.float32)), _ops.offsets_tensor((np.arange(1, 6) * 1024).tolist(), cuda)],
+                 dev(np.zeros(5 * 1024, np.int64)))
+        assert np.isfinite(step(batches[0], labels[0]).item())
+        step.close()
+        step_ref.close()
+
+
+def test_ragged_seg_step_equals_the_plain_eager_pass():
+    """The capacity-sized network against the reference-shaped eager pass on the SAME weights, batch by batch (no optimizer): the loss to
+    1e-6 relative, every gradient to the tolerance two fp32 evaluations with different summation orders allow -- the BatchNorm sums of
+    a capacity-sized launch are grouped into other partial rows than those of a batch-sized launch, the coefficients differ in the
+    last bit, and about one ReLU mask per step (of ~10 M pre-activations) flips, which moves every upstream gradient by O(1e-3)
+    (tools/ragged_debug2.py: one flipped element of 328 192 accounts for all of a 5e-3 difference).  The strict statement is
+    tests/test_ragged_gpu.py: every building block under NaN-padded capacity rows."""
+    import copy
+    from repsurf_amd.graph import RaggedSegStep
+    from repsurf_amd.head import CrossEntropyLoss
+    layouts, batches, labels = _ragged_batches()
+    crit = CrossEntropyLoss(ignore_index=255)
+    with subproject("segmentation"):
+        eager = _seg_model()
+        eager.surface_constructor.random_inv = False
+        twin = copy.deepcopy(eager)
+        step = RaggedSegStep(twin, crit, None, batches[0], labels[0], capacity=4 * 1024)
+        worst_loss, worst_grad = 0.0, 0.0
+        for s in range(5):
+            b = s % 4
+            par = step.parity
+            loss = step(batches[(s + 1) % 4], labels[(s + 1) % 4]).item()
+            torch.cuda.synchronize()
+            for p in eager.parameters():
+                p.grad = None
+            le = crit(eager(batches[b]), labels[b])
+            le.backward()
+            torch.cuda.synchronize()
+            worst_loss = max(worst_loss, abs(loss - le.item()) / abs(le.item()))
+            for (name, pe), g in zip(eager.named_parameters(), step.grads[par]):
+                a, c = pe.grad.double().flatten(), g.double().flatten()
+                if float(a.norm()) > 1e-5:
+                    worst_grad = max(worst_grad, float((a - c).norm() / a.norm()))
+        step.close()
+    parity_report("ragged_seg_step_vs_plain_eager", loss_rel=worst_loss, grad_rel_l2=worst_grad)
+    assert worst_loss <= 1e-6, worst_loss
+    assert worst_grad <= 5e-2, worst_grad
