@@ -35,7 +35,9 @@ class Capacity:
                 self.slots[rows] = len(self.formulas)
                 self.formulas.append((li, mul))
         self.table = torch.zeros((len(self.formulas),), dtype=torch.int32, device=device)
-        self.host = torch.zeros((len(self.formulas),), dtype=torch.int32).pin_memory()
+        self.host = torch.zeros((len(self.formulas),), dtype=torch.int32)
+        if torch.device(device).type == "cuda":
+            self.host = self.host.pin_memory()
 
     def fill(self, counts):
         """counts[l] = rows of level l in the batch about to run (each <= its capacity)."""

@@ -89,3 +89,30 @@ def test_three_bf16_parts_carry_an_fp32_product():
     plain = np.abs(a @ w - ref).max()
     assert six <= 2 * plain and six < 2e-6, (six, plain)
     assert three > 5e-6, three                               # what the third part buys
+
+
+def test_ragged_capacity_table_maps_launch_sizes_to_counts():
+    """repsurf_amd.ragged (host logic; CPU tensors stand in for the device table): the capacities of one step are pairwise distinct, the
+    row count a launch is sized for finds its slot, `fill` writes level counts times the group sizes, counts above a capacity and
+    colliding capacities are refused, and nothing is looked up outside a `with` block."""
+    import torch
+    from repsurf_amd import ragged
+    cap = ragged.Capacity([4096, 1024, 256, 64, 16], 32, 9, "cpu")
+    assert ragged.dev(4096) is None                                   # no active capacity: every kernel takes its scalar row count
+    cap.fill([3000, 700, 170, 40, 9])
+    with cap:
+        base = cap.table.data_ptr()
+        slots = {rows: (ragged.dev(rows) - base) // 4 for rows in (4096, 9 * 4096, 1024, 32 * 1024, 256, 32 * 256, 64, 32 * 64, 16, 32 * 16)}
+        assert sorted(slots.values()) == list(range(10))
+        assert ragged.dev(4095) is None and ragged.dev(128) is None   # not a capacity of this step
+        want = {4096: 3000, 9 * 4096: 27000, 1024: 700, 32 * 1024: 22400, 256: 170, 32 * 256: 5440, 64: 40, 32 * 64: 1280, 16: 9, 32 * 16: 288}
+        for rows, slot in slots.items():
+            assert int(cap.table[slot]) == want[rows]
+        with pytest.raises(RuntimeError):
+            with cap:
+                pass
+    assert ragged.dev(4096) is None
+    with pytest.raises(ValueError, match="captured for at most"):
+        cap.fill([4097, 1, 1, 1, 1])
+    with pytest.raises(ValueError, match="appears twice"):
+        ragged.Capacity([288, 9], 32, 9, "cpu")                        # 9 x 32 = 288: a level-0 capacity that is not a multiple of 256
