@@ -263,6 +263,16 @@ def call(name, *args):
         raise RepSurfHipError(f"{name} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
+def device_key(device):
+    """'cuda:<index>' (index resolved: torch.device('cuda') and 'cuda' name the CURRENT device) -- the key of the per-device counter tables
+    (mlp_hip.sync_row_mismatch_count, ops.inverse_index_overflow_count, head.bad_label_count: ADVICE r5, a query with 'cuda' read 0)."""
+    import torch
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return str(d)
+
+
 def device_info():
     lib = load()
     cu, wave, lds = c_int(), c_int(), c_int()

@@ -216,7 +216,7 @@ _unit = {}
 def unit_gradient(device):
     """A persistent scalar 1.0 to pass as `loss.backward(unit_gradient(device))`: autograd then neither fills a fresh
     ones tensor nor multiplies the loss gradient by it (two launches per step)."""
-    key = str(torch.device(device))
+    key = _lib.device_key(device)
     if key not in _unit:
         _unit[key] = torch.ones((), dtype=torch.float32, device=device)
     return _unit[key]
@@ -231,7 +231,7 @@ _bad = {}
 
 
 def _bad_counter(device):
-    key = str(torch.device(device))
+    key = _lib.device_key(device)
     if key not in _bad:
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             # created inside a capture, the counter would live in the graph's pool and its zero fill would be replayed: every

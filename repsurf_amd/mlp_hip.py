@@ -207,7 +207,7 @@ def sync_row_mismatch_count(device=None):
     rides in the reduction itself (sum rows, sum rows^2) and costs no host synchronisation; read this where the loss is read."""
     if device is None:
         return sum(int(t.item()) for t in _sync_mismatch.values())
-    t = _sync_mismatch.get(str(torch.device(device)))
+    t = _sync_mismatch.get(_lib.device_key(device))
     return 0 if t is None else int(t.item())
 
 
@@ -230,7 +230,7 @@ def sync_partials(part, sync, rows=None):
     part[1:].zero_()
     part[0].copy_(buf[:-2].view_as(part[0]))
     if rows is not None:
-        key = str(part.device)
+        key = _lib.device_key(part.device)
         if key not in _sync_mismatch:
             if part.is_cuda and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("SyncBatchNorm: the first synchronized pass on a device must run eagerly (warm-up) before capture")

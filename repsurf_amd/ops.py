@@ -452,7 +452,7 @@ def _inverse_overflow(device):
     """Persistent per-device counter rs_inverse_index adds to when a cloud holds more rows than the host-side offsets said (a stale
     `_rs_host` cache: the lists of that cloud are then not written).  Allocated eagerly -- inside a capture it would live in the graph's
     pool and every replay would reset it -- and read by `inverse_index_overflow_count`."""
-    key = str(torch.device(device))
+    key = _lib.device_key(device)
     if key not in _inv_overflow:
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("repsurf_amd.ops.inverse_index: the first call on a device must run eagerly (one warm-up pass) before capture")
@@ -465,7 +465,7 @@ def inverse_index_overflow_count(device=None):
     launch was sized from; the backward of such a cloud read unwritten lists.  0 in a healthy run: check it where the loss is read."""
     if device is None:
         return sum(int(t.item()) for t in _inv_overflow.values())
-    t = _inv_overflow.get(str(torch.device(device)))
+    t = _inv_overflow.get(_lib.device_key(device))
     return 0 if t is None else int(t.item())
 
 

@@ -116,3 +116,10 @@ def test_ragged_capacity_table_maps_launch_sizes_to_counts():
         cap.fill([4097, 1, 1, 1, 1])
     with pytest.raises(ValueError, match="appears twice"):
         ragged.Capacity([288, 9], 32, 9, "cpu")                        # 9 x 32 = 288: a level-0 capacity that is not a multiple of 256
+
+
+def test_device_key_resolves_an_indexless_cuda_device():
+    """the per-device counter tables were keyed by str(device); a query with 'cuda' read a table stored under 'cuda:0' as 0."""
+    from repsurf_amd import _lib
+    assert _lib.device_key("cuda") == _lib.device_key(torch.device("cuda")) == _lib.device_key("cuda:0")
+    assert _lib.device_key("cuda:3") == "cuda:3" and _lib.device_key("cpu") == "cpu"
