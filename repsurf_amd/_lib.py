@@ -263,6 +263,24 @@ def call(name, *args):
         raise RepSurfHipError(f"{name} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
+_raw_stream = None
+
+
+def current_stream():
+    """Raw hipStream_t of torch's current stream on the current device -- what every operator hands to the ABI.  Through torch's raw
+    accessor: `torch.cuda.current_stream().cuda_stream` builds a Stream object per call (~4 us; an eagerly launched step makes ~450
+    of them, a tenth of its host time: tools/eager_host_profile.py)."""
+    global _raw_stream
+    import torch
+    if _raw_stream is None:
+        get_raw, get_dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if get_raw is not None and get_dev is not None:
+            _raw_stream = lambda: get_raw(get_dev())      # noqa: E731
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream      # noqa: E731
+    return _raw_stream()
+
+
 def device_key(device):
     """'cuda:<index>' (index resolved: torch.device('cuda') and 'cuda' name the CURRENT device) -- the key of the per-device counter tables
     (mlp_hip.sync_row_mismatch_count, ops.inverse_index_overflow_count, head.bad_label_count: ADVICE r5, a query with 'cuda' read 0)."""

@@ -40,7 +40,7 @@ class HeadLayerBwd(ctypes.Structure):        # rs_head_layer_bwd
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 _state = {}

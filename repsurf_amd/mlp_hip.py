@@ -84,7 +84,7 @@ class BackwardTail(ctypes.Structure):        # rs_backward_tail_work
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 def _ptr(t, offset=0):

@@ -17,7 +17,7 @@ from . import ragged as _ragged
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 def _need_gpu(*tensors):

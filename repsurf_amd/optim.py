@@ -99,7 +99,7 @@ class Adam(torch.optim.Optimizer):
                 if torch.cuda.is_current_stream_capturing():
                     raise _lib.RepSurfHipError("repsurf_amd.optim.Adam: run one eager step (or sync_hyper()) before capture")
                 self.sync_hyper()
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _lib.current_stream()
             keep = []
             for c0 in range(0, len(ps), MAX_TENSORS):
                 chunk = ps[c0:c0 + MAX_TENSORS]

@@ -29,7 +29,7 @@ def _p(t):
 
 
 def _s():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 def _cl(t):          # (b, c, n) -> contiguous (b, n, c)
