@@ -2699,6 +2699,8 @@ static int gemm_rows_impl(bool bf, long long rows, const int *rows_dev, int kdim
   int bn = cols <= 32 ? 32 : (cols <= 64 ? 64 : 128);
   static const int bn_small = env_int("RS_GEMM_BN64_BELOW", 256), bn_small64 = env_int("RS_GEMM_BN64_BELOW64", 512);
   if (bn == 128 && tiles * rs_cdiv(cols, 128) < (bm == 64 ? bn_small64 : bn_small) && ep.pool_ns == 0) bn = 64;   // few rows (group_all stage): 2x the workgroups
+  static const int gtail64 = env_int("RS_GEMM_TAIL64", 0);      // a ragged last column tile (138 = 128 + 10): 3 x 64 columns of work instead of 2 x 128 (measured: no gain, off by default)
+  if (gtail64 && bn == 128 && bm == 64 && ep.pool_ns == 0 && (cols % 128) != 0 && (cols % 128) <= 64) bn = 64;
   static const int bn32_below = env_int("RS_GEMM_BN32_BELOW", 256);
   if (bm == GM_BM && bn == 64 && cols > 64 && tiles * rs_cdiv(cols, 64) < bn32_below && ep.pool_ns == 0) bn = 32;   // still under one workgroup per CU: 4096 x 512 -> 256 runs 22 us instead of 30
   // (32-row tiles -- 1 x 4 waves, 42 KB of LDS, 168 VGPRs for three workgroups per CU -- were measured for the compacted
@@ -2783,6 +2785,10 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
   static const int small_on = env_int("RS_WGRAD_SMALL", 1);
   static const int wnarrow_on = env_int("RS_WGRAD_NARROW", 1);
   static const int wide_form = env_int("RS_WGRAD_SPLIT3_WIDE", 2);      // (unit 4) 2: the 128 x 128 block on one LDS stage; 1: 128 x 64 blocks
+  // a ragged last block (138 = 128 + 10 columns of Q: the 10 normal channels next to 128 features) costs a whole 128-wide block:
+  // 64-wide blocks then do 192 columns' work instead of 256 (RS_WGRAD_TAIL64=1; measured round 6, profiles/r06/tail64_ab.txt: no gain -- these launches are not bound by the matrix pipe -- so off by default)
+  static const int tail64 = env_int("RS_WGRAD_TAIL64", 0);
+  const bool ragged_tail = tail64 && RS_SPLIT && kcols > 64 && (kcols % 128) != 0 && (kcols % 128) <= 64;
   // (kcols <= 32 with <= 64 columns of P through this kernel -- the 32 / 64-column layers of the segmentation step's 524 288-row
   // stage, whose 32 x 32 / 64 x 32 products keep one or two of the tiled kernel's four waves on the matrix pipe -- was measured in
   // round 4: 3.72 against 3.67 ms per step; its one-float-per-lane loads cost more than the idle waves.)
@@ -2823,7 +2829,7 @@ static int wgrad_impl(bool bf, long long rows, const int *rows_dev, int ncols, i
     return rs_sp_wgrad(rows, rows_dev, ncols, kcols, p, q, partial, chunks, dw, stream);
   } else
 #endif
-  if (kcols > 64 && (!RS_SPLIT || wide_form == 2)) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
+  if (kcols > 64 && (!RS_SPLIT || wide_form == 2) && !ragged_tail) {          // 128 x 128 output block: waves 2 x 2, 2 x 2 tiles each
       launch_wgrad<2, 2, 2, 2>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 128)), st, rows, rows_dev, ncols, kcols, P, Q, partial);
   } else if (kcols > 32) {   // 128 x 64: waves 4 x 1, 1 x 2 tiles (unit 4: also the wider products, 64 columns of Q per workgroup)
     launch_wgrad<4, 1, 1, 2>(bf, vp, vq, dim3(chunks, rs_cdiv(ncols, 128), rs_cdiv(kcols, 64)), st, rows, rows_dev, ncols, kcols, P, Q, partial);
