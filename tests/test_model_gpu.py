@@ -255,3 +255,44 @@ def test_an_eager_step_frees_its_activations_without_the_cycle_collector():
         gc.enable()
     assert not pinned, f"{len(pinned)} device tensors were reachable only through a reference cycle"
     assert a1 - a0 <= (1 << 20), f"{(a1 - a0) >> 20} MiB stayed allocated after two eager steps"
+
+
+def test_bf16_mode_against_the_rounded_operand_network():
+    """BASELINE configs[4] ("tolerance re-stated vs fp32 reference"), VERDICT r5 item 7.  The bf16 step against a RESTATEMENT of itself --
+    tests/torch_executor.py, backend "torch_bf16": plain torch fp32 ops with every operand / storage rounding of the bf16 kernels at the
+    same points, forward and backward.  ONE stack on identical inputs agrees with its restatement to gradient cosines >= 0.9999
+    (tests/test_mlp_gpu.py::test_bf16_sa_stack_equals_the_rounded_operand_stack: bf16 x bf16 products are exact in fp32, only the
+    summation order differs).  The whole MODEL cannot: an element that a 1e-7 difference pushes across a bf16 rounding boundary moves
+    by 4e-3, every activation behind it by ~1e-3 -- a quarter of a bf16 ulp, which flips a quarter of THEIR roundings: two evaluations
+    of the same rounded-operand network with different summation orders decorrelate at the level of the bf16 noise itself.  Measured:
+    log-probabilities 0.040 apart, gradient cosine 0.959 -- against 0.078 / 0.925 for the fp32 network (test_bf16_mode_classifier_step).
+    Asserted: closer to the restatement than to fp32 on both counts."""
+    from repsurf_amd import mlp
+    from util.utils import SmoothClsLoss
+    xyz, label = cloud(21, 16, 1024), (np.arange(16) % 15).astype(np.int64)
+    res = {}
+    for tag, backend, prec in (("hip_bf16", "hip", "bf16"), ("restated", "torch_bf16", "fp32"), ("fp32", "hip", "fp32")):
+        torch_executor.set_backend(backend)
+        mlp.set_precision(prec)
+        try:
+            model = build_model()
+            torch.manual_seed(5)
+            pred = model(torch.from_numpy(xyz).cuda().permute(0, 2, 1).contiguous())
+            loss = SmoothClsLoss()(pred, torch.from_numpy(label).long().cuda())
+            loss.backward()
+            torch.cuda.synchronize()
+            res[tag] = (pred.detach().cpu().numpy(), float(loss.detach()),
+                        {n: p.grad.detach().cpu().numpy().ravel().astype(np.float64) for n, p in model.named_parameters()})
+        finally:
+            mlp.set_precision("fp32")
+            torch_executor.set_backend("hip")
+    names = [n for n in res["restated"][2] if not is_pre_bn_bias(n)]
+
+    def against(other):
+        a, b = (np.concatenate([res[k][2][n] for n in names]) for k in ("hip_bf16", other))
+        return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))), float(np.abs(res["hip_bf16"][0] - res[other][0]).max())
+    (cos_r, err_r), (cos_f, err_f) = against("restated"), against("fp32")
+    parity_report("bf16_vs_rounded_operand_network", logp_max_abs=err_r, grad_cosine=cos_r, logp_max_abs_vs_fp32=err_f, grad_cosine_vs_fp32=cos_f)
+    print("bf16 kernels vs the rounded-operand network: log-probability max-abs %.3f, gradient cosine %.4f (vs fp32: %.3f, %.4f)" % (err_r, cos_r, err_f, cos_f))
+    assert cos_r >= 0.94 and err_r <= 6e-2, (cos_r, err_r)
+    assert cos_r >= cos_f and err_r <= err_f, (cos_r, cos_f, err_r, err_f)
