@@ -754,7 +754,7 @@ def main_seg(args):
             # ONE captured network graph for every batch layout (repsurf_amd.graph.RaggedSegStep: launches sized for a row capacity,
             # counts read from a device table; the next batch's geometry launched eagerly on a side stream under the running graph)
             from repsurf_amd.graph import RaggedSegStep
-            rstep = RaggedSegStep(model, criterion, optim, batches[0][0], batches[0][1], capacity=clouds * pts, warmup=max(2, args.warmup))
+            rstep = RaggedSegStep(model, criterion, optim, batches[0][0], batches[0][1], capacity=clouds * pts, warmup=max(2, args.warmup), max_cloud_rows=pts)
             for i in range(max(args.warmup, len(batches))):
                 rstep(batches[(i + 1) % len(batches)][0], batches[(i + 1) % len(batches)][1], sync=False)
             fence()

@@ -231,6 +231,10 @@ int rs_group_features(int b, int n, int m, int nsample, int cn, int cf, int pola
 int rs_group_features_backward(int b, int n, int m, int nsample, int cn, int cf, int polar,
                                const float *grad_out, const int *idx, float *grad_normal,
                                float *grad_feature, int pos_pad, int ldo, void *stream);
+/* the same with the group count as device data (b = 1; see rs_bn_item): groups [min(m, *groups_dev), m) are not read or scattered */
+int rs_group_features_backward_dev(int b, int n, int m, int nsample, int cn, int cf, int polar,
+                                   const float *grad_out, const int *idx, float *grad_normal,
+                                   float *grad_feature, int pos_pad, int ldo, const int *groups_dev, void *stream);
 /* Compacted form of rs_group_features: a ball-query row is cnt distinct neighbours followed by copies of the
  * first one (classification/modules/pointnet2_utils.py:92-94) and the shared MLP maps equal rows to equal outputs, so
  * only the distinct slots are materialised.  rows of group g = [offsets[g], offsets[g+1]) with

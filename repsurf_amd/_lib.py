@@ -31,6 +31,7 @@ SIGNATURES = {
     "rs_umbrella_features_grid": [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P],
     "rs_group_features": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P],
     "rs_group_features_backward": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P],
+    "rs_group_features_backward_dev": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P, P],
     "rs_group_all_features": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
     "rs_exclusive_scan": [c_int, P, P, P],
     "rs_compact_index": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P],

@@ -110,9 +110,10 @@ group_tail_kernel(long long rows, int per_cloud_rows, int n, int cf, int c0, int
 // One thread owns (group, channel): gradients of all slots that point at the first neighbour are summed in
 // a register and leave as ONE atomic; only the remaining distinct neighbours cost an atomic each.
 __global__ void __launch_bounds__(GR_THREADS)
-group_scatter_kernel(long long groups, int nsample, int groups_per_cloud, int n, int cw, int c0, int ctot,
+group_scatter_kernel(long long groups_arg, const int *__restrict__ groups_dev, int nsample, int groups_per_cloud, int n, int cw, int c0, int ctot,
                      const float *__restrict__ grad_out, const int *__restrict__ idx,
                      float *__restrict__ grad_src) {
+  const long long groups = groups_dev ? min(groups_arg, (long long)*groups_dev) : groups_arg;      // (groups beyond a device count are not read)
   const long long total = groups * cw;
   for (long long e = (long long)blockIdx.x * GR_THREADS + threadIdx.x; e < total;
        e += (long long)gridDim.x * GR_THREADS) {
@@ -640,10 +641,19 @@ extern "C" int rs_group_features(int b, int n, int m, int nsample, int cn, int c
   return RS_OK;
 }
 
+extern "C" int rs_group_features_backward_dev(int, int, int, int, int, int, int, const float *, const int *, float *, float *, int, int, const int *, void *);
+
 extern "C" int rs_group_features_backward(int b, int n, int m, int nsample, int cn, int cf, int polar,
                                           const float *grad_out, const int *idx, float *grad_normal,
                                           float *grad_feature, int pos_pad, int ldo, void *stream) {
+  return rs_group_features_backward_dev(b, n, m, nsample, cn, cf, polar, grad_out, idx, grad_normal, grad_feature, pos_pad, ldo, nullptr, stream);
+}
+
+extern "C" int rs_group_features_backward_dev(int b, int n, int m, int nsample, int cn, int cf, int polar,
+                                              const float *grad_out, const int *idx, float *grad_normal,
+                                              float *grad_feature, int pos_pad, int ldo, const int *groups_dev, void *stream) {
   RS_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0 && cn >= 0 && cf >= 0 && pos_pad >= 0, "rs_group_features_backward: negative size");
+  RS_REQUIRE(!groups_dev || b == 1, "rs_group_features_backward_dev: a device group count needs a packed batch (b = 1)");
   const long long rows = (long long)b * m * nsample;
   if (rows == 0) return RS_OK;
   RS_REQUIRE(grad_out && idx, "rs_group_features_backward: null pointer");
@@ -653,10 +663,10 @@ extern "C" int rs_group_features_backward(int b, int n, int m, int nsample, int 
   hipStream_t st = (hipStream_t)stream;
   const long long groups = (long long)b * m;
   if (grad_normal && cn > 0)
-    hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(groups * cn)), dim3(GR_THREADS), 0, st, groups, nsample,
+    hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(groups * cn)), dim3(GR_THREADS), 0, st, groups, groups_dev, nsample,
                        m, n, cn, pw, ldo, grad_out, idx, grad_normal);
   if (grad_feature && cf > 0)
-    hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(groups * cf)), dim3(GR_THREADS), 0, st, groups, nsample,
+    hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(groups * cf)), dim3(GR_THREADS), 0, st, groups, groups_dev, nsample,
                        m, n, cf, pw + cn, ldo, grad_out, idx, grad_feature);
   RS_CHECK_LAUNCH("rs_group_features_backward");
   return RS_OK;

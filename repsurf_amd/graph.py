@@ -716,12 +716,18 @@ class RaggedSegStep:
         loss1 = step(batch2, label2)          # trains on batch 1, prepares batch 2 ...
     Results: those of the eager loop up to the summation order of the row reductions (their slab boundaries follow the capacity,
     not the batch): tests/test_seg_gpu.py::test_ragged_seg_step_* compares three different ragged batches step for step.
-    Limits: every cloud at most 16 384 rows (the gather form of the grouping's backward, ops.inverse_index); level-0 capacity a
-    multiple of 256; fp32; per-GPU BatchNorm statistics; criterion = repsurf_amd.head.CrossEntropyLoss (ignored rows get exact
+    Limits: level-0 capacity a multiple of 256; clouds of at most `max_cloud_rows` rows (above 16 384 the grouping's backward of the
+    first stage(s) is the atomic scatter instead of the gather over ops.inverse_index); fp32; per-GPU BatchNorm statistics; criterion = repsurf_amd.head.CrossEntropyLoss (ignored rows get exact
     zero gradients) with mean reduction."""
 
-    def __init__(self, net, criterion, optimizer, batch, label, capacity=None, warmup=2, ignore_index=None, restore=True, capture=True):
-        """restore=True: parameters, BatchNorm running statistics and optimizer state are put back after the eager warm-up passes (in
+    def __init__(self, net, criterion, optimizer, batch, label, capacity=None, warmup=2, ignore_index=None, restore=True, capture=True,
+                 max_cloud_rows=None):
+        """max_cloud_rows: the largest cloud (rows at level 0) any batch will hold; default: the capacity (one cloud may fill it).  It
+        fixes, per stage, the form of the grouping's backward in the captured graph: the gather over the inverse index
+        (ops.inverse_index: deterministic, no atomics) where a cloud of the stage's source level has at most 16 384 rows, the
+        atomic scatter (with the group count as device data) above that -- the reference's S3DIS clouds of up to 80 000 points take
+        the scatter at the first stage(s), the gather below.
+        restore=True: parameters, BatchNorm running statistics and optimizer state are put back after the eager warm-up passes (in
         place), so that the sequence of updates is the eager loop's: one per batch.
         capture=False: the same capacity-sized network launched EAGERLY under the device row counts (no hipGraph) -- the reference a
         replay must equal bit for bit (same kernels, same launch sizes, same summation order), and the fallback when capture fails."""
@@ -742,6 +748,11 @@ class RaggedSegStep:
         for st in self.strides:
             self.levels.append(self.levels[-1] // st)
         self.fan = net.surface_constructor.k
+        self.max_cloud_rows = int(max_cloud_rows if max_cloud_rows is not None else capacity)
+        self.use_csr, rows = [], self.max_cloud_rows
+        for st in self.strides:
+            self.use_csr.append(rows <= 16384)          # the stage whose SOURCE level holds clouds of `rows` rows
+            rows //= st
         ns = nsample.pop()
         self.caps = [ragged.Capacity(self.levels, ns, self.fan, dev) for _ in (0, 1)]
         self.coord = [torch.zeros((capacity, 3), dtype=torch.float32, device=dev) for _ in (0, 1)]
@@ -807,8 +818,8 @@ class RaggedSegStep:
         for li, (n, cap) in enumerate(zip(counts, self.levels)):
             if n > cap:
                 raise ValueError(f"RaggedSegStep: this batch holds {n} rows at level {li}, the step was captured for at most {cap} (capacity {self.levels[0]})")
-        if largest > 16384:
-            raise ValueError(f"RaggedSegStep: a cloud of {largest} rows (at most 16 384: the gather form of the grouping's backward)")
+        if largest > self.max_cloud_rows:
+            raise ValueError(f"RaggedSegStep: a cloud of {largest} rows, the step was built for clouds of at most {self.max_cloud_rows} (max_cloud_rows)")
         if feat.shape[1] != self.feat[q].shape[1]:
             raise ValueError("RaggedSegStep: feature width differs from the captured one")
         n0 = counts[0]
@@ -834,11 +845,13 @@ class RaggedSegStep:
         feat = z((lv[0],) + tuple(fresh.feat.shape[1:]), fresh.feat)
         stages = []
         for li, g in enumerate(fresh.stages):
-            if g.fps_idx is None or g.csr is None:
-                raise ValueError("RaggedSegStep: every stage must sample (stride > 1) and carry the inverse grouping index (training mode, clouds <= 16 384 rows)")
+            if g.fps_idx is None:
+                raise ValueError("RaggedSegStep: every stage must sample (stride > 1)")
+            if self.use_csr[li] and g.csr is None:
+                raise ValueError("RaggedSegStep: the geometry carries no inverse grouping index (training mode, REPSURF_GATHER_BACKWARD=1 expected)")
             m = lv[li + 1]
-            stages.append(StageGeometry(z((m,), g.fps_idx), z((m, 3), g.new_center), self.offset, z((m,) + tuple(g.group_idx.shape[1:]), g.group_idx),
-                                        (z((lv[li] + 1,), g.csr[0]), z((m * g.group_idx.shape[1],), g.csr[1]))))
+            csr = (torch.zeros((lv[li] + 1,), dtype=torch.int32, device=dev), torch.zeros((m * g.group_idx.shape[1],), dtype=torch.int32, device=dev)) if self.use_csr[li] else None
+            stages.append(StageGeometry(z((m,), g.fps_idx), z((m, 3), g.new_center), self.offset, z((m,) + tuple(g.group_idx.shape[1:]), g.group_idx), csr))
         fps = []
         for (fine, _coarse), f in zip(((3, 4), (2, 3), (1, 2), (0, 1)), fresh.fps):
             if len(f) > 2 and f[2] is not None:
@@ -851,15 +864,19 @@ class RaggedSegStep:
         if fresh.moments is not None:
             pairs.append((state.moments, fresh.moments))
         for li, (s_, g) in enumerate(zip(state.stages, fresh.stages)):
-            pairs += [(s_.fps_idx, g.fps_idx), (s_.new_center, g.new_center), (s_.group_idx, g.group_idx), (s_.csr[1], g.csr[1]), (s_.csr[0], g.csr[0])]
+            pairs += [(s_.fps_idx, g.fps_idx), (s_.new_center, g.new_center), (s_.group_idx, g.group_idx)]
+            if s_.csr is not None:
+                if g.csr is None:
+                    raise ValueError(f"RaggedSegStep: stage {li} was captured with the gather form of the grouping's backward, this batch's geometry has no inverse index")
+                pairs += [(s_.csr[1], g.csr[1]), (s_.csr[0], g.csr[0])]
         for s_, f in zip(state.fps, fresh.fps):
             pairs += [(s_[0], f[0]), (s_[1], f[1])]
         for dt in sorted({d.dtype for d, _ in pairs}, key=str):      # one multi-tensor launch per dtype
             sel = [(d[:s_.shape[0]], s_) for d, s_ in pairs if d.dtype == dt]
             torch._foreach_copy_([a for a, _ in sel], [b_ for _, b_ in sel])
         for li, (s_, g) in enumerate(zip(state.stages, fresh.stages)):
-            # source rows beyond the batch's count read zero edges: the offsets continue with the total
-            s_.csr[0][g.csr[0].shape[0]:].fill_(int(g.csr[1].shape[0]))
+            if s_.csr is not None:      # source rows beyond the batch's count read zero edges: the offsets continue with the total
+                s_.csr[0][g.csr[0].shape[0]:].fill_(int(g.csr[1].shape[0]))
 
     def _network(self, p):
         if self.optimizer is not None:

@@ -511,8 +511,13 @@ class _GroupFeatures(Function):
             return None, None, gn, gf, None, None, None, None
         gn, gf = _zero_pair(b * n, cn if ctx.need[0] else 0, cf if ctx.need[1] else 0, (b, n), dev)
         if gn is not None or gf is not None:
-            _lib.call("rs_group_features_backward", b, n, m, ns, cn, cf, polar, _p(grad_out), _p(idx),
-                      _p(gn), _p(gf), pad, ldo, _stream())
+            groups_dev = _ragged.dev(m) if b == 1 else None      # (a packed batch under a captured capacity: groups beyond the count are not scattered)
+            if groups_dev is not None:
+                _lib.call("rs_group_features_backward_dev", b, n, m, ns, cn, cf, polar, _p(grad_out), _p(idx),
+                          _p(gn), _p(gf), pad, ldo, groups_dev, _stream())
+            else:
+                _lib.call("rs_group_features_backward", b, n, m, ns, cn, cf, polar, _p(grad_out), _p(idx),
+                          _p(gn), _p(gf), pad, ldo, _stream())
         return None, None, gn, gf, None, None, None, None
 
 

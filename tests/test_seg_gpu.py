@@ -749,14 +749,17 @@ def _ragged_batches():
     return layouts, batches, labels
 
 
-def test_ragged_seg_step_serves_different_batches_from_one_capture():
+@pytest.mark.parametrize("max_cloud_rows", [None, 70000])
+def test_ragged_seg_step_serves_different_batches_from_one_capture(max_cloud_rows):
     """the reference's loader emits packed batches whose cloud boundaries -- and with them every level's row count --
     differ from step to step (segmentation/util/data_util.py:15-23, segmentation/tool/train.py:280-290).  ONE captured network graph
     (RaggedSegStep: launches sized for a capacity, row counts read from a device table, eager geometry on the side stream) serves
     four different ragged batches, six calls.  Against the same capacity-sized network launched eagerly (capture=False: same kernels,
     same launch sizes, same summation order) every loss is BIT-EQUAL -- the forward has no atomics -- and every gradient agrees to the
     noise of the interpolation / gather backward's float atomics: what the capture, the two buffer sets, the refilled count tables
-    and the stale rows of earlier, larger batches must not change.  Then the same with Adam inside the graph."""
+    and the stale rows of earlier, larger batches must not change.  Then the same with Adam inside the graph.
+    max_cloud_rows = 70 000 (the reference's S3DIS clouds hold up to 80 000 points): the grouping's backward of the first two stages is
+    the atomic scatter with the group count as device data instead of the gather over the inverse index."""
     import copy
     from repsurf_amd import ops as _ops
     from repsurf_amd.graph import RaggedSegStep
@@ -771,7 +774,8 @@ def test_ragged_seg_step_serves_different_batches_from_one_capture():
         runs = []
         for capture in (False, True):
             model = copy.deepcopy(base)
-            step = RaggedSegStep(model, crit, None, batches[0], labels[0], capacity=4 * 1024, capture=capture)
+            step = RaggedSegStep(model, crit, None, batches[0], labels[0], capacity=4 * 1024, capture=capture, max_cloud_rows=max_cloud_rows)
+            assert step.use_csr == ([True] * 4 if max_cloud_rows is None else [False, False, True, True])
             losses, grads = [], []
             for s in range(6):
                 nxt = (s + 1) % 4
@@ -795,8 +799,8 @@ def test_ragged_seg_step_serves_different_batches_from_one_capture():
         # ... and with the optimizer inside the graph: six updates on four batch layouts, a batch above the capacity refused
         model, ref = copy.deepcopy(base), copy.deepcopy(base)
         opt, opt_ref = Adam(model.parameters(), lr=1e-3), Adam(ref.parameters(), lr=1e-3)
-        step = RaggedSegStep(model, crit, opt, batches[0], labels[0], capacity=4 * 1024)
-        step_ref = RaggedSegStep(ref, crit, opt_ref, batches[0], labels[0], capacity=4 * 1024, capture=False)
+        step = RaggedSegStep(model, crit, opt, batches[0], labels[0], capacity=4 * 1024, max_cloud_rows=max_cloud_rows)
+        step_ref = RaggedSegStep(ref, crit, opt_ref, batches[0], labels[0], capacity=4 * 1024, capture=False, max_cloud_rows=max_cloud_rows)
         got = [step(batches[(s + 1) % 4], labels[(s + 1) % 4]).item() for s in range(6)]
         want = [step_ref(batches[(s + 1) % 4], labels[(s + 1) % 4]).item() for s in range(2)]
         assert got[0] == want[0] and abs(got[1] - want[1]) <= 1e-5, (got, want)      # (the warm-up passes of the capture left no trace: the first update is the eager one)
@@ -810,7 +814,8 @@ def test_ragged_seg_step_serves_different_batches_from_one_capture():
         step_ref.close()
 
 
-def test_ragged_seg_step_equals_the_plain_eager_pass():
+@pytest.mark.parametrize("max_cloud_rows", [None, 70000])
+def test_ragged_seg_step_equals_the_plain_eager_pass(max_cloud_rows):
     """The capacity-sized network against the reference-shaped eager pass on the SAME weights, batch by batch (no optimizer): the loss to
     1e-6 relative, every gradient to the tolerance two fp32 evaluations with different summation orders allow -- the BatchNorm sums of
     a capacity-sized launch are grouped into other partial rows than those of a batch-sized launch, the coefficients differ in the
@@ -826,7 +831,7 @@ def test_ragged_seg_step_equals_the_plain_eager_pass():
         eager = _seg_model()
         eager.surface_constructor.random_inv = False
         twin = copy.deepcopy(eager)
-        step = RaggedSegStep(twin, crit, None, batches[0], labels[0], capacity=4 * 1024)
+        step = RaggedSegStep(twin, crit, None, batches[0], labels[0], capacity=4 * 1024, max_cloud_rows=max_cloud_rows)
         worst_loss, worst_grad = 0.0, 0.0
         for s in range(5):
             b = s % 4
@@ -847,3 +852,47 @@ def test_ragged_seg_step_equals_the_plain_eager_pass():
     parity_report("ragged_seg_step_vs_plain_eager", loss_rel=worst_loss, grad_rel_l2=worst_grad)
     assert worst_loss <= 1e-6, worst_loss
     assert worst_grad <= 5e-2, worst_grad
+
+
+def test_ragged_seg_step_with_clouds_above_the_gather_limit():
+    """Clouds of 20 000 - 30 000 rows (the reference trains S3DIS on clouds of up to 80 000 points, segmentation/tool/train.py `voxel_max`;
+    sectorized FPS from 10 000 rows): no inverse grouping index exists for the first stage (ops.inverse_index: at most 16 384 source rows
+    per cloud), its backward is the atomic scatter with the group count read from the device table.  Two different batches through one
+    captured graph: each loss equals the plain eager pass on the same weights to 1e-6, gradients finite and close."""
+    import copy
+    from repsurf_amd import ops as _ops
+    from repsurf_amd.graph import RaggedSegStep
+    from repsurf_amd.head import CrossEntropyLoss
+    cuda = torch.device("cuda")
+    layouts = [[20000, 9000], [12000, 30000]]
+    batches, labels = [], []
+    for seed, sizes in enumerate(layouts):
+        xyz, _ = packed_cloud(60 + seed, sizes)
+        r = np.random.RandomState(70 + seed)
+        n = sum(sizes)
+        batches.append([dev(xyz), dev(r.rand(n, 3).astype(np.float32)), _ops.offsets_tensor(np.cumsum(sizes).tolist(), cuda)])
+        labels.append(dev(r.randint(0, 13, n).astype(np.int64)))
+    crit = CrossEntropyLoss(ignore_index=255)
+    with subproject("segmentation"):
+        eager = _seg_model()
+        eager.surface_constructor.random_inv = False
+        twin = copy.deepcopy(eager)
+        step = RaggedSegStep(twin, crit, None, batches[0], labels[0], capacity=45056, max_cloud_rows=32768)
+        assert step.use_csr == [False, True, True, True]
+        for s in range(3):
+            b = s % 2
+            par = step.parity
+            loss = step(batches[(s + 1) % 2], labels[(s + 1) % 2]).item()
+            torch.cuda.synchronize()
+            for p in eager.parameters():
+                p.grad = None
+            le = crit(eager(batches[b]), labels[b])
+            le.backward()
+            torch.cuda.synchronize()
+            assert abs(loss - le.item()) <= 1e-6 * abs(le.item()), (s, loss, le.item())
+            for (name, pe), g in zip(eager.named_parameters(), step.grads[par]):
+                assert torch.isfinite(g).all(), name
+                a, c = pe.grad.double().flatten(), g.double().flatten()
+                if float(a.norm()) > 1e-5:
+                    assert float((a - c).norm() / a.norm()) <= 5e-2, (s, name)
+        step.close()
