@@ -90,7 +90,7 @@ template <int PPT, int NW, bool TIE>     // points per thread, waves per workgro
 __global__ void __launch_bounds__(64 * NW)
 fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *__restrict__ start,
                const int *__restrict__ offset, const int *__restrict__ new_offset,
-               int *__restrict__ idx_out, int tie_bs, int tie_q, int tie_shift, const int *__restrict__ tie_n_dev) {
+               int *__restrict__ idx_out, int tie_bs, int tie_q, int tie_shift, const int *__restrict__ tie_n_dev, int guard) {
   __shared__ int2 red_key[2][16];     // (max distance bits, point index) per wave, double buffered
   __shared__ float4 red_xyz[2][16];
 
@@ -109,14 +109,16 @@ fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *_
     tie_bs = 1 << bits;
     tie_q = (nr + tie_bs - 1) >> bits;
     tie_shift = 32 - bits;
+    // guard (sectorized FPS whose host-side bound -- the whole cloud -- exceeds this kernel's positions): the launch pairs this kernel
+    // with fps_global_kernel, and the largest SECTOR, known on the device only, decides which of the two works (uniformly: the
+    // position -> point map depends on the largest sector, not on this workgroup's)
+    if (guard && tie_bs * tie_q > PPT * 64 * NW) return;
   }
 
-  float px[PPT], py[PPT], pz[PPT], md[PPT];
-  int kid[PPT];                       // TIE: the point each slot holds (the blocked layout needs no table)
-#pragma unroll
+  float px[PPT], py[PPT], pz[PPT], md[PPT];      // (TIE: the point a slot holds is recomputed by the one lane that publishes it -- a table
+#pragma unroll                                   //  of them cost PPT registers, the difference between 16 and 24 points per lane at 1 024 threads)
   for (int j = 0; j < PPT; ++j) {
     const int p = TIE ? fps_point_of(tid * PPT + j, tie_bs, tie_q, tie_shift) : tid * PPT + j;
-    kid[j] = p;
     const int pl = p < n ? p : 0;     // padding: a real point's coordinates, distance pinned at -1 -> below every real
     px[j] = pts[pl * 3 + 0];          // distance (>= +0) in the signed comparison, so it never wins, not even a tie at 0
     py[j] = pts[pl * 3 + 1];
@@ -170,11 +172,10 @@ fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *_
     const unsigned long long cand = __ballot(slot < PPT);
     const int wl = __ffsll((long long)cand) - 1;   // lowest lane holding the max (cand != 0 always)
     auto pick = [&](int &sk, float &sx, float &sy, float &sz) {
-      sk = TIE ? kid[0] : tid * PPT + slot; sx = px[0]; sy = py[0]; sz = pz[0];
+      sk = TIE ? fps_point_of(tid * PPT + slot, tie_bs, tie_q, tie_shift) : tid * PPT + slot; sx = px[0]; sy = py[0]; sz = pz[0];
 #pragma unroll
       for (int j = 1; j < PPT; ++j) {
         const bool hit = slot == j;
-        if (TIE) sk = hit ? kid[j] : sk;
         sx = hit ? px[j] : sx; sy = hit ? py[j] : sy; sz = hit ? pz[j] : sz;
       }
     };
@@ -214,15 +215,109 @@ fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *_
   }
 }
 
+// Round 6: clouds / sectors of 16 385 .. 24 576 positions (the reference trains S3DIS on clouds of up to 80 000 points: 4 sectors of
+// ~20 000 at the first stage, 20 000-point clouds at the second).  Coordinates in registers (3 PPT of the 128 VGPRs a 1 024-thread
+// workgroup would have per lane -- hence 512 threads, 48 / 64 points per lane, 256 VGPRs), the RUNNING DISTANCE in LDS ([slot][thread]:
+// conflict-free, 96 / 128 KB), nothing global inside the loop.
+// fps_global_kernel re-reads coordinates and distances through L1 / L2 for every pick -- 320 KB per pick at 20 000 rows, 6.7 us per pick,
+// 75 % of an S3DIS-sized training step.  Same ownership, tie rules and padding as fps_reg_kernel (position p = tid * PPT + j; lowest
+// lane, lowest slot wins): the picks are the same, bit for bit.  The cross-wave pick: one candidate per lane of a 16-lane row, four
+// DPP steps on (distance bits, 15 - wave), then ONE broadcast read of the winner's point -- not 16 candidates in registers per lane.
+template <int PPT, int NT, bool TIE>      // points per lane, threads (512: 8 waves = 2 per SIMD = 256 VGPRs each; 1 024 threads leave 128 and spill)
+__global__ void __launch_bounds__(NT)
+fps_lds_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *__restrict__ start,
+               const int *__restrict__ offset, const int *__restrict__ new_offset,
+               int *__restrict__ idx_out, int tie_bs, int tie_q, int tie_shift, const int *__restrict__ tie_n_dev, int guard) {
+  extern __shared__ float fps_dl[];     // [PPT][NT] running distances
+  constexpr int NW = NT / 64;
+  __shared__ int2 red_key[2][16];
+  const FpsSeg seg = fps_segment(blockIdx.x, n_arg, m_arg, start, offset, new_offset);
+  const int n = seg.n, m = seg.m;
+  if (m <= 0 || n <= 0) return;
+  const float *pts = xyz + (size_t)seg.row0 * 3;
+  int *out = idx_out + seg.out0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (TIE && tie_n_dev) {
+    const int nr = max(*tie_n_dev, 1);
+    const int bits = min(31 - __clz(nr), 10);
+    tie_bs = 1 << bits;
+    tie_q = (nr + tie_bs - 1) >> bits;
+    tie_shift = 32 - bits;
+  }
+  if (guard) {      // paired launch (fps_dispatch): 1 = this kernel works only when the largest sector fits its positions
+    if (tie_bs * tie_q > PPT * NT) return;
+  }
+  float px[PPT], py[PPT], pz[PPT];
+  float *dl = fps_dl + tid;
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int p = TIE ? fps_point_of(tid * PPT + j, tie_bs, tie_q, tie_shift) : tid * PPT + j;
+    const int pl = p < n ? p : 0;
+    px[j] = pts[pl * 3 + 0]; py[j] = pts[pl * 3 + 1]; pz[j] = pts[pl * 3 + 2];
+    dl[j * NT] = p < n ? 1e10f : -1.0f;
+  }
+  int cur = seg.start;
+  if (cur < 0 || cur >= n) cur = 0;
+  float cx = pts[cur * 3 + 0], cy = pts[cur * 3 + 1], cz = pts[cur * 3 + 2];
+  for (int it = 0; it < m; ++it) {
+    if (tid == 0) out[it] = cur + seg.idx_base;
+    if (it == m - 1) break;
+    int lmax = (int)0x80000000, slot = 0;
+#pragma unroll
+    for (int g = 0; g < PPT; g += 8) {      // eight slots at a time: their LDS reads in flight together, but not all PPT of them (registers)
+      float o[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o[u] = dl[(g + u) * NT];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = g + u;
+        const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        const int v = min(__float_as_int(d), __float_as_int(o[u]));            // (distances >= +0, padding -1.0f: integer order = float order)
+        dl[j * NT] = __int_as_float(v);
+        if (v > lmax) { lmax = v; slot = j; }                                  // strict: the lowest slot among equals
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int wmax = __builtin_amdgcn_readfirstlane(rs_wave_max_i32(lmax));
+    const unsigned long long cand = __ballot(lmax == wmax);
+    const int wl = __ffsll((long long)cand) - 1;
+    const int par = it & 1;
+    // (the winner's coordinates are re-read from the cloud after the cross-wave pick, ~1 us of L2 latency per pick: selecting them out of
+    //  3 PPT registers -- in a second pass or riding with the maximum -- makes the compiler spill 100-170 of the registers this kernel lives on)
+    if (lane == wl)
+      red_key[par][wave] = make_int2(wmax, TIE ? fps_point_of(tid * PPT + slot, tie_bs, tie_q, tie_shift) : tid * PPT + slot);
+    __syncthreads();
+    int hi = (lane & 15) < NW ? red_key[par][lane & 15].x : (int)0x80000000, lo = 15 - (lane & 15);      // greatest distance, then the lowest wave
+    auto step = [&](int ohi, int olo) {
+      const bool take = ohi > hi || (ohi == hi && olo > lo);
+      hi = take ? ohi : hi; lo = take ? olo : lo;
+    };
+    step((int)rs_dpp<RS_DPP_QUAD_XOR1>((unsigned)hi), (int)rs_dpp<RS_DPP_QUAD_XOR1>((unsigned)lo));
+    step((int)rs_dpp<RS_DPP_QUAD_XOR2>((unsigned)hi), (int)rs_dpp<RS_DPP_QUAD_XOR2>((unsigned)lo));
+    step((int)rs_dpp<RS_DPP_ROW_HALF_MIRROR>((unsigned)hi), (int)rs_dpp<RS_DPP_ROW_HALF_MIRROR>((unsigned)lo));
+    step((int)rs_dpp<RS_DPP_ROW_MIRROR>((unsigned)hi), (int)rs_dpp<RS_DPP_ROW_MIRROR>((unsigned)lo));
+    const int ww = __builtin_amdgcn_readfirstlane(15 - lo);
+    cur = __builtin_amdgcn_readfirstlane(red_key[par][ww].y);
+    cx = pts[cur * 3 + 0]; cy = pts[cur * 3 + 1]; cz = pts[cur * 3 + 2];
+    // (the other parity's slots are rewritten only after the NEXT barrier: no second barrier)
+  }
+}
+
 // Fallback for clouds too large for registers: distances in `temp` (global), one pass per pick, 1024 threads.
 // Classification: blocked ownership, lowest index on ties.  Packed batches: the reference kernel's own strided
 // ownership (such clouds have > 8192 rows, so its block size is 1024 too) and its bit-reversed-thread tie rule.
 __global__ void __launch_bounds__(1024)
 fps_global_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *__restrict__ start,
                   const int *__restrict__ offset, const int *__restrict__ new_offset,
-                  float *__restrict__ temp, int *__restrict__ idx_out, int tie, int tie_n, const int *__restrict__ tie_n_dev) {
+                  float *__restrict__ temp, int *__restrict__ idx_out, int tie, int tie_n, const int *__restrict__ tie_n_dev, int skip_positions) {
   __shared__ uint2 red_key[2][16];
   __shared__ unsigned red_tie[2][16];
+  if (skip_positions && tie_n_dev) {      // paired with a guarded fps_reg_kernel: that one works when the largest sector fits its positions
+    const int nr = max(*tie_n_dev, 1);
+    const int bits = min(31 - __clz(nr), 10);
+    if ((((nr + (1 << bits) - 1) >> bits) << bits) <= skip_positions) return;
+  }
   const FpsSeg seg = fps_segment(blockIdx.x, n_arg, m_arg, start, offset, new_offset);
   const int n = seg.n, m = seg.m;
   if (m <= 0 || n <= 0) return;
@@ -245,14 +340,26 @@ fps_global_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int
     if (it == m - 1) break;
     const float cx = pts[cur * 3 + 0], cy = pts[cur * 3 + 1], cz = pts[cur * 3 + 2];
     unsigned lmax = 0u; int larg = 0x7fffffff;
-    for (int p = p0; p < p1; p += pstep) {
-      const float dx = pts[p * 3 + 0] - cx, dy = pts[p * 3 + 1] - cy, dz = pts[p * 3 + 2] - cz;
-      const float d = (dx * dx + dy * dy) + dz * dz;
-      const float o = dist[p];
-      const float v = d < o ? d : o;
-      dist[p] = v;
-      const unsigned vb = __float_as_uint(v);
-      if (vb > lmax || larg == 0x7fffffff) { lmax = vb; larg = p; }
+    // eight rows per trip, all their loads requested before the first is used (round 6: one row per trip was a chain of dependent
+    // L2 round trips -- 20 of them per pick at 20 000 rows, 6.7 us per pick, 75 % of an S3DIS-sized training step)
+    for (int pb = p0; pb < p1; pb += 8 * pstep) {
+      float x[8], y[8], z[8], o[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = min(pb + u * pstep, p1 - 1 >= p0 ? (p0 + ((p1 - 1 - p0) / pstep) * pstep) : p0);      // (clamped to this thread's last row)
+        x[u] = pts[p * 3 + 0]; y[u] = pts[p * 3 + 1]; z[u] = pts[p * 3 + 2]; o[u] = dist[p];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = pb + u * pstep;
+        if (p >= p1) break;
+        const float dx = x[u] - cx, dy = y[u] - cy, dz = z[u] - cz;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        const float v = d < o[u] ? d : o[u];
+        dist[p] = v;
+        const unsigned vb = __float_as_uint(v);
+        if (vb > lmax || larg == 0x7fffffff) { lmax = vb; larg = p; }
+      }
     }
     if (p0 >= p1) { lmax = 0u; larg = 0x7fffffff; }
     const bool has = larg != 0x7fffffff;
@@ -285,17 +392,17 @@ int env_int(const char *name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-struct FpsTie { int bs, q, shift; const int *n_dev; };
+struct FpsTie { int bs, q, shift; const int *n_dev; int guard; };
 
 template <int PPT, int NW>
 void launch_reg2(int blocks, int n, int m, const float *xyz, const int *start, const int *offset,
                  const int *new_offset, int *idx, FpsTie tie, hipStream_t st) {
   if (tie.bs > 0)
     hipLaunchKernelGGL((fps_reg_kernel<PPT, NW, true>), dim3(blocks), dim3(64 * NW), 0, st, n, m, xyz, start, offset,
-                       new_offset, idx, tie.bs, tie.q, tie.shift, tie.n_dev);
+                       new_offset, idx, tie.bs, tie.q, tie.shift, tie.n_dev, tie.guard);
   else
     hipLaunchKernelGGL((fps_reg_kernel<PPT, NW, false>), dim3(blocks), dim3(64 * NW), 0, st, n, m, xyz, start, offset,
-                       new_offset, idx, 0, 1, 0, (const int *)nullptr);
+                       new_offset, idx, 0, 1, 0, (const int *)nullptr, 0);
 }
 template <int PPT>
 void launch_reg(int blocks, int waves, int n, int m, const float *xyz, const int *start,
@@ -334,7 +441,7 @@ int fps_dispatch(int blocks, int n_max, int n, int m, const float *xyz, const in
   hipLaunchKernelGGL(fake_fps_kernel, dim3(blocks), dim3(256), 0, st, n, m, offset, new_offset, idx);
   return RS_OK;
 #endif
-  FpsTie tie = {0, 1, 0, n_dev};
+  FpsTie tie = {0, 1, 0, n_dev, 0};
   int positions = n_max;              // priority positions a workgroup must hold
   if (packed) {
     tie.bs = ref_block_size(n_max);
@@ -355,16 +462,50 @@ int fps_dispatch(int blocks, int n_max, int n, int m, const float *xyz, const in
   waves = w;
   int ppt = (positions + waves * 64 - 1) / (waves * 64);
   while (ppt > 16 && waves < 16) { waves *= 2; ppt = (positions + waves * 64 - 1) / (waves * 64); }
-  if (ppt > 16) {   // > 16384 positions per cloud: distances no longer fit the register file
+  // Round 6: 24 points per lane at 16 waves (coordinates + running distance = 96 of the 128 VGPRs a 1 024-thread workgroup has per lane):
+  // 24 576 positions in registers -- the 20 000-point clouds / sectors of the reference's S3DIS batches (80 000 points, 4 sectors at
+  // the first stage, stride 4) -- instead of 16 384; above that the distances live in `temp` (fps_global_kernel: 6.7 us per pick at
+  // 20 000 points against ~2 here).  RS_FPS_REG24=0: the round-5 limit.
+  static const int reg24 = env_int("RS_FPS_REG24", 0);      // (off: at 1 024 threads the 24-point instances need ~180 VGPRs and spill 140 of them)
+  const int ppt_max = reg24 ? 24 : 16;
+  // 16 385 .. 24 576 positions: coordinates in registers, distances in LDS (fps_lds_kernel; RS_FPS_LDS=0: fps_global_kernel as in round 5)
+  static const int lds_on = env_int("RS_FPS_LDS", 1);
+  if (lds_on && ppt > ppt_max && waves == 16) {
+    const bool bound_only = packed && n_dev;      // sectorized: `positions` is a bound from the whole cloud, the largest sector lives on the device
+    if (positions <= 48 * 512 || bound_only) {
+      // 48 points per lane x 512 threads = 24 576 positions (64 per lane spill ~100 registers: built, measured, not kept)
+      FpsTie g = tie;
+      g.guard = (bound_only && positions > 48 * 512) ? 1 : 0;
+      const size_t lds = (size_t)48 * 512 * sizeof(float);
+      if (tie.bs > 0) hipLaunchKernelGGL((fps_lds_kernel<48, 512, true>), dim3(blocks), dim3(512), lds, st, n, m, xyz, start, offset, new_offset, idx, g.bs, g.q, g.shift, g.n_dev, g.guard);
+      else hipLaunchKernelGGL((fps_lds_kernel<48, 512, false>), dim3(blocks), dim3(512), lds, st, n, m, xyz, start, offset, new_offset, idx, 0, 1, 0, (const int *)nullptr, 0);
+      if (!g.guard) return RS_OK;
+      // paired: the largest sector (device) decides -- this kernel when it fits 24 576 positions, fps_global_kernel otherwise
+      if (!temp) { rs_set_error("rs_furthestsampling: n=%d needs the `temp` scratch (one float per row)", n_max); return RS_ERR_ARG; }
+      hipLaunchKernelGGL(fps_global_kernel, dim3(blocks), dim3(1024), 0, st, n, m, xyz, start, offset, new_offset, temp, idx, 1, n_max, n_dev, 48 * 512);
+      return RS_OK;
+    }
+  }
+  if (ppt > ppt_max) {   // the distances no longer fit the register file
     if (!temp) { rs_set_error("rs_furthestsampling: n=%d needs the `temp` scratch (one float per row)", n_max); return RS_ERR_ARG; }
-    hipLaunchKernelGGL(fps_global_kernel, dim3(blocks), dim3(1024), 0, st, n, m, xyz, start, offset, new_offset, temp, idx, packed ? 1 : 0, n_max, n_dev);
+    int skip = 0;
+    if (reg24 && packed && n_dev) {
+      // sectorized FPS: the host bounds a sector by its whole cloud; the largest sector (on the device) usually fits the registers.
+      // Both kernels are launched, the device value decides which one works (the other's workgroups return at once).
+      FpsTie g = tie;
+      g.guard = 1;
+      launch_reg<24>(blocks, 16, n, m, xyz, start, offset, new_offset, idx, g, st);
+      skip = 24 * 1024;
+    }
+    hipLaunchKernelGGL(fps_global_kernel, dim3(blocks), dim3(1024), 0, st, n, m, xyz, start, offset, new_offset, temp, idx, packed ? 1 : 0, n_max, n_dev, skip);
     return RS_OK;
   }
   if (ppt <= 1) launch_reg<1>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, tie, st);
   else if (ppt <= 2) launch_reg<2>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, tie, st);
   else if (ppt <= 4) launch_reg<4>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, tie, st);
   else if (ppt <= 8) launch_reg<8>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, tie, st);
-  else launch_reg<16>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, tie, st);
+  else if (ppt <= 16) launch_reg<16>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, tie, st);
+  else launch_reg<24>(blocks, waves, n, m, xyz, start, offset, new_offset, idx, tie, st);
   return RS_OK;
 }
 

@@ -94,3 +94,25 @@ def test_reference_segmentation_operators_over_the_hip_library():
     assert (out.detach() - plain).abs().max().item() <= 1e-6
     out.sum().backward()
     assert torch.isfinite(cf.grad).all() and abs(cf.grad.sum().item() - coord.shape[0] * 5) <= 1e-2 * coord.shape[0]
+
+
+@pytest.mark.parametrize("sizes", [[60000, 30000], [20000, 120000]])
+def test_sectorized_fps_of_large_clouds_equals_the_reference_host_loop(sizes):
+    """Clouds of the reference's S3DIS size (up to 80 000 points, 4 sectors from 10 000 points: segmentation/modules/pointops/functions/
+    pointops.py:52-108).  Device path (repsurf_amd.ops.sectorized_fps): the host bounds a sector by its whole cloud, so the launch pairs
+    fps_lds_kernel (coordinates in registers, running distance in LDS, <= 24 576 positions) with fps_global_kernel and the largest
+    sector -- known on the device only -- decides which of the two works.  Against the reference's OWN host loop over this library's
+    FPS entry point, which is handed each launch's exact largest sector: same rows, bit for bit, whichever kernels either side took
+    ([60000, 30000]: sectors of ~15 000 / 7 500 rows; [20000, 120000]: a 30 000-row sector pushes the device path to the global kernel)."""
+    import repsurf_amd.pointops_cuda as pc
+    from repsurf_amd import ops
+    pc.install("segmentation")
+    P = load_by_path("ref_seg_pointops", SEG)
+    r = np.random.RandomState(len(sizes) + sizes[0])
+    n = sum(sizes)
+    coord = (r.rand(n, 3) * 2 - 1).astype(np.float32)
+    offset = np.cumsum(sizes).astype(np.int32)
+    new_offset = np.cumsum([s // 4 for s in sizes]).astype(np.int32)
+    want = P.sectorized_fps(dev(coord), dev(offset), dev(new_offset), 4, 10000).cpu().numpy()
+    got = ops.sectorized_fps(dev(coord), dev(offset), dev(new_offset), 4, 10000).cpu().numpy()
+    assert np.array_equal(got, want)

@@ -191,12 +191,12 @@ def test_sample_and_group_matches_oracle_and_fixture(ops, polar):
 
 @pytest.mark.parametrize("sizes,kind,stride", [([343], "grid", 4), ([500, 300], "dup", 4), ([1331, 100, 7], "grid", 4),
                                                 ([3000], "dup", 4), ([4096, 4096], "uniform", 4), ([1100, 64], "grid", 2),
-                                                ([20000], "dup", 40), ([17000, 900], "uniform", 50)])
+                                                ([20000], "dup", 40), ([17000, 900], "uniform", 50), ([24576, 3000], "uniform", 64), ([24577], "uniform", 80)])
 def test_packed_fps_follows_the_reference_kernels_tie_rule(ops, sizes, kind, stride):
     """Exact distance ties (lattices, duplicated rows): the reference kernel's strided scan + shared-memory tree picks
     the thread with the lowest bit-reversed id, then its lowest row (sampling_cuda_kernel.cu:44-58, __update :7-12);
     oracle_fps_offset restates that and is pinned against the kernel itself (tests/test_oracle_ref.py).  Clouds beyond
-    16 384 rows take the global-memory fallback kernel."""
+    16 384 rows: distances in LDS (fps_lds_kernel, up to 24 576 rows), in global memory above (fps_global_kernel)."""
     xyz, offset = packed_cloud(13, sizes, kind)
     new_offset = np.cumsum([max(n // stride, 1) for n in sizes]).astype(np.int32)
     got = ops.furthestsampling_offset(dev(xyz), dev(offset), dev(new_offset)).cpu().numpy()
