@@ -115,10 +115,13 @@ fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *_
     if (guard && tie_bs * tie_q > PPT * 64 * NW) return;
   }
 
-  float px[PPT], py[PPT], pz[PPT], md[PPT];      // (TIE: the point a slot holds is recomputed by the one lane that publishes it -- a table
-#pragma unroll                                   //  of them cost PPT registers, the difference between 16 and 24 points per lane at 1 024 threads)
+  float px[PPT], py[PPT], pz[PPT], md[PPT];
+  constexpr bool TABLE = TIE && PPT <= 16;       // TIE: the point each slot holds, as a table up to 16 points per lane; above that the ONE lane
+  int kid[TABLE ? PPT : 1];                      // that publishes recomputes it (an integer division per pick: 1.21 -> 1.30 us per pick at 4 096 rows)
+#pragma unroll
   for (int j = 0; j < PPT; ++j) {
     const int p = TIE ? fps_point_of(tid * PPT + j, tie_bs, tie_q, tie_shift) : tid * PPT + j;
+    if constexpr (TABLE) kid[j] = p;
     const int pl = p < n ? p : 0;     // padding: a real point's coordinates, distance pinned at -1 -> below every real
     px[j] = pts[pl * 3 + 0];          // distance (>= +0) in the signed comparison, so it never wins, not even a tie at 0
     py[j] = pts[pl * 3 + 1];
@@ -172,10 +175,11 @@ fps_reg_kernel(int n_arg, int m_arg, const float *__restrict__ xyz, const int *_
     const unsigned long long cand = __ballot(slot < PPT);
     const int wl = __ffsll((long long)cand) - 1;   // lowest lane holding the max (cand != 0 always)
     auto pick = [&](int &sk, float &sx, float &sy, float &sz) {
-      sk = TIE ? fps_point_of(tid * PPT + slot, tie_bs, tie_q, tie_shift) : tid * PPT + slot; sx = px[0]; sy = py[0]; sz = pz[0];
+      sk = TABLE ? kid[0] : (TIE ? fps_point_of(tid * PPT + slot, tie_bs, tie_q, tie_shift) : tid * PPT + slot); sx = px[0]; sy = py[0]; sz = pz[0];
 #pragma unroll
       for (int j = 1; j < PPT; ++j) {
         const bool hit = slot == j;
+        if constexpr (TABLE) sk = hit ? kid[j] : sk;
         sx = hit ? px[j] : sx; sy = hit ? py[j] : sy; sz = hit ? pz[j] : sz;
       }
     };
