@@ -2,7 +2,7 @@
 # copy the merged outputs of tools/r05_evidence.sh (gpurun_out/r0Nev, gpurun_out/prof_r0N_*) into profiles/<round>/ under the names DESIGN.md cites
 R=${1:-r03}; P=profiles/$R; H=gpurun_out/${R}h; [ -d gpurun_out/${R}ev ] && H=gpurun_out/${R}ev
 mkdir -p $P
-for f in bench_cls bench_cls_real bench_cls_dense bench_cls_2x bench_cls_nopipe bench_cls_bf16_b64 bench_seg; do [ -f $H/$f.json ] && tail -1 $H/$f.json > $P/$f.json; done
+for f in bench_cls bench_cls_real bench_cls_dense bench_cls_2x bench_cls_nopipe bench_cls_bf16_b64 bench_seg bench_seg_ragged bench_seg_ragged_s3dis; do [ -f $H/$f.json ] && tail -1 $H/$f.json > $P/$f.json; done
 [ -f $H/parity_report.jsonl ] && cp $H/parity_report.jsonl $P/parity_report.jsonl
 cp gpurun_out/prof_${R}_cls/graph_kernel_stats.csv $P/cls_graph_kernel_stats.csv
 cp gpurun_out/prof_${R}_cls/graph_kernel_stats_by_grid.csv $P/cls_graph_kernel_stats_by_grid.csv
@@ -13,7 +13,7 @@ cp gpurun_out/prof_${R}_seg/graph_kernel_stats.csv $P/seg_graph_kernel_stats.csv
 cp gpurun_out/prof_${R}_seg/graph_kernel_stats_by_grid.csv $P/seg_graph_kernel_stats_by_grid.csv
 cp gpurun_out/prof_${R}_seg/traffic.json $P/traffic_seg.json
 [ -f $H/ballquery_phases.txt ] && cp $H/ballquery_phases.txt $P/ballquery_cells_phase_costs_final.txt
-for f in umb_bench.txt grid_meet.txt sharded_time.txt bench_spawn_dry_run.json gpu_tests.log gpu_tests_x5.log sharded_soak.txt smoke.log knn_grid_bench.txt umbrella_grid_bench.txt; do [ -f $H/$f ] && cp $H/$f $P/$f; done
+for f in umb_bench.txt grid_meet.txt sharded_time.txt bench_spawn_dry_run.json gpu_tests.log gpu_tests_x5.log gpu_tests_x2.log sharded_soak.txt smoke.log knn_grid_bench.txt umbrella_grid_bench.txt; do [ -f $H/$f ] && cp $H/$f $P/$f; done
 python3 - <<PY
 import csv,json
 rows=list(csv.DictReader(open('$P/cls_graph_kernel_stats_by_grid.csv')))

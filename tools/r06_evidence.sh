@@ -36,6 +36,7 @@ bench)
   timeout 600 python bench.py --no-cpu-baseline --dtype bf16 --batch 64 --points 2048 > $O/bench_cls_bf16_b64.json 2>/dev/null; echo "bf16 b64 rc=$?"
   timeout 900 python bench.py --workload seg > $O/bench_seg.json 2> $O/bench_seg.err; echo "seg rc=$?"
   timeout 600 python bench.py --workload seg --ragged --steps 40 --warmup 5 > $O/bench_seg_ragged.json 2> $O/bench_seg_ragged.err; echo "seg ragged rc=$?"
+  timeout 600 python bench.py --workload seg --ragged --batch 8 --points 80000 --steps 16 --warmup 3 > $O/bench_seg_ragged_s3dis.json 2> $O/bench_seg_ragged_s3dis.err; echo "seg ragged S3DIS-sized rc=$?"
   for f in $O/bench_*.json; do python - <<PY
 import json
 try:
