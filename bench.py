@@ -80,6 +80,9 @@ def parse():
                     help="--workload seg: what the reference's loader emits -- every step a DIFFERENT packed batch (cloud sizes drawn in "
                          "[points/2, points], segmentation/util/data_util.py:15-23) through ONE captured network graph (RaggedSegStep: row counts "
                          "as device data); the eager loop is timed beside it (--no-graph: only the eager loop)")
+    ap.add_argument("--ragged-overlap", action="store_true",
+                    help="--workload seg --ragged: time ONLY RaggedSegStep(overlap=True) -- the eager geometry beside the replaying graph; bench.py "
+                         "runs this form in a child started with GPU_FLUSH_ON_EXECUTION=1 (profiles/r06/eager_beside_graph.txt)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check: spawn / join the ranks, one all-reduce over the process group (gloo where there is no "
                          "HIP device), rank 0 prints one JSON line; no model, no kernels (tests/test_ddp_gloo.py)")
@@ -754,18 +757,35 @@ def main_seg(args):
             # ONE captured network graph for every batch layout (repsurf_amd.graph.RaggedSegStep: launches sized for a row capacity,
             # counts read from a device table; the next batch's geometry launched eagerly on a side stream under the running graph)
             from repsurf_amd.graph import RaggedSegStep
-            rstep = RaggedSegStep(model, criterion, optim, batches[0][0], batches[0][1], capacity=clouds * pts, warmup=max(2, args.warmup), max_cloud_rows=pts)
-            for i in range(max(args.warmup, len(batches))):
-                rstep(batches[(i + 1) % len(batches)][0], batches[(i + 1) % len(batches)][1], sync=False)
-            fence()
-            t0 = time.perf_counter()
-            for i in range(args.steps):      # (the warm-up left batch `max(warmup, 8) % 8` = 0's successor chain intact: step i trains batch i % 8)
-                nxt = batches[(max(args.warmup, len(batches)) + i + 1) % len(batches)]
-                loss = rstep(nxt[0], nxt[1], sync=False)
-            fence()
-            dt = time.perf_counter() - t0
-            loss_val = float(loss.item())
-            rstep.close()
+
+            def timed_ragged(overlap):
+                # (the step restores parameters / statistics / optimizer state after its warm-up passes; both forms start from the same weights
+                #  only approximately -- the timed steps train -- which does not matter to the time)
+                rs = RaggedSegStep(model, criterion, optim, batches[0][0], batches[0][1], capacity=clouds * pts, warmup=max(2, args.warmup),
+                                   max_cloud_rows=pts, overlap=overlap)
+                w = max(args.warmup, len(batches))
+                for i in range(w):
+                    rs(batches[(i + 1) % len(batches)][0], batches[(i + 1) % len(batches)][1], sync=False)
+                fence()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    nxt = batches[(w + i + 1) % len(batches)]
+                    loss_ = rs(nxt[0], nxt[1], sync=False)
+                fence()
+                dt_ = time.perf_counter() - t0
+                lv = float(loss_.item())
+                rs.close()
+                return dt_, lv
+            if args.ragged_overlap:      # child leg: the overlapped form alone (the parent started this process with GPU_FLUSH_ON_EXECUTION=1)
+                odt, olv = timed_ragged(True)
+                if rank == 0:
+                    print(json.dumps({"metric": "ragged, overlapped", "value": round(clouds * args.steps / odt, 2), "ms_per_step": round(odt / args.steps * 1e3, 4),
+                                      "flush_on_execution": os.environ.get("GPU_FLUSH_ON_EXECUTION"), "loss": round(olv, 5)}), flush=True)
+                rdist.finish()
+                return
+            dt, loss_val = timed_ragged(False)
+            rec = child_leg(args, ("--ragged", "--ragged-overlap"), {"GPU_FLUSH_ON_EXECUTION": "1"}, steps=args.steps)
+            overlap_ms = None if rec is None else rec["ms_per_step"]
             eager_dt, _ = timed_eager(min(args.steps, 16))
             eager_ms = eager_dt / min(args.steps, 16) * 1e3
         else:
@@ -773,8 +793,8 @@ def main_seg(args):
             loss_val, eager_ms = float(loss.item()), None
         if rank == 0:
             launch = ("ONE captured network hipGraph for every batch layout: launches sized for the row capacity, row counts read from a device table "
-                      "(include/repsurf_hip.h: rows_dev), the next batch's geometry launched eagerly on a side stream under the running graph "
-                      "(repsurf_amd.graph.RaggedSegStep)") if graphed else "eager launches"
+                      "(include/repsurf_hip.h: rows_dev), the next batch's geometry launched eagerly on a side stream BEHIND the graph "
+                      "(repsurf_amd.graph.RaggedSegStep, overlap=False: the default)") if graphed else "eager launches"
             out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, RAGGED packed batches" + ("" if graphed else " (eager launches)"),
                    "value": round(clouds * world * args.steps / dt, 2), "unit": "clouds/s", "points_per_s": round(rows * world / dt), "n_gpus": world,
                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -782,6 +802,12 @@ def main_seg(args):
                    "config": {"workload": f"configs[3] shape with ragged clouds: B={clouds} clouds of {pts // 2}..{pts} points (mean {int(np.mean([b_[2] for b_ in batches]))} rows per batch, "
                                           f"capacity {clouds * pts}): what the reference's loader emits (segmentation/util/data_util.py:15-23)",
                               "launch": launch, "parallelism": f"dp{world}", "optimizer_step": not args.no_optim, "loss": round(loss_val, 5)}}
+            if graphed:
+                out["overlapped_ms_per_step"] = overlap_ms
+                out["overlapped_note"] = ("RaggedSegStep(overlap=True) in a child started with GPU_FLUSH_ON_EXECUTION=1: the eager geometry BESIDE the replaying graph (as "
+                                          "PipelinedStep overlaps two graphs).  Under the runtime's default command batching eager launches beside a graph replay were "
+                                          "seen to read stale predecessor output (~0.5 % of geometry passes; 0 of 6 400 with the flag: profiles/r06/eager_beside_graph.txt), "
+                                          "so `value` is the form that is safe without it: the geometry BEHIND the graph")
             if eager_ms is not None:
                 out["eager_ms_per_step"] = round(eager_ms, 4)
                 out["eager_clouds_per_s"] = round(clouds * 1e3 / eager_ms, 2)

@@ -226,6 +226,41 @@ def replay_calls(calls, stream):
             raise RepSurfHipError(f"{name} (replayed) failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
+# Submit-per-launch (round 6).  The runtime batches the AQL packets of a stream and rings the doorbell when the batch is flushed.  Eager
+# launches issued back to back on one stream WHILE a hipGraph replays on another were seen to read what the previous launch had just
+# written as it was BEFORE that launch -- 16-point chunks of the segmentation constructor's fan features computed from an older
+# neighbour list, 8 of 1 600 geometry passes (tools/ragged_flake3.py; 0 of 1 600 with the network graph finished, 0 of 1 600 under
+# GPU_FLUSH_ON_EXECUTION=1, unchanged by AMD_OPT_FLUSH=0: profiles/r06/eager_beside_graph.txt).  `submit_each_launch(True)` makes every
+# ABI call end with hipStreamQuery on its stream, which submits the batch: what RaggedSegStep wraps its eager geometry in.
+_submit_each = 0
+_hip_query = None
+SUBMIT_ALWAYS = os.environ.get("REPSURF_SUBMIT_EACH_LAUNCH", "0") != "0"      # (diagnosis: every launch of the process)
+
+
+class submit_each_launch:
+    """with submit_each_launch(): ... every ABI launch is submitted to the hardware queue at once (hipStreamQuery after it)."""
+
+    def __enter__(self):
+        global _submit_each
+        _submit_each += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _submit_each
+        _submit_each -= 1
+
+
+def submit(stream=None):
+    """hipStreamQuery(stream): submits what the runtime has batched for this stream (result ignored: not-ready is the normal answer)."""
+    global _hip_query
+    if _hip_query is None:
+        h = ctypes.CDLL("libamdhip64.so")
+        h.hipStreamQuery.argtypes = [c_void_p]
+        h.hipStreamQuery.restype = c_int
+        _hip_query = h.hipStreamQuery
+    _hip_query(current_stream() if stream is None else stream)
+
+
 def call(name, *args):
     """Invoke an ABI function; non-zero return -> RepSurfHipError with the library's message."""
     lib = load()
@@ -259,6 +294,10 @@ def call(name, *args):
         _profile.append((name, dims, e0, e1, slot))
     else:
         rc = getattr(lib, name)(*args)
+    if _submit_each or SUBMIT_ALWAYS:
+        import torch
+        if not torch.cuda.is_current_stream_capturing():      # (a query would invalidate a capture; captured launches are graph nodes anyway)
+            submit(args[-1])
     if rc != 0:
         msg = lib.rs_last_error()
         raise RepSurfHipError(f"{name} failed (code {rc}): {msg.decode() if msg else '?'}")
@@ -275,7 +314,7 @@ def current_stream():
     import torch
     if _raw_stream is None:
         get_raw, get_dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
-        if get_raw is not None and get_dev is not None:
+        if get_raw is not None and get_dev is not None and os.environ.get("REPSURF_STREAM_OBJECT", "0") == "0":
             _raw_stream = lambda: get_raw(get_dev())      # noqa: E731
         else:
             _raw_stream = lambda: torch.cuda.current_stream().cuda_stream      # noqa: E731

@@ -707,9 +707,10 @@ class RaggedSegStep:
         kernels that reduce over rows read the batch's counts from a device table the host refills before each replay
         (repsurf_amd.ragged: `rows_dev` of include/repsurf_hip.h).  Labels beyond the batch's rows hold `ignore_index`;
       * the GEOMETRY (FPS, kNN, fan features, 3-NN: ~50 launches that read coordinates only) runs EAGERLY -- its launches are sized by
-        the cloud boundaries the host knows from the collate function -- on a side stream, for the NEXT batch while the current
-        batch's network graph runs (as in PipelinedStep), and its results are copied into capacity-sized state buffers (indices
-        beyond the batch's rows keep older, in-range values; the inverse index' offsets are padded with their last value).
+        the cloud boundaries the host knows from the collate function -- on a side stream for the NEXT batch, behind the current
+        batch's network graph (overlap=True: beside it, as in PipelinedStep; see __init__ for why that is opt-in), and its results
+        are copied into capacity-sized state buffers (indices beyond the batch's rows keep older, in-range values; the inverse
+        index' offsets are padded with their last value).
 
         step = RaggedSegStep(net, criterion, optimizer, batch0, label0, capacity=16 * 4096)     # geometry of batch 0 runs here
         loss0 = step(batch1, label1)          # trains on batch 0, prepares batch 1
@@ -721,8 +722,17 @@ class RaggedSegStep:
     zero gradients) with mean reduction."""
 
     def __init__(self, net, criterion, optimizer, batch, label, capacity=None, warmup=2, ignore_index=None, restore=True, capture=True,
-                 max_cloud_rows=None):
-        """max_cloud_rows: the largest cloud (rows at level 0) any batch will hold; default: the capacity (one cloud may fill it).  It
+                 max_cloud_rows=None, overlap=None):
+        """overlap=False: the next batch's eager geometry starts when the current network graph has FINISHED (the side stream waits for it);
+        the step costs network + geometry.  overlap=True: the geometry runs BESIDE the network graph, as in PipelinedStep -- 1.6x faster
+        at BASELINE's sizes, and NOT safe under the runtime's default command batching: eagerly launched kernels that run while a
+        hipGraph replays on another stream were seen to read their predecessor's output as it was before that launch (16-point chunks
+        of the constructor's fan features from an older neighbour list: 5-13 of 1 600 geometry passes; 0 of 4 800 once the graph has
+        finished, 0 of 6 400 with GPU_FLUSH_ON_EXECUTION=1 in the process environment: tools/ragged_flake3.py,
+        profiles/r06/eager_beside_graph.txt).  Graph-beside-graph (PipelinedStep) has not shown it.
+        overlap=None (default): True when the process was STARTED with GPU_FLUSH_ON_EXECUTION=1 (the runtime reads it once, at
+        initialisation: setting it from Python afterwards does nothing), else False.
+        max_cloud_rows: the largest cloud (rows at level 0) any batch will hold; default: the capacity (one cloud may fill it).  It
         fixes, per stage, the form of the grouping's backward in the captured graph: the gather over the inverse index
         (ops.inverse_index: deterministic, no atomics) where a cloud of the stage's source level has at most 16 384 rows, the
         atomic scatter (with the group count as device data) above that -- the reference's S3DIS clouds of up to 80 000 points take
@@ -735,6 +745,7 @@ class RaggedSegStep:
         coord, feat, offset = batch
         dev = coord.device
         self.net, self.criterion, self.optimizer = net, criterion, optimizer
+        self.overlap = (os.environ.get("GPU_FLUSH_ON_EXECUTION", "0") == "1") if overlap is None else bool(overlap)
         self.ignore = int(ignore_index if ignore_index is not None else getattr(criterion, "ignore_index", 255))
         sas = [net.sa1, net.sa2, net.sa3, net.sa4]
         self.strides = [sa.stride for sa in sas]
@@ -921,6 +932,8 @@ class RaggedSegStep:
         if next_batch is not None:
             with torch.cuda.stream(self.side):
                 self.side.wait_stream(caller)
+                if not self.overlap:
+                    self.side.wait_event(self.net_done[p])      # eager launches never run beside the replaying graph (see __init__)
                 self._prepare(1 - p, next_batch, next_label)
                 self.geo_done[1 - p].record(self.side)
         if sync:
