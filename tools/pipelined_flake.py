@@ -21,15 +21,47 @@ b0 = bench.synthetic_batch(125, 32, 1024, dev)
 b1 = bench.synthetic_batch(777, 32, 1024, dev)
 rng._cpu_draw_orig = rng._cpu_draw
 rng._cpu_draw = lambda kind, b, n: (torch.ones(b) if kind == "flip" else torch.zeros(b, dtype=torch.int32))      # fixed draws: the loss depends on the batch only
-step = PipelinedStep(model, crit, None, b0[0], b0[1], warmup=2)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+if len(sys.argv) > 2 and sys.argv[2] == "single":
+    # ONE graph on one stream (GraphedStep): geometry and network in sequence, the inputs copied eagerly in front of each replay
+    from repsurf_amd.graph import GraphedStep
+    g = GraphedStep(model, crit, None, b0[0].clone(), b0[1].clone(), warmup=2)
+    seen = {0: {}, 1: {}}
+    for s in range(N):
+        k = s % 2
+        nb = b1 if k else b0
+        g.points.copy_(nb[0]); g.label.copy_(nb[1])
+        loss = g().item()
+        seen[k][loss] = seen[k].get(loss, 0) + 1
+    print("single graph, batch 0 losses", seen[0])
+    print("single graph, batch 1 losses", seen[1])
+    sys.exit(0)
+step = PipelinedStep(model, crit, None, b0[0], b0[1], warmup=2)
 seen = {0: {}, 1: {}}
 cur = 0                                   # the batch the NEXT call trains on (b0 sits in both buffers at first)
+ref_state, major = {}, {}
+geo_bad = net_bad = 0
 for s in range(N):
     nxt = (s + 1) % 2
     nb = b1 if nxt else b0
+    p = step.parity
     loss = step(nb[0], nb[1]).item()
+    torch.cuda.synchronize()
     seen[cur][loss] = seen[cur].get(loss, 0) + 1
+    if s in (4, 5):                       # steady state: the geometry state the network of this parity just read
+        ref_state[p] = [t.clone() for t in step.state[p].tensors()]
+        major[p] = loss
+    elif s > 5 and loss != major[p]:
+        # state[p] is rewritten by the geometry graph that runs beside the NEXT network of the other parity: still intact here? it was
+        # consumed by the network that just ran; the geometry replay enqueued in this call writes state[1 - p]
+        diff = [(i, int((a != b).sum())) for i, (a, b) in enumerate(zip(step.state[p].tensors(), ref_state[p])) if not torch.equal(a, b)]
+        if diff:
+            geo_bad += 1
+        else:
+            net_bad += 1
+        if geo_bad + net_bad <= 12:
+            print(f"step {s} parity {p}: loss {loss} (usual {major[p]}); geometry state tensors differing from the reference: {diff if diff else 'none -> the NETWORK graph computed something else'}")
     cur = nxt
+print("deviating steps: geometry state differed", geo_bad, "; geometry state identical (network side)", net_bad)
 print("batch 0 losses", seen[0])
 print("batch 1 losses", seen[1])
