@@ -80,9 +80,6 @@ def parse():
                     help="--workload seg: what the reference's loader emits -- every step a DIFFERENT packed batch (cloud sizes drawn in "
                          "[points/2, points], segmentation/util/data_util.py:15-23) through ONE captured network graph (RaggedSegStep: row counts "
                          "as device data); the eager loop is timed beside it (--no-graph: only the eager loop)")
-    ap.add_argument("--ragged-overlap", action="store_true",
-                    help="--workload seg --ragged: time ONLY RaggedSegStep(overlap=True) -- the eager geometry beside the replaying graph; bench.py "
-                         "runs this form in a child started with GPU_FLUSH_ON_EXECUTION=1 (profiles/r06/eager_beside_graph.txt)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check: spawn / join the ranks, one all-reduce over the process group (gloo where there is no "
                          "HIP device), rank 0 prints one JSON line; no model, no kernels (tests/test_ddp_gloo.py)")
@@ -625,6 +622,11 @@ def bracketing_legs(args, value, cpu):
     return out
 
 
+TWO_STREAM_NOTE = ("open hazard (DESIGN.md section 6, profiles/r06/eager_beside_graph.txt): beside the split-product GEMMs of the network graph, the "
+                   "umbrella fan-feature kernel of the geometry stream computed 16 consecutive points' features from other operands in 0.1-0.6 % of "
+                   "the pipelined steps (0 of 16 000 under RS_GEMM_SPLIT3=0 = fp32_mfma_ms_per_step; 0 on one stream = the nopipe leg); the parity "
+                   "tests run the kernels on one stream")
+
 def mlp_hip_split3():
     from repsurf_amd import mlp_hip
     return mlp_hip.gemm_split3()
@@ -776,16 +778,11 @@ def main_seg(args):
                 lv = float(loss_.item())
                 rs.close()
                 return dt_, lv
-            if args.ragged_overlap:      # child leg: the overlapped form alone (the parent started this process with GPU_FLUSH_ON_EXECUTION=1)
-                odt, olv = timed_ragged(True)
-                if rank == 0:
-                    print(json.dumps({"metric": "ragged, overlapped", "value": round(clouds * args.steps / odt, 2), "ms_per_step": round(odt / args.steps * 1e3, 4),
-                                      "flush_on_execution": os.environ.get("GPU_FLUSH_ON_EXECUTION"), "loss": round(olv, 5)}), flush=True)
-                rdist.finish()
-                return
-            dt, loss_val = timed_ragged(False)
-            rec = child_leg(args, ("--ragged", "--ragged-overlap"), {"GPU_FLUSH_ON_EXECUTION": "1"}, steps=args.steps)
-            overlap_ms = None if rec is None else rec["ms_per_step"]
+            # the overlapped form (the default) first: a serialized instance run earlier in the process leaves the two streams on one hardware
+            # queue for the instance that follows (measured: 4.67 ms instead of 2.89)
+            dt, loss_val = timed_ragged(True)
+            serial_dt, _ = timed_ragged(False)
+            serial_ms = serial_dt / args.steps * 1e3
             eager_dt, _ = timed_eager(min(args.steps, 16))
             eager_ms = eager_dt / min(args.steps, 16) * 1e3
         else:
@@ -793,8 +790,8 @@ def main_seg(args):
             loss_val, eager_ms = float(loss.item()), None
         if rank == 0:
             launch = ("ONE captured network hipGraph for every batch layout: launches sized for the row capacity, row counts read from a device table "
-                      "(include/repsurf_hip.h: rows_dev), the next batch's geometry launched eagerly on a side stream BEHIND the graph "
-                      "(repsurf_amd.graph.RaggedSegStep, overlap=False: the default)") if graphed else "eager launches"
+                      "(include/repsurf_hip.h: rows_dev), the next batch's geometry launched eagerly on a side stream BESIDE the graph "
+                      "(repsurf_amd.graph.RaggedSegStep, overlap=True: the default)") if graphed else "eager launches"
             out = {"metric": "point-clouds/sec fwd+bwd, RepSurf-U S3DIS seg, RAGGED packed batches" + ("" if graphed else " (eager launches)"),
                    "value": round(clouds * world * args.steps / dt, 2), "unit": "clouds/s", "points_per_s": round(rows * world / dt), "n_gpus": world,
                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -803,11 +800,7 @@ def main_seg(args):
                                           f"capacity {clouds * pts}): what the reference's loader emits (segmentation/util/data_util.py:15-23)",
                               "launch": launch, "parallelism": f"dp{world}", "optimizer_step": not args.no_optim, "loss": round(loss_val, 5)}}
             if graphed:
-                out["overlapped_ms_per_step"] = overlap_ms
-                out["overlapped_note"] = ("RaggedSegStep(overlap=True) in a child started with GPU_FLUSH_ON_EXECUTION=1: the eager geometry BESIDE the replaying graph (as "
-                                          "PipelinedStep overlaps two graphs).  Under the runtime's default command batching eager launches beside a graph replay were "
-                                          "seen to read stale predecessor output (~0.5 % of geometry passes; 0 of 6 400 with the flag: profiles/r06/eager_beside_graph.txt), "
-                                          "so `value` is the form that is safe without it: the geometry BEHIND the graph")
+                out["serialized_ms_per_step"] = round(serial_ms, 4)      # RaggedSegStep(overlap=False): the geometry BEHIND the graph
             if eager_ms is not None:
                 out["eager_ms_per_step"] = round(eager_ms, 4)
                 out["eager_clouds_per_s"] = round(clouds * 1e3 / eager_ms, 2)
@@ -933,6 +926,8 @@ def main_seg(args):
         out["arithmetic"] = ARITHMETIC[mlp_hip_split3()] if args.dtype == "fp32" else "bf16 MFMA operands, fp32 accumulate"
         if world == 1 and args.dtype == "fp32" and mlp_hip_split3() and not args.no_alt_arithmetic:
             out["fp32_mfma_ms_per_step"] = alt_arithmetic_ms(args)
+        if mode.startswith("2 hipgraphs") and args.dtype == "fp32" and mlp_hip_split3():
+            out["two_stream_note"] = TWO_STREAM_NOTE
         print(json.dumps(out), flush=True)
     held = locals().get("pstep")
     pstep = step = None
@@ -1158,6 +1153,8 @@ def main():
             out["allreduce_us"] = None if allreduce_us is None else round(allreduce_us, 1)      # (also in config: the step's one data-path collective, alone)
         if world == 1 and args.dtype == "fp32" and mlp_hip_split3() and not args.no_alt_arithmetic:
             out["fp32_mfma_ms_per_step"] = alt_arithmetic_ms(args)      # the same step under RS_GEMM_SPLIT3=0, 30 steps, child process
+        if mode.startswith("2 hipgraphs") and args.dtype == "fp32" and mlp_hip_split3():
+            out["two_stream_note"] = TWO_STREAM_NOTE
         if world == 1 and args.dtype == "fp32" and use_graph and mlp.COMPACT_GROUPS and not args.no_extra_legs:
             out.update(bracketing_legs(args, value, cpu))
         print(json.dumps(out), flush=True)

@@ -15,6 +15,7 @@ from . import dist as _rdist
 from . import head as _head
 from . import mlp_hip
 from . import rng
+from . import streams as _streams
 
 
 class GraphedStep:
@@ -274,8 +275,9 @@ class PipelinedStep:
         self.points = [_clone_inputs(points), _clone_inputs(points)]
         self.label = [label.clone(), label.clone()]
         self.draws = rng.StaticDraws(dev)
-        self.main = torch.cuda.Stream()          # M
-        self.side = torch.cuda.Stream()          # S
+        # M and S on DISJOINT compute units (repsurf_amd.streams: the fan-feature arithmetic of the geometry is not reproducible while the
+        # split-product GEMMs share its compute units)
+        self.main, self.side = _streams.pair(dev)
         self.comm = torch.cuda.Stream() if sharded else None     # the early bucket's branch of the captured network graph
         self.main.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.main), self.draws:
@@ -481,7 +483,7 @@ class PipelinedStep:
         self.net_done[1 - p].synchronize()                 # the previous network is done with buffers 1 - p
         with torch.cuda.stream(self.side):
             if next_points is not None or next_label is not None:
-                self.side.wait_stream(caller)              # they were produced on the caller's stream
+                _streams.after(self.side, caller)          # they were produced on the caller's stream
             if next_points is not None:
                 _copy_inputs(self.points[1 - p], next_points)
             if next_label is not None:
@@ -707,8 +709,8 @@ class RaggedSegStep:
         kernels that reduce over rows read the batch's counts from a device table the host refills before each replay
         (repsurf_amd.ragged: `rows_dev` of include/repsurf_hip.h).  Labels beyond the batch's rows hold `ignore_index`;
       * the GEOMETRY (FPS, kNN, fan features, 3-NN: ~50 launches that read coordinates only) runs EAGERLY -- its launches are sized by
-        the cloud boundaries the host knows from the collate function -- on a side stream for the NEXT batch, behind the current
-        batch's network graph (overlap=True: beside it, as in PipelinedStep; see __init__ for why that is opt-in), and its results
+        the cloud boundaries the host knows from the collate function -- on a side stream for the NEXT batch, beside the current
+        batch's network graph (overlap=False: behind it), and its results
         are copied into capacity-sized state buffers (indices beyond the batch's rows keep older, in-range values; the inverse
         index' offsets are padded with their last value).
 
@@ -723,15 +725,11 @@ class RaggedSegStep:
 
     def __init__(self, net, criterion, optimizer, batch, label, capacity=None, warmup=2, ignore_index=None, restore=True, capture=True,
                  max_cloud_rows=None, overlap=None):
-        """overlap=False: the next batch's eager geometry starts when the current network graph has FINISHED (the side stream waits for it);
-        the step costs network + geometry.  overlap=True: the geometry runs BESIDE the network graph, as in PipelinedStep -- 1.6x faster
-        at BASELINE's sizes, and NOT safe under the runtime's default command batching: eagerly launched kernels that run while a
-        hipGraph replays on another stream were seen to read their predecessor's output as it was before that launch (16-point chunks
-        of the constructor's fan features from an older neighbour list: 5-13 of 1 600 geometry passes; 0 of 4 800 once the graph has
-        finished, 0 of 6 400 with GPU_FLUSH_ON_EXECUTION=1 in the process environment: tools/ragged_flake3.py,
-        profiles/r06/eager_beside_graph.txt).  Graph-beside-graph (PipelinedStep) has not shown it.
-        overlap=None (default): True when the process was STARTED with GPU_FLUSH_ON_EXECUTION=1 (the runtime reads it once, at
-        initialisation: setting it from Python afterwards does nothing), else False.
+        """overlap=True (default): the next batch's eager geometry runs BESIDE the current network graph, as in PipelinedStep -- 1.6x
+        faster at BASELINE's sizes than overlap=False, where the side stream waits for the network graph first (step = network +
+        geometry).  (Until the geometry kernels were rebuilt without compiler-vectorized packed-fp32 code -- Makefile, DESIGN.md section 6 --
+        the overlapped form computed 16-point chunks of the fan features from other operands in 5-15 of 1 600 geometry passes; since: 0 of
+        4 800, tools/ragged_flake3.py, profiles/r06/eager_beside_graph.txt.)
         max_cloud_rows: the largest cloud (rows at level 0) any batch will hold; default: the capacity (one cloud may fill it).  It
         fixes, per stage, the form of the grouping's backward in the captured graph: the gather over the inverse index
         (ops.inverse_index: deterministic, no atomics) where a cloud of the stage's source level has at most 16 384 rows, the
@@ -745,7 +743,7 @@ class RaggedSegStep:
         coord, feat, offset = batch
         dev = coord.device
         self.net, self.criterion, self.optimizer = net, criterion, optimizer
-        self.overlap = (os.environ.get("GPU_FLUSH_ON_EXECUTION", "0") == "1") if overlap is None else bool(overlap)
+        self.overlap = True if overlap is None else bool(overlap)
         self.ignore = int(ignore_index if ignore_index is not None else getattr(criterion, "ignore_index", 255))
         sas = [net.sa1, net.sa2, net.sa3, net.sa4]
         self.strides = [sa.stride for sa in sas]
@@ -770,7 +768,7 @@ class RaggedSegStep:
         self.feat = [torch.zeros((capacity, feat.shape[1]), dtype=torch.float32, device=dev) for _ in (0, 1)]
         self.label = [torch.full((capacity,), self.ignore, dtype=label.dtype, device=dev) for _ in (0, 1)]
         self.offset = ops.offsets_tensor([capacity], dev)      # (the network never reads offsets: a placeholder of the list input)
-        self.main, self.side = torch.cuda.Stream(), torch.cuda.Stream()
+        self.main, self.side = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)      # (streams.pair does not help EAGER launches: see streams.py)
         self.state = [None, None]
         self.counts = [None, None]
         caller = torch.cuda.current_stream()
@@ -933,7 +931,7 @@ class RaggedSegStep:
             with torch.cuda.stream(self.side):
                 self.side.wait_stream(caller)
                 if not self.overlap:
-                    self.side.wait_event(self.net_done[p])      # eager launches never run beside the replaying graph (see __init__)
+                    self.side.wait_event(self.net_done[p])      # (overlap=False: the geometry starts when the network graph has finished)
                 self._prepare(1 - p, next_batch, next_label)
                 self.geo_done[1 - p].record(self.side)
         if sync:

@@ -57,6 +57,19 @@ for s in range(N):
         diff = [(i, int((a != b).sum())) for i, (a, b) in enumerate(zip(step.state[p].tensors(), ref_state[p])) if not torch.equal(a, b)]
         if diff:
             geo_bad += 1
+            if geo_bad <= 6:
+                a, b = step.state[p].tensors()[0], ref_state[p][0]
+                a2, b2 = a.reshape(-1, a.shape[-2], a.shape[-1]), b.reshape(-1, b.shape[-2], b.shape[-1])      # (points, fan, 10)
+                pts_bad = torch.nonzero((a2 != b2).flatten(1).any(1)).flatten()
+                print(f"   shape {tuple(a.shape)}; points differing {pts_bad.numel()}: {pts_bad[:20].tolist()}")
+                q = int(pts_bad[0])
+                ch = (a2[q] != b2[q])
+                print(f"   point {q}: channels differing per triangle {ch.sum(1).tolist()}; columns differing {ch.any(0).tolist()}")
+                print("     got ", [round(v, 5) for v in a2[q, 0].tolist()])
+                print("     want", [round(v, 5) for v in b2[q, 0].tolist()])
+                # is the wrong fan a permutation / other start of the right one?  compare the SET of centroids (columns 0..2 in the classification order)
+                same_set = sorted(map(tuple, a2[q, :, 0:3].round(decimals=5).tolist())) == sorted(map(tuple, b2[q, :, 0:3].round(decimals=5).tolist()))
+                print("     same set of triangle centroids (another order / sign only):", same_set)
         else:
             net_bad += 1
         if geo_bad + net_bad <= 12:

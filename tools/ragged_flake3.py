@@ -50,6 +50,13 @@ with subproject("segmentation"):
                 # is the wrong content the truth of ANOTHER batch at the same rows (stale memory), or of other rows of this batch?
                 stale = [k for k, t in TRUTH.items() if k != int(n0) and t.shape[0] > int(rows[-1]) and torch.equal(t[rows], fw[rows])]
                 nanc = int(torch.isnan(fw[rows]).sum())
+                # which triangles (10 columns each) of the wrong rows differ, and is a wrong row the truth of ANOTHER row of this batch?
+                tri = (fw[rows] != truth[rows]).reshape(rows.numel(), -1, 10).any(2).sum(1).tolist()
+                moved = []
+                for r_ in rows[:4].tolist():
+                    hit = torch.nonzero((truth.flatten(1) == fw[r_].flatten()).all(1)).flatten().tolist()
+                    moved.append((r_, hit[:2]))
+                print(f"   triangles differing per wrong row {tri[:16]}; wrong row == truth of rows {moved}")
                 print(f"   {w} wrong in rows {r0}..{int(rows[-1])} ({rows.numel()}); equals the features of a batch with {stale} rows at the same positions; nans {nanc}; "
                       f"wrong[0][:6] {fw[r0].flatten()[:6].tolist()} truth {truth[r0].flatten()[:6].tolist()}")
             if not torch.equal(_s.state[q].feat[:n0], f1):

@@ -1,0 +1,95 @@
+// Synthetic victims for the two-stream hazard (diagnosis; tools/victim_probe.py): long dependent VALU chains, one thread per value, no LDS,
+// no scratch, coalesced store.  KIND 0: fused multiply-adds only.  1: v_rcp_f32 + v_sqrt_f32 in the chain.  2: IEEE division and sqrt
+// (v_div_scale / v_div_fmas / v_div_fixup).  3: atan2f / acosf.  4: gather loads through an index table, no arithmetic to speak of.
+// 5 / 6: a 9-key sorting network with lane-mask selects / with VGPR-mask selects.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+template <int KIND>
+__global__ void __launch_bounds__(256) victim_kernel(float *__restrict__ out, const int *__restrict__ table, const float *__restrict__ src,
+                                                     int n, int iters, float scale) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float x = 0.25f + (float)(t % 977) * (1.f / 1024.f), y = 0.5f + (float)(t % 313) * (1.f / 512.f), acc = 0.f;
+  for (int i = 0; i < iters; ++i) {
+    if (KIND == 0) {
+      x = __builtin_fmaf(x, 0.99f, 0.013f); y = __builtin_fmaf(y, 0.98f, x * 0.01f); acc = __builtin_fmaf(x, y, acc * 0.5f);
+    } else if (KIND == 1) {
+      x = __builtin_amdgcn_rcpf(x + 1.5f) + 0.3f; y = __builtin_amdgcn_sqrtf(y + x); acc = __builtin_fmaf(x, y, acc * 0.5f);
+    } else if (KIND == 2) {
+      x = 1.0f / (x + 1.5f) + 0.3f; y = sqrtf(y + x) / (1.0f + x); acc = __builtin_fmaf(x, y, acc * 0.5f);
+    } else if (KIND == 3) {
+      x = atan2f(y + 0.1f, x + 0.2f) * 0.3f + 0.3f; y = acosf(x * 0.5f) * 0.4f + 0.1f; acc = __builtin_fmaf(x, y, acc * 0.5f);
+    } else if (KIND == 4) {
+      const int p = table[(t * 9 + i) % n];
+      acc += src[p * 3] - src[(p * 3 + 1) % n];
+    } else if (KIND == 5 || KIND == 6) {
+      // odd-even transposition sort of 9 keys with a payload, as the fan kernel's: 5 = compare -> lane mask (SGPR pair) -> v_cndmask selects;
+      // 6 = the same decisions as integer sign bits in VGPRs and v_bfi selects (no lane mask anywhere)
+      float k[9], v[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        k[j] = __builtin_fmaf((float)((t * 31 + j * 17 + i * 7) % 1009), 1.f / 1009.f, x * 0.001f);
+        v[j] = (float)j + y;
+      }
+#pragma unroll
+      for (int round = 0; round < 9; ++round) {
+#pragma unroll
+        for (int j = (round & 1); j + 1 < 9; j += 2) {
+          if (KIND == 5) {
+            const bool sw = k[j + 1] < k[j];
+            const float tk = k[j], tv = v[j];
+            k[j] = sw ? k[j + 1] : tk; v[j] = sw ? v[j + 1] : tv;
+            k[j + 1] = sw ? tk : k[j + 1]; v[j + 1] = sw ? tv : v[j + 1];
+          } else {
+            const unsigned m = (unsigned)(__float_as_int(k[j + 1] - k[j]) >> 31);      // all ones where k[j+1] < k[j] (keys are finite, distinct or equal)
+            const unsigned a = __float_as_uint(k[j]), b = __float_as_uint(k[j + 1]), c = __float_as_uint(v[j]), d = __float_as_uint(v[j + 1]);
+            k[j] = __uint_as_float((b & m) | (a & ~m)); k[j + 1] = __uint_as_float((a & m) | (b & ~m));
+            v[j] = __uint_as_float((d & m) | (c & ~m)); v[j + 1] = __uint_as_float((c & m) | (d & ~m));
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc = __builtin_fmaf(acc, 0.5f, v[j] * (float)(j + 1));
+      x = __builtin_fmaf(x, 0.99f, 0.013f); y = __builtin_fmaf(y, 0.98f, 0.007f);
+    } else if (KIND == 7 || KIND == 10 || KIND == 11) {
+      // packed fp32 arithmetic written as 2-vectors: 7 = v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on VGPR operands only; 10 = one operand a
+      // wave-uniform value (an SGPR pair / op_sel broadcast); 11 = inline constants and negated operands (neg_lo / neg_hi)
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      v2f a = {x, y}, b = {y, x + 0.25f}, c = {acc, 0.5f};
+#pragma unroll 8
+      for (int u = 0; u < 8; ++u) {
+        if (KIND == 7) {
+          const v2f w = {b.y, a.x};
+          c = __builtin_elementwise_fma(a, w, c); a = a * b + w; b = (b + a) * w;
+        } else if (KIND == 10) {
+          const v2f s2 = {scale, scale};
+          c = __builtin_elementwise_fma(a, s2, c); a = a * s2 + b; b = (b + a) * s2;
+        } else {
+          c = __builtin_elementwise_fma(a, (v2f){0.5f, 0.5f}, -c); a = a * (v2f){-0.5f, -0.5f} - b; b = (b - a) * (v2f){0.5f, 0.5f};
+        }
+        a = {a.x - (float)(int)a.x, a.y - (float)(int)a.y}; b = {b.x - (float)(int)b.x, b.y - (float)(int)b.y};
+      }
+      x = a.x * 0.5f + 0.25f; y = b.y * 0.5f + 0.5f; acc = c.x * 0.5f + c.y;
+    }
+  }
+  out[t] = acc + x + y;
+}
+
+extern "C" int victim_launch(int kind, float *out, const int *table, const float *src, int n, int iters, void *stream) {
+  const dim3 grid((n + 255) / 256), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(victim_kernel<0>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 1: hipLaunchKernelGGL(victim_kernel<1>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 2: hipLaunchKernelGGL(victim_kernel<2>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 3: hipLaunchKernelGGL(victim_kernel<3>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 4: hipLaunchKernelGGL(victim_kernel<4>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 5: hipLaunchKernelGGL(victim_kernel<5>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 6: hipLaunchKernelGGL(victim_kernel<6>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 7: hipLaunchKernelGGL(victim_kernel<7>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 10: hipLaunchKernelGGL(victim_kernel<10>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    default: hipLaunchKernelGGL(victim_kernel<11>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+  }
+  return (int)hipGetLastError();
+}
