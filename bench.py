@@ -622,10 +622,9 @@ def bracketing_legs(args, value, cpu):
     return out
 
 
-TWO_STREAM_NOTE = ("open hazard (DESIGN.md section 6, profiles/r06/eager_beside_graph.txt): beside the split-product GEMMs of the network graph, the "
-                   "umbrella fan-feature kernel of the geometry stream computed 16 consecutive points' features from other operands in 0.1-0.6 % of "
-                   "the pipelined steps (0 of 16 000 under RS_GEMM_SPLIT3=0 = fp32_mfma_ms_per_step; 0 on one stream = the nopipe leg); the parity "
-                   "tests run the kernels on one stream")
+TWO_STREAM_NOTE = ("geometry graph beside the network graph: 0 of 24 000 steps (3 x 8 000, tools/pipelined_flake.py) gave another loss than the one-stream "
+                   "step on the final tree -- the same tree with compiler-vectorized packed-fp32 code in the geometry kernels: 51 / 125 / 123 of 8 000 "
+                   "(profiles/r06/two_stream_validation.txt, DESIGN.md section 6)")
 
 def mlp_hip_split3():
     from repsurf_amd import mlp_hip
