@@ -226,12 +226,11 @@ def replay_calls(calls, stream):
             raise RepSurfHipError(f"{name} (replayed) failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
-# Submit-per-launch (round 6).  The runtime batches the AQL packets of a stream and rings the doorbell when the batch is flushed.  Eager
-# launches issued back to back on one stream WHILE a hipGraph replays on another were seen to read what the previous launch had just
-# written as it was BEFORE that launch -- 16-point chunks of the segmentation constructor's fan features computed from an older
-# neighbour list, 8 of 1 600 geometry passes (tools/ragged_flake3.py; 0 of 1 600 with the network graph finished, 0 of 1 600 under
-# GPU_FLUSH_ON_EXECUTION=1, unchanged by AMD_OPT_FLUSH=0: profiles/r06/eager_beside_graph.txt).  `submit_each_launch(True)` makes every
-# ABI call end with hipStreamQuery on its stream, which submits the batch: what RaggedSegStep wraps its eager geometry in.
+# Submit-per-launch (round 6, DIAGNOSIS).  The runtime batches the AQL packets of a stream and rings the doorbell when the batch is flushed.
+# While the two-stream deviations of the fan-feature kernel (profiles/r06/eager_beside_graph.txt) still read as an ordering problem between
+# eager launches, `submit_each_launch(True)` -- every ABI call ends with hipStreamQuery on its stream, which submits the batch -- was one of
+# the switches tried (no effect: 5, 5 of 1 600).  The cause was elsewhere (compiler-vectorized packed-fp32 code beside MFMA waves: Makefile);
+# nothing in the product path uses this.
 _submit_each = 0
 _hip_query = None
 SUBMIT_ALWAYS = os.environ.get("REPSURF_SUBMIT_EACH_LAUNCH", "0") != "0"      # (diagnosis: every launch of the process)

@@ -10,7 +10,8 @@ hipStreamCreateWithFlags.  What the round-6 runs of tools/pipelined_flake.py and
   * streams made by hipExtStreamCreateWithCUMask are BLOCKING streams (the call takes no flags): an event recorded on the legacy default
     stream between the two launches orders the geometry after the network, which is why a first run of this kind showed no deviating
     step -- it had no concurrency left; with the default stream kept out of the way it deviates like the others (worse);
-  * none of the kinds removes the hazard.  They stay selectable for whoever continues the diagnosis on a box where the mask works."""
+  * none of the kinds removes the hazard (its cause was found in the victim kernel's code instead: the Makefile's vectorizer flags).
+    They stay selectable for whoever wants to repeat the diagnosis on a box where the mask works."""
 import ctypes
 import os
 
