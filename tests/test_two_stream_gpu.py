@@ -2,8 +2,8 @@
 
 Round 6: the fan-feature kernel, built with the compiler's SLP vectorizer, computed lanes 48..63 of a wave from other operands in 1-3 % of
 its launches while split-product GEMMs of the other stream shared its compute units (profiles/r06/eager_beside_graph.txt); the geometry
-translation units are compiled without the vectorizers since (Makefile).  A build that loses the flags fails here: 3 000 launches beside
-the replaying graph, every output equal to the kernel's output alone (the vectorized build: 20-50 deviating launches expected)."""
+translation units are compiled without the vectorizers since (Makefile).  A build that loses the flags fails here: 8 000 launches beside
+the replaying graph, every output equal to the kernel's output alone (the same tree built with the vectorizers: 53 of 8 000 deviate, each in lanes 48..63 of a wave)."""
 import os
 import re
 
@@ -26,30 +26,41 @@ def test_geometry_units_build_without_the_vectorizers():
 
 @pytest.mark.gpu
 def test_fan_features_beside_the_replaying_network_graph_equal_the_kernel_alone():
-    from repsurf_amd import ops
+    from repsurf_amd import _lib, ops
     from repsurf_amd.graph import RaggedSegStep
     from repsurf_amd.head import CrossEntropyLoss
-    from tests.test_seg_gpu import _ragged_batches, _seg_model
-    _, batches, labels = _ragged_batches()
+    from tests.test_seg_gpu import _seg_model
+    cuda = torch.device("cuda")
+    r = np.random.RandomState(1)
+    clouds, pts = 16, 4096                                   # the network graph of bench.py --workload seg --ragged: ~2.5 ms of GEMM-heavy replay
+    sizes = r.randint(pts // 2, pts + 1, clouds)
+    n = int(sizes.sum())
+    batch = [torch.from_numpy((r.rand(n, 3) * 2 - 1).astype(np.float32)).to(cuda), torch.from_numpy(r.rand(n, 3).astype(np.float32)).to(cuda),
+             ops.offsets_tensor(np.cumsum(sizes).tolist(), cuda)]
+    label = torch.from_numpy(r.randint(0, 13, n).astype(np.int64)).to(cuda)
     with subproject("segmentation"):
         model = _seg_model()
-        step = RaggedSegStep(model, CrossEntropyLoss(ignore_index=255), None, batches[0], labels[0], capacity=4096)
-        coord, off = batches[1][0], batches[1][2]
+        step = RaggedSegStep(model, CrossEntropyLoss(ignore_index=255), None, batch, label, capacity=clouds * pts, max_cloud_rows=pts)
+        coord, off = batch[0][:4096].contiguous(), ops.offsets_tensor([4096], cuda)
         idx, _ = ops.knnquery_offset(9, coord, coord, off, off)
         alone = ops.umbrella_fan_offset(coord, coord, idx, off, None, True)
         torch.cuda.synchronize()
+        ring = torch.empty((200,) + tuple(alone.shape), dtype=alone.dtype, device=cuda)
         deviating, launches = 0, 0
-        for _ in range(150):
-            with torch.cuda.stream(step.main):
-                step.g_net[0].replay()
-            with torch.cuda.stream(step.side):
-                outs = [ops.umbrella_fan_offset(coord, coord, idx, off, None, True) for _ in range(20)]
+        for _ in range(40):                                      # 40 x (25 back-to-back replays, 8 fan launches under each) = 8 000 launches
+            for rep in range(25):
+                with torch.cuda.stream(step.main):
+                    step.g_net[0].replay()
+                with torch.cuda.stream(step.side):
+                    for k in range(8):
+                        _lib.call("rs_umbrella_fan_offset", 4096, 9, 1, 1, coord.data_ptr(), coord.data_ptr(), idx.data_ptr(), off.data_ptr(), None,
+                                  ring[rep * 8 + k].data_ptr(), step.side.cuda_stream)
             torch.cuda.synchronize()
-            launches += len(outs)
-            for o in outs:
-                if not torch.equal(o, alone):
-                    rows = torch.nonzero((o != alone).flatten(1).any(1)).flatten()
-                    deviating += 1
-                    print(f"deviating launch: rows {rows[:3].tolist()}..{rows[-1:].tolist()} (mod 64: {sorted({int(r) % 64 for r in rows})[:4]}..)")
+            launches += 200
+            bad = (ring != alone).flatten(1).any(1)
+            for k in torch.nonzero(bad).flatten().tolist():
+                rows = torch.nonzero((ring[k] != alone).flatten(1).any(1)).flatten()
+                deviating += 1
+                print(f"deviating launch: rows {rows[:3].tolist()}..{rows[-1:].tolist()} (mod 64: {sorted({int(r) % 64 for r in rows})[:4]}..)")
         step.close()
     assert deviating == 0, f"{deviating} of {launches} fan-feature launches beside the network graph differ from the kernel alone"
