@@ -12,9 +12,10 @@ SRCS := $(CSRC)/rs_lib.cpp $(CSRC)/fps.hip $(CSRC)/ballquery.hip $(CSRC)/knn_umb
 OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS)) build/mlp_bf16.hip.o build/mlp_sb.hip.o build/mlp_split.hip.o
 
 # The geometry kernels run on a side stream BESIDE the network's MFMA kernels (graph.PipelinedStep / RaggedSegStep).  Packed-fp32 VALU
-# instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: what the SLP vectorizer makes of neighbouring float operations) of such a kernel
-# gave other results in lanes 48..63 of a wave in ~2.5 % of its launches beside the split-product (bf16 MFMA) GEMMs -- 0 of 20 000 launches of
-# the same kernel built without them, 0 alone on a stream (tools/victim_probe.py, profiles/r06/eager_beside_graph.txt).  Those translation
+# instructions as the SLP vectorizer makes them of neighbouring float operations -- precisely: v_pk_add_f32 / v_pk_fma_f32 with op_sel on
+# their second source -- gave other results in lanes 48..63 of a wave in ~1-2.5 % of a kernel's launches beside the split-product (bf16
+# MFMA) GEMMs; 0 of 20 000 launches of the same kernel built without them, 0 alone on a stream (tools/victim_probe.py,
+# profiles/r06/eager_beside_graph.txt).  Those translation
 # units -- and, at no measured cost (tools/slp_ab.sh), every other one without MFMA loops -- are compiled without the SLP and loop vectorizers; their
 # arithmetic is the same IEEE operations either way.
 GEOM_TUS := fps ballquery knn_umbrella knn_wide group interp seg_geom scene_knn grid_knn umbrella_mlp head adam

@@ -24,6 +24,29 @@ def test_geometry_units_build_without_the_vectorizers():
     assert re.search(r"\$\(foreach t,\$\(GEOM_TUS\).*-fno-slp-vectorize -fno-vectorize", mk)
 
 
+SIDE_STREAM_UNITS = ("seg_geom", "knn_umbrella", "grid_knn", "ballquery", "fps", "scene_knn", "knn_wide", "group", "interp")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.mark.parametrize("unit", SIDE_STREAM_UNITS)
+def test_side_stream_units_hold_no_packed_fp32_with_op_sel_on_the_second_source(unit, tmp_path):
+    """The instruction the hazard was traced to (profiles/r06/eager_beside_graph.txt: v_pk_add_f32 / v_pk_fma_f32 whose src1 carries op_sel)
+    must not appear in anything the side stream launches -- checked in the device code of the built objects."""
+    import shutil
+    import subprocess
+    obj = os.path.join(ROOT, "build", unit + ".hip.o")
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("no built object / no llvm tools here (make builds build/*.hip.o)")
+    work = shutil.copy(obj, tmp_path / "unit.o")          # (llvm-objcopy rewrites its input)
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={tmp_path / 'unit.bundle'}", str(work)])
+    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                           f"--input={tmp_path / 'unit.bundle'}", f"--output={tmp_path / 'unit.elf'}"])
+    text = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", str(tmp_path / "unit.elf")], text=True)
+    assert "s_endpgm" in text, "no device code disassembled"
+    bad = [ln.strip() for ln in text.splitlines() if re.search(r"v_pk_(add|fma)_f32\b.*op_sel:\[[01],1", ln)]
+    assert not bad, f"{unit}: {len(bad)} packed-fp32 instructions with op_sel on src1, e.g. {bad[0]}"
+
+
 @pytest.mark.gpu
 def test_fan_features_beside_the_replaying_network_graph_equal_the_kernel_alone():
     from repsurf_amd import _lib, ops

@@ -71,6 +71,28 @@ __global__ void __launch_bounds__(256) victim_kernel(float *__restrict__ out, co
         a = {a.x - (float)(int)a.x, a.y - (float)(int)a.y}; b = {b.x - (float)(int)b.x, b.y - (float)(int)b.y};
       }
       x = a.x * 0.5f + 0.25f; y = b.y * 0.5f + 0.5f; acc = c.x * 0.5f + c.y;
+    } else if (KIND >= 12 && KIND <= 21) {
+      // the operand forms the SLP vectorizer produced in the fan kernel, as assembly statements (values stay in [0, 2): a contraction):
+      // 12 v_pk_fma_f32 with an SGPR-pair operand broadcast by op_sel_hi; 13 v_pk_mul_f32 by an SGPR pair; 14 v_pk_add_f32 with op_sel:[0,1]
+      // (the high half of a source feeding the low lane element) and negation; 15 v_pk_mul_f32 by an inline constant; 16 all four in turn
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      v2f a = {x, y}, b = {y * 0.5f, x * 0.5f};
+      const v2f s2 = {scale, scale * 0.5f};
+#pragma unroll 4
+      for (int u = 0; u < 16; ++u) {
+        if (KIND == 12 || KIND == 16) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(a), "s"(s2), "v"(b));
+        if (KIND == 13 || KIND == 16) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b) : "v"(a), "s"(s2));
+        if (KIND == 14 || KIND == 16) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(a) : "v"(a), "v"(b));
+        if (KIND == 15 || KIND == 16) asm volatile("v_pk_mul_f32 %0, %1, 0.5 op_sel_hi:[1,0]" : "=v"(b) : "v"(a));
+        // 17 op_sel:[0,1] alone; 18 the negation alone; 19 v_pk_mul_f32 with op_sel:[0,1]; 20 v_pk_fma_f32 with op_sel:[0,1,0]; 21 op_sel:[1,0]
+        if (KIND == 17) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(a) : "v"(a), "v"(b));
+        if (KIND == 18) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(a) : "v"(a), "v"(b));
+        if (KIND == 19) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(a) : "v"(a), "v"(b));
+        if (KIND == 20) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(a) : "v"(a), "v"(b), "v"(b));
+        if (KIND == 21) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(a) : "v"(a), "v"(b));
+        if (KIND == 14 || KIND >= 17) { b = b * 0.75f; a = a * 0.5f; }
+      }
+      x = a.x - (float)(int)a.x + 0.25f; y = b.y - (float)(int)b.y + 0.5f; acc = __builtin_fmaf(a.y, b.x, acc * 0.5f);
     }
   }
   out[t] = acc + x + y;
@@ -89,7 +111,17 @@ extern "C" int victim_launch(int kind, float *out, const int *table, const float
     case 6: hipLaunchKernelGGL(victim_kernel<6>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
     case 7: hipLaunchKernelGGL(victim_kernel<7>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
     case 10: hipLaunchKernelGGL(victim_kernel<10>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
-    default: hipLaunchKernelGGL(victim_kernel<11>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 11: hipLaunchKernelGGL(victim_kernel<11>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 12: hipLaunchKernelGGL(victim_kernel<12>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 13: hipLaunchKernelGGL(victim_kernel<13>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 14: hipLaunchKernelGGL(victim_kernel<14>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 15: hipLaunchKernelGGL(victim_kernel<15>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 16: hipLaunchKernelGGL(victim_kernel<16>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 17: hipLaunchKernelGGL(victim_kernel<17>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 18: hipLaunchKernelGGL(victim_kernel<18>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 19: hipLaunchKernelGGL(victim_kernel<19>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    case 20: hipLaunchKernelGGL(victim_kernel<20>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+    default: hipLaunchKernelGGL(victim_kernel<21>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
   }
   return (int)hipGetLastError();
 }

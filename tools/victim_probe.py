@@ -40,7 +40,7 @@ i0, _ = ops.knnquery_offset(9, c0, c0, off0, off0)
 fan_ref = ops.umbrella_fan_offset(c0, c0, i0, off0, None, True).clone()
 table = torch.from_numpy(r.randint(0, n // 3 - 1, n).astype(np.int32)).to(dev)
 src = torch.rand(n, device=dev)
-names = {7: "packed fp32, VGPR operands", 10: "packed fp32, uniform operand", 11: "packed fp32, constants / neg", 8: "FPS (32 x 1024 -> 512)", 9: "the fan-feature kernel", 5: "sort, lane-mask selects", 6: "sort, VGPR-mask selects", 0: "fma chain", 1: "v_rcp / v_sqrt chain", 2: "IEEE division + sqrt", 3: "atan2f / acosf", 4: "gather loads"}
+names = {17: "asm v_pk_add op_sel:[0,1]", 18: "asm v_pk_add neg only", 19: "asm v_pk_mul op_sel:[0,1]", 20: "asm v_pk_fma op_sel:[0,1,0]", 21: "asm v_pk_add op_sel:[1,0]", 12: "asm v_pk_fma, SGPR op_sel_hi", 13: "asm v_pk_mul, SGPR", 14: "asm v_pk_add op_sel:[0,1] neg", 15: "asm v_pk_mul, constant", 16: "asm, the four in turn", 7: "packed fp32, VGPR operands", 10: "packed fp32, uniform operand", 11: "packed fp32, constants / neg", 8: "FPS (32 x 1024 -> 512)", 9: "the fan-feature kernel", 5: "sort, lane-mask selects", 6: "sort, VGPR-mask selects", 0: "fma chain", 1: "v_rcp / v_sqrt chain", 2: "IEEE division + sqrt", 3: "atan2f / acosf", 4: "gather loads"}
 for kind in ([int(k) for k in sys.argv[5].split(',')] if len(sys.argv) > 5 else (9, 0, 1, 2, 3, 4, 5, 6)):
     ref = torch.empty(n, device=dev)
     if kind == 8:
