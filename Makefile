@@ -33,9 +33,11 @@ build/mlp.hip.o: HIPFLAGS += -DRS_MLP_TU=0
 build/mlp_bf16.hip.o: $(CSRC)/mlp.hip $(CSRC)/rs_common.h include/repsurf_hip.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -DRS_MLP_TU=1 -x hip -c $< -o $@
+# (the only GEMM unit where the vectorizer produced the instruction form of the note above -- 10 of them, in two weight-gradient instances; built
+#  without it the bf16 lines read the same: tools/sb_ab.sh)
 build/mlp_sb.hip.o: $(CSRC)/mlp.hip $(CSRC)/rs_common.h include/repsurf_hip.h
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DRS_MLP_TU=3 -x hip -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -DRS_MLP_TU=3 -x hip -c $< -o $@
 # unit 4: the fp32 product as six bf16 MFMAs over three-part operands (the default of the tiled kernels; RS_GEMM_SPLIT3=0: fp32 MFMAs)
 build/mlp_split.hip.o: $(CSRC)/mlp.hip $(CSRC)/rs_common.h include/repsurf_hip.h
 	@mkdir -p build
