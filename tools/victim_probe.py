@@ -31,6 +31,30 @@ batch = [torch.from_numpy((r.rand(nn, 3) * 2 - 1).astype(np.float32)).to(dev), t
          ops.offsets_tensor(np.cumsum(sizes).tolist(), dev)]
 label = torch.from_numpy(r.randint(0, 13, nn).astype(np.int64)).to(dev)
 rs = RaggedSegStep(model, crit, opt, batch, label, capacity=clouds * pts, max_cloud_rows=pts, overlap=True)
+AGG = os.environ.get("AGG", "graph")      # what runs on the main stream: the replayed network graph | fwd | fwdbwd (an eager GEMM stack) | matmul
+if AGG in ("fwd", "fwdbwd"):
+    from repsurf_amd import mlp as _mlp
+    a_convs = torch.nn.ModuleList([torch.nn.Conv2d(64, 128, 1), torch.nn.Conv2d(128, 256, 1), torch.nn.Conv2d(256, 512, 1)]).to(dev)
+    a_bns = torch.nn.ModuleList([torch.nn.BatchNorm2d(128), torch.nn.BatchNorm2d(256), torch.nn.BatchNorm2d(512)]).to(dev).train()
+    a_x = torch.randn(2048 * 32, 64, device=dev, requires_grad=True)
+if AGG == "matmul":
+    m_a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16); m_b = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+
+
+def aggressor():
+    if AGG == "graph":
+        rs.g_net[0].replay()
+    elif AGG == "matmul":
+        for _ in range(4):
+            torch.matmul(m_a, m_b)
+    else:
+        for _ in range(3):
+            out_ = _mlp.sa_mlp_plain(a_x, a_convs, a_bns, 32)
+            if AGG == "fwdbwd":
+                out_.sum().backward()
+                a_x.grad = None
+
+
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
@@ -65,7 +89,7 @@ for kind in ([int(k) for k in sys.argv[5].split(',')] if len(sys.argv) > 5 else 
         while done < L:
             if beside:
                 with torch.cuda.stream(rs.main):
-                    rs.g_net[0].replay()
+                    aggressor()
             with torch.cuda.stream(rs.side):
                 for _ in range(min(per, L - done)):             # `per` victim launches under one network replay
                     if kind == 8:
@@ -89,7 +113,7 @@ for kind in ([int(k) for k in sys.argv[5].split(',')] if len(sys.argv) > 5 else 
         else:
             bad = (out != ref).any(1)
         nbad = int(bad.sum())
-        msg = f"{names[kind]:24s} {'beside the network graph' if beside else 'alone on the side stream'}: {nbad} of {L} launches wrote other values"
+        msg = f"{names[kind]:24s} {('beside ' + AGG) if beside else 'alone on the side stream'}: {nbad} of {L} launches wrote other values"
         if nbad:
             k = int(torch.nonzero(bad)[0])
             lanes = torch.nonzero((out[k].view(torch.int32) != ref.to(torch.int32)) if kind == 8 else (out[k] != ref)).flatten()
