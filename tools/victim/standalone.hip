@@ -3,7 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o tools/victim/standalone tools/victim/standalone.hip && tools/victim/standalone [launches] [aggressor]
 //   aggressor: 0 none, 1 v_mfma_f32_32x32x16_bf16 loop, 2 v_mfma_f32_32x32x2_f32 loop, 3 fp32 FMA loop (no MFMA), 4 LDS-DMA loop,
 //   5 LDS-DMA + bf16 MFMA loop, 6 four independent bf16 MFMA chains fed from LDS,
-//   7 v_cvt_pk_bf16_f32 loop (no MFMA)
+//   7 v_cvt_pk_bf16_f32 loop (no MFMA), 8 bf16 MFMAs with the accumulator in architectural VGPRs
 // Prints, per victim form, how many launches wrote other values than the same kernel alone, and the lanes (thread index mod 64) that differ.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -67,6 +67,21 @@ __global__ void __launch_bounds__(256) aggressor(float *sink, int iters, const f
         c[0] += f.x; c[1] += f.y; c[2] += f.z; c[3] += f.w;
       }
     }
+  } else if (KIND == 8) {
+    // bf16 MFMAs whose accumulator lives in ARCHITECTURAL VGPRs (v_mfma ... v[..], v[..], v[..], v[..]: what this package's GEMM kernels
+    // issue) instead of AGPRs (what the compiler picks for the loops above, and what library GEMMs use)
+    v8bf a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x + j)); b[j] = (__bf16)(0.002f * (threadIdx.x - j)); }
+    v16f c1 = {};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(b), "v"(a));
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    for (int u = 0; u < 16; ++u) c[u] += c1[u];
   } else if (KIND == 7) {
     // no MFMA at all: v_cvt_pk_bf16_f32 (two fp32 -> packed bf16, new on gfx950) in a VALU loop
     float a = 0.001f * threadIdx.x, b = 0.5f + 0.002f * threadIdx.x;
@@ -134,7 +149,7 @@ int main(int argc, char **argv) {
   CHECK(hipMalloc(&out, (size_t)ring * n * 4)); CHECK(hipMalloc(&ref, n * 4)); CHECK(hipMalloc(&sink, 1024));
   std::vector<float> h((size_t)ring * n), hr(n);
   const char *names[3] = {"v_pk_add_f32 op_sel:[0,1]", "v_pk_add_f32 op_sel:[1,0]", "v_pk_add_f32 (no op_sel)"};
-  const char *agg[8] = {"nothing", "a v_mfma_f32_32x32x16_bf16 loop", "a v_mfma_f32_32x32x2_f32 loop", "an fp32 FMA loop", "an LDS-DMA loop", "an LDS-DMA + bf16 MFMA loop", "4 independent bf16 MFMA chains fed from LDS", "a v_cvt_pk_bf16_f32 loop (no MFMA)"};
+  const char *agg[9] = {"nothing", "a v_mfma_f32_32x32x16_bf16 loop", "a v_mfma_f32_32x32x2_f32 loop", "an fp32 FMA loop", "an LDS-DMA loop", "an LDS-DMA + bf16 MFMA loop", "4 independent bf16 MFMA chains fed from LDS", "a v_cvt_pk_bf16_f32 loop (no MFMA)", "bf16 MFMAs accumulating in VGPRs"};
   for (int form = 0; form < 3; ++form) {
     auto launch_victim = [&](float *dst) {
       if (form == 0) hipLaunchKernelGGL(victim<0>, dim3(n / 256), dim3(256), 0, sv, dst, viters, 0.7071f);
@@ -155,6 +170,7 @@ int main(int argc, char **argv) {
         if (kind == 5) hipLaunchKernelGGL(aggressor<5>, dim3(1024), dim3(256), 0, sa, sink, 200, src);
         if (kind == 6) hipLaunchKernelGGL(aggressor<6>, dim3(1024), dim3(256), 0, sa, sink, 100, src);
         if (kind == 7) hipLaunchKernelGGL(aggressor<7>, dim3(1024), dim3(256), 0, sa, sink, 100, src);
+        if (kind == 8) hipLaunchKernelGGL(aggressor<8>, dim3(1024), dim3(256), 0, sa, sink, 400, src);
         for (int k = 0; k < per; ++k) launch_victim(out + (size_t)(r * per + k) * n);
       }
       CHECK(hipEventRecord(e1, sv));
