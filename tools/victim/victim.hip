@@ -4,6 +4,10 @@
 // 5 / 6: a 9-key sorting network with lane-mask selects / with VGPR-mask selects.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdint.h>
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 template <int KIND>
 __global__ void __launch_bounds__(256) victim_kernel(float *__restrict__ out, const int *__restrict__ table, const float *__restrict__ src,
@@ -122,6 +126,160 @@ extern "C" int victim_launch(int kind, float *out, const int *table, const float
     case 19: hipLaunchKernelGGL(victim_kernel<19>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
     case 20: hipLaunchKernelGGL(victim_kernel<20>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
     default: hipLaunchKernelGGL(victim_kernel<21>, grid, block, 0, st, out, table, src, n, iters, 0.7071f); break;
+  }
+  return (int)hipGetLastError();
+}
+
+
+// ---- aggressors (tools/victim_probe.py AGG=custom:<kind>): candidate properties of the GEMM kernels, one at a time, launched on the main stream
+__device__ __forceinline__ void glds16(const void *base, unsigned voff, const float *lds) {
+  const unsigned dst = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)lds;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) aggressor(float *sink, int iters, const float *src) {
+  v16f c = {};
+  __shared__ __attribute__((aligned(16))) float stage[2][4096];           // 2 x 16 KB
+  if (KIND == 4 || KIND == 5) {
+    // LDS-DMA (global -> LDS without registers) of 16 KB per step, read back through ds_read; 5: with bf16 MFMAs on the fragments
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    v8bf a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x + j)); b[j] = (__bf16)(0.002f * (threadIdx.x - j)); }
+    for (int i = 0; i < iters; ++i) {
+      float *st = stage[i & 1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        glds16(src + (size_t)((blockIdx.x * 7 + i) % 64) * 4096, (unsigned)((wave * 4 + q) * 1024 + lane * 16), st + (wave * 4 + q) * 256);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const float4 f = reinterpret_cast<const float4 *>(st)[threadIdx.x];
+      if (KIND == 5) {
+        a[0] = (__bf16)f.x; b[0] = (__bf16)f.y;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+      } else {
+        c[0] += f.x; c[1] += f.y; c[2] += f.z; c[3] += f.w;
+      }
+    }
+  } else if (KIND == 9) {
+    // everything at once: LDS-DMA staging, fragments read from LDS, v_cvt_pk_bf16_f32 of loaded values written back to LDS, four independent
+    // bf16 MFMA chains accumulating in architectural VGPRs, barriers
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v16f c1 = {}, c2 = {}, c3 = {};
+    for (int j = threadIdx.x; j < 2 * 4096; j += 256) (&stage[0][0])[j] = 0.001f * (j % 251);
+    __syncthreads();
+    for (int i = 0; i < iters; ++i) {
+      float *st = stage[i & 1];
+      glds16(src + (size_t)((blockIdx.x * 7 + i) % 64) * 4096, (unsigned)(wave * 1024 + lane * 16), st + wave * 256);
+      const float g0 = src[(blockIdx.x * 64 + i + lane) & 65535], g1 = src[(blockIdx.x * 64 + i + lane + 64) & 65535];
+      unsigned pk;
+      asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(g0), "v"(g1));
+      reinterpret_cast<unsigned *>(st)[2048 + threadIdx.x] = pk;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const v4f fa = *reinterpret_cast<const v4f *>(&st[((threadIdx.x + u * 64) & 1023) * 4]);
+        const v4f fb = *reinterpret_cast<const v4f *>(&stage[(i + 1) & 1][((threadIdx.x + u * 32) & 1023) * 4]);
+        const v8bf a = __builtin_bit_cast(v8bf, fa), b = __builtin_bit_cast(v8bf, fb);
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(b), "v"(a));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c2) : "v"(a), "v"(a));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c3) : "v"(b), "v"(b));
+      }
+      __syncthreads();
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    for (int u = 0; u < 16; ++u) c[u] += c1[u] + c2[u] + c3[u];
+  } else if (KIND == 8) {
+    // bf16 MFMAs whose accumulator lives in ARCHITECTURAL VGPRs (v_mfma ... v[..], v[..], v[..], v[..]: what this package's GEMM kernels
+    // issue) instead of AGPRs (what the compiler picks for the loops above, and what library GEMMs use)
+    v8bf a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x + j)); b[j] = (__bf16)(0.002f * (threadIdx.x - j)); }
+    v16f c1 = {};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(b), "v"(a));
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    for (int u = 0; u < 16; ++u) c[u] += c1[u];
+  } else if (KIND == 7) {
+    // no MFMA at all: v_cvt_pk_bf16_f32 (two fp32 -> packed bf16, new on gfx950) in a VALU loop
+    float a = 0.001f * threadIdx.x, b = 0.5f + 0.002f * threadIdx.x;
+    unsigned r = 0;
+    for (int i = 0; i < iters * 16; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        unsigned p;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));
+        r ^= p; a = __builtin_fmaf(a, 0.999f, 0.001f); b = __builtin_fmaf(b, 0.998f, 0.002f);
+      }
+    }
+    c[0] = (float)r;
+  } else if (KIND == 6) {
+    // closer to a GEMM main loop: four independent accumulators, back-to-back bf16 MFMAs, the fragments re-read from LDS every step
+    v16f c1 = {}, c2 = {}, c3 = {};
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    for (int j = threadIdx.x; j < 2 * 4096; j += 256) (&stage[0][0])[j] = 0.001f * (j % 251);
+    __syncthreads();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const v4f fa = *reinterpret_cast<const v4f *>(&stage[(i + u) & 1][((threadIdx.x + u * 64) & 1023) * 4]);
+        const v4f fb = *reinterpret_cast<const v4f *>(&stage[(i + u + 1) & 1][((threadIdx.x + u * 32) & 1023) * 4]);
+        const v8bf a = __builtin_bit_cast(v8bf, fa), b = __builtin_bit_cast(v8bf, fb);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, c3, 0, 0, 0);
+      }
+    }
+    for (int u = 0; u < 16; ++u) c[u] += c1[u] + c2[u] + c3[u];
+  } else if (KIND == 1) {
+    v8bf a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x + j)); b[j] = (__bf16)(0.002f * (threadIdx.x - j)); }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+  } else if (KIND == 2) {
+    const float a = 0.001f * threadIdx.x, b = 0.002f * threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+  } else {
+    float a = 0.001f * threadIdx.x;
+    for (int i = 0; i < iters * 64; ++i) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) c[u] = __builtin_fmaf(c[u], 0.999f, a);
+    }
+  }
+  float s = 0.f;
+  for (int u = 0; u < 16; ++u) s += c[u];
+  if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
+
+extern "C" int aggressor_launch(int kind, float *sink, const float *src, int grid, int iters, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (kind) {
+    case 1: hipLaunchKernelGGL(aggressor<1>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
+    case 2: hipLaunchKernelGGL(aggressor<2>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
+    case 3: hipLaunchKernelGGL(aggressor<3>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
+    case 4: hipLaunchKernelGGL(aggressor<4>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
+    case 5: hipLaunchKernelGGL(aggressor<5>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
+    case 6: hipLaunchKernelGGL(aggressor<6>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
+    case 7: hipLaunchKernelGGL(aggressor<7>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
+    case 8: hipLaunchKernelGGL(aggressor<8>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
+    default: hipLaunchKernelGGL(aggressor<9>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
   }
   return (int)hipGetLastError();
 }

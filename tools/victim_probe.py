@@ -37,6 +37,9 @@ if AGG in ("fwd", "fwdbwd"):
     a_convs = torch.nn.ModuleList([torch.nn.Conv2d(64, 128, 1), torch.nn.Conv2d(128, 256, 1), torch.nn.Conv2d(256, 512, 1)]).to(dev)
     a_bns = torch.nn.ModuleList([torch.nn.BatchNorm2d(128), torch.nn.BatchNorm2d(256), torch.nn.BatchNorm2d(512)]).to(dev).train()
     a_x = torch.randn(2048 * 32, 64, device=dev, requires_grad=True)
+if AGG.startswith("custom:"):
+    lib.aggressor_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    c_kind = int(AGG.split(":")[1]); c_sink = torch.zeros(1024, device=dev); c_src = torch.zeros(64 * 4096 + 65536, device=dev)
 if AGG == "matmul":
     m_a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16); m_b = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
 
@@ -44,6 +47,9 @@ if AGG == "matmul":
 def aggressor():
     if AGG == "graph":
         rs.g_net[0].replay()
+    elif AGG.startswith("custom:"):
+        for _ in range(3):
+            lib.aggressor_launch(c_kind, c_sink.data_ptr(), c_src.data_ptr(), 1024, {1: 400, 8: 400}.get(c_kind, 150), rs.main.cuda_stream)
     elif AGG == "matmul":
         for _ in range(4):
             torch.matmul(m_a, m_b)
