@@ -3,7 +3,7 @@
 graph of the ragged segmentation step, ever writes other values than it does alone?  usage: victim_probe.py [launches] [iters]  (GPU box;
 build first: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -shared -fPIC
 -o tools/victim/libvictim.so tools/victim/victim.hip)"""
-import os, sys, ctypes, argparse
+import os, sys, time, ctypes, argparse
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "repsurf_amd", "segmentation"))
@@ -92,6 +92,7 @@ for kind in ([int(k) for k in sys.argv[5].split(',')] if len(sys.argv) > 5 else 
         out = torch.empty((L, ref.numel()), device=dev)
         torch.cuda.synchronize()
         done = 0
+        t_start = time.perf_counter()
         while done < L:
             if beside:
                 with torch.cuda.stream(rs.main):
@@ -119,7 +120,8 @@ for kind in ([int(k) for k in sys.argv[5].split(',')] if len(sys.argv) > 5 else 
         else:
             bad = (out != ref).any(1)
         nbad = int(bad.sum())
-        msg = f"{names[kind]:24s} {('beside ' + AGG) if beside else 'alone on the side stream'}: {nbad} of {L} launches wrote other values"
+        wall_ms = (time.perf_counter() - t_start) * 1e3
+        msg = f"[{wall_ms:7.0f} ms] {names[kind]:24s} {('beside ' + AGG) if beside else 'alone on the side stream'}: {nbad} of {L} launches wrote other values"
         if nbad:
             k = int(torch.nonzero(bad)[0])
             lanes = torch.nonzero((out[k].view(torch.int32) != ref.to(torch.int32)) if kind == 8 else (out[k] != ref)).flatten()
