@@ -195,6 +195,27 @@ __global__ void __launch_bounds__(256) aggressor(float *sink, int iters, const f
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     for (int u = 0; u < 16; ++u) c[u] += c1[u] + c2[u] + c3[u];
+  } else if (KIND == 10) {
+    // as 8 (bf16 MFMAs accumulating in VGPRs), with operands whose bits change every step (xorshift: every operand bit toggles at random, as
+    // real activations / weights do) instead of constant tiny values
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u ra = {threadIdx.x * 2654435761u + 1u, threadIdx.x * 40503u + 7u, blockIdx.x * 2246822519u + 3u, 0x9E3779B9u ^ threadIdx.x};
+    v4u rb = {threadIdx.x * 3266489917u + 5u, threadIdx.x * 668265263u + 11u, blockIdx.x * 374761393u + 13u, 0x85EBCA6Bu ^ threadIdx.x};
+    v16f c1 = {}, c2 = {}, c3 = {};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        ra ^= ra << 13; ra ^= ra >> 17; ra ^= ra << 5; rb ^= rb << 13; rb ^= rb >> 17; rb ^= rb << 5;
+        const v4u ma = (ra & 0x807F807Fu) | 0x3F003F00u, mb = (rb & 0x807F807Fu) | 0x3F003F00u;      // bf16 values of magnitude 0.5 .. 1, random sign / mantissa
+        const v8bf a = __builtin_bit_cast(v8bf, ma), b = __builtin_bit_cast(v8bf, mb);
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(b), "v"(a));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c2) : "v"(a), "v"(a));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c3) : "v"(b), "v"(b));
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    for (int u = 0; u < 16; ++u) c[u] += c1[u] + c2[u] + c3[u];
   } else if (KIND == 8) {
     // bf16 MFMAs whose accumulator lives in ARCHITECTURAL VGPRs (v_mfma ... v[..], v[..], v[..], v[..]: what this package's GEMM kernels
     // issue) instead of AGPRs (what the compiler picks for the loops above, and what library GEMMs use)
@@ -279,6 +300,7 @@ extern "C" int aggressor_launch(int kind, float *sink, const float *src, int gri
     case 6: hipLaunchKernelGGL(aggressor<6>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
     case 7: hipLaunchKernelGGL(aggressor<7>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
     case 8: hipLaunchKernelGGL(aggressor<8>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
+    case 10: hipLaunchKernelGGL(aggressor<10>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
     default: hipLaunchKernelGGL(aggressor<9>, dim3(grid), dim3(256), 0, st, sink, iters, src); break;
   }
   return (int)hipGetLastError();

@@ -49,7 +49,7 @@ def aggressor():
         rs.g_net[0].replay()
     elif AGG.startswith("custom:"):
         for _ in range(3):
-            lib.aggressor_launch(c_kind, c_sink.data_ptr(), c_src.data_ptr(), 1024, {1: 400, 8: 400}.get(c_kind, 150), rs.main.cuda_stream)
+            lib.aggressor_launch(c_kind, c_sink.data_ptr(), c_src.data_ptr(), 1024, {1: 400, 8: 400, 10: 400}.get(c_kind, 150), rs.main.cuda_stream)
     elif AGG == "matmul":
         for _ in range(4):
             torch.matmul(m_a, m_b)
